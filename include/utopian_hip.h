@@ -1,0 +1,247 @@
+/*
+ * utopian_hip.h — C ABI of libutopian_hip.so: the MI355X (gfx950) replacement for the
+ * reference's path-tracing + ReSTIR render-graph nodes.
+ *
+ * Every entry point below replaces one verb of the reference's Rust/Vulkan surface for this
+ * path (citations are relative to the reference checkout):
+ *
+ *   uh_create                 Renderer::new + Raytracing::new + the graph resources of
+ *                             build_path_tracing_render_graph   (utopian/src/renderer.rs:123,
+ *                             utopian/src/raytracing.rs:36, utopian/src/renderers/mod.rs:199-244)
+ *   uh_add_texture_rgba8      Renderer::add_bindless_texture    (utopian/src/renderer.rs:301)
+ *   uh_add_mesh               Renderer::add_model, per mesh     (utopian/src/renderer.rs:222-299)
+ *                             + one row of fill_instance_array  (utopian/src/raytracing.rs:218-277)
+ *   uh_add_light              Renderer::add_light               (utopian/src/renderer.rs:391-410)
+ *   uh_set_instance_transform gizmo edit + rebuild_tlas         (utopian/src/raytracing.rs:400-459)
+ *   uh_build_acceleration     Raytracing::initialize            (utopian/src/raytracing.rs:89-111)
+ *   uh_render_frame           the 6 graph passes gbuffer→reset→initial_ris→temporal→spatial→pt
+ *                             (utopian/src/renderers/mod.rs:246-358), one ViewUniformData memcpy
+ *                             per frame (prototype/src/main.rs:477-478)
+ *   uh_reset_accumulation     total_samples = 0 semantics       (prototype/src/main.rs:400-413)
+ *   uh_read_*                 pt_accumulation_image / pt_output_image / reservoir SSBO read-back
+ *   uh_set_tile_partition,
+ *   uh_pack_tiles, uh_unpack_tiles, uh_resolve_output
+ *                             multi-GPU framebuffer tile partition; no reference counterpart
+ *                             (the reference is single-device, utopian/src/device.rs:45)
+ *
+ * Contract: plain C, POD in / status out, no exceptions cross the boundary. One context per
+ * GPU; all calls on one context are serialised by the caller (the reference has a single render
+ * thread, utopian/src/graph.rs:1004-1007). The library fails loudly (UH_ERR_NO_DEVICE) when no
+ * HIP device is present: there is no CPU fallback.
+ */
+#ifndef UTOPIAN_HIP_H
+#define UTOPIAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- POD structs, byte-identical to the reference's GPU structs ------------------------ */
+
+/* utopian/src/primitive.rs:9-17 == shaders/include/bindless.glsl:4-11 (std430, 80 B) */
+typedef struct UhVertex {
+   float pos[4];     /* @0  */
+   float normal[4];  /* @16 */
+   float uv[2];      /* @32 */
+   float _pad[2];    /* @40 */
+   float color[4];   /* @48 */
+   float tangent[4]; /* @64 */
+} UhVertex;
+
+/* utopian/src/renderer.rs:20-36 == bindless.glsl:13-28 (scalar layout, 64 B) */
+typedef struct UhGpuMaterial {
+   uint32_t diffuse_map;
+   uint32_t normal_map;
+   uint32_t metallic_roughness_map;
+   uint32_t occlusion_map;
+   float base_color_factor[4];   /* @16 */
+   float metallic_factor;        /* @32 */
+   float roughness_factor;       /* @36 */
+   float padding[2];             /* @40 */
+   float raytrace_properties[4]; /* @48: x = 0 lambertian,1 metal,2 dielectric,3 diffuse light; y = fuzz | ior */
+} UhGpuMaterial;
+
+/* utopian/src/renderer.rs:38-44 (12 B) */
+typedef struct UhGpuMesh {
+   uint32_t vertex_buffer;
+   uint32_t index_buffer;
+   uint32_t material;
+} UhGpuMesh;
+
+/* utopian/src/renderer.rs:46-59 == bindless.glsl:37-49 (scalar layout, 96 B) */
+typedef struct UhGpuLight {
+   float color[4];       /* @0  */
+   float position[3];    /* @16 */
+   float range;          /* @28 */
+   float direction[3];   /* @32 */
+   float spot;           /* @44 */
+   float attenuation[3]; /* @48 */
+   float light_type;     /* @60 */
+   float intensity[3];   /* @64 */
+   float id;             /* @76 */
+   float padding[4];     /* @80 */
+} UhGpuLight;
+
+/* utopian/src/renderer.rs:84-120 == shaders/include/view.glsl:1-35 (std140, 448 B).
+ * Matrices are column-major (glam::Mat4): m[c*4 + r]. */
+typedef struct UhViewUniformData {
+   float view[16];                       /* @0   */
+   float projection[16];                 /* @64  */
+   float inverse_view[16];               /* @128 */
+   float inverse_projection[16];         /* @192 */
+   float prev_frame_projection_view[16]; /* @256 */
+   float eye_pos[3];                     /* @320 */
+   uint32_t samples_per_frame;           /* @332 */
+   float sun_dir[3];                     /* @336 */
+   uint32_t total_samples;               /* @348 */
+   uint32_t num_bounces;                 /* @352 */
+   uint32_t viewport_width;              /* @356 */
+   uint32_t viewport_height;             /* @360 */
+   float time;                           /* @364 */
+   uint32_t num_lights;                  /* @368 */
+   uint32_t shadows_enabled;             /* @372 */
+   uint32_t ssao_enabled;                /* @376 */
+   uint32_t fxaa_enabled;                /* @380 */
+   uint32_t cubemap_enabled;             /* @384 */
+   uint32_t ibl_enabled;                 /* @388 */
+   uint32_t sky_enabled;                 /* @392 */
+   uint32_t sun_shadow_enabled;          /* @396 */
+   uint32_t lights_enabled;              /* @400 */
+   uint32_t max_num_lights_used;         /* @404 */
+   uint32_t marching_cubes_enabled;      /* @408 */
+   uint32_t temporal_reuse_enabled;      /* @412 */
+   uint32_t spatial_reuse_enabled;       /* @416 */
+   uint32_t rebuild_tlas;                /* @420 */
+   uint32_t accumulation_limit;          /* @424 */
+   uint32_t use_ris_light_sampling;      /* @428 */
+   uint32_t raytracing_supported;        /* @432 */
+   uint32_t _tail_pad[3];                /* @436 → 448 */
+} UhViewUniformData;
+
+/* shaders/include/restir_sampling.glsl:51-57 (16 B) */
+typedef struct UhReservoir {
+   int32_t Y;
+   float W_sum;
+   float W_X;
+   int32_t M;
+} UhReservoir;
+
+/* ---- pass mask for uh_render_frame (pass order of renderers/mod.rs:246-358) -------------- */
+enum {
+   UH_PASS_GBUFFER = 1u << 0,        /* gbuffer_pass (position only; produced by primary-ray cast) */
+   UH_PASS_RESET_RESERVOIRS = 1u << 1,
+   UH_PASS_INITIAL_RIS = 1u << 2,
+   UH_PASS_TEMPORAL_REUSE = 1u << 3,
+   UH_PASS_SPATIAL_REUSE = 1u << 4,
+   UH_PASS_REFERENCE_PT = 1u << 5,
+   UH_PASS_RESTIR = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 3) | (1u << 4),
+   UH_PASS_ALL = 0x3f
+};
+
+/* ---- status codes ---------------------------------------------------------------------- */
+enum {
+   UH_OK = 0,
+   UH_ERR_INVALID_ARGUMENT = 1,
+   UH_ERR_NO_DEVICE = 2,
+   UH_ERR_HIP = 3,
+   UH_ERR_CAPACITY = 4,   /* > 1024 materials/meshes/lights (utopian/src/renderer.rs:5-7) */
+   UH_ERR_NOT_BUILT = 5,  /* render before uh_build_acceleration */
+   UH_ERR_OUT_OF_MEMORY = 6
+};
+
+enum { UH_MAX_GPU_MATERIALS = 1024, UH_MAX_GPU_MESHES = 1024, UH_MAX_GPU_LIGHTS = 1024 };
+
+/* ray kinds counted in UhStats.rays[] ("ray" = one traceRayEXT-equivalent query) */
+enum { UH_RAY_PRIMARY = 0, UH_RAY_BOUNCE = 1, UH_RAY_SUN_SHADOW = 2, UH_RAY_LIGHT_SHADOW = 3, UH_RAY_GBUFFER = 4, UH_RAY_KINDS = 5 };
+
+typedef struct UhStats {
+   uint64_t rays[UH_RAY_KINDS]; /* since the last uh_reset_stats */
+   uint64_t nodes_visited;      /* BVH4 nodes fetched by closest-hit traversals (only with uh_set_option("count_visits",1)) */
+   uint64_t tris_tested;        /* triangle packets tested by closest-hit traversals (same option) */
+   uint64_t shadow_nodes_visited;
+   uint64_t shadow_tris_tested;
+   uint64_t closest_hits;       /* closest-hit shader invocations for path rays */
+   uint64_t misses;             /* miss (sky) evaluations for path rays */
+   uint64_t frames;
+   uint32_t bvh_nodes;          /* BVH4 node count */
+   uint32_t bvh_triangles;
+   float build_ms;              /* last uh_build_acceleration, host wall time */
+   float last_frame_ms;         /* hipEvent time of the last uh_render_frame (all passes) */
+   float trace_closest_ms;      /* summed hipEvent time of closest-hit traversal launches since reset (option "time_kernels") */
+   float trace_shadow_ms;
+   float shade_ms;
+   uint32_t trace_closest_launches;
+} UhStats;
+
+typedef struct uh_ctx uh_ctx;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out);
+void uh_destroy(uh_ctx* ctx);
+const char* uh_last_error(uh_ctx* ctx); /* ctx may be NULL: returns the last creation error */
+const char* uh_version(void);
+
+/* ---- scene ----------------------------------------------------------------------------- */
+int uh_add_texture_rgba8(uh_ctx* ctx, const uint8_t* pixels, uint32_t w, uint32_t h, uint32_t* out_index);
+/* material->diffuse_map must be an index returned by uh_add_texture_rgba8.
+ * world3x4: row-major 3x4 object-to-world (VkTransformMatrixKHR layout, raytracing.rs:233-248). */
+int uh_add_mesh(uh_ctx* ctx, const UhVertex* vertices, uint32_t num_vertices, const uint32_t* indices,
+                uint32_t num_indices, const UhGpuMaterial* material, const float world3x4[12],
+                uint32_t* out_mesh_index);
+int uh_add_light(uh_ctx* ctx, const UhGpuLight* light, uint32_t* out_index);
+int uh_get_num_lights(uh_ctx* ctx, uint32_t* out); /* Renderer::get_num_lights (renderer.rs:412) */
+int uh_set_instance_transform(uh_ctx* ctx, uint32_t mesh_index, const float world3x4[12]);
+int uh_build_acceleration(uh_ctx* ctx);
+
+/* ---- per frame ------------------------------------------------------------------------- */
+int uh_render_frame(uh_ctx* ctx, const UhViewUniformData* view, uint32_t pass_mask);
+int uh_reset_accumulation(uh_ctx* ctx);
+int uh_synchronize(uh_ctx* ctx);
+
+/* ---- read-back (host pointers; each call synchronises the context's stream) ------------ */
+int uh_read_accumulation(uh_ctx* ctx, float* rgba32f /* W*H*4 */);
+int uh_read_output_bgra8(uh_ctx* ctx, uint8_t* bgra /* W*H*4 */);
+int uh_read_reservoirs(uh_ctx* ctx, int which /* 0 initial, 1 temporal, 2 spatial */, UhReservoir* out /* W*H */);
+int uh_read_gbuffer_position(uh_ctx* ctx, float* rgba32f /* W*H*4, un-filtered texels */);
+/* upload a reservoir buffer (tests seed the temporal history with it) */
+int uh_write_reservoirs(uh_ctx* ctx, int which, const UhReservoir* in /* W*H */);
+
+/* ---- stand-alone ray queries through the same traversal kernels (parity tests) ---------- */
+/* rays: n * 8 floats (ox,oy,oz,tmin,dx,dy,dz,tmax); hits: n * 4 words (t,u,v as f32, then
+ * (mesh_index << 22 | primitive) as u32, 0xffffffff on miss... see DESIGN.md "hit record") */
+int uh_trace_closest(uh_ctx* ctx, const float* rays, uint32_t n, float* out_tuv /* n*3 */,
+                     uint32_t* out_mesh /* n */, uint32_t* out_prim /* n */);
+int uh_trace_any(uh_ctx* ctx, const float* rays, uint32_t n, uint8_t* out_occluded /* n */);
+
+/* ---- stats / options ------------------------------------------------------------------- */
+int uh_get_stats(uh_ctx* ctx, UhStats* out);
+int uh_reset_stats(uh_ctx* ctx);
+/* options: "count_visits" (0/1), "time_kernels" (0/1), "full_frame_restir" (0/1; 1 = documented
+ * divergence: use the reservoir for every pixel instead of the reference's x > W/2 split) */
+int uh_set_option(uh_ctx* ctx, const char* name, int value);
+
+/* ---- multi-GPU framebuffer tile partition (one process per GPU) ------------------------ */
+/* After this call uh_render_frame path-traces only pixels of tiles t with t % world == rank
+ * (tile_size x tile_size tiles, row-major tile ids). ReSTIR passes stay full-frame. */
+int uh_set_tile_partition(uh_ctx* ctx, uint32_t rank, uint32_t world, uint32_t tile_size);
+/* number of float4 pixels uh_pack_tiles writes for `rank` (padded: whole tiles) */
+int uh_tile_pack_count(uh_ctx* ctx, uint32_t rank, uint64_t* out_pixels);
+/* pack this rank's owned tiles of the RGBA32F accumulation into a contiguous DEVICE buffer */
+int uh_pack_tiles(uh_ctx* ctx, void* device_out, uint64_t capacity_pixels);
+/* scatter `from_rank`'s packed tiles (DEVICE buffer) into this context's accumulation image */
+int uh_unpack_tiles(uh_ctx* ctx, uint32_t from_rank, const void* device_in, uint64_t num_pixels);
+/* recompute pt_output_image from the accumulation image (after uh_unpack_tiles on the root) */
+int uh_resolve_output(uh_ctx* ctx, uint32_t total_samples, uint32_t accumulation_limit);
+/* raw device pointers (zero-copy wrap by the caller, e.g. for RCCL): 0 accumulation RGBA32F,
+ * 1 output BGRA8 */
+int uh_device_pointer(uh_ctx* ctx, int which, void** out);
+/* the HIP stream all work of this context is enqueued on (hipStream_t as void*) */
+int uh_stream(uh_ctx* ctx, void** out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* UTOPIAN_HIP_H */
