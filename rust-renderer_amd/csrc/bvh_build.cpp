@@ -1,0 +1,403 @@
+// bvh_build.cpp — host builder of the flattened BVH4 (see bvh.h). Replaces
+// Raytracing::create_bottom_level_acceleration_structure / create_top_level_acceleration_structure
+// (reference: utopian/src/raytracing.rs:113-217, :279-398), whose build runs inside the Vulkan
+// driver. Binned SAH (16 bins, 3 axes) -> BVH2 -> greedy collapse to 4-wide nodes by surface area.
+#include "bvh.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace uh {
+namespace {
+
+struct Box {
+   float lo[3], hi[3];
+   void reset() {
+      for (int a = 0; a < 3; a++) {
+         lo[a] = INFINITY;
+         hi[a] = -INFINITY;
+      }
+   }
+   void grow(const Box& b) {
+      for (int a = 0; a < 3; a++) {
+         lo[a] = std::fmin(lo[a], b.lo[a]);
+         hi[a] = std::fmax(hi[a], b.hi[a]);
+      }
+   }
+   void grow_pt(const float* p) {
+      for (int a = 0; a < 3; a++) {
+         lo[a] = std::fmin(lo[a], p[a]);
+         hi[a] = std::fmax(hi[a], p[a]);
+      }
+   }
+   float half_area() const {
+      float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+      if (!(dx >= 0) || !(dy >= 0) || !(dz >= 0)) return 0.0f;
+      return dx * dy + dy * dz + dz * dx;
+   }
+};
+
+struct Node2 {
+   Box box;
+   int32_t left, right;    // children (interior) or -1
+   uint32_t first, count;  // leaf range in the permuted index array
+};
+
+struct Builder {
+   const std::vector<Box>& tb;
+   const std::vector<float>& cen;  // 3 per triangle
+   std::vector<uint32_t>& idx;
+   std::vector<Node2> nodes;
+   uint32_t max_depth = 0;
+
+   Builder(const std::vector<Box>& tb_, const std::vector<float>& cen_, std::vector<uint32_t>& idx_) : tb(tb_), cen(cen_), idx(idx_) {}
+
+   // builds the subtree over idx[first, first+count) ; returns node index
+   int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
+      int32_t me = (int32_t)nodes.size();
+      nodes.push_back(Node2());
+      Box box, cb;
+      box.reset();
+      cb.reset();
+      for (uint32_t k = first; k < first + count; k++) {
+         box.grow(tb[idx[k]]);
+         cb.grow_pt(&cen[3 * (size_t)idx[k]]);
+      }
+      nodes[me].box = box;
+      max_depth = std::max(max_depth, depth);
+      if (count <= kMaxLeafTris) {
+         nodes[me].left = nodes[me].right = -1;
+         nodes[me].first = first;
+         nodes[me].count = count;
+         return me;
+      }
+      constexpr int NB = 16;
+      float best_cost = INFINITY;
+      int best_axis = -1, best_split = -1;
+      for (int a = 0; a < 3; a++) {
+         float lo = cb.lo[a], ext = cb.hi[a] - cb.lo[a];
+         if (!(ext > 0)) continue;
+         Box bb[NB];
+         uint32_t bc[NB];
+         for (int b = 0; b < NB; b++) {
+            bb[b].reset();
+            bc[b] = 0;
+         }
+         float scale = (float)NB / ext;
+         for (uint32_t k = first; k < first + count; k++) {
+            uint32_t t = idx[k];
+            int b = (int)((cen[3 * (size_t)t + a] - lo) * scale);
+            b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+            bb[b].grow(tb[t]);
+            bc[b]++;
+         }
+         float right_area[NB];
+         uint32_t right_cnt[NB];
+         Box acc;
+         acc.reset();
+         uint32_t c = 0;
+         for (int b = NB - 1; b > 0; b--) {
+            acc.grow(bb[b]);
+            c += bc[b];
+            right_area[b] = acc.half_area();
+            right_cnt[b] = c;
+         }
+         acc.reset();
+         c = 0;
+         for (int b = 0; b < NB - 1; b++) {
+            acc.grow(bb[b]);
+            c += bc[b];
+            if (c == 0 || right_cnt[b + 1] == 0) continue;
+            float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+            if (cost < best_cost) {
+               best_cost = cost;
+               best_axis = a;
+               best_split = b;
+            }
+         }
+      }
+      uint32_t mid;
+      if (best_axis < 0 || depth > 48) {
+         // degenerate centroids (or runaway depth): split the range in half along the widest axis
+         int a = 0;
+         for (int k = 1; k < 3; k++)
+            if (cb.hi[k] - cb.lo[k] > cb.hi[a] - cb.lo[a]) a = k;
+         mid = first + count / 2;
+         std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count,
+                          [&](uint32_t x, uint32_t y) { return cen[3 * (size_t)x + a] < cen[3 * (size_t)y + a]; });
+      } else {
+         float lo = cb.lo[best_axis], scale = (float)NB / (cb.hi[best_axis] - cb.lo[best_axis]);
+         auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t t) {
+            int b = (int)((cen[3 * (size_t)t + best_axis] - lo) * scale);
+            b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+            return b <= best_split;
+         });
+         mid = (uint32_t)(it - idx.begin());
+         if (mid == first || mid == first + count) mid = first + count / 2;
+      }
+      int32_t l = build(first, mid - first, depth + 1);
+      int32_t r = build(mid, first + count - mid, depth + 1);
+      nodes[me].left = l;
+      nodes[me].right = r;
+      nodes[me].first = first;
+      nodes[me].count = count;
+      return me;
+   }
+};
+
+// Conservative padding: the kernels' slab test must never cull a triangle that the
+// ray/triangle test would accept (DESIGN.md "Arithmetic contract", order-independence).
+inline void padded(const Box& b, float* lo, float* hi) {
+   for (int a = 0; a < 3; a++) {
+      float pad = 1e-4f + 1e-5f * std::fmax(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+      lo[a] = b.lo[a] - pad;
+      hi[a] = b.hi[a] + pad;
+   }
+}
+
+}  // namespace
+
+void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads) {
+   out.nodes.clear();
+   out.tri_order.clear();
+   out.max_depth = 0;
+   const uint32_t n = in.count;
+   std::vector<Box> tb(n);
+   std::vector<float> cen(3 * (size_t)n);
+   for (uint32_t i = 0; i < n; i++) {
+      const float* c = in.corners + 9 * (size_t)i;
+      Box b;
+      b.reset();
+      b.grow_pt(c);
+      b.grow_pt(c + 3);
+      b.grow_pt(c + 6);
+      tb[i] = b;
+      for (int a = 0; a < 3; a++) cen[3 * (size_t)i + a] = 0.5f * (b.lo[a] + b.hi[a]);
+   }
+   out.tri_order.resize(n);
+   for (uint32_t i = 0; i < n; i++) out.tri_order[i] = i;
+
+   // ---- BVH2. The top of the tree is built serially down to `num_threads`-ish subtrees, which
+   // are then built concurrently on disjoint ranges of the index array.
+   std::vector<Node2> n2;
+   if (n == 0) {
+      Node4 root;
+      std::memset(&root, 0, sizeof(root));
+      for (int k = 0; k < 4; k++) root.child[k] = kEmptyRef;
+      out.nodes.push_back(root);
+      return;
+   }
+   {
+      Builder top(tb, cen, out.tri_order);
+      if (num_threads <= 1 || n < 65536) {
+         top.build(0, n, 0);
+         n2.swap(top.nodes);
+         out.max_depth = top.max_depth;
+      } else {
+         // serial top: split until ranges are small enough, recording open jobs
+         struct Job {
+            uint32_t first, count, depth;
+            int32_t parent;
+            bool is_left;
+         };
+         // Simple approach: build whole tree serially for the top levels by limiting leaf size
+         // through a recursive lambda that stops at `grain` triangles.
+         const uint32_t grain = std::max<uint32_t>(16384, n / (uint32_t)(num_threads * 4));
+         std::vector<Job> jobs;
+         std::vector<Node2>& nodes = top.nodes;
+         struct Frame {
+            uint32_t first, count, depth;
+            int32_t parent;
+            bool is_left;
+         };
+         std::vector<Frame> st;
+         st.push_back(Frame{0, n, 0, -1, false});
+         while (!st.empty()) {
+            Frame f = st.back();
+            st.pop_back();
+            if (f.count <= grain) {
+               jobs.push_back(Job{f.first, f.count, f.depth, f.parent, f.is_left});
+               continue;
+            }
+            // one SAH split step, reusing Builder::build's logic on a throw-away builder would
+            // recurse fully; instead do a median split on the widest centroid axis for the few top
+            // levels (they matter little for SAH quality: < log2(threads*4) levels).
+            Box box, cb;
+            box.reset();
+            cb.reset();
+            for (uint32_t k = f.first; k < f.first + f.count; k++) {
+               box.grow(tb[out.tri_order[k]]);
+               cb.grow_pt(&cen[3 * (size_t)out.tri_order[k]]);
+            }
+            int32_t me = (int32_t)nodes.size();
+            nodes.push_back(Node2());
+            nodes[me].box = box;
+            nodes[me].left = nodes[me].right = -1;
+            nodes[me].first = f.first;
+            nodes[me].count = f.count;
+            if (f.parent >= 0) (f.is_left ? nodes[f.parent].left : nodes[f.parent].right) = me;
+            // binned SAH on this range (same as Builder::build)
+            constexpr int NB = 16;
+            float best_cost = INFINITY;
+            int best_axis = -1, best_split = -1;
+            for (int a = 0; a < 3; a++) {
+               float lo = cb.lo[a], ext = cb.hi[a] - cb.lo[a];
+               if (!(ext > 0)) continue;
+               Box bb[NB];
+               uint32_t bc[NB];
+               for (int b = 0; b < NB; b++) {
+                  bb[b].reset();
+                  bc[b] = 0;
+               }
+               float scale = (float)NB / ext;
+               for (uint32_t k = f.first; k < f.first + f.count; k++) {
+                  uint32_t t = out.tri_order[k];
+                  int b = (int)((cen[3 * (size_t)t + a] - lo) * scale);
+                  b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                  bb[b].grow(tb[t]);
+                  bc[b]++;
+               }
+               float ra[NB];
+               uint32_t rc[NB];
+               Box acc;
+               acc.reset();
+               uint32_t c = 0;
+               for (int b = NB - 1; b > 0; b--) {
+                  acc.grow(bb[b]);
+                  c += bc[b];
+                  ra[b] = acc.half_area();
+                  rc[b] = c;
+               }
+               acc.reset();
+               c = 0;
+               for (int b = 0; b < NB - 1; b++) {
+                  acc.grow(bb[b]);
+                  c += bc[b];
+                  if (c == 0 || rc[b + 1] == 0) continue;
+                  float cost = acc.half_area() * (float)c + ra[b + 1] * (float)rc[b + 1];
+                  if (cost < best_cost) {
+                     best_cost = cost;
+                     best_axis = a;
+                     best_split = b;
+                  }
+               }
+            }
+            uint32_t mid;
+            if (best_axis < 0) {
+               mid = f.first + f.count / 2;
+            } else {
+               float lo = cb.lo[best_axis], scale = (float)NB / (cb.hi[best_axis] - cb.lo[best_axis]);
+               auto it = std::partition(out.tri_order.begin() + f.first, out.tri_order.begin() + f.first + f.count, [&](uint32_t t) {
+                  int b = (int)((cen[3 * (size_t)t + best_axis] - lo) * scale);
+                  b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                  return b <= best_split;
+               });
+               mid = (uint32_t)(it - out.tri_order.begin());
+               if (mid == f.first || mid == f.first + f.count) mid = f.first + f.count / 2;
+            }
+            st.push_back(Frame{mid, f.first + f.count - mid, f.depth + 1, me, false});
+            st.push_back(Frame{f.first, mid - f.first, f.depth + 1, me, true});
+         }
+         // parallel subtrees
+         std::vector<std::vector<Node2>> sub(jobs.size());
+         std::vector<uint32_t> sub_depth(jobs.size(), 0);
+         std::atomic<size_t> next(0);
+         auto worker = [&]() {
+            for (;;) {
+               size_t j = next.fetch_add(1);
+               if (j >= jobs.size()) break;
+               Builder b(tb, cen, out.tri_order);
+               b.build(jobs[j].first, jobs[j].count, jobs[j].depth);
+               sub[j].swap(b.nodes);
+               sub_depth[j] = b.max_depth;
+            }
+         };
+         std::vector<std::thread> th;
+         for (int t = 0; t < num_threads; t++) th.emplace_back(worker);
+         for (auto& t : th) t.join();
+         // stitch
+         for (size_t j = 0; j < jobs.size(); j++) {
+            int32_t base = (int32_t)nodes.size();
+            for (Node2 nd : sub[j]) {
+               if (nd.left >= 0) {
+                  nd.left += base;
+                  nd.right += base;
+               }
+               nodes.push_back(nd);
+            }
+            if (jobs[j].parent >= 0) (jobs[j].is_left ? nodes[jobs[j].parent].left : nodes[jobs[j].parent].right) = base;
+            out.max_depth = std::max(out.max_depth, sub_depth[j]);
+         }
+         n2.swap(nodes);
+      }
+   }
+
+   // ---- collapse to BVH4, breadth-first emission
+   struct Slot {
+      int32_t n2;        // source BVH2 node
+   };
+   std::vector<int32_t> queue;  // BVH2 node index of each emitted BVH4 node
+   queue.push_back(0);
+   out.nodes.reserve(n2.size() / 2 + 1);
+   out.nodes.push_back(Node4());
+   for (size_t qi = 0; qi < queue.size(); qi++) {
+      const Node2& src = n2[queue[qi]];
+      int32_t ch[4];
+      int nc = 0;
+      if (src.left < 0) {
+         ch[nc++] = queue[qi];  // a leaf at the root: wrap it
+      } else {
+         ch[nc++] = src.left;
+         ch[nc++] = src.right;
+         for (;;) {
+            if (nc == 4) break;
+            int pick = -1;
+            float pa = -1.0f;
+            for (int k = 0; k < nc; k++)
+               if (n2[ch[k]].left >= 0) {
+                  float a = n2[ch[k]].box.half_area();
+                  if (a > pa) {
+                     pa = a;
+                     pick = k;
+                  }
+               }
+            if (pick < 0) break;
+            int32_t c = ch[pick];
+            ch[pick] = n2[c].left;
+            ch[nc++] = n2[c].right;
+         }
+      }
+      Node4 nd;
+      std::memset(&nd, 0, sizeof(nd));
+      for (int k = 0; k < 4; k++) {
+         nd.child[k] = kEmptyRef;
+         nd.lox[k] = nd.loy[k] = nd.loz[k] = 0.0f;
+         nd.hix[k] = nd.hiy[k] = nd.hiz[k] = 0.0f;
+      }
+      for (int k = 0; k < nc; k++) {
+         const Node2& c = n2[ch[k]];
+         float lo[3], hi[3];
+         padded(c.box, lo, hi);
+         nd.lox[k] = lo[0];
+         nd.loy[k] = lo[1];
+         nd.loz[k] = lo[2];
+         nd.hix[k] = hi[0];
+         nd.hiy[k] = hi[1];
+         nd.hiz[k] = hi[2];
+         if (c.left < 0) {
+            nd.child[k] = kLeafBit | (c.count << kLeafCountShift) | (c.first & kLeafFirstMask);
+         } else {
+            nd.child[k] = (uint32_t)out.nodes.size();
+            out.nodes.push_back(Node4());
+            queue.push_back(ch[k]);
+         }
+      }
+      nd.meta[0] = (uint32_t)nc;
+      out.nodes[qi] = nd;
+   }
+}
+
+}  // namespace uh

@@ -1,0 +1,852 @@
+// context.hip — the C ABI of include/utopian_hip.h: context lifetime, scene upload, acceleration
+// structure build, the per-frame pass chain and read-backs. Host-side counterpart of
+// utopian::Renderer (utopian/src/renderer.rs), utopian::Raytracing (utopian/src/raytracing.rs) and
+// build_path_tracing_render_graph (utopian/src/renderers/mod.rs:189-375) for this path only.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bvh.h"
+#include "device_types.h"
+#include "utopian_hip.h"
+
+using namespace uh;
+
+namespace {
+
+std::string g_create_error;
+
+struct HostMesh {
+   std::vector<UhVertex> vertices;
+   std::vector<uint32_t> indices;
+   UhGpuMaterial material;
+   float o2w[12];
+   float w2o[9];
+};
+
+struct EventPair {
+   hipEvent_t start, stop;
+   int kind;  // 0 trace_closest, 1 trace_shadow, 2 shade
+};
+
+template <typename T>
+struct DevBuf {
+   T* p = nullptr;
+   size_t n = 0;
+   hipError_t alloc(size_t count) {
+      release();
+      n = count;
+      if (count == 0) return hipSuccess;
+      return hipMalloc((void**)&p, count * sizeof(T));
+   }
+   void release() {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      n = 0;
+   }
+};
+
+}  // namespace
+
+struct uh_ctx {
+   int device = 0;
+   hipStream_t stream = nullptr;
+   uint32_t W = 0, H = 0;
+   uint32_t num_cus = 256;
+   uint32_t trace_blocks_per_cu = 4;
+   std::string err;
+
+   // host scene
+   std::vector<HostMesh> meshes;
+   std::vector<UhGpuLight> lights;
+   struct HostTex {
+      uint32_t w, h;
+      uchar4* dev;
+   };
+   std::vector<HostTex> textures;
+   bool built = false;
+
+   // device scene
+   DevBuf<float4> d_nodes, d_tris, d_shade, d_lights;
+   DevBuf<MeshShade> d_meshes;
+   DevBuf<TexInfo> d_tex;
+   DevBuf<float> d_lut;
+   SceneDev scene{};
+
+   // per-pixel state
+   DevBuf<float4> ray_o, ray_d, hit, thr, rad, pixcol, accumulation, gbuffer;
+   DevBuf<uint2> rng;
+   DevBuf<uint32_t> queues[5];
+   DevBuf<uchar4> output;
+   DevBuf<UhReservoir> reservoirs[3];
+   DevBuf<Control> control;
+   DevBuf<DeviceStats> dstats;
+   PathState ps{};
+   Images im{};
+
+   // options / stats
+   bool count_visits = false, time_kernels = false, full_frame_restir = false;
+   uint64_t frames = 0;
+   float build_ms = 0.0f, last_frame_ms = 0.0f;
+   float ms_by_kind[3] = {0, 0, 0};
+   uint32_t trace_closest_launches = 0;
+   hipEvent_t frame_start = nullptr, frame_stop = nullptr;
+   bool frame_timed = false;
+   std::vector<EventPair> pending, free_events;
+   uint32_t bvh_nodes = 0, bvh_tris = 0;
+
+   // tile partition
+   uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
+};
+
+namespace {
+
+int fail(uh_ctx* c, int code, const std::string& msg) {
+   if (c)
+      c->err = msg;
+   else
+      g_create_error = msg;
+   return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+   do {                                                                                                      \
+      hipError_t e_ = (expr);                                                                                \
+      if (e_ != hipSuccess) return fail(ctx, e_ == hipErrorOutOfMemory ? UH_ERR_OUT_OF_MEMORY : UH_ERR_HIP, \
+                                        std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+   } while (0)
+
+bool is_identity3x4(const float* m) {
+   static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+   return std::memcmp(m, I, sizeof(I)) == 0;
+}
+
+// inverse of the upper 3x3 of a row-major 3x4 by cofactors (arithmetic contract: cofactor * (1/det))
+void invert3x3(const float* m, float* inv) {
+   float a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+   float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+   float det = (a * A + b * B) + c * C;
+   float id = 1.0f / det;
+   inv[0] = A * id;
+   inv[1] = -(b * i - c * h) * id;
+   inv[2] = (b * f - c * e) * id;
+   inv[3] = B * id;
+   inv[4] = (a * i - c * g) * id;
+   inv[5] = -(a * f - c * d) * id;
+   inv[6] = C * id;
+   inv[7] = -(a * h - b * g) * id;
+   inv[8] = (a * e - b * d) * id;
+}
+
+void set_transform(HostMesh& m, const float* w) {
+   std::memcpy(m.o2w, w, sizeof(m.o2w));
+   if (is_identity3x4(w)) {
+      static const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      std::memcpy(m.w2o, I, sizeof(I));
+   } else {
+      invert3x3(w, m.w2o);
+   }
+}
+
+LaunchCfg cfg(uh_ctx* c) { return LaunchCfg{c->stream, c->num_cus, c->trace_blocks_per_cu, c->count_visits}; }
+
+void begin_timed(uh_ctx* c, int kind) {
+   if (!c->time_kernels) return;
+   EventPair ep;
+   if (!c->free_events.empty()) {
+      ep = c->free_events.back();
+      c->free_events.pop_back();
+   } else {
+      (void)hipEventCreate(&ep.start);
+      (void)hipEventCreate(&ep.stop);
+   }
+   ep.kind = kind;
+   (void)hipEventRecord(ep.start, c->stream);
+   c->pending.push_back(ep);
+}
+void end_timed(uh_ctx* c) {
+   if (!c->time_kernels) return;
+   (void)hipEventRecord(c->pending.back().stop, c->stream);
+}
+void drain_timed(uh_ctx* c) {
+   for (EventPair& ep : c->pending) {
+      float ms = 0.0f;
+      if (hipEventSynchronize(ep.stop) == hipSuccess && hipEventElapsedTime(&ms, ep.start, ep.stop) == hipSuccess) {
+         c->ms_by_kind[ep.kind] += ms;
+         if (ep.kind == 0) c->trace_closest_launches++;
+      }
+      c->free_events.push_back(ep);
+   }
+   c->pending.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* uh_version(void) { return "utopian-hip 0.1 (gfx950)"; }
+
+const char* uh_last_error(uh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out) {
+   if (!out || width == 0 || height == 0 || (uint64_t)width * height > (1ull << 26)) return fail(nullptr, UH_ERR_INVALID_ARGUMENT, "bad size");
+   int ndev = 0;
+   hipError_t e = hipGetDeviceCount(&ndev);
+   if (e != hipSuccess || ndev == 0)
+      return fail(nullptr, UH_ERR_NO_DEVICE, std::string("no HIP device visible (") + hipGetErrorString(e) + "); this library has no CPU fallback");
+   if (device_ordinal < 0 || device_ordinal >= ndev) return fail(nullptr, UH_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+   uh_ctx* c = new uh_ctx();
+   c->device = device_ordinal;
+   c->W = width;
+   c->H = height;
+   auto bail = [&](int code) {
+      g_create_error = c->err;
+      uh_destroy(c);
+      return code;
+   };
+#define CREATE_TRY(expr)                                                                      \
+   do {                                                                                       \
+      hipError_t e_ = (expr);                                                                 \
+      if (e_ != hipSuccess) {                                                                 \
+         c->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+         return bail(e_ == hipErrorOutOfMemory ? UH_ERR_OUT_OF_MEMORY : UH_ERR_HIP);          \
+      }                                                                                       \
+   } while (0)
+   CREATE_TRY(hipSetDevice(device_ordinal));
+   hipDeviceProp_t prop;
+   CREATE_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+   c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
+   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+   CREATE_TRY(hipEventCreate(&c->frame_start));
+   CREATE_TRY(hipEventCreate(&c->frame_stop));
+   c->trace_blocks_per_cu = query_trace_occupancy();
+   const size_t n = (size_t)width * height;
+   CREATE_TRY(c->ray_o.alloc(n));
+   CREATE_TRY(c->ray_d.alloc(n));
+   CREATE_TRY(c->hit.alloc(n));
+   CREATE_TRY(c->thr.alloc(n));
+   CREATE_TRY(c->rad.alloc(n));
+   CREATE_TRY(c->pixcol.alloc(n));
+   CREATE_TRY(c->accumulation.alloc(n));
+   CREATE_TRY(c->gbuffer.alloc(n));
+   CREATE_TRY(c->rng.alloc(n));
+   for (auto& q : c->queues) CREATE_TRY(q.alloc(n));
+   CREATE_TRY(c->output.alloc(n));
+   for (auto& r : c->reservoirs) CREATE_TRY(r.alloc(n));
+   CREATE_TRY(c->control.alloc(1));
+   CREATE_TRY(c->dstats.alloc(1));
+   CREATE_TRY(hipMemsetAsync(c->accumulation.p, 0, n * sizeof(float4), c->stream));
+   CREATE_TRY(hipMemsetAsync(c->output.p, 0, n * sizeof(uchar4), c->stream));
+   CREATE_TRY(hipMemsetAsync(c->gbuffer.p, 0, n * sizeof(float4), c->stream));
+   for (auto& r : c->reservoirs) CREATE_TRY(hipMemsetAsync(r.p, 0, n * sizeof(UhReservoir), c->stream));
+   CREATE_TRY(hipMemsetAsync(c->dstats.p, 0, sizeof(DeviceStats), c->stream));
+   CREATE_TRY(hipMemsetAsync(c->control.p, 0, sizeof(Control), c->stream));
+   // c / 255.0f table (exact host division; replaces 12 IEEE divides per bilinear fetch)
+   float lut[256];
+   for (int i = 0; i < 256; i++) lut[i] = (float)i / 255.0f;
+   CREATE_TRY(c->d_lut.alloc(256));
+   CREATE_TRY(hipMemcpy(c->d_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice));
+   CREATE_TRY(hipStreamSynchronize(c->stream));
+#undef CREATE_TRY
+   c->ps.ray_o = c->ray_o.p;
+   c->ps.ray_d = c->ray_d.p;
+   c->ps.hit = c->hit.p;
+   c->ps.thr = c->thr.p;
+   c->ps.rad = c->rad.p;
+   c->ps.pixcol = c->pixcol.p;
+   c->ps.rng = c->rng.p;
+   for (int i = 0; i < 5; i++) c->ps.queue[i] = c->queues[i].p;
+   c->im.accumulation = c->accumulation.p;
+   c->im.output = c->output.p;
+   c->im.gbuffer_pos = c->gbuffer.p;
+   for (int i = 0; i < 3; i++) c->im.reservoirs[i] = c->reservoirs[i].p;
+   *out = c;
+   return UH_OK;
+}
+
+void uh_destroy(uh_ctx* c) {
+   if (!c) return;
+   (void)hipSetDevice(c->device);
+   if (c->stream) (void)hipStreamSynchronize(c->stream);
+   for (auto& t : c->textures)
+      if (t.dev) (void)hipFree(t.dev);
+   for (auto& ep : c->pending) {
+      (void)hipEventDestroy(ep.start);
+      (void)hipEventDestroy(ep.stop);
+   }
+   for (auto& ep : c->free_events) {
+      (void)hipEventDestroy(ep.start);
+      (void)hipEventDestroy(ep.stop);
+   }
+   c->d_nodes.release();
+   c->d_tris.release();
+   c->d_shade.release();
+   c->d_lights.release();
+   c->d_meshes.release();
+   c->d_tex.release();
+   c->d_lut.release();
+   c->ray_o.release();
+   c->ray_d.release();
+   c->hit.release();
+   c->thr.release();
+   c->rad.release();
+   c->pixcol.release();
+   c->accumulation.release();
+   c->gbuffer.release();
+   c->rng.release();
+   for (auto& q : c->queues) q.release();
+   c->output.release();
+   for (auto& r : c->reservoirs) r.release();
+   c->control.release();
+   c->dstats.release();
+   if (c->frame_start) (void)hipEventDestroy(c->frame_start);
+   if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
+   if (c->stream) (void)hipStreamDestroy(c->stream);
+   delete c;
+}
+
+int uh_add_texture_rgba8(uh_ctx* c, const uint8_t* pixels, uint32_t w, uint32_t h, uint32_t* out_index) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!pixels || !w || !h) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_add_texture_rgba8: null or empty texture");
+   HIP_TRY(c, hipSetDevice(c->device));
+   uchar4* dev = nullptr;
+   HIP_TRY(c, hipMalloc((void**)&dev, (size_t)w * h * 4));
+   hipError_t e = hipMemcpy(dev, pixels, (size_t)w * h * 4, hipMemcpyHostToDevice);
+   if (e != hipSuccess) {
+      (void)hipFree(dev);
+      return fail(c, UH_ERR_HIP, std::string("texture upload: ") + hipGetErrorString(e));
+   }
+   c->textures.push_back(uh_ctx::HostTex{w, h, dev});
+   c->built = false;
+   if (out_index) *out_index = (uint32_t)c->textures.size() - 1;
+   return UH_OK;
+}
+
+int uh_add_mesh(uh_ctx* c, const UhVertex* vertices, uint32_t num_vertices, const uint32_t* indices, uint32_t num_indices,
+                const UhGpuMaterial* material, const float world3x4[12], uint32_t* out_mesh_index) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!vertices || !indices || !material || !world3x4 || num_indices % 3 != 0)
+      return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_add_mesh: null argument or index count not a multiple of 3");
+   if (c->meshes.size() >= UH_MAX_GPU_MESHES) return fail(c, UH_ERR_CAPACITY, "uh_add_mesh: more than 1024 meshes (MAX_NUM_GPU_MESHES)");
+   if (num_indices / 3 > (1u << kPrimBits)) return fail(c, UH_ERR_CAPACITY, "uh_add_mesh: more than 4 Mi triangles in one mesh");
+   for (uint32_t i = 0; i < num_indices; i++)
+      if (indices[i] >= num_vertices) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_add_mesh: index out of range");
+   HostMesh m;
+   m.vertices.assign(vertices, vertices + num_vertices);
+   m.indices.assign(indices, indices + num_indices);
+   m.material = *material;
+   set_transform(m, world3x4);
+   c->meshes.push_back(std::move(m));
+   c->built = false;
+   if (out_mesh_index) *out_mesh_index = (uint32_t)c->meshes.size() - 1;
+   return UH_OK;
+}
+
+int uh_add_light(uh_ctx* c, const UhGpuLight* light, uint32_t* out_index) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!light) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_add_light: null light");
+   if (c->lights.size() >= UH_MAX_GPU_LIGHTS) return fail(c, UH_ERR_CAPACITY, "uh_add_light: more than 1024 lights (MAX_NUM_GPU_LIGHTS)");
+   c->lights.push_back(*light);
+   c->built = false;
+   if (out_index) *out_index = (uint32_t)c->lights.size() - 1;
+   return UH_OK;
+}
+
+int uh_get_num_lights(uh_ctx* c, uint32_t* out) {
+   if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
+   *out = (uint32_t)c->lights.size();
+   return UH_OK;
+}
+
+int uh_set_instance_transform(uh_ctx* c, uint32_t mesh_index, const float world3x4[12]) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (mesh_index >= c->meshes.size() || !world3x4) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_set_instance_transform: bad mesh index");
+   set_transform(c->meshes[mesh_index], world3x4);
+   c->built = false;
+   return UH_OK;
+}
+
+int uh_build_acceleration(uh_ctx* c) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));
+   auto t0 = std::chrono::steady_clock::now();
+   // bake instance transforms: world = ((m0*x + m1*y) + m2*z) + m3 per row (identity: verbatim)
+   size_t total = 0;
+   for (const HostMesh& m : c->meshes) total += m.indices.size() / 3;
+   if (total > kLeafFirstMask) return fail(c, UH_ERR_CAPACITY, "scene has more than 2^27 triangles");
+   std::vector<float> corners(9 * total);
+   std::vector<uint32_t> keys(total);
+   size_t t = 0;
+   for (uint32_t mi = 0; mi < c->meshes.size(); mi++) {
+      const HostMesh& m = c->meshes[mi];
+      const bool ident = is_identity3x4(m.o2w);
+      const float* w = m.o2w;
+      const uint32_t nt = (uint32_t)m.indices.size() / 3;
+      for (uint32_t p = 0; p < nt; p++, t++) {
+         for (int k = 0; k < 3; k++) {
+            const UhVertex& vx = m.vertices[m.indices[3 * (size_t)p + k]];
+            float x = vx.pos[0], y = vx.pos[1], z = vx.pos[2];
+            float* o = &corners[9 * t + 3 * k];
+            if (ident) {
+               o[0] = x;
+               o[1] = y;
+               o[2] = z;
+            } else {
+               o[0] = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
+               o[1] = ((w[4] * x + w[5] * y) + w[6] * z) + w[7];
+               o[2] = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
+            }
+         }
+         keys[t] = (mi << kPrimBits) | p;
+      }
+   }
+   BuildInput in{corners.data(), keys.data(), (uint32_t)total};
+   BuildOutput bo;
+   int threads = (int)std::thread::hardware_concurrency();
+   if (threads < 1) threads = 1;
+   if (threads > 32) threads = 32;
+   build_bvh4(in, bo, threads);
+
+   // packets in leaf order
+   std::vector<TriPacket> tp(total);
+   std::vector<ShadePacket> sp(total);
+   for (size_t i = 0; i < total; i++) {
+      uint32_t src = bo.tri_order[i];
+      const float* cr = &corners[9 * (size_t)src];
+      TriPacket& q = tp[i];
+      q.v0[0] = cr[0];
+      q.v0[1] = cr[1];
+      q.v0[2] = cr[2];
+      q.e1x = cr[3] - cr[0];
+      q.e1yz[0] = cr[4] - cr[1];
+      q.e1yz[1] = cr[5] - cr[2];
+      q.e2[0] = cr[6] - cr[0];
+      q.e2[1] = cr[7] - cr[1];
+      q.e2z = cr[8] - cr[2];
+      q.key = keys[src];
+      q.pad[0] = q.pad[1] = 0;
+      uint32_t mi = keys[src] >> kPrimBits, p = keys[src] & kPrimMask;
+      const HostMesh& m = c->meshes[mi];
+      const UhVertex* v[3] = {&m.vertices[m.indices[3 * (size_t)p]], &m.vertices[m.indices[3 * (size_t)p + 1]], &m.vertices[m.indices[3 * (size_t)p + 2]]};
+      ShadePacket& s = sp[i];
+      for (int a = 0; a < 3; a++) {
+         s.n0[a] = v[0]->normal[a];
+         s.n1[a] = v[1]->normal[a];
+         s.n2[a] = v[2]->normal[a];
+      }
+      for (int a = 0; a < 2; a++) {
+         s.uv0[a] = v[0]->uv[a];
+         s.uv1[a] = v[1]->uv[a];
+         s.uv2[a] = v[2]->uv[a];
+      }
+      s.mesh = mi;
+   }
+   std::vector<MeshShade> ms(c->meshes.size());
+   for (size_t i = 0; i < c->meshes.size(); i++) {
+      const HostMesh& m = c->meshes[i];
+      std::memcpy(ms[i].w2o, m.w2o, sizeof(m.w2o));
+      ms[i].diffuse_map = m.material.diffuse_map;
+      for (int a = 0; a < 3; a++) ms[i].base_color[a] = m.material.base_color_factor[a];
+      ms[i].type = m.material.raytrace_properties[0];
+      ms[i].property = m.material.raytrace_properties[1];
+      ms[i].pad = 0;
+   }
+   std::vector<float4> lights(2 * c->lights.size());
+   for (size_t i = 0; i < c->lights.size(); i++) {
+      const UhGpuLight& l = c->lights[i];
+      lights[2 * i] = make_float4(l.position[0], l.position[1], l.position[2], 0.0f);
+      lights[2 * i + 1] = make_float4(l.intensity[0], l.intensity[1], l.intensity[2], 0.0f);
+   }
+   std::vector<TexInfo> tex(c->textures.size());
+   for (size_t i = 0; i < tex.size(); i++) tex[i] = TexInfo{c->textures[i].dev, c->textures[i].w, c->textures[i].h};
+
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   HIP_TRY(c, c->d_nodes.alloc(bo.nodes.size() * 8));
+   HIP_TRY(c, c->d_tris.alloc(total * 3));
+   HIP_TRY(c, c->d_shade.alloc(total * 4));
+   HIP_TRY(c, c->d_meshes.alloc(ms.size()));
+   HIP_TRY(c, c->d_lights.alloc(lights.size()));
+   HIP_TRY(c, c->d_tex.alloc(tex.size()));
+   HIP_TRY(c, hipMemcpy(c->d_nodes.p, bo.nodes.data(), bo.nodes.size() * sizeof(Node4), hipMemcpyHostToDevice));
+   if (total) {
+      HIP_TRY(c, hipMemcpy(c->d_tris.p, tp.data(), total * sizeof(TriPacket), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(c->d_shade.p, sp.data(), total * sizeof(ShadePacket), hipMemcpyHostToDevice));
+   }
+   if (!ms.empty()) HIP_TRY(c, hipMemcpy(c->d_meshes.p, ms.data(), ms.size() * sizeof(MeshShade), hipMemcpyHostToDevice));
+   if (!lights.empty()) HIP_TRY(c, hipMemcpy(c->d_lights.p, lights.data(), lights.size() * sizeof(float4), hipMemcpyHostToDevice));
+   if (!tex.empty()) HIP_TRY(c, hipMemcpy(c->d_tex.p, tex.data(), tex.size() * sizeof(TexInfo), hipMemcpyHostToDevice));
+   c->scene.nodes = c->d_nodes.p;
+   c->scene.tris = c->d_tris.p;
+   c->scene.shade = c->d_shade.p;
+   c->scene.meshes = c->d_meshes.p;
+   c->scene.textures = c->d_tex.p;
+   c->scene.lights = c->d_lights.p;
+   c->scene.unorm_lut = c->d_lut.p;
+   c->scene.num_nodes = (uint32_t)bo.nodes.size();
+   c->scene.num_tris = (uint32_t)total;
+   c->scene.num_meshes = (uint32_t)ms.size();
+   c->scene.num_textures = (uint32_t)tex.size();
+   c->scene.num_lights = (uint32_t)c->lights.size();
+   c->bvh_nodes = c->scene.num_nodes;
+   c->bvh_tris = c->scene.num_tris;
+   c->built = true;
+   c->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+   return UH_OK;
+}
+
+static FrameParams make_params(uh_ctx* c, const UhViewUniformData& v) {
+   FrameParams fp;
+   std::memset(&fp, 0, sizeof(fp));
+   std::memcpy(fp.inv_view, v.inverse_view, sizeof(fp.inv_view));
+   std::memcpy(fp.inv_proj, v.inverse_projection, sizeof(fp.inv_proj));
+   std::memcpy(fp.prev_pv, v.prev_frame_projection_view, sizeof(fp.prev_pv));
+   // normalize(view.sun_dir) (reference.rgen:64, reference.rmiss:18): v * (1 / sqrt(dot))
+   float d = (v.sun_dir[0] * v.sun_dir[0] + v.sun_dir[1] * v.sun_dir[1]) + v.sun_dir[2] * v.sun_dir[2];
+   float inv = 1.0f / std::sqrt(d);
+   for (int a = 0; a < 3; a++) fp.sun_dir[a] = v.sun_dir[a] * inv;
+   fp.W = c->W;
+   fp.H = c->H;
+   // reference.rgen:24: int(float(total_samples) + time * 10000.0)
+   fp.frame_number = (uint32_t)(int32_t)((float)v.total_samples + v.time * 10000.0f);
+   fp.samples_per_frame = v.samples_per_frame;
+   fp.total_samples = v.total_samples;
+   fp.num_bounces = v.num_bounces;
+   fp.accumulation_limit = v.accumulation_limit;
+   fp.sky_enabled = v.sky_enabled;
+   fp.sun_shadow_enabled = v.sun_shadow_enabled;
+   fp.lights_enabled = v.lights_enabled;
+   fp.use_ris = v.use_ris_light_sampling;
+   fp.full_frame_restir = c->full_frame_restir ? 1u : 0u;
+   fp.num_lights_used = v.num_lights < v.max_num_lights_used ? v.num_lights : v.max_num_lights_used;
+   fp.temporal_enabled = v.temporal_reuse_enabled;
+   fp.spatial_enabled = v.spatial_reuse_enabled;
+   fp.tp_rank = c->tp_rank;
+   fp.tp_world = c->tp_world;
+   fp.tp_tile = c->tp_tile;
+   fp.tiles_x = (c->W + c->tp_tile - 1) / c->tp_tile;
+   return fp;
+}
+
+int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!view) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frame: null view");
+   if (!c->built) return fail(c, UH_ERR_NOT_BUILT, "uh_render_frame before uh_build_acceleration");
+   if (view->num_bounces > kMaxBounces) return fail(c, UH_ERR_INVALID_ARGUMENT, "num_bounces > 64");
+   if (view->num_lights > c->lights.size() && (view->lights_enabled == 1 || (pass_mask & UH_PASS_RESTIR)))
+      return fail(c, UH_ERR_INVALID_ARGUMENT, "view.num_lights exceeds the lights added with uh_add_light");
+   HIP_TRY(c, hipSetDevice(c->device));
+   const FrameParams fp = make_params(c, *view);
+   const LaunchCfg lc = cfg(c);
+   Control* ctl = c->control.p;
+   DeviceStats* st = c->dstats.p;
+   HIP_TRY(c, hipEventRecord(c->frame_start, c->stream));
+
+   if (pass_mask & UH_PASS_GBUFFER) {
+      HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(Control), c->stream));
+      launch_gbuffer(lc, fp, c->scene, c->ps, c->im, ctl, st);
+   }
+   if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(lc, fp, c->im);
+   if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(lc, fp, c->scene, c->im);
+   if (pass_mask & UH_PASS_TEMPORAL_REUSE) launch_temporal_reuse(lc, fp, c->scene, c->im);
+   if (pass_mask & UH_PASS_SPATIAL_REUSE) launch_spatial_reuse(lc, fp, c->scene, c->im);
+
+   if (pass_mask & UH_PASS_REFERENCE_PT) {
+      // reference.rgen:28: samples of one frame run back to back (the raygen RNG state carries over)
+      for (uint32_t s = 0; s < fp.samples_per_frame; s++) {
+         HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(Control), c->stream));
+         uint32_t slot = 0;
+         launch_generate(lc, fp, c->ps, ctl, s);
+         for (uint32_t b = 0; b < fp.num_bounces; b++) {
+            begin_timed(c, 0);
+            launch_trace_closest(lc, c->scene, c->ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
+            end_timed(c);
+            begin_timed(c, 2);
+            launch_shade_miss(lc, fp, c->ps, ctl, b);
+            launch_shade_hit(lc, fp, c->scene, c->ps, c->im, ctl, st, b);
+            end_timed(c);
+            if (fp.sun_shadow_enabled == 1) {
+               begin_timed(c, 1);
+               launch_trace_shadow(lc, fp, c->scene, c->ps, ctl, st, b, slot++, false);
+               end_timed(c);
+            }
+            if (fp.lights_enabled == 1) {
+               begin_timed(c, 1);
+               launch_trace_shadow(lc, fp, c->scene, c->ps, ctl, st, b, slot++, true);
+               end_timed(c);
+            }
+         }
+         launch_finish_sample(lc, fp, c->ps, c->im, s, s + 1 == fp.samples_per_frame);
+      }
+      if (fp.samples_per_frame == 0) {
+         // zero samples: the raygen still runs its accumulate / store tail
+         launch_resolve(lc, c->im, c->W, c->H, fp.total_samples, fp.accumulation_limit);
+      }
+   }
+   HIP_TRY(c, hipEventRecord(c->frame_stop, c->stream));
+   c->frame_timed = true;
+   c->frames++;
+   HIP_TRY(c, hipGetLastError());
+   return UH_OK;
+}
+
+int uh_reset_accumulation(uh_ctx* c) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));
+   HIP_TRY(c, hipMemsetAsync(c->accumulation.p, 0, c->accumulation.n * sizeof(float4), c->stream));
+   HIP_TRY(c, hipMemsetAsync(c->output.p, 0, c->output.n * sizeof(uchar4), c->stream));
+   return UH_OK;
+}
+
+int uh_synchronize(uh_ctx* c) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   return UH_OK;
+}
+
+static int read_back(uh_ctx* c, void* dst, const void* src, size_t bytes) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!dst) return fail(c, UH_ERR_INVALID_ARGUMENT, "null destination");
+   HIP_TRY(c, hipSetDevice(c->device));
+   HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   return UH_OK;
+}
+
+int uh_read_accumulation(uh_ctx* c, float* out) { return read_back(c, out, c ? c->accumulation.p : nullptr, c ? c->accumulation.n * sizeof(float4) : 0); }
+int uh_read_output_bgra8(uh_ctx* c, uint8_t* out) { return read_back(c, out, c ? c->output.p : nullptr, c ? c->output.n * sizeof(uchar4) : 0); }
+int uh_read_gbuffer_position(uh_ctx* c, float* out) { return read_back(c, out, c ? c->gbuffer.p : nullptr, c ? c->gbuffer.n * sizeof(float4) : 0); }
+int uh_read_reservoirs(uh_ctx* c, int which, UhReservoir* out) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (which < 0 || which > 2) return fail(c, UH_ERR_INVALID_ARGUMENT, "reservoir buffer index must be 0..2");
+   return read_back(c, out, c->reservoirs[which].p, c->reservoirs[which].n * sizeof(UhReservoir));
+}
+int uh_write_reservoirs(uh_ctx* c, int which, const UhReservoir* in) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (which < 0 || which > 2 || !in) return fail(c, UH_ERR_INVALID_ARGUMENT, "reservoir buffer index must be 0..2");
+   HIP_TRY(c, hipSetDevice(c->device));
+   HIP_TRY(c, hipMemcpyAsync(c->reservoirs[which].p, in, c->reservoirs[which].n * sizeof(UhReservoir), hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   return UH_OK;
+}
+
+int uh_trace_closest(uh_ctx* c, const float* rays, uint32_t n, float* out_tuv, uint32_t* out_mesh, uint32_t* out_prim) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!c->built) return fail(c, UH_ERR_NOT_BUILT, "uh_trace_closest before uh_build_acceleration");
+   if (n == 0) return UH_OK;
+   if (!rays || !out_tuv || !out_mesh || !out_prim) return fail(c, UH_ERR_INVALID_ARGUMENT, "null argument");
+   HIP_TRY(c, hipSetDevice(c->device));
+   std::vector<float4> o(n), d(n);
+   for (uint32_t i = 0; i < n; i++) {
+      const float* r = rays + 8 * (size_t)i;
+      o[i] = make_float4(r[0], r[1], r[2], r[3]);
+      d[i] = make_float4(r[4], r[5], r[6], r[7]);
+   }
+   DevBuf<float4> d_o, dd, dh;
+   DevBuf<uint32_t> cur;
+   HIP_TRY(c, d_o.alloc(n));
+   HIP_TRY(c, dd.alloc(n));
+   HIP_TRY(c, dh.alloc(n));
+   HIP_TRY(c, cur.alloc(1));
+   HIP_TRY(c, hipMemcpyAsync(d_o.p, o.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(c, hipMemcpyAsync(dd.p, d.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(c, hipMemsetAsync(cur.p, 0, sizeof(uint32_t), c->stream));
+   launch_trace_closest_raw(cfg(c), c->scene, d_o.p, dd.p, dh.p, n, cur.p);
+   std::vector<float4> h(n);
+   HIP_TRY(c, hipMemcpyAsync(h.data(), dh.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   // packet index -> key needs the packet table: read keys back once
+   std::vector<TriPacket> tp(c->scene.num_tris);
+   if (!tp.empty()) HIP_TRY(c, hipMemcpy(tp.data(), c->d_tris.p, tp.size() * sizeof(TriPacket), hipMemcpyDeviceToHost));
+   for (uint32_t i = 0; i < n; i++) {
+      uint32_t idx;
+      std::memcpy(&idx, &h[i].w, 4);
+      if (idx == kEmptyRef || idx >= tp.size()) {
+         out_tuv[3 * i] = -1.0f;
+         out_tuv[3 * i + 1] = out_tuv[3 * i + 2] = 0.0f;
+         out_mesh[i] = out_prim[i] = 0xffffffffu;
+      } else {
+         out_tuv[3 * i] = h[i].x;
+         out_tuv[3 * i + 1] = h[i].y;
+         out_tuv[3 * i + 2] = h[i].z;
+         out_mesh[i] = tp[idx].key >> kPrimBits;
+         out_prim[i] = tp[idx].key & kPrimMask;
+      }
+   }
+   d_o.release();
+   dd.release();
+   dh.release();
+   cur.release();
+   return UH_OK;
+}
+
+int uh_trace_any(uh_ctx* c, const float* rays, uint32_t n, uint8_t* out_occluded) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!c->built) return fail(c, UH_ERR_NOT_BUILT, "uh_trace_any before uh_build_acceleration");
+   if (n == 0) return UH_OK;
+   if (!rays || !out_occluded) return fail(c, UH_ERR_INVALID_ARGUMENT, "null argument");
+   HIP_TRY(c, hipSetDevice(c->device));
+   std::vector<float4> o(n), d(n);
+   for (uint32_t i = 0; i < n; i++) {
+      const float* r = rays + 8 * (size_t)i;
+      o[i] = make_float4(r[0], r[1], r[2], r[3]);
+      d[i] = make_float4(r[4], r[5], r[6], r[7]);
+   }
+   DevBuf<float4> d_o, dd;
+   DevBuf<uint32_t> occ, cur;
+   HIP_TRY(c, d_o.alloc(n));
+   HIP_TRY(c, dd.alloc(n));
+   HIP_TRY(c, occ.alloc(n));
+   HIP_TRY(c, cur.alloc(1));
+   HIP_TRY(c, hipMemcpyAsync(d_o.p, o.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(c, hipMemcpyAsync(dd.p, d.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(c, hipMemsetAsync(cur.p, 0, sizeof(uint32_t), c->stream));
+   launch_trace_any_raw(cfg(c), c->scene, d_o.p, dd.p, occ.p, n, cur.p);
+   std::vector<uint32_t> h(n);
+   HIP_TRY(c, hipMemcpyAsync(h.data(), occ.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   for (uint32_t i = 0; i < n; i++) out_occluded[i] = h[i] ? 1 : 0;
+   d_o.release();
+   dd.release();
+   occ.release();
+   cur.release();
+   return UH_OK;
+}
+
+int uh_get_stats(uh_ctx* c, UhStats* out) {
+   if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   DeviceStats ds;
+   HIP_TRY(c, hipMemcpy(&ds, c->dstats.p, sizeof(ds), hipMemcpyDeviceToHost));
+   drain_timed(c);
+   if (c->frame_timed) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, c->frame_start, c->frame_stop) == hipSuccess) c->last_frame_ms = ms;
+   }
+   std::memset(out, 0, sizeof(*out));
+   for (int i = 0; i < UH_RAY_KINDS; i++) out->rays[i] = ds.rays[i];
+   out->nodes_visited = ds.nodes_visited;
+   out->tris_tested = ds.tris_tested;
+   out->shadow_nodes_visited = ds.shadow_nodes_visited;
+   out->shadow_tris_tested = ds.shadow_tris_tested;
+   out->closest_hits = ds.closest_hits;
+   out->misses = ds.misses;
+   out->frames = c->frames;
+   out->bvh_nodes = c->bvh_nodes;
+   out->bvh_triangles = c->bvh_tris;
+   out->build_ms = c->build_ms;
+   out->last_frame_ms = c->last_frame_ms;
+   out->trace_closest_ms = c->ms_by_kind[0];
+   out->trace_shadow_ms = c->ms_by_kind[1];
+   out->shade_ms = c->ms_by_kind[2];
+   out->trace_closest_launches = c->trace_closest_launches;
+   return UH_OK;
+}
+
+int uh_reset_stats(uh_ctx* c) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   drain_timed(c);
+   HIP_TRY(c, hipMemset(c->dstats.p, 0, sizeof(DeviceStats)));
+   c->frames = 0;
+   c->ms_by_kind[0] = c->ms_by_kind[1] = c->ms_by_kind[2] = 0.0f;
+   c->trace_closest_launches = 0;
+   return UH_OK;
+}
+
+int uh_set_option(uh_ctx* c, const char* name, int value) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!name) return fail(c, UH_ERR_INVALID_ARGUMENT, "null option name");
+   std::string n(name);
+   if (n == "count_visits")
+      c->count_visits = value != 0;
+   else if (n == "time_kernels") {
+      if (c->time_kernels && !value) {
+         (void)hipStreamSynchronize(c->stream);
+         drain_timed(c);
+      }
+      c->time_kernels = value != 0;
+   } else if (n == "full_frame_restir")
+      c->full_frame_restir = value != 0;
+   else if (n == "trace_blocks_per_cu") {
+      if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, "trace_blocks_per_cu must be 1..8");
+      c->trace_blocks_per_cu = (uint32_t)value;
+   } else
+      return fail(c, UH_ERR_INVALID_ARGUMENT, "unknown option: " + n);
+   return UH_OK;
+}
+
+int uh_set_tile_partition(uh_ctx* c, uint32_t rank, uint32_t world, uint32_t tile_size) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (world == 0 || rank >= world || tile_size == 0) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_set_tile_partition: need rank < world, tile_size > 0");
+   c->tp_rank = rank;
+   c->tp_world = world;
+   c->tp_tile = tile_size;
+   return UH_OK;
+}
+
+int uh_tile_pack_count(uh_ctx* c, uint32_t rank, uint64_t* out_pixels) {
+   if (!c || !out_pixels) return UH_ERR_INVALID_ARGUMENT;
+   if (rank >= c->tp_world) return fail(c, UH_ERR_INVALID_ARGUMENT, "rank >= world");
+   uint32_t tiles = ((c->W + c->tp_tile - 1) / c->tp_tile) * ((c->H + c->tp_tile - 1) / c->tp_tile);
+   uint32_t owned = tiles > rank ? (tiles - rank + c->tp_world - 1) / c->tp_world : 0;
+   *out_pixels = (uint64_t)owned * c->tp_tile * c->tp_tile;
+   return UH_OK;
+}
+
+int uh_pack_tiles(uh_ctx* c, void* device_out, uint64_t capacity_pixels) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   uint64_t need = 0;
+   uh_tile_pack_count(c, c->tp_rank, &need);
+   if (!device_out || capacity_pixels < need) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_pack_tiles: buffer too small");
+   HIP_TRY(c, hipSetDevice(c->device));
+   launch_pack_tiles(cfg(c), c->accumulation.p, (float4*)device_out, c->W, c->H, c->tp_rank, c->tp_world, c->tp_tile);
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   return UH_OK;
+}
+
+int uh_unpack_tiles(uh_ctx* c, uint32_t from_rank, const void* device_in, uint64_t num_pixels) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   uint64_t need = 0;
+   if (uh_tile_pack_count(c, from_rank, &need) != UH_OK) return UH_ERR_INVALID_ARGUMENT;
+   if (!device_in || num_pixels < need) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_unpack_tiles: buffer too small");
+   HIP_TRY(c, hipSetDevice(c->device));
+   launch_unpack_tiles(cfg(c), c->accumulation.p, (const float4*)device_in, c->W, c->H, from_rank, c->tp_world, c->tp_tile);
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   return UH_OK;
+}
+
+int uh_resolve_output(uh_ctx* c, uint32_t total_samples, uint32_t accumulation_limit) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));
+   launch_resolve(cfg(c), c->im, c->W, c->H, total_samples, accumulation_limit);
+   HIP_TRY(c, hipGetLastError());
+   return UH_OK;
+}
+
+int uh_device_pointer(uh_ctx* c, int which, void** out) {
+   if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
+   if (which == 0)
+      *out = c->accumulation.p;
+   else if (which == 1)
+      *out = c->output.p;
+   else
+      return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_device_pointer: which must be 0 or 1");
+   return UH_OK;
+}
+
+int uh_stream(uh_ctx* c, void** out) {
+   if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
+   *out = (void*)c->stream;
+   return UH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+// device_math.h — gfx950 device functions for the shading side of the path: RNG, view helpers,
+// sky, textures, closest-hit material evaluation, reservoir math. Each function cites the GLSL it
+// replaces (paths relative to the reference's utopian/shaders/). Arithmetic follows DESIGN.md
+// "Arithmetic contract": plain IEEE f32 ops in the written order (the library is compiled with
+// -ffp-contract=off), fused multiply-adds only where fmaf() is spelled out, correctly rounded
+// division and sqrt; only the sky's exp/pow use the hardware approximations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace uh {
+
+struct V3 {
+   float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 vneg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float length3(V3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ V3 normalize3(V3 a) {
+   float inv = 1.0f / sqrtf(dot3(a, a));
+   return a * inv;
+}
+__device__ __forceinline__ V3 xyz(float4 v) { return v3(v.x, v.y, v.z); }
+
+// column-major mat4 * vec4: ((c0*x + c1*y) + c2*z) + c3*w
+__device__ __forceinline__ float4 mat4_mul(const float* m, float x, float y, float z, float w) {
+   float4 r;
+   r.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w;
+   r.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w;
+   r.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w;
+   r.w = ((m[3] * x + m[7] * y) + m[11] * z) + m[15] * w;
+   return r;
+}
+
+// ---- include/random.glsl -----------------------------------------------------------------
+__device__ __forceinline__ uint32_t jenkins_hash(uint32_t x) {  // random.glsl:5-12
+   x += x << 10;
+   x ^= x >> 6;
+   x += x << 3;
+   x ^= x >> 11;
+   x += x << 15;
+   return x;
+}
+__device__ __forceinline__ uint32_t init_rng(uint32_t px, uint32_t py, uint32_t resx, uint32_t frame) {  // random.glsl:14-18
+   float d = (float)px * 1.0f + (float)py * (float)resx;
+   return jenkins_hash((uint32_t)d ^ jenkins_hash(frame));
+}
+__device__ __forceinline__ float random_float(uint32_t& s) {  // random.glsl:21-34
+   s = s * 747796405u + 1u;
+   uint32_t word = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+   word = (word >> 22) ^ word;
+   return (float)word * 2.3283064365386963e-10f;  // exact: / 2^32 (4294967295.0f rounds to 2^32)
+}
+__device__ __forceinline__ V3 random_point_in_unit_sphere(uint32_t& s) {  // random.glsl:36-46
+   for (;;) {
+      float a = random_float(s), b = random_float(s), c = random_float(s);
+      V3 p = v3(2.0f * a - 1.0f, 2.0f * b - 1.0f, 2.0f * c - 1.0f);
+      if (dot3(p, p) < 1.0f) return p;
+   }
+}
+
+// ---- include/view.glsl -------------------------------------------------------------------
+__device__ __forceinline__ float luminance(V3 c) { return dot3(c, v3(0.2126f, 0.7152f, 0.0722f)); }  // view.glsl:46-50
+__device__ __forceinline__ float linear_to_srgb(float c) {                                            // view.glsl:52-60
+   if (c < 0.0031308f) return c * 12.92f;
+   return 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+}
+__device__ __forceinline__ V3 offset_ray(V3 p, V3 n) {  // view.glsl:92-108
+   const float origin = 1.0f / 32.0f, float_scale = 1.0f / 65536.0f, int_scale = 256.0f;
+   int ox = (int)(int_scale * n.x), oy = (int)(int_scale * n.y), oz = (int)(int_scale * n.z);
+   float pix = __uint_as_float(__float_as_uint(p.x) + (uint32_t)((p.x < 0) ? -ox : ox));
+   float piy = __uint_as_float(__float_as_uint(p.y) + (uint32_t)((p.y < 0) ? -oy : oy));
+   float piz = __uint_as_float(__float_as_uint(p.z) + (uint32_t)((p.z < 0) ? -oz : oz));
+   return v3(fabsf(p.x) < origin ? p.x + float_scale * n.x : pix, fabsf(p.y) < origin ? p.y + float_scale * n.y : piy,
+             fabsf(p.z) < origin ? p.z + float_scale * n.z : piz);
+}
+__device__ __forceinline__ uint32_t unorm8(float x) {
+   if (!(x > 0.0f)) x = 0.0f;
+   if (x > 1.0f) x = 1.0f;
+   return (uint32_t)rintf(x * 255.0f);
+}
+
+// ---- include/atmosphere.glsl ---------------------------------------------------------------
+// exp/pow use the hardware exp2/log2 path (v_exp_f32 / v_log_f32): the sky is a smooth integrand,
+// the ~1e-6 relative difference to libm is far inside the 1e-3 parity tolerance.
+namespace sky {
+constexpr float PLANET_RADIUS = 6371000.0f;
+constexpr float ATMOSPHERE_HEIGHT = 100000.0f;
+constexpr float RAYLEIGH_HEIGHT = ATMOSPHERE_HEIGHT * 0.08f;
+constexpr float MIE_HEIGHT = ATMOSPHERE_HEIGHT * 0.012f;
+constexpr float PI = 3.14159265359f;
+__device__ __forceinline__ V3 C_RAYLEIGH() { return v3(5.802f, 13.558f, 33.100f) * 1e-6f; }
+__device__ __forceinline__ V3 C_MIE() { return v3(3.996f, 3.996f, 3.996f) * 1e-6f; }
+__device__ __forceinline__ V3 C_OZONE() { return v3(0.650f, 1.881f, 0.085f) * 1e-6f; }
+__device__ __forceinline__ V3 PLANET_CENTER() { return v3(0.0f, -PLANET_RADIUS, 0.0f); }
+
+__device__ __forceinline__ void atmosphere_intersection(V3 s, V3 d, float& t0, float& t1) {  // atmosphere.glsl:53-77
+   const float radius = PLANET_RADIUS + ATMOSPHERE_HEIGHT;
+   s = s - PLANET_CENTER();
+   float a = dot3(d, d);
+   float b = 2.0f * dot3(s, d);
+   float c = dot3(s, s) - (radius * radius);
+   float disc = b * b - 4.0f * a * c;
+   if (disc < 0) {
+      t0 = -1.0f;
+      t1 = -1.0f;
+   } else {
+      disc = sqrtf(disc);
+      t0 = (-b - disc) / (2.0f * a);
+      t1 = (-b + disc) / (2.0f * a);
+   }
+}
+__device__ __forceinline__ float atmosphere_height(V3 p) { return length3(p - PLANET_CENTER()) - PLANET_RADIUS; }  // :95-98
+__device__ __forceinline__ V3 atmosphere_density(float h) {                                                        // :99-115
+   float r = __expf(-fmaxf(0.0f, h / RAYLEIGH_HEIGHT));
+   float m = __expf(-fmaxf(0.0f, h / MIE_HEIGHT));
+   float o = fmaxf(0.0f, 1.0f - fabsf(h - 25000.0f) / 15000.0f);
+   return v3(r, m, o);
+}
+__device__ __forceinline__ V3 absorb(V3 od) {  // :146-150
+   V3 a = (od.x * C_RAYLEIGH() + od.y * C_MIE() * 1.1f + od.z * C_OZONE()) * 1.0f;
+   return v3(__expf(-a.x), __expf(-a.y), __expf(-a.z));
+}
+__device__ __forceinline__ V3 integrate_optical_depth(V3 start, V3 dir) {  // :123-143
+   float t0, t1;
+   atmosphere_intersection(start, dir, t0, t1);
+   float step = t1 / 8.0f;
+   V3 od = v3(0, 0, 0);
+#pragma unroll 2
+   for (int i = 0; i < 8; i++) {
+      V3 p = start + dir * ((float)i + 0.5f) * step;
+      od = od + atmosphere_density(atmosphere_height(p)) * step;
+   }
+   return od;
+}
+__device__ __noinline__ V3 integrate_scattering(V3 start, V3 dir, float ray_length, V3 light_dir) {  // :154-214 (lightColor = 1)
+   float ray_height = atmosphere_height(start);
+   float c = 1.0f - ray_height / ATMOSPHERE_HEIGHT;
+   c = fminf(fmaxf(c, 0.0f), 1.0f);
+   float exponent = 1.0f + c * 8.0f;
+   float i0, i1;
+   atmosphere_intersection(start, dir, i0, i1);
+   ray_length = fminf(ray_length, i1);
+   if (i0 > 0) {
+      start = start + dir * i0;
+      ray_length -= i0;
+   }
+   float costh = dot3(dir, light_dir);
+   float phaseR = 3.0f * (1.0f + costh * costh) / (16.0f * PI);
+   float g = fminf(0.85f, 0.9381f);
+   float k = 1.55f * g - 0.55f * g * g * g;
+   float kcosth = k * costh;
+   float phaseM = (1.0f - k * k) / ((4.0f * PI) * (1.0f - kcosth) * (1.0f - kcosth));
+   V3 od = v3(0, 0, 0), rayleigh = v3(0, 0, 0), mie = v3(0, 0, 0);
+   float prev = 0.0f;
+   for (int i = 0; i < 16; i++) {
+      float ray_time = __powf((float)i / 16.0f, exponent) * ray_length;
+      float step = ray_time - prev;
+      V3 p = start + dir * ray_time;
+      V3 dens = atmosphere_density(atmosphere_height(p));
+      od = od + dens * step;
+      V3 view_t = absorb(od);
+      V3 light_t = absorb(integrate_optical_depth(p, light_dir));
+      rayleigh = rayleigh + view_t * light_t * phaseR * dens.x * step;
+      mie = mie + view_t * light_t * phaseM * dens.y * step;
+      prev = ray_time;
+   }
+   return (rayleigh * C_RAYLEIGH() + mie * C_MIE()) * v3(1, 1, 1) * 20.0f;
+}
+}  // namespace sky
+
+// ---- texture sampling (utopian/src/texture.rs:85-98: RGBA8 UNORM, LINEAR, MIRRORED_REPEAT) ---
+__device__ __forceinline__ int mirror_index(int i, int n) {
+   int period = 2 * n;
+   int m = i % period;
+   if (m < 0) m += period;
+   return m < n ? m : period - 1 - m;
+}
+__device__ __forceinline__ V3 sample_texture(const SceneDev& sc, uint32_t index, float u, float v) {
+   if (index >= sc.num_textures) return v3(1, 1, 1);
+   TexInfo t = sc.textures[index];
+   float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+   if (!(fabsf(x) < 1e9f) || !(fabsf(y) < 1e9f)) return v3(0, 0, 0);
+   float fx = floorf(x), fy = floorf(y);
+   float ax = x - fx, ay = y - fy;
+   int x0 = mirror_index((int)fx, (int)t.w), x1 = mirror_index((int)fx + 1, (int)t.w);
+   int y0 = mirror_index((int)fy, (int)t.h), y1 = mirror_index((int)fy + 1, (int)t.h);
+   const float* lut = sc.unorm_lut;
+   auto tx = [&](int xx, int yy) {
+      uchar4 p = t.texels[(size_t)yy * t.w + xx];
+      return v3(lut[p.x], lut[p.y], lut[p.z]);
+   };
+   V3 t00 = tx(x0, y0), t10 = tx(x1, y0), t01 = tx(x0, y1), t11 = tx(x1, y1);
+   V3 a = t00 * (1.0f - ax) + t10 * ax;
+   V3 b = t01 * (1.0f - ax) + t11 * ax;
+   return a * (1.0f - ay) + b * ay;
+}
+
+// ---- include/restir_sampling.glsl ------------------------------------------------------------
+// lights: 2 float4 per light (pos, intensity). Out-of-range index (Y = -1, or idx = n when
+// xi == 1.0 — both out-of-bounds reads in the reference): p_hat = 0.
+template <typename LightPtr>
+__device__ __forceinline__ float target_function(LightPtr lights, uint32_t num_lights, int light_index, V3 hit_position) {  // :59-69
+   if (light_index < 0 || (uint32_t)light_index >= num_lights) return 0.0f;
+   float4 lp = lights[2 * light_index], li = lights[2 * light_index + 1];
+   float d = length3(xyz(lp) - hit_position);
+   float d2 = d * d;  // pow(d, 2.0)
+   return luminance(v3(li.x / d2, li.y / d2, li.z / d2));
+}
+__device__ __forceinline__ void sample_light_uniform(uint32_t num_used, uint32_t& rng, int& idx, float& w) {  // :71-77
+   idx = (int)(random_float(rng) * (float)num_used);
+   w = 1.0f / (float)num_used;
+}
+__device__ __forceinline__ void finalize_resampling(UhReservoir& r, float p_hat) {  // :79-82
+   r.W_X = (p_hat == 0.0f) ? 0.0f : (1.0f / p_hat) * r.W_sum / (float)r.M;
+}
+__device__ __forceinline__ void update_reservoir(uint32_t& rng, UhReservoir& r, int Xi, float w_i, int M) {  // :85-94
+   r.W_sum += w_i;
+   r.M += M;
+   if (random_float(rng) * r.W_sum < w_i) r.Y = Xi;
+}
+
+// ---- pathtrace_reference/reference.rgen:31-38 ---------------------------------------------
+__device__ __forceinline__ void primary_ray(const FrameParams& fp, uint32_t px, uint32_t py, float jx, float jy, V3& org, V3& dir) {
+   float cx = (float)px + jx, cy = (float)py + jy;
+   float u = cx / (float)fp.W, v = cy / (float)fp.H;
+   v = 1.0f - v;
+   float dx = u * 2.0f - 1.0f, dy = v * 2.0f - 1.0f;
+   float4 o4 = mat4_mul(fp.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
+   float4 tg = mat4_mul(fp.inv_proj, dx, dy, 1.0f, 1.0f);
+   V3 nt = normalize3(v3(tg.x, tg.y, tg.z));
+   float4 d4 = mat4_mul(fp.inv_view, nt.x, nt.y, nt.z, 0.0f);
+   org = v3(o4.x, o4.y, o4.z);
+   dir = v3(d4.x, d4.y, d4.z);
+}
+
+__device__ __forceinline__ bool owns_pixel(const FrameParams& fp, uint32_t x, uint32_t y) {
+   if (fp.tp_world <= 1) return true;
+   uint32_t tile = (y / fp.tp_tile) * fp.tiles_x + (x / fp.tp_tile);
+   return tile % fp.tp_world == fp.tp_rank;
+}
+
+// ---- wave64 helpers ---------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Wave-aggregated queue append: one atomic per wave, lanes get consecutive slots (ballot +
+// popcount prefix). Must be reached by all lanes of the wave that are still in the loop.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
+   unsigned long long mask = __ballot(pred);
+   uint32_t n = (uint32_t)__popcll(mask);
+   uint32_t base = 0;
+   if (n) {
+      int leader = __ffsll((long long)mask) - 1;
+      if ((int)lane_id() == leader) base = atomicAdd(counter, n);
+      base = __shfl(base, leader);
+   }
+   uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+   return base + prefix;
+}
+
+}  // namespace uh

@@ -1,0 +1,121 @@
+// device_types.h — structs passed between the host context (context.hip) and the kernels
+// (kernels.hip). Device pointers only; everything here is plain data.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bvh.h"
+#include "utopian_hip.h"
+
+namespace uh {
+
+constexpr uint32_t kMaxBounces = 64;
+constexpr uint32_t kQueueKinds = 4;  // per bounce: RAY, HIT, MISS, LIGHT
+enum { Q_RAY = 0, Q_HIT = 1, Q_MISS = 2, Q_LIGHT = 3 };
+constexpr uint32_t kLaunchSlots = kMaxBounces * 6 + 16;
+
+// Zeroed once per sample pass by one hipMemsetAsync.
+struct Control {
+   uint32_t q_count[(kMaxBounces + 1) * kQueueKinds];
+   uint32_t cursor[kLaunchSlots];  // persistent-thread work cursors, one per launch of the pass
+};
+
+// Persistent across frames; read back by uh_get_stats.
+struct DeviceStats {
+   unsigned long long rays[UH_RAY_KINDS];
+   unsigned long long nodes_visited, tris_tested, shadow_nodes_visited, shadow_tris_tested;
+   unsigned long long closest_hits, misses;
+};
+
+// per-mesh shading record (64 B): inverse instance rotation/scale + the material fields the
+// closest-hit shader reads (reference.rchit:22-23,32,40-41,47-89)
+struct alignas(16) MeshShade {
+   float w2o[9];  // row-major inverse of the object-to-world upper 3x3
+   uint32_t diffuse_map;
+   float base_color[3];
+   float type;      // raytrace_properties.x
+   float property;  // raytrace_properties.y
+   uint32_t pad;
+};
+static_assert(sizeof(MeshShade) == 64, "mesh shading record");
+
+struct TexInfo {
+   const uchar4* texels;
+   uint32_t w, h;
+};
+
+struct SceneDev {
+   const float4* nodes;   // 8 float4 per Node4
+   const float4* tris;    // 3 float4 per TriPacket
+   const float4* shade;   // 4 float4 per ShadePacket
+   const MeshShade* meshes;
+   const TexInfo* textures;
+   const float4* lights;  // 2 float4 per light: (pos, 0), (intensity, 0)
+   const float* unorm_lut;  // 256 entries: c / 255.0f (host-computed, exact)
+   uint32_t num_nodes, num_tris, num_meshes, num_textures, num_lights;
+};
+
+struct FrameParams {
+   float inv_view[16], inv_proj[16], prev_pv[16];
+   float sun_dir[3];  // normalize(view.sun_dir), computed on the host with the contract's normalize
+   uint32_t W, H, frame_number;
+   uint32_t samples_per_frame, total_samples, num_bounces, accumulation_limit;
+   uint32_t sky_enabled, sun_shadow_enabled, lights_enabled, use_ris, full_frame_restir;
+   uint32_t num_lights_used;  // min(view.num_lights, view.max_num_lights_used)
+   uint32_t temporal_enabled, spatial_enabled;
+   uint32_t tp_rank, tp_world, tp_tile, tiles_x;
+};
+
+// Path / ray state, SoA over pixels (path id == pixel id). 16-byte records so that every lane
+// moves one dwordx4 per access.
+struct PathState {
+   float4* ray_o;   // origin.xyz, tmin
+   float4* ray_d;   // direction.xyz (un-normalised, reference.rgen:61), tmax
+   float4* hit;     // t, u, v, packet index (bits); miss: index = 0xffffffff
+   float4* thr;     // throughput.rgb, light weight f (radiance += thr * f when the light is visible)
+   float4* rad;     // radiance.rgb, light index (bits)
+   float4* pixcol;  // sum over the frame's samples
+   uint2* rng;      // x = raygen rngState, y = rayPayload.randomSeed
+   uint32_t* queue[5];  // 0,1 = ray ping-pong; 2 = hit; 3 = miss; 4 = light
+};
+
+struct Images {
+   float4* accumulation;  // pt_accumulation_image RGBA32F
+   uchar4* output;        // pt_output_image B8G8R8A8_UNORM
+   float4* gbuffer_pos;   // gbuffer_position RGBA32F, un-filtered texels
+   UhReservoir* reservoirs[3];
+};
+
+// launch wrappers implemented in kernels.hip --------------------------------------------------
+struct LaunchCfg {
+   hipStream_t stream;
+   uint32_t num_cus;
+   uint32_t trace_blocks_per_cu;
+   bool count_visits;
+};
+
+void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);
+void launch_trace_closest(const LaunchCfg&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce, uint32_t cursor_slot,
+                          int ray_kind);
+void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t bounce);
+void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
+void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
+                         uint32_t cursor_slot, bool light);
+void launch_finish_sample(const LaunchCfg&, const FrameParams&, const PathState&, const Images&, uint32_t sample, bool last);
+void launch_resolve(const LaunchCfg&, const Images&, uint32_t W, uint32_t H, uint32_t total_samples, uint32_t limit);
+// G-buffer + ReSTIR
+void launch_gbuffer(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*);
+void launch_reset_reservoirs(const LaunchCfg&, const FrameParams&, const Images&);
+void launch_initial_ris(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);
+void launch_temporal_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);
+void launch_spatial_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);
+// stand-alone queries (n rays in ray_o/ray_d[0..n), identity queue)
+void launch_trace_closest_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n, uint32_t* cursor);
+void launch_trace_any_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n, uint32_t* cursor);
+// tiles
+void launch_pack_tiles(const LaunchCfg&, const float4* acc, float4* out, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);
+void launch_unpack_tiles(const LaunchCfg&, float4* acc, const float4* in, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);
+uint32_t query_trace_occupancy();
+
+}  // namespace uh

@@ -1,0 +1,818 @@
+// kernels.hip — gfx950 kernels of the wavefront path tracer and the ReSTIR passes.
+//
+// Replaces (reference, utopian/shaders/): pathtrace_reference/reference.{rgen,rchit,rmiss},
+// restir/{reset_reservoirs.comp,initial_ris.rgen,temporal_reuse.rgen,spatial_reuse.rgen} and the
+// driver's traceRayEXT traversal. One launch of reference.rgen (vkCmdTraceRaysKHR(W,H,1),
+// utopian/src/renderers/mod.rs:357) becomes, per sample and bounce, a short chain of launches over
+// compacted queues of path ids:
+//     generate -> [ trace_closest -> shade_miss | shade_hit -> trace_shadow(sun) -> trace_shadow(light) ]*
+//              -> finish_sample
+// Traversal kernels are persistent: a grid that just fills the chip pulls 64-ray batches from a
+// device-side cursor until the queue (whose length only the device knows) is drained.
+#include <hip/hip_runtime.h>
+
+#include "device_math.h"
+#include "device_types.h"
+
+namespace uh {
+
+constexpr int kBlock = 256;                 // 4 waves
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kLdsStack = 24;               // per-lane traversal stack entries kept in LDS
+constexpr int kSpillStack = 40;             // overflow entries in private memory (rarely touched)
+
+// ------------------------------------------------------------------------------------------
+// BVH4 traversal (thread per ray). Closest hit: min t over all triangles with tmin < t < tmax,
+// ties broken by the smaller key (mesh << 22 | prim) — independent of traversal order, because
+// node boxes are padded conservatively by the builder. Any hit: first triangle with
+// tmin < t < tmax and t <= tlimit.
+// ------------------------------------------------------------------------------------------
+struct Hit {
+   float t, u, v;
+   uint32_t idx;  // packet index, kEmptyRef = miss
+   uint32_t key;
+};
+
+__device__ __forceinline__ float dot_fma(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 cross_fma(V3 a, V3 b) {
+   return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+template <bool ANY>
+__device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, uint32_t i, V3 o, V3 d, float tmin, float tlimit, Hit& best) {
+   float4 a = tris[3 * (size_t)i + 0], b = tris[3 * (size_t)i + 1], c = tris[3 * (size_t)i + 2];
+   V3 v0 = v3(a.x, a.y, a.z), e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, c.x);
+   uint32_t key = __float_as_uint(c.y);
+   V3 p = cross_fma(d, e2);
+   float det = dot_fma(e1, p);
+   if (det == 0.0f) return false;
+   float inv = 1.0f / det;
+   V3 tv = o - v0;
+   float u = dot_fma(tv, p) * inv;
+   if (!(u >= 0.0f && u <= 1.0f)) return false;
+   V3 q = cross_fma(tv, e1);
+   float v = dot_fma(d, q) * inv;
+   if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+   float t = dot_fma(e2, q) * inv;
+   if (!(t > tmin)) return false;
+   if (ANY) {
+      return t < best.t && t <= tlimit;
+   } else {
+      if (t < best.t || (t == best.t && key < best.key)) {
+         best.t = t;
+         best.u = u;
+         best.v = v;
+         best.idx = i;
+         best.key = key;
+         return true;
+      }
+      return false;
+   }
+}
+
+__device__ __forceinline__ float safe_rcp_dir(float x) {
+   // the slab test only has to be conservative; a zero component becomes +-1e-30 so no inf/NaN appears
+   return 1.0f / (fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x);
+}
+
+struct StackRef {
+   uint32_t* lds;  // this lane's column: entry k at lds[k * 64]
+};
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, float tlimit, Hit& best, uint32_t* lds_col,
+                                         uint32_t& n_nodes, uint32_t& n_tris) {
+   best.t = tmax;
+   best.u = best.v = 0.0f;
+   best.idx = kEmptyRef;
+   best.key = 0xffffffffu;
+   const float4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   const V3 idir = v3(safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z));
+   const V3 ood = v3(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
+   uint32_t spill[kSpillStack];
+   int sp = 0;
+   uint32_t cur = 0;  // root is always an interior node
+   auto push = [&](uint32_t ref) {
+      if (sp < kLdsStack)
+         lds_col[sp * 64] = ref;
+      else if (sp < kLdsStack + kSpillStack)
+         spill[sp - kLdsStack] = ref;
+      else
+         return;  // deeper than any tree the builder emits (depth cap 48 -> <= 3*depth entries is far above need)
+      sp++;
+   };
+   auto pop = [&]() -> uint32_t {
+      if (sp == 0) return kEmptyRef;
+      sp--;
+      return sp < kLdsStack ? lds_col[sp * 64] : spill[sp - kLdsStack];
+   };
+   while (cur != kEmptyRef) {
+      if (!(cur & kLeafBit)) {
+         const float4* n = nodes + 8 * (size_t)cur;
+         float4 lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
+         uint4 ch = *reinterpret_cast<const uint4*>(n + 6);
+         if (COUNT) n_nodes++;
+         float tn[4];
+         uint32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
+         const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
+         const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+#pragma unroll
+         for (int k = 0; k < 4; k++) {
+            float t0x = fmaf(lx[k], idir.x, ood.x), t1x = fmaf(hx[k], idir.x, ood.x);
+            float t0y = fmaf(ly[k], idir.y, ood.y), t1y = fmaf(hy[k], idir.y, ood.y);
+            float t0z = fmaf(lz[k], idir.z, ood.z), t1z = fmaf(hz[k], idir.z, ood.z);
+            float tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+            float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
+            bool hit = (tnear <= tfar) && (cr[k] != kEmptyRef);
+            tn[k] = hit ? tnear : INFINITY;
+         }
+         if (!ANY) {
+            // 5-comparator sorting network, ascending by entry distance
+            auto cswap = [&](int i, int j) {
+               bool s = tn[j] < tn[i];
+               float ta = s ? tn[j] : tn[i], tb = s ? tn[i] : tn[j];
+               uint32_t ca = s ? cr[j] : cr[i], cb = s ? cr[i] : cr[j];
+               tn[i] = ta;
+               tn[j] = tb;
+               cr[i] = ca;
+               cr[j] = cb;
+            };
+            cswap(0, 1);
+            cswap(2, 3);
+            cswap(0, 2);
+            cswap(1, 3);
+            cswap(1, 2);
+            if (tn[3] < INFINITY) push(cr[3]);
+            if (tn[2] < INFINITY) push(cr[2]);
+            if (tn[1] < INFINITY) push(cr[1]);
+            cur = (tn[0] < INFINITY) ? cr[0] : pop();
+         } else {
+            uint32_t next = kEmptyRef;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+               if (tn[k] < INFINITY) {
+                  if (next == kEmptyRef)
+                     next = cr[k];
+                  else
+                     push(cr[k]);
+               }
+            cur = (next != kEmptyRef) ? next : pop();
+         }
+      } else {
+         uint32_t first = cur & kLeafFirstMask, cnt = (cur >> kLeafCountShift) & 0xf;
+         if (COUNT) n_tris += cnt;
+         for (uint32_t k = 0; k < cnt; k++) {
+            bool h = tri_test<ANY>(tris, first + k, o, d, tmin, tlimit, best);
+            if (ANY && h) return true;
+         }
+         cur = pop();
+      }
+   }
+   return ANY ? false : (best.idx != kEmptyRef);
+}
+
+// persistent-thread batch fetch: lane 0 pulls the next 64-item batch
+__device__ __forceinline__ uint32_t next_batch(uint32_t* cursor) {
+   uint32_t base = 0;
+   if (lane_id() == 0) base = atomicAdd(cursor, 64u);
+   return __builtin_amdgcn_readfirstlane(base);
+}
+
+// ------------------------------------------------------------------------------------------
+// trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes
+// ------------------------------------------------------------------------------------------
+template <bool COUNT, bool RAW>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                          float4* __restrict__ hit_out, const uint32_t* __restrict__ queue,
+                                                          const uint32_t* __restrict__ count_ptr, uint32_t raw_count, uint32_t* cursor,
+                                                          uint32_t* q_hit, uint32_t* n_hit, uint32_t* q_miss, uint32_t* n_miss, DeviceStats* stats,
+                                                          int ray_kind) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   const uint32_t lane = lane_id();
+   const uint32_t wave = threadIdx.x >> 6;
+   uint32_t* lds_col = &s_stack[wave][0][lane];
+   const uint32_t count = RAW ? raw_count : *count_ptr;
+   uint32_t n_nodes = 0, n_tris = 0;
+   for (;;) {
+      uint32_t base = next_batch(cursor);
+      if (base >= count) break;
+      uint32_t i = base + lane;
+      bool active = i < count;
+      uint32_t id = 0;
+      Hit h;
+      h.idx = kEmptyRef;
+      h.t = 0.0f;
+      h.u = h.v = 0.0f;
+      if (active) {
+         id = RAW ? i : queue[i];
+         float4 ro = ray_o[id], rd = ray_d[id];
+         traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
+         hit_out[id] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
+      }
+      if (!RAW) {
+         bool is_hit = active && h.idx != kEmptyRef, is_miss = active && h.idx == kEmptyRef;
+         uint32_t slot = wave_append(n_hit, is_hit);
+         if (is_hit) q_hit[slot] = id;
+         slot = wave_append(n_miss, is_miss);
+         if (is_miss) q_miss[slot] = id;
+      }
+   }
+   if (!RAW) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
+      if (COUNT) {
+         atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
+         atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// trace_shadow — reference.rgen:67 (sun) and :115 (light): visibility only. The reference runs
+// its closest-hit / miss shaders on these rays too, but the raygen reads nothing except
+// colorDistance.w (rgen:69,118-119), so the sky integral and material fetch are dead work here.
+// Occluded <=> some triangle has tmin < t < tmax (sun) and additionally t <= distance_to_light.
+// ------------------------------------------------------------------------------------------
+template <bool COUNT, bool LIGHT>
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, const uint32_t* __restrict__ queue,
+                                                         const uint32_t* __restrict__ count_ptr, uint32_t* cursor, DeviceStats* stats) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   const uint32_t lane = lane_id();
+   const uint32_t wave = threadIdx.x >> 6;
+   uint32_t* lds_col = &s_stack[wave][0][lane];
+   const uint32_t count = *count_ptr;
+   const float tmin = 0.001f, tmax = 10000.0f;
+   uint32_t n_nodes = 0, n_tris = 0;
+   for (;;) {
+      uint32_t base = next_batch(cursor);
+      if (base >= count) break;
+      uint32_t i = base + lane;
+      if (i < count) {
+         uint32_t id = queue[i];
+         float4 ro = ps.ray_o[id];
+         V3 o = v3(ro.x, ro.y, ro.z);
+         float4 thr = ps.thr[id], rad = ps.rad[id];
+         V3 dir;
+         float tlimit = INFINITY, f = 1.0f;
+         if (LIGHT) {
+            int light_index = (int)__float_as_uint(rad.w);
+            V3 lpos = v3(0, 0, 0);
+            if (light_index >= 0 && (uint32_t)light_index < sc.num_lights) lpos = xyz(sc.lights[2 * light_index]);
+            dir = normalize3(lpos - o);      // rgen:113
+            tlimit = length3(lpos - o);      // rgen:114
+            f = thr.w;
+         } else {
+            dir = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);  // rgen:64
+         }
+         Hit h;
+         bool occluded = traverse<true, COUNT>(sc, o, dir, tmin, tmax, tlimit, h, lds_col, n_nodes, n_tris);
+         if (!occluded) {  // rgen:69-78 / :118-122
+            if (LIGHT)
+               ps.rad[id] = make_float4(rad.x + thr.x * f, rad.y + thr.y * f, rad.z + thr.z * f, rad.w);
+            else
+               ps.rad[id] = make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w);
+         }
+      }
+   }
+   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
+   if (COUNT) {
+      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
+   }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_any_raw(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                          uint32_t* __restrict__ occluded, uint32_t count, uint32_t* cursor) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   const uint32_t lane = lane_id();
+   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
+   uint32_t n_nodes = 0, n_tris = 0;
+   for (;;) {
+      uint32_t base = next_batch(cursor);
+      if (base >= count) break;
+      uint32_t i = base + lane;
+      if (i < count) {
+         float4 ro = ray_o[i], rd = ray_d[i];
+         Hit h;
+         occluded[i] = traverse<true, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, INFINITY, h, lds_col, n_nodes, n_tris) ? 1u : 0u;
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// generate — reference.rgen:24-40: RNG init, payload seed copy, jitter, primary ray
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState ps, Control* ctl, uint32_t sample) {
+   const uint32_t n = fp.W * fp.H;
+   for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+      uint32_t id = base + threadIdx.x;
+      bool own = false;
+      if (id < n) {
+         uint32_t px = id % fp.W, py = id / fp.W;
+         own = owns_pixel(fp, px, py);
+         if (own) {
+            uint32_t rng = sample == 0 ? init_rng(px, py, fp.W, fp.frame_number) : ps.rng[id].x;  // rgen:24
+            uint32_t seed = rng;                                                                 // rgen:30
+            float jx = random_float(rng), jy = random_float(rng);                                // rgen:31
+            V3 o, d;
+            primary_ray(fp, px, py, jx, jy, o, d);
+            ps.ray_o[id] = make_float4(o.x, o.y, o.z, 0.001f);
+            ps.ray_d[id] = make_float4(d.x, d.y, d.z, 10000.0f);
+            ps.thr[id] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            ps.rad[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            ps.rng[id] = make_uint2(rng, seed);
+            if (sample == 0) ps.pixcol[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+         }
+      }
+      uint32_t slot = wave_append(&ctl->q_count[0 * kQueueKinds + Q_RAY], own);
+      if (own) ps.queue[0][slot] = id;
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// shade_miss — reference.rmiss:10-31 + rgen:48-57 for paths whose ray left the scene
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState ps, const uint32_t* __restrict__ queue,
+                                                       const uint32_t* __restrict__ count_ptr) {
+   const uint32_t count = *count_ptr;
+   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+      uint32_t id = queue[i];
+      V3 sky_color = v3(0.0f, 0.0f, 0.0f);
+      if (fp.sky_enabled == 1) {
+         float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
+         V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
+         sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
+      }
+      float4 thr = ps.thr[id], rad = ps.rad[id];
+      V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
+      ps.rad[id] = make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w);   // rgen:55
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// shade_hit — reference.rchit:20-92 + rgen:48-61 and the light-sample selection of rgen:81-110
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float schlick_reflectance(float cosine, float ref_idx) {  // rchit:12-18
+   float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+   r0 = r0 * r0;
+   float x = 1.0f - cosine;
+   float x5 = ((x * x) * (x * x)) * x;  // pow(x, 5.0)
+   return r0 + (1.0f - r0) * x5;
+}
+__device__ __forceinline__ V3 reflect3(V3 I, V3 N) { return I - N * (2.0f * dot3(N, I)); }
+__device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
+   float dn = dot3(N, I);
+   float k = 1.0f - eta * eta * (1.0f - dn * dn);
+   if (k < 0.0f) return v3(0, 0, 0);
+   return I * eta - N * (eta * dn + sqrtf(k));
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, const UhReservoir* __restrict__ spatial_reservoirs,
+                                                      Control* ctl, DeviceStats* stats, uint32_t bounce) {
+   const uint32_t count = ctl->q_count[bounce * kQueueKinds + Q_HIT];
+   const uint32_t* __restrict__ queue = ps.queue[2];
+   uint32_t* q_next = ps.queue[(bounce + 1) & 1];
+   uint32_t* n_next = &ctl->q_count[(bounce + 1) * kQueueKinds + Q_RAY];
+   uint32_t* q_light = ps.queue[4];
+   uint32_t* n_light = &ctl->q_count[bounce * kQueueKinds + Q_LIGHT];
+   const uint32_t rounds = (count + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+   for (uint32_t r = 0; r < rounds; r++) {
+      uint32_t i = (r * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      bool scattered = false, want_light = false;
+      uint32_t id = 0;
+      if (i < count) {
+         id = queue[i];
+         float4 hr = ps.hit[id];
+         float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
+         const V3 ray_dir = v3(rd.x, rd.y, rd.z);
+         const float t = hr.x, bu = hr.y, bv = hr.z;
+         const uint32_t pk = __float_as_uint(hr.w);
+         const float4* sp = sc.shade + 4 * (size_t)pk;
+         float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+         const V3 n0 = v3(s0.x, s0.y, s0.z), n1 = v3(s0.w, s1.x, s1.y), n2 = v3(s1.z, s1.w, s2.x);
+         const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
+         const uint32_t mesh_index = __float_as_uint(s3.w);
+         const MeshShade ms = sc.meshes[mesh_index];                                   // rchit:22-23
+         const float bx = 1.0f - bu - bv, by = bu, bz = bv;                            // rchit:30
+         V3 normal = (n0 * bx + n1 * by) + n2 * bz;                                    // rchit:31
+         V3 wn = v3((normal.x * ms.w2o[0] + normal.y * ms.w2o[3]) + normal.z * ms.w2o[6],
+                    (normal.x * ms.w2o[1] + normal.y * ms.w2o[4]) + normal.z * ms.w2o[7],
+                    (normal.x * ms.w2o[2] + normal.y * ms.w2o[5]) + normal.z * ms.w2o[8]);  // rchit:32
+         V3 world_normal = normalize3(wn);
+         if (dot3(world_normal, ray_dir) > 0.0f) world_normal = vneg(world_normal);   // rchit:35-37
+         float uu = (uv0x * bx + uv1x * by) + uv2x * bz;                               // rchit:39
+         float vv = (uv0y * bx + uv1y * by) + uv2y * bz;
+         V3 color = sample_texture(sc, ms.diffuse_map, uu, vv);                        // rchit:40
+         color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
+
+         uint2 rng = ps.rng[id];
+         uint32_t seed = rng.y;
+         V3 scatter = v3(0, 0, 0);
+         if (ms.type == 0.0f) {                                                        // rchit:47-50
+            scatter = world_normal + random_point_in_unit_sphere(seed);
+            scattered = dot3(ray_dir, world_normal) < 0.0f;
+         } else if (ms.type == 1.0f) {                                                 // rchit:52-59
+            scatter = reflect3(normalize3(ray_dir), world_normal);
+            scatter = scatter + ms.property * random_point_in_unit_sphere(seed);
+            scattered = true;
+            color = v3(1, 1, 1);
+         } else if (ms.type == 2.0f) {                                                 // rchit:61-83
+            V3 nd = normalize3(ray_dir);
+            float dnd = dot3(nd, world_normal);
+            V3 outward = dnd > 0 ? vneg(world_normal) : world_normal;
+            float ratio = ms.property;
+            ratio = dnd > 0 ? ratio : 1.0f / ratio;
+            float cos_theta = fminf(dot3(-1.0f * nd, outward), 1.0f);
+            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            bool cannot_refract = ratio * sin_theta > 1.0f;
+            float reflectance = schlick_reflectance(cos_theta, ratio);
+            if (cannot_refract || reflectance > random_float(seed))
+               scatter = reflect3(nd, outward);
+            else
+               scatter = refract3(nd, outward, ratio);
+            scattered = true;
+            color = v3(1, 1, 1);
+         } else {                                                                      // rchit:85-89
+            scattered = false;
+            color = v3(1, 1, 1);
+         }
+         rng.y = seed;                                                                 // rchit:91
+
+         float4 thr4 = ps.thr[id], rad4 = ps.rad[id];
+         V3 thr = v3(thr4.x, thr4.y, thr4.z) * color;                                  // rgen:48
+         if (!scattered) {                                                             // rgen:53-57
+            ps.rad[id] = make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, rad4.w);
+            ps.rng[id] = rng;
+         } else {
+            V3 origin = v3(ro.x, ro.y, ro.z) + t * ray_dir;                            // rgen:59
+            origin = offset_ray(origin, world_normal);                                 // rgen:60
+            ps.ray_o[id] = make_float4(origin.x, origin.y, origin.z, 0.001f);
+            ps.ray_d[id] = make_float4(scatter.x, scatter.y, scatter.z, 10000.0f);     // rgen:61
+            float f = 0.0f;
+            int light_index = 0;
+            if (fp.lights_enabled == 1) {                                              // rgen:81-110
+               float light_sample_weight = 0.0f, total_weights = 1.0f;
+               uint32_t px = id % fp.W;
+               bool use_reservoir = (px > fp.W / 2 || fp.full_frame_restir) && fp.use_ris == 1;  // rgen:87
+               if (use_reservoir) {
+                  UhReservoir rs = spatial_reservoirs[id];                             // rgen:98
+                  light_sample_weight = rs.W_X;
+                  total_weights = rs.W_sum;
+                  light_index = rs.Y;
+               } else {
+                  sample_light_uniform(fp.num_lights_used, rng.x, light_index, light_sample_weight);  // rgen:107
+                  light_sample_weight = 1.0f / light_sample_weight;                    // rgen:108
+               }
+               if (total_weights != 0.0f) {                                            // rgen:112
+                  want_light = true;
+                  f = target_function(sc.lights, sc.num_lights, light_index, origin) * light_sample_weight;  // rgen:121
+               }
+            }
+            ps.thr[id] = make_float4(thr.x, thr.y, thr.z, f);
+            ps.rad[id] = make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index));
+            ps.rng[id] = rng;
+         }
+      }
+      uint32_t slot = wave_append(n_next, scattered);
+      if (scattered) q_next[slot] = id;
+      slot = wave_append(n_light, want_light);
+      if (want_light) q_light[slot] = id;
+   }
+   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->closest_hits, (unsigned long long)count);
+}
+
+__global__ void k_count_misses(Control* ctl, DeviceStats* stats, uint32_t bounce) {
+   atomicAdd(&stats->misses, (unsigned long long)ctl->q_count[bounce * kQueueKinds + Q_MISS]);
+}
+
+// ------------------------------------------------------------------------------------------
+// finish_sample — reference.rgen:127 (pixelColor += radiance) and, after the last sample of the
+// frame, rgen:130-144 (accumulate, sRGB, store both images)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uchar4 resolve_color(float4 acc, uint32_t total_samples, uint32_t limit) {
+   float denom = (float)min(total_samples, limit);
+   V3 c = v3(acc.x / denom, acc.y / denom, acc.z / denom);                               // rgen:140
+   c = v3(linear_to_srgb(c.x), linear_to_srgb(c.y), linear_to_srgb(c.z));               // rgen:141
+   return make_uchar4((unsigned char)unorm8(c.z), (unsigned char)unorm8(c.y), (unsigned char)unorm8(c.x), 0);  // B8G8R8A8, alpha 0
+}
+
+__global__ __launch_bounds__(kBlock) void k_finish_sample(FrameParams fp, PathState ps, Images im, bool last) {
+   const uint32_t n = fp.W * fp.H;
+   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+      uint32_t px = id % fp.W, py = id / fp.W;
+      if (!owns_pixel(fp, px, py)) continue;
+      float4 pc = ps.pixcol[id], rad = ps.rad[id];
+      pc = make_float4(pc.x + rad.x, pc.y + rad.y, pc.z + rad.z, 0.0f);                  // rgen:127
+      if (!last) {
+         ps.pixcol[id] = pc;
+         continue;
+      }
+      float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (fp.total_samples != fp.samples_per_frame) acc = im.accumulation[id];          // rgen:131-134
+      if (fp.total_samples <= fp.accumulation_limit) acc = make_float4(acc.x + pc.x, acc.y + pc.y, acc.z + pc.z, 0.0f);  // rgen:136-138
+      acc.w = 0.0f;
+      im.accumulation[id] = acc;                                                         // rgen:143
+      im.output[id] = resolve_color(acc, fp.total_samples, fp.accumulation_limit);       // rgen:144
+   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_resolve(Images im, uint32_t n, uint32_t total_samples, uint32_t limit) {
+   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock)
+      im.output[id] = resolve_color(im.accumulation[id], total_samples, limit);
+}
+
+// ------------------------------------------------------------------------------------------
+// G-buffer position by primary-ray cast (replaces the raster gbuffer_pass for this input only:
+// utopian/src/renderers/gbuffer.rs:11-52, shaders/gbuffer/gbuffer.frag:47; clear colour
+// (1,1,1,0): utopian/src/pass.rs:210-214)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_gbuffer_generate(FrameParams fp, PathState ps) {
+   const uint32_t n = fp.W * fp.H;
+   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+      V3 o, d;
+      primary_ray(fp, id % fp.W, id / fp.W, 0.5f, 0.5f, o, d);
+      ps.ray_o[id] = make_float4(o.x, o.y, o.z, 0.001f);
+      ps.ray_d[id] = make_float4(d.x, d.y, d.z, 10000.0f);
+   }
+}
+__global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(FrameParams fp, PathState ps, Images im, DeviceStats* stats) {
+   const uint32_t n = fp.W * fp.H;
+   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+      float4 h = ps.hit[id];
+      if (__float_as_uint(h.w) != kEmptyRef) {
+         float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
+         V3 p = v3(ro.x, ro.y, ro.z) + h.x * v3(rd.x, rd.y, rd.z);
+         im.gbuffer_pos[id] = make_float4(p.x, p.y, p.z, 1.0f);
+      } else {
+         im.gbuffer_pos[id] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+      }
+   }
+   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[UH_RAY_GBUFFER], (unsigned long long)n);
+}
+
+// texture(in_gbuffer_position, vec2(px) / vec2(size)) through the LINEAR + MIRRORED_REPEAT sampler
+// (restir/initial_ris.rgen:22-23): the texel corner, i.e. the mean of the 2x2 texels up-left
+__device__ __forceinline__ V3 gbuffer_fetch(const float4* __restrict__ g, uint32_t W, uint32_t px, uint32_t py) {
+   uint32_t x0 = px == 0 ? 0 : px - 1, y0 = py == 0 ? 0 : py - 1;
+   float4 a = g[(size_t)y0 * W + x0], b = g[(size_t)y0 * W + px], c = g[(size_t)py * W + x0], d = g[(size_t)py * W + px];
+   return ((xyz(a) + xyz(b)) + (xyz(c) + xyz(d))) * 0.25f;
+}
+
+// ------------------------------------------------------------------------------------------
+// ReSTIR passes. The light table (pos + intensity, 32 B/light, <= 32 KiB) is staged in LDS.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kMaxLdsLights = UH_MAX_GPU_LIGHTS;
+
+__device__ __forceinline__ void stage_lights(float4* s_lights, const SceneDev& sc) {
+   for (uint32_t i = threadIdx.x; i < 2 * sc.num_lights; i += blockDim.x) s_lights[i] = sc.lights[i];
+   __syncthreads();
+}
+
+// restir/reset_reservoirs.comp:24-45
+__global__ __launch_bounds__(kBlock) void k_reset_reservoirs(Images im, uint32_t n) {
+   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+      UhReservoir z = {-1, 0.0f, 0.0f, 0};
+      im.reservoirs[0][id] = z;
+      im.reservoirs[1][id] = z;
+   }
+}
+
+// restir/initial_ris.rgen:19-39 + restir_sampling.glsl:96-131 (resample, 32 candidates)
+__global__ __launch_bounds__(kBlock) void k_initial_ris(FrameParams fp, SceneDev sc, Images im) {
+   __shared__ float4 s_lights[2 * kMaxLdsLights];
+   stage_lights(s_lights, sc);
+   const uint32_t n = fp.W * fp.H;
+   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+      uint32_t px = id % fp.W, py = id / fp.W;
+      uint32_t rng = init_rng(px, py, fp.W, fp.frame_number);
+      V3 hit_position = gbuffer_fetch(im.gbuffer_pos, fp.W, px, py);
+      UhReservoir r = {-1, 0.0f, 0.0f, 0};
+      for (int i = 0; i < 32; i++) {
+         int cand;
+         float p;
+         sample_light_uniform(fp.num_lights_used, rng, cand, p);
+         float m_i = 1.0f / 32.0f;
+         float p_hat = target_function(s_lights, sc.num_lights, cand, hit_position);
+         float W_Xi = 1.0f / p;
+         float w_i = m_i * p_hat * W_Xi;
+         update_reservoir(rng, r, cand, w_i, 1);
+      }
+      r.M = 1;
+      if (r.Y != -1) finalize_resampling(r, target_function(s_lights, sc.num_lights, r.Y, hit_position));
+      UhReservoir nr = {-1, 0.0f, 0.0f, 0};
+      update_reservoir(rng, nr, r.Y, r.W_sum * (float)r.M, r.M);
+      finalize_resampling(nr, target_function(s_lights, sc.num_lights, nr.Y, hit_position));
+      im.reservoirs[0][id] = nr;
+   }
+}
+
+// restir/temporal_reuse.rgen:35-119
+__global__ __launch_bounds__(kBlock) void k_temporal_reuse(FrameParams fp, SceneDev sc, Images im) {
+   __shared__ float4 s_lights[2 * kMaxLdsLights];
+   stage_lights(s_lights, sc);
+   const uint32_t n = fp.W * fp.H;
+   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+      if (fp.temporal_enabled == 0) {
+         im.reservoirs[1][id] = im.reservoirs[0][id];
+         continue;
+      }
+      uint32_t px = id % fp.W, py = id / fp.W;
+      uint32_t rng = init_rng(px, py, fp.W, fp.frame_number);
+      V3 hit_position = gbuffer_fetch(im.gbuffer_pos, fp.W, px, py);
+      UhReservoir nr = {-1, 0.0f, 0.0f, 0};
+      UhReservoir ir = im.reservoirs[0][id];
+      float p_hat = target_function(s_lights, sc.num_lights, ir.Y, hit_position);
+      update_reservoir(rng, nr, ir.Y, p_hat * ir.W_X * (float)ir.M, ir.M);
+      UhReservoir pr = {-1, 0.0f, 0.0f, 0};
+      float4 puv = mat4_mul(fp.prev_pv, hit_position.x, hit_position.y, hit_position.z, 1.0f);
+      float ux = puv.x / puv.w, uy = puv.y / puv.w;
+      ux = ux * 0.5f + 0.5f;
+      uy = uy * 0.5f + 0.5f;
+      uy = 1.0f - uy;
+      if (ux >= 0.0f && ux <= 1.0f && uy >= 0.0f && uy <= 1.0f) {
+         int ix = (int)(ux * (float)fp.W + 0.5f), iy = (int)(uy * (float)fp.H + 0.5f);
+         uint32_t ti = (uint32_t)iy * fp.W + (uint32_t)ix;  // may be one past the end in the reference (y == H)
+         if (ti > n - 1) ti = n - 1;
+         pr = im.reservoirs[2][ti];  // last frame's spatial_reuse_reservoirs (renderers/mod.rs:294)
+      }
+      p_hat = pr.Y == -1 ? 0.0f : target_function(s_lights, sc.num_lights, pr.Y, hit_position);
+      pr.M = min(20 * ir.M, pr.M);
+      update_reservoir(rng, nr, pr.Y, p_hat * pr.W_X * (float)pr.M, pr.M);
+      if (nr.Y != -1) finalize_resampling(nr, target_function(s_lights, sc.num_lights, nr.Y, hit_position));
+      im.reservoirs[1][id] = nr;
+   }
+}
+
+// restir/spatial_reuse.rgen:23-73
+__global__ __launch_bounds__(kBlock) void k_spatial_reuse(FrameParams fp, SceneDev sc, Images im) {
+   __shared__ float4 s_lights[2 * kMaxLdsLights];
+   stage_lights(s_lights, sc);
+   const uint32_t n = fp.W * fp.H;
+   const UhReservoir* __restrict__ temporal = im.reservoirs[1];
+   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+      if (fp.spatial_enabled == 0) {
+         im.reservoirs[2][id] = temporal[id];
+         continue;
+      }
+      uint32_t px = id % fp.W, py = id / fp.W;
+      uint32_t rng = init_rng(px, py, fp.W, fp.frame_number);
+      V3 hit_position = gbuffer_fetch(im.gbuffer_pos, fp.W, px, py);
+      UhReservoir nr = {-1, 0.0f, 0.0f, 0};
+      UhReservoir tr = temporal[id];
+      float p_hat = target_function(s_lights, sc.num_lights, tr.Y, hit_position);
+      update_reservoir(rng, nr, tr.Y, p_hat * tr.W_X * (float)tr.M, tr.M);
+      for (int i = 0; i < 5; i++) {
+         float ox = random_float(rng) * 2.0f - 1.0f, oy = random_float(rng) * 2.0f - 1.0f;
+         ox *= 30.0f;
+         oy *= 30.0f;
+         // uvec2(offset) of a negative float: pinned as (uint)(int)trunc(x); clamp(uvec2) then
+         // sends a wrapped-negative coordinate to size-1
+         uint32_t nx = px + (uint32_t)(int)ox, ny = py + (uint32_t)(int)oy;
+         nx = min(nx, fp.W - 1);
+         ny = min(ny, fp.H - 1);
+         UhReservoir nb = temporal[(size_t)ny * fp.W + nx];
+         float ph = target_function(s_lights, sc.num_lights, nb.Y, hit_position);
+         update_reservoir(rng, nr, nb.Y, ph * nb.W_X * (float)nb.M, nb.M);
+      }
+      if (nr.Y != -1) finalize_resampling(nr, target_function(s_lights, sc.num_lights, nr.Y, hit_position));
+      im.reservoirs[2][id] = nr;
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU tile pack / unpack of the RGBA32F accumulation image
+// ------------------------------------------------------------------------------------------
+template <bool PACK>
+__global__ __launch_bounds__(kBlock) void k_tiles(float4* acc, float4* packed, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile) {
+   const uint32_t tiles_x = (W + tile - 1) / tile, tiles_y = (H + tile - 1) / tile;
+   const uint32_t num_tiles = tiles_x * tiles_y;
+   const uint32_t owned = num_tiles > rank ? (num_tiles - rank + world - 1) / world : 0;
+   const uint64_t total = (uint64_t)owned * tile * tile;
+   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+      uint32_t local = (uint32_t)(i / (tile * tile)), within = (uint32_t)(i % (tile * tile));
+      uint32_t t = rank + local * world;
+      uint32_t x = (t % tiles_x) * tile + within % tile, y = (t / tiles_x) * tile + within / tile;
+      bool inside = x < W && y < H;
+      if (PACK)
+         packed[i] = inside ? acc[(size_t)y * W + x] : make_float4(0, 0, 0, 0);
+      else if (inside)
+         acc[(size_t)y * W + x] = packed[i];
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+static inline dim3 stream_grid(const LaunchCfg& c, uint32_t n) {
+   uint32_t blocks = (n + kBlock - 1) / kBlock;
+   uint32_t cap = c.num_cus * 8;
+   return dim3(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+static inline dim3 trace_grid(const LaunchCfg& c) { return dim3(c.num_cus * c.trace_blocks_per_cu); }
+
+uint32_t query_trace_occupancy() {
+   int a = 0, b = 0;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<false, false>, kBlock, 0) != hipSuccess) a = 4;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kBlock, 0) != hipSuccess) b = 4;
+   int m = a < b ? a : b;
+   if (m < 1) m = 1;
+   if (m > 8) m = 8;
+   return (uint32_t)m;
+}
+
+void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, uint32_t sample) {
+   k_generate<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ctl, sample);
+}
+
+void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+                          uint32_t cursor_slot, int ray_kind) {
+   const uint32_t* queue = ps.queue[bounce & 1];
+   const uint32_t* count = &ctl->q_count[bounce * kQueueKinds + Q_RAY];
+   uint32_t* n_hit = &ctl->q_count[bounce * kQueueKinds + Q_HIT];
+   uint32_t* n_miss = &ctl->q_count[bounce * kQueueKinds + Q_MISS];
+   if (c.count_visits)
+      k_trace_closest<true, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, queue, count, 0, &ctl->cursor[cursor_slot],
+                                                                          ps.queue[2], n_hit, ps.queue[3], n_miss, stats, ray_kind);
+   else
+      k_trace_closest<false, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, queue, count, 0, &ctl->cursor[cursor_slot],
+                                                                           ps.queue[2], n_hit, ps.queue[3], n_miss, stats, ray_kind);
+}
+
+void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, uint32_t bounce) {
+   k_shade_miss<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ps.queue[3], &ctl->q_count[bounce * kQueueKinds + Q_MISS]);
+}
+
+void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
+                      DeviceStats* stats, uint32_t bounce) {
+   k_shade_hit<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, im.reservoirs[2], ctl, stats, bounce);
+   k_count_misses<<<1, 1, 0, c.stream>>>(ctl, stats, bounce);
+}
+
+void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
+                         uint32_t bounce, uint32_t cursor_slot, bool light) {
+   uint32_t* cursor = &ctl->cursor[cursor_slot];
+   if (light) {
+      const uint32_t* count = &ctl->q_count[bounce * kQueueKinds + Q_LIGHT];
+      if (c.count_visits)
+         k_trace_shadow<true, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ps.queue[4], count, cursor, stats);
+      else
+         k_trace_shadow<false, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ps.queue[4], count, cursor, stats);
+   } else {
+      const uint32_t* count = &ctl->q_count[(bounce + 1) * kQueueKinds + Q_RAY];
+      const uint32_t* queue = ps.queue[(bounce + 1) & 1];
+      if (c.count_visits)
+         k_trace_shadow<true, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, queue, count, cursor, stats);
+      else
+         k_trace_shadow<false, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, queue, count, cursor, stats);
+   }
+}
+
+void launch_finish_sample(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, const Images& im, uint32_t sample, bool last) {
+   (void)sample;
+   k_finish_sample<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, im, last);
+}
+
+void launch_resolve(const LaunchCfg& c, const Images& im, uint32_t W, uint32_t H, uint32_t total_samples, uint32_t limit) {
+   k_resolve<<<stream_grid(c, W * H), kBlock, 0, c.stream>>>(im, W * H, total_samples, limit);
+}
+
+void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
+                    DeviceStats* stats) {
+   const uint32_t n = fp.W * fp.H;
+   k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps);
+   // identity queue, cursor = the last launch slot of the (already zeroed) control block
+   k_trace_closest<false, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, nullptr, nullptr, n, &ctl->cursor[kLaunchSlots - 1],
+                                                                       nullptr, nullptr, nullptr, nullptr, stats, UH_RAY_GBUFFER);
+   k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats);
+}
+
+void launch_reset_reservoirs(const LaunchCfg& c, const FrameParams& fp, const Images& im) {
+   k_reset_reservoirs<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(im, fp.W * fp.H);
+}
+void launch_initial_ris(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const Images& im) {
+   k_initial_ris<<<dim3(c.num_cus * 4), kBlock, 0, c.stream>>>(fp, sc, im);
+}
+void launch_temporal_reuse(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const Images& im) {
+   k_temporal_reuse<<<dim3(c.num_cus * 4), kBlock, 0, c.stream>>>(fp, sc, im);
+}
+void launch_spatial_reuse(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const Images& im) {
+   k_spatial_reuse<<<dim3(c.num_cus * 4), kBlock, 0, c.stream>>>(fp, sc, im);
+}
+
+void launch_trace_closest_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n, uint32_t* cursor) {
+   k_trace_closest<false, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, hit, nullptr, nullptr, n, cursor, nullptr, nullptr, nullptr,
+                                                                       nullptr, nullptr, 0);
+}
+void launch_trace_any_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n, uint32_t* cursor) {
+   k_trace_any_raw<false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, occluded, n, cursor);
+}
+
+void launch_pack_tiles(const LaunchCfg& c, const float4* acc, float4* out, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile) {
+   k_tiles<true><<<stream_grid(c, W * H), kBlock, 0, c.stream>>>(const_cast<float4*>(acc), out, W, H, rank, world, tile);
+}
+void launch_unpack_tiles(const LaunchCfg& c, float4* acc, const float4* in, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile) {
+   k_tiles<false><<<stream_grid(c, W * H), kBlock, 0, c.stream>>>(acc, const_cast<float4*>(in), W, H, rank, world, tile);
+}
+
+}  // namespace uh

@@ -1,0 +1,186 @@
+"""-m gpu: the HIP path (called through the C ABI) against the CPU oracle on the same seeded
+inputs. Integer results (hit ids, ray counts, reservoir Y / M) are compared bit-exactly; linear
+radiance within the per-pixel L2 tolerance BASELINE.json states (1e-3); the 8-bit output image
+within 1 LSB (sRGB pow differs by an ulp between libm and the device library)."""
+import numpy as np
+import pytest
+
+import oracle_api as oa
+import rust_renderer_amd as rr
+from util import L2_TOL, make_pair, per_pixel_l2, random_rays, run_frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cornell():
+    return rr.scenes.cornell_scene(subdivisions=2, tex_size=16)
+
+
+@pytest.fixture(scope="module")
+def atrium():
+    return rr.scenes.sponza_class_scene(detail=0.12, tex_size=32, with_spheres=True, num_lights=64, sphere_subdivisions=2)
+
+
+def test_trace_closest_bit_exact(atrium):
+    gpu, cpu = make_pair(atrium, 8, 8)
+    rays = random_rays(((-15, 0.2, -7), (15, 9, 7)), 200_000, seed=11)
+    tg, mg, pg = gpu.trace_closest(rays)
+    tc, mc, pc = cpu.trace_closest(rays)
+    assert np.array_equal(mg, mc) and np.array_equal(pg, pc)
+    assert np.array_equal(tg.view(np.uint32), tc.view(np.uint32)), "t/u/v must match the oracle bit for bit"
+    assert (mg != 0xFFFFFFFF).mean() > 0.5
+
+
+def test_trace_closest_matches_brute_force(cornell):
+    gpu, cpu = make_pair(cornell, 8, 8, brute_force=True)
+    rays = random_rays(((-0.9, 0.1, -0.9), (0.9, 1.9, 0.9)), 20_000, seed=5)
+    tg, mg, pg = gpu.trace_closest(rays)
+    tc, mc, pc = cpu.trace_closest(rays)
+    assert np.array_equal(mg, mc) and np.array_equal(pg, pc)
+    assert np.array_equal(tg.view(np.uint32), tc.view(np.uint32))
+
+
+def test_trace_any_matches_closest(atrium):
+    gpu, cpu = make_pair(atrium, 8, 8)
+    rays = random_rays(((-15, 0.2, -7), (15, 9, 7)), 100_000, seed=3, tmax=6.0)
+    occ = gpu.trace_any(rays)
+    _, mc, _ = cpu.trace_closest(rays)
+    assert np.array_equal(occ.astype(bool), mc != 0xFFFFFFFF)
+
+
+def test_axis_aligned_and_degenerate_rays(atrium):
+    gpu, cpu = make_pair(atrium, 8, 8)
+    dirs = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 0.9863939, 0.1643990], [1, 1, 0], [0, 1e-20, 1]], dtype=np.float32)
+    base = random_rays(((-15, 0.2, -7), (15, 9, 7)), 4096, seed=17)
+    rays = np.repeat(base, len(dirs), axis=0)
+    rays[:, 4:7] = np.tile(dirs, (len(base), 1))
+    tg, mg, pg = gpu.trace_closest(rays)
+    tc, mc, pc = cpu.trace_closest(rays)
+    assert np.array_equal(mg, mc) and np.array_equal(pg, pc)
+    assert np.array_equal(tg.view(np.uint32), tc.view(np.uint32))
+
+
+@pytest.mark.parametrize("frames,spp", [(1, 1), (3, 1), (2, 3)])
+def test_path_trace_matches_oracle(cornell, frames, spp):
+    W, H = 96, 80
+    gpu, cpu = make_pair(cornell, W, H)
+    for r in (gpu, cpu):
+        run_frames(r, cornell, W, H, frames, rr.PASS_REFERENCE_PT, samples_per_frame=spp)
+    total = frames * spp
+    a, b = gpu.read_accumulation(), cpu.read_accumulation()
+    assert np.isfinite(a).all()
+    l2 = per_pixel_l2(a / total, b / total)
+    assert l2 <= L2_TOL, f"per-pixel L2 {l2}"
+    sg, sc = gpu.get_stats(), cpu.get_stats()
+    assert list(sg.rays)[:4] == list(sc.rays)[:4], "ray counts by kind must equal the oracle's"
+    assert sg.closest_hits == sc.closest_hits and sg.misses == sc.misses
+    og, oc = gpu.read_output_bgra8().astype(np.int32), cpu.read_output_bgra8().astype(np.int32)
+    assert np.abs(og - oc).max() <= 1
+    assert (og[..., 3] == 0).all()
+
+
+def test_path_trace_atrium_all_materials(atrium):
+    W, H = 160, 90
+    gpu, cpu = make_pair(atrium, W, H)
+    for r in (gpu, cpu):
+        run_frames(r, atrium, W, H, 2, rr.PASS_REFERENCE_PT, use_ris_light_sampling=0)
+    a, b = gpu.read_accumulation(), cpu.read_accumulation()
+    l2 = per_pixel_l2(a / 2, b / 2)
+    assert l2 <= L2_TOL, f"per-pixel L2 {l2}"
+    assert list(gpu.get_stats().rays)[:4] == list(cpu.get_stats().rays)[:4]
+
+
+def test_gbuffer_and_restir_chain_bit_exact(atrium):
+    W, H = 128, 72
+    gpu, cpu = make_pair(atrium, W, H)
+    for r in (gpu, cpu):
+        run_frames(r, atrium, W, H, 3, rr.PASS_RESTIR)
+    gg, gc = gpu.read_gbuffer_position(), cpu.read_gbuffer_position()
+    assert np.array_equal(gg.view(np.uint32), gc.view(np.uint32)), "G-buffer positions must match bit for bit"
+    for which in range(3):
+        rg, rc = gpu.read_reservoirs(which), cpu.read_reservoirs(which)
+        assert np.array_equal(rg["Y"], rc["Y"]) and np.array_equal(rg["M"], rc["M"]), f"reservoir {which} Y/M"
+        assert np.array_equal(rg["W_sum"].view(np.uint32), rc["W_sum"].view(np.uint32)), f"reservoir {which} W_sum"
+        assert np.array_equal(rg["W_X"].view(np.uint32), rc["W_X"].view(np.uint32)), f"reservoir {which} W_X"
+    assert (gpu.read_reservoirs(2)["M"] > 1).any(), "temporal history must build up over frames"
+
+
+def test_full_frame_with_restir(atrium):
+    W, H = 128, 72
+    gpu, cpu = make_pair(atrium, W, H)
+    for r in (gpu, cpu):
+        run_frames(r, atrium, W, H, 3, rr.PASS_ALL)
+    a, b = gpu.read_accumulation(), cpu.read_accumulation()
+    l2 = per_pixel_l2(a / 3, b / 3)
+    assert l2 <= L2_TOL, f"per-pixel L2 {l2}"
+    assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays)
+
+
+def test_restir_flags_off_copy_through(atrium):
+    W, H = 64, 36
+    gpu, cpu = make_pair(atrium, W, H)
+    for r in (gpu, cpu):
+        run_frames(r, atrium, W, H, 2, rr.PASS_RESTIR, temporal_reuse_enabled=0, spatial_reuse_enabled=0)
+    r0, r2 = gpu.read_reservoirs(0), gpu.read_reservoirs(2)
+    assert np.array_equal(r0.view(np.uint8), r2.view(np.uint8))
+    assert np.array_equal(r2.view(np.uint8), cpu.read_reservoirs(2).view(np.uint8))
+
+
+def test_tile_partition_composes_to_full_frame(cornell):
+    W, H = 96, 80
+    world, tile = 3, 16
+    full = cornell.upload(rr.Renderer(W, H))
+    run_frames(full, cornell, W, H, 2, rr.PASS_REFERENCE_PT)
+    ref = full.read_accumulation()
+    root = None
+    import torch  # device staging buffers only (the tiles travel as plain device pointers)
+
+    parts = []
+    for rank in range(world):
+        r = cornell.upload(rr.Renderer(W, H))
+        r.set_tile_partition(rank, world, tile)
+        run_frames(r, cornell, W, H, 2, rr.PASS_REFERENCE_PT)
+        n = r.tile_pack_count(rank)
+        buf = torch.empty((n, 4), dtype=torch.float32, device="cuda:0")
+        r.pack_tiles(buf.data_ptr(), n)
+        parts.append((rank, buf))
+        if rank == 0:
+            root = r
+    for rank, buf in parts[1:]:
+        root.unpack_tiles(rank, buf.data_ptr(), buf.shape[0])
+    root.resolve_output(2)
+    assert np.array_equal(root.read_accumulation().view(np.uint32), ref.view(np.uint32)), "tile-partitioned frame must be bit-identical"
+    assert np.array_equal(root.read_output_bgra8(), full.read_output_bgra8())
+
+
+def test_error_paths():
+    r = rr.Renderer(16, 16)
+    with pytest.raises(rr.UtopianError, match="NOT_BUILT"):
+        r.render_frame(rr.scenes.cornell_scene(1, 4).make_view(16, 16))
+    with pytest.raises(rr.UtopianError):
+        r.set_instance_transform(5, rr.identity3x4())
+    with pytest.raises(rr.UtopianError):
+        r.set_option("no_such_option", 1)
+
+
+def test_empty_scene_renders_sky():
+    W, H = 32, 32
+    scene = rr.scenes.Scene("empty", [], [], rr.camera.Camera((0, 1, 0), (0, 1, -1), 60.0, 1.0), dict(lights_enabled=0))
+    gpu, cpu = make_pair(scene, W, H)
+    for r in (gpu, cpu):
+        run_frames(r, scene, W, H, 1, rr.PASS_REFERENCE_PT)
+    a, b = gpu.read_accumulation(), cpu.read_accumulation()
+    assert per_pixel_l2(a, b) <= L2_TOL
+    assert a[..., :3].max() > 0.05
+    assert gpu.get_stats().rays[0] == W * H and gpu.get_stats().rays[1] == 0
+
+
+def test_instance_transform_rebuild(cornell):
+    W, H = 64, 64
+    gpu, cpu = make_pair(cornell, W, H)
+    for r in (gpu, cpu):
+        r.set_instance_transform(6, rr.transform3x4((0.25, 0.35, 0.25), (-0.3, 0.5, 0.1)))
+        r.initialize_raytracing()
+        run_frames(r, cornell, W, H, 1, rr.PASS_REFERENCE_PT)
+    assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
