@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric: Mrays/s and ms/frame on the Sponza-class 1080p path trace.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one frame = one pass of reference_pt_pass over the 1920x1080 framebuffer at 1 sample per
+pixel and 5 bounces (the reference's per-frame dispatch, renderers/mod.rs:357; 64 steps = the
+64 spp headline image). The scene, BVH, textures and all path state are resident in HBM before the
+timed region. N > 1: the framebuffer is tile-partitioned (64x64 tiles, round-robin) — each rank
+traces only its tiles, and ONE RCCL gather of the RGBA32F accumulation tiles to rank 0 (inside the
+timed region, after the last step) composes the final image. Total work is fixed => "strong".
+
+Prints ONE JSON line (rank 0). `roofline` is for the dominant kernel, k_trace_closest, timed live
+with HIP events on the library's own stream; `cpu_baseline` is the CPU oracle on this box's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs index: 1 = Sponza-class diffuse (headline), 2 = + 1024 lights ReSTIR")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--tex-size", type=int, default=1024)
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=str, default="960x540x3", help="WxHxframes rendered by the CPU oracle")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
+        args.gpus = world
+
+    import numpy as np
+
+    import rust_renderer_amd as rr  # binds libutopian_hip.so to torch's bundled HIP runtime (api._preload_hip_runtime)
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    scene = rr.scenes.scene_for_config(args.config, detail=args.detail, tex_size=args.tex_size)
+    renderer = scene.upload(rr.Renderer(W, H, device=local_rank))
+    if world > 1:
+        renderer.set_tile_partition(rank, world, args.tile)
+    pass_mask = rr.PASS_REFERENCE_PT if args.config == 1 else rr.PASS_ALL
+    view = scene.make_view(W, H)
+    loop = rr.FrameLoop(renderer, view)
+
+    def sync_all():
+        renderer.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    # ---- untimed: one counted frame gives nodes / triangles visited per ray (deterministic)
+    renderer.set_option("count_visits", 1)
+    renderer.reset_stats()
+    loop.frame(pass_mask)
+    cs = renderer.get_stats()
+    closest_rays = cs.rays[rr.RAY_PRIMARY] + cs.rays[rr.RAY_BOUNCE]
+    nodes_per_ray = cs.nodes_visited / max(closest_rays, 1)
+    tris_per_ray = cs.tris_tested / max(closest_rays, 1)
+    renderer.set_option("count_visits", 0)
+
+    # ---- warmup
+    for _ in range(args.warmup):
+        loop.frame(pass_mask)
+    loop.reset()
+    renderer.reset_stats()
+    renderer.set_option("time_kernels", 1)
+
+    gather_buf = gather_list = None
+    if world > 1:
+        counts = [renderer.tile_pack_count(r) for r in range(world)]
+        gather_buf = torch.empty((max(counts), 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+        if rank == 0:
+            gather_list = [torch.empty_like(gather_buf) for _ in range(world)]
+
+    # ---- timed region: exactly K steps (+ the composition gather for N > 1)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loop.frame(pass_mask)
+    if world > 1:
+        renderer.pack_tiles(gather_buf.data_ptr(), gather_buf.shape[0])  # synchronises the renderer's stream
+        dist.gather(gather_buf, gather_list, dst=0)
+        if rank == 0:
+            torch.cuda.synchronize()
+            for r in range(1, world):
+                renderer.unpack_tiles(r, gather_list[r].data_ptr(), counts[r])
+            renderer.resolve_output(view.total_samples, view.accumulation_limit)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    st = renderer.get_stats()
+    my_rays = float(st.path_rays)
+    my_closest = float(st.rays[rr.RAY_PRIMARY] + st.rays[rr.RAY_BOUNCE])
+    if world > 1:
+        t = torch.tensor([elapsed, my_rays, my_closest, st.trace_closest_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, total_rays = float(tmax[0]), float(t[1])
+    else:
+        total_rays = my_rays
+
+    if rank == 0:
+        # roofline of the dominant kernel on THIS rank: algorithmic bytes per SURVEY.md §8d
+        # (48 B ray record + hit record, 128 B per BVH4 node visited, 48 B per triangle tested)
+        algo_bytes = my_closest * (48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0)
+        launches = max(st.trace_closest_launches, 1)
+        avg_ms = st.trace_closest_ms / launches
+        achieved = (algo_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_trace_closest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (path rays: primary + bounce + sun-shadow + light-shadow) at 1080p, 64 spp = 64 frames x 1 spp",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE.json configs[{args.config}]: Sponza-class procedural atrium ({scene.num_triangles} tris, {scene.num_meshes} meshes, 25 textured Lambertian materials), "
+                f"{W}x{H}, 1 spp/frame x {args.steps} frames, 5 bounces, sky + sun shadow rays" + (", 1024 lights ReSTIR DI" if args.config == 2 else ", lights off"),
+                "rays_per_frame": total_rays / args.steps,
+                "partition": f"{args.tile}x{args.tile} tiles round-robin over {world} rank(s), 1 RCCL gather" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": "k_trace_closest",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "avg_launch_ms": avg_ms,
+                "launches": st.trace_closest_launches,
+                "nodes_per_ray": nodes_per_ray,
+                "tris_per_ray": tris_per_ray,
+                "kernel_share_of_step": st.trace_closest_ms / (elapsed * 1e3),
+                "trace_shadow_ms": st.trace_shadow_ms,
+                "shade_ms": st.shade_ms,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, scene)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def usable_cores():
+    """host threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(args, scene):
+    """The CPU oracle (port of the reference shaders, oracle/oracle.cpp) on this box's host cores,
+    same scene / camera / flags, on a bounded sample of the workload."""
+    import oracle_api as oa
+    import rust_renderer_amd as rr
+
+    w, h, frames = (int(x) for x in args.cpu_sample.split("x"))
+    cores = usable_cores()
+    o = scene.upload(oa.OracleRenderer(w, h, threads=cores))
+    loop = rr.FrameLoop(o, scene.make_view(w, h))
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        loop.frame(rr.PASS_REFERENCE_PT if args.config == 1 else rr.PASS_ALL)
+    dt = time.perf_counter() - t0
+    s = o.get_stats()
+    return {
+        "value": s.path_rays / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"same scene and camera at {w}x{h}, {frames} frames x 1 spp, 5 bounces ({s.path_rays} rays in {dt:.1f} s)",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -70,11 +70,35 @@ class CApi:
         self.destroy.argtypes, self.destroy.restype = [vp], None
 
 
+_lib_cache = {}
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process. The PyTorch-ROCm wheel bundles its own libamdhip64.so (same
+    soname as /opt/rocm's); if both get loaded the second one sees no devices. When torch is
+    installed, load ITS copy first (by path, without importing torch): libutopian_hip.so then binds
+    to it by soname and a later `import torch` (bench.py's RCCL leg) reuses the same object."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library(path=LIB_PATH):
     """Load libutopian_hip.so. Fails loudly if it has not been built: there is no fallback."""
+    if path in _lib_cache:
+        return _lib_cache[path]
     if not os.path.exists(path):
         raise UtopianError(f"{path} not built - run `python -c 'import __graft_entry__ as g; g.build()'`")
+    _preload_hip_runtime()
     lib = C.CDLL(path)
+    _lib_cache[path] = lib
     lib.uh_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     lib.uh_create.restype = C.c_int
     lib.uh_last_error.argtypes, lib.uh_last_error.restype = [C.c_void_p], C.c_char_p
