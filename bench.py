@@ -99,25 +99,15 @@ def main():
     renderer.reset_stats()
     renderer.set_option("time_kernels", 1)
 
-    gather_buf = gather_list = None
-    if world > 1:
-        counts = [renderer.tile_pack_count(r) for r in range(world)]
-        gather_buf = torch.empty((max(counts), 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-        if rank == 0:
-            gather_list = [torch.empty_like(gather_buf) for _ in range(world)]
-
     # ---- timed region: exactly K steps (+ the composition gather for N > 1)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loop.frame(pass_mask)
     if world > 1:
-        renderer.pack_tiles(gather_buf.data_ptr(), gather_buf.shape[0])  # synchronises the renderer's stream
-        dist.gather(gather_buf, gather_list, dst=0)
+        # the ONE collective of the data path: RCCL gather of the packed accumulation tiles to rank 0
+        rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}")
         if rank == 0:
-            torch.cuda.synchronize()
-            for r in range(1, world):
-                renderer.unpack_tiles(r, gather_list[r].data_ptr(), counts[r])
             renderer.resolve_output(view.total_samples, view.accumulation_limit)
     sync_all()
     elapsed = time.perf_counter() - t0

@@ -236,7 +236,11 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    CREATE_TRY(c->accumulation.alloc(n));
    CREATE_TRY(c->gbuffer.alloc(n));
    CREATE_TRY(c->rng.alloc(n));
-   for (auto& q : c->queues) CREATE_TRY(q.alloc(n));
+   // sharded queues: capacity per shard = the pixels (64-pixel runs) a shard can own
+   const uint32_t runs = (uint32_t)((n + 63) / 64);
+   const uint32_t shard_cap = ((runs + kShards - 1) / kShards) * 64;
+   for (auto& q : c->queues) CREATE_TRY(q.alloc((size_t)shard_cap * kShards));
+   c->ps.shard_cap = shard_cap;
    CREATE_TRY(c->output.alloc(n));
    for (auto& r : c->reservoirs) CREATE_TRY(r.alloc(n));
    CREATE_TRY(c->control.alloc(1));
@@ -567,7 +571,7 @@ int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask
             launch_trace_closest(lc, c->scene, c->ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
             end_timed(c);
             begin_timed(c, 2);
-            launch_shade_miss(lc, fp, c->ps, ctl, b);
+            launch_shade_miss(lc, fp, c->ps, ctl, st, b);
             launch_shade_hit(lc, fp, c->scene, c->ps, c->im, ctl, st, b);
             end_timed(c);
             if (fp.sun_shadow_enabled == 1) {
@@ -649,15 +653,12 @@ int uh_trace_closest(uh_ctx* c, const float* rays, uint32_t n, float* out_tuv, u
       d[i] = make_float4(r[4], r[5], r[6], r[7]);
    }
    DevBuf<float4> d_o, dd, dh;
-   DevBuf<uint32_t> cur;
    HIP_TRY(c, d_o.alloc(n));
    HIP_TRY(c, dd.alloc(n));
    HIP_TRY(c, dh.alloc(n));
-   HIP_TRY(c, cur.alloc(1));
    HIP_TRY(c, hipMemcpyAsync(d_o.p, o.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
    HIP_TRY(c, hipMemcpyAsync(dd.p, d.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-   HIP_TRY(c, hipMemsetAsync(cur.p, 0, sizeof(uint32_t), c->stream));
-   launch_trace_closest_raw(cfg(c), c->scene, d_o.p, dd.p, dh.p, n, cur.p);
+   launch_trace_closest_raw(cfg(c), c->scene, d_o.p, dd.p, dh.p, n);
    std::vector<float4> h(n);
    HIP_TRY(c, hipMemcpyAsync(h.data(), dh.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -682,7 +683,6 @@ int uh_trace_closest(uh_ctx* c, const float* rays, uint32_t n, float* out_tuv, u
    d_o.release();
    dd.release();
    dh.release();
-   cur.release();
    return UH_OK;
 }
 
@@ -699,15 +699,13 @@ int uh_trace_any(uh_ctx* c, const float* rays, uint32_t n, uint8_t* out_occluded
       d[i] = make_float4(r[4], r[5], r[6], r[7]);
    }
    DevBuf<float4> d_o, dd;
-   DevBuf<uint32_t> occ, cur;
+   DevBuf<uint32_t> occ;
    HIP_TRY(c, d_o.alloc(n));
    HIP_TRY(c, dd.alloc(n));
    HIP_TRY(c, occ.alloc(n));
-   HIP_TRY(c, cur.alloc(1));
    HIP_TRY(c, hipMemcpyAsync(d_o.p, o.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
    HIP_TRY(c, hipMemcpyAsync(dd.p, d.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-   HIP_TRY(c, hipMemsetAsync(cur.p, 0, sizeof(uint32_t), c->stream));
-   launch_trace_any_raw(cfg(c), c->scene, d_o.p, dd.p, occ.p, n, cur.p);
+   launch_trace_any_raw(cfg(c), c->scene, d_o.p, dd.p, occ.p, n);
    std::vector<uint32_t> h(n);
    HIP_TRY(c, hipMemcpyAsync(h.data(), occ.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -715,7 +713,6 @@ int uh_trace_any(uh_ctx* c, const float* rays, uint32_t n, uint8_t* out_occluded
    d_o.release();
    dd.release();
    occ.release();
-   cur.release();
    return UH_OK;
 }
 

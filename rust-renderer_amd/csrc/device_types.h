@@ -13,13 +13,23 @@ namespace uh {
 constexpr uint32_t kMaxBounces = 64;
 constexpr uint32_t kQueueKinds = 4;  // per bounce: RAY, HIT, MISS, LIGHT
 enum { Q_RAY = 0, Q_HIT = 1, Q_MISS = 2, Q_LIGHT = 3 };
-constexpr uint32_t kLaunchSlots = kMaxBounces * 6 + 16;
+constexpr uint32_t kLaunchSlots = kMaxBounces * 3 + 4;
+
+// Queues are sharded: pixel p lives in shard (p / 64) % kShards for its whole life, every queue
+// has one segment (capacity PathState::shard_cap) and one counter per shard, and the blocks of a
+// launch are bound to shards by blockIdx % kShards. A single device-wide counter saturates at
+// ~88 atomics/us on MI355X (MI355X_MICROARCH.md "dequeue"), which capped every queue-building
+// kernel of the unsharded first version (profiles/r01a_*): 32 shards lift that ceiling 32x.
+// Blocks b and b + 8 share an XCD under the observed round-robin dispatch, so shard s is served by
+// XCD s % 8 and its queue segments stay in that XCD's L2 between producer and consumer launches.
+constexpr uint32_t kShards = 32;
 
 // Zeroed once per sample pass by one hipMemsetAsync.
 struct Control {
-   uint32_t q_count[(kMaxBounces + 1) * kQueueKinds];
-   uint32_t cursor[kLaunchSlots];  // persistent-thread work cursors, one per launch of the pass
+   uint32_t q_count[(kMaxBounces + 1) * kQueueKinds * kShards];
+   uint32_t cursor[kLaunchSlots * kShards];  // persistent-thread work cursors, one row per launch of the pass
 };
+__host__ __device__ inline uint32_t qc_index(uint32_t bounce, uint32_t kind, uint32_t shard) { return (bounce * kQueueKinds + kind) * kShards + shard; }
 
 // Persistent across frames; read back by uh_get_stats.
 struct DeviceStats {
@@ -77,7 +87,8 @@ struct PathState {
    float4* rad;     // radiance.rgb, light index (bits)
    float4* pixcol;  // sum over the frame's samples
    uint2* rng;      // x = raygen rngState, y = rayPayload.randomSeed
-   uint32_t* queue[5];  // 0,1 = ray ping-pong; 2 = hit; 3 = miss; 4 = light
+   uint32_t* queue[5];  // 0,1 = ray ping-pong; 2 = hit; 3 = miss; 4 = light; each kShards * shard_cap entries
+   uint32_t shard_cap;  // entries per shard segment = pixels a shard can own (multiple of 64)
 };
 
 struct Images {
@@ -98,7 +109,7 @@ struct LaunchCfg {
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);
 void launch_trace_closest(const LaunchCfg&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce, uint32_t cursor_slot,
                           int ray_kind);
-void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t bounce);
+void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, DeviceStats*, uint32_t bounce);
 void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
 void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
                          uint32_t cursor_slot, bool light);
@@ -111,8 +122,8 @@ void launch_initial_ris(const LaunchCfg&, const FrameParams&, const SceneDev&, c
 void launch_temporal_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);
 void launch_spatial_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);
 // stand-alone queries (n rays in ray_o/ray_d[0..n), identity queue)
-void launch_trace_closest_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n, uint32_t* cursor);
-void launch_trace_any_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n, uint32_t* cursor);
+void launch_trace_closest_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n);
+void launch_trace_any_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n);
 // tiles
 void launch_pack_tiles(const LaunchCfg&, const float4* acc, float4* out, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);
 void launch_unpack_tiles(const LaunchCfg&, float4* acc, const float4* in, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);

@@ -172,27 +172,44 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
    return ANY ? false : (best.idx != kEmptyRef);
 }
 
-// persistent-thread batch fetch: lane 0 pulls the next 64-item batch
+// persistent-thread batch fetch: lane 0 pulls the next 64-item batch of its shard
 __device__ __forceinline__ uint32_t next_batch(uint32_t* cursor) {
    uint32_t base = 0;
    if (lane_id() == 0) base = atomicAdd(cursor, 64u);
    return __builtin_amdgcn_readfirstlane(base);
 }
 
+// blocks are bound to queue shards by blockIdx % kShards (device_types.h)
+struct ShardCtx {
+   uint32_t shard, lb, nb;  // shard id, this block's index within the shard, blocks per shard
+};
+__device__ __forceinline__ ShardCtx shard_ctx() {
+   ShardCtx c;
+   c.shard = blockIdx.x % kShards;
+   c.lb = blockIdx.x / kShards;
+   c.nb = gridDim.x / kShards;
+   return c;
+}
+
 // ------------------------------------------------------------------------------------------
 // trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes
 // ------------------------------------------------------------------------------------------
-template <bool COUNT, bool RAW>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                          float4* __restrict__ hit_out, const uint32_t* __restrict__ queue,
-                                                          const uint32_t* __restrict__ count_ptr, uint32_t raw_count, uint32_t* cursor,
-                                                          uint32_t* q_hit, uint32_t* n_hit, uint32_t* q_miss, uint32_t* n_miss, DeviceStats* stats,
-                                                          int ray_kind) {
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+                                                          uint32_t cursor_slot, int ray_kind) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    const uint32_t lane = lane_id();
    const uint32_t wave = threadIdx.x >> 6;
    uint32_t* lds_col = &s_stack[wave][0][lane];
-   const uint32_t count = RAW ? raw_count : *count_ptr;
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
+   uint32_t* q_hit = ps.queue[2] + seg;
+   uint32_t* q_miss = ps.queue[3] + seg;
+   uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
+   uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
+   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
    uint32_t n_nodes = 0, n_tris = 0;
    for (;;) {
       uint32_t base = next_batch(cursor);
@@ -205,25 +222,35 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(SceneDev sc, const flo
       h.t = 0.0f;
       h.u = h.v = 0.0f;
       if (active) {
-         id = RAW ? i : queue[i];
-         float4 ro = ray_o[id], rd = ray_d[id];
+         id = queue[i];
+         float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
          traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
-         hit_out[id] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
+         ps.hit[id] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
       }
-      if (!RAW) {
-         bool is_hit = active && h.idx != kEmptyRef, is_miss = active && h.idx == kEmptyRef;
-         uint32_t slot = wave_append(n_hit, is_hit);
-         if (is_hit) q_hit[slot] = id;
-         slot = wave_append(n_miss, is_miss);
-         if (is_miss) q_miss[slot] = id;
-      }
+      bool is_hit = active && h.idx != kEmptyRef, is_miss = active && h.idx == kEmptyRef;
+      uint32_t slot = wave_append(n_hit, is_hit);
+      if (is_hit) q_hit[slot] = id;
+      slot = wave_append(n_miss, is_miss);
+      if (is_miss) q_miss[slot] = id;
    }
-   if (!RAW) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
-      if (COUNT) {
-         atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
-         atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
-      }
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
+   if (COUNT) {
+      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+   }
+}
+
+// stand-alone closest-hit query over n rays (identity queue): uh_trace_closest and the G-buffer cast
+__global__ __launch_bounds__(kBlock) void k_trace_closest_raw(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                              float4* __restrict__ hit_out, uint32_t count) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane_id()];
+   uint32_t n_nodes = 0, n_tris = 0;
+   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+      float4 ro = ray_o[i], rd = ray_d[i];
+      Hit h;
+      traverse<false, false>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
+      hit_out[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
    }
 }
 
@@ -234,13 +261,18 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(SceneDev sc, const flo
 // Occluded <=> some triangle has tmin < t < tmax (sun) and additionally t <= distance_to_light.
 // ------------------------------------------------------------------------------------------
 template <bool COUNT, bool LIGHT>
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, const uint32_t* __restrict__ queue,
-                                                         const uint32_t* __restrict__ count_ptr, uint32_t* cursor, DeviceStats* stats) {
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+                                                         uint32_t cursor_slot) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    const uint32_t lane = lane_id();
    const uint32_t wave = threadIdx.x >> 6;
    uint32_t* lds_col = &s_stack[wave][0][lane];
-   const uint32_t count = *count_ptr;
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   // sun rays leave from every scattered path = the next bounce's ray queue; light rays from Q_LIGHT
+   const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[4] : ps.queue[(bounce + 1) & 1]) + seg;
+   const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
    const float tmin = 0.001f, tmax = 10000.0f;
    uint32_t n_nodes = 0, n_tris = 0;
    for (;;) {
@@ -274,29 +306,22 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(SceneDev sc, FrameParam
          }
       }
    }
-   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
    if (COUNT) {
       atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
       atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
    }
 }
 
-template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_any_raw(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                          uint32_t* __restrict__ occluded, uint32_t count, uint32_t* cursor) {
+                                                          uint32_t* __restrict__ occluded, uint32_t count) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
-   const uint32_t lane = lane_id();
-   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
+   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane_id()];
    uint32_t n_nodes = 0, n_tris = 0;
-   for (;;) {
-      uint32_t base = next_batch(cursor);
-      if (base >= count) break;
-      uint32_t i = base + lane;
-      if (i < count) {
-         float4 ro = ray_o[i], rd = ray_d[i];
-         Hit h;
-         occluded[i] = traverse<true, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, INFINITY, h, lds_col, n_nodes, n_tris) ? 1u : 0u;
-      }
+   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+      float4 ro = ray_o[i], rd = ray_d[i];
+      Hit h;
+      occluded[i] = traverse<true, false>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, INFINITY, h, lds_col, n_nodes, n_tris) ? 1u : 0u;
    }
 }
 
@@ -305,8 +330,16 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_raw(SceneDev sc, const flo
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState ps, Control* ctl, uint32_t sample) {
    const uint32_t n = fp.W * fp.H;
-   for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-      uint32_t id = base + threadIdx.x;
+   const ShardCtx sx = shard_ctx();
+   uint32_t* queue = ps.queue[0] + sx.shard * ps.shard_cap;
+   uint32_t* n_ray = &ctl->q_count[qc_index(0, Q_RAY, sx.shard)];
+   const uint32_t lane = lane_id();
+   const uint32_t waves_in_shard = sx.nb * kWavesPerBlock;
+   // shard s owns the 64-pixel runs r = s, s + kShards, ...; one wave per run
+   for (uint32_t j = sx.lb * kWavesPerBlock + (threadIdx.x >> 6);; j += waves_in_shard) {
+      uint32_t run = sx.shard + kShards * j;
+      if (run * 64u >= n) break;
+      uint32_t id = run * 64u + lane;
       bool own = false;
       if (id < n) {
          uint32_t px = id % fp.W, py = id / fp.W;
@@ -325,18 +358,19 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
             if (sample == 0) ps.pixcol[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
          }
       }
-      uint32_t slot = wave_append(&ctl->q_count[0 * kQueueKinds + Q_RAY], own);
-      if (own) ps.queue[0][slot] = id;
+      uint32_t slot = wave_append(n_ray, own);
+      if (own) queue[slot] = id;
    }
 }
 
 // ------------------------------------------------------------------------------------------
 // shade_miss — reference.rmiss:10-31 + rgen:48-57 for paths whose ray left the scene
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState ps, const uint32_t* __restrict__ queue,
-                                                       const uint32_t* __restrict__ count_ptr) {
-   const uint32_t count = *count_ptr;
-   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+__global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
+   const ShardCtx sx = shard_ctx();
+   const uint32_t* __restrict__ queue = ps.queue[3] + sx.shard * ps.shard_cap;
+   const uint32_t count = ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
+   for (uint32_t i = sx.lb * kBlock + threadIdx.x; i < count; i += sx.nb * kBlock) {
       uint32_t id = queue[i];
       V3 sky_color = v3(0.0f, 0.0f, 0.0f);
       if (fp.sky_enabled == 1) {
@@ -348,6 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState
       V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
       ps.rad[id] = make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w);   // rgen:55
    }
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->misses, (unsigned long long)count);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -370,15 +405,18 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
 
 __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, const UhReservoir* __restrict__ spatial_reservoirs,
                                                       Control* ctl, DeviceStats* stats, uint32_t bounce) {
-   const uint32_t count = ctl->q_count[bounce * kQueueKinds + Q_HIT];
-   const uint32_t* __restrict__ queue = ps.queue[2];
-   uint32_t* q_next = ps.queue[(bounce + 1) & 1];
-   uint32_t* n_next = &ctl->q_count[(bounce + 1) * kQueueKinds + Q_RAY];
-   uint32_t* q_light = ps.queue[4];
-   uint32_t* n_light = &ctl->q_count[bounce * kQueueKinds + Q_LIGHT];
-   const uint32_t rounds = (count + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t count = ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
+   const uint32_t* __restrict__ queue = ps.queue[2] + seg;
+   uint32_t* q_next = ps.queue[(bounce + 1) & 1] + seg;
+   uint32_t* n_next = &ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   uint32_t* q_light = ps.queue[4] + seg;
+   uint32_t* n_light = &ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)];
+   const uint32_t stride = sx.nb * kBlock;
+   const uint32_t rounds = (count + stride - 1) / stride;
    for (uint32_t r = 0; r < rounds; r++) {
-      uint32_t i = (r * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
       bool scattered = false, want_light = false;
       uint32_t id = 0;
       if (i < count) {
@@ -479,11 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
       slot = wave_append(n_light, want_light);
       if (want_light) q_light[slot] = id;
    }
-   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->closest_hits, (unsigned long long)count);
-}
-
-__global__ void k_count_misses(Control* ctl, DeviceStats* stats, uint32_t bounce) {
-   atomicAdd(&stats->misses, (unsigned long long)ctl->q_count[bounce * kQueueKinds + Q_MISS]);
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->closest_hits, (unsigned long long)count);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -709,11 +743,20 @@ static inline dim3 stream_grid(const LaunchCfg& c, uint32_t n) {
    uint32_t cap = c.num_cus * 8;
    return dim3(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
-static inline dim3 trace_grid(const LaunchCfg& c) { return dim3(c.num_cus * c.trace_blocks_per_cu); }
+// grids of sharded kernels are whole multiples of kShards (blockIdx % kShards = shard)
+static inline dim3 sharded_grid(uint32_t blocks) {
+   uint32_t g = (blocks / kShards) * kShards;
+   return dim3(g < kShards ? kShards : g);
+}
+static inline dim3 trace_grid(const LaunchCfg& c) { return sharded_grid(c.num_cus * c.trace_blocks_per_cu); }
+static inline dim3 shade_grid(const LaunchCfg& c, uint32_t n) {
+   uint32_t blocks = (n + kBlock - 1) / kBlock, cap = c.num_cus * 8;
+   return sharded_grid(blocks < cap ? blocks : cap);
+}
 
 uint32_t query_trace_occupancy() {
    int a = 0, b = 0;
-   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<false, false>, kBlock, 0) != hipSuccess) a = 4;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<false>, kBlock, 0) != hipSuccess) a = 4;
    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kBlock, 0) != hipSuccess) b = 4;
    int m = a < b ? a : b;
    if (m < 1) m = 1;
@@ -722,49 +765,38 @@ uint32_t query_trace_occupancy() {
 }
 
 void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, uint32_t sample) {
-   k_generate<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ctl, sample);
+   k_generate<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ctl, sample);
 }
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                           uint32_t cursor_slot, int ray_kind) {
-   const uint32_t* queue = ps.queue[bounce & 1];
-   const uint32_t* count = &ctl->q_count[bounce * kQueueKinds + Q_RAY];
-   uint32_t* n_hit = &ctl->q_count[bounce * kQueueKinds + Q_HIT];
-   uint32_t* n_miss = &ctl->q_count[bounce * kQueueKinds + Q_MISS];
    if (c.count_visits)
-      k_trace_closest<true, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, queue, count, 0, &ctl->cursor[cursor_slot],
-                                                                          ps.queue[2], n_hit, ps.queue[3], n_miss, stats, ray_kind);
+      k_trace_closest<true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
    else
-      k_trace_closest<false, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, queue, count, 0, &ctl->cursor[cursor_slot],
-                                                                           ps.queue[2], n_hit, ps.queue[3], n_miss, stats, ray_kind);
+      k_trace_closest<false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
 }
 
-void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, uint32_t bounce) {
-   k_shade_miss<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ps.queue[3], &ctl->q_count[bounce * kQueueKinds + Q_MISS]);
+void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
+   k_shade_miss<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ctl, stats, bounce);
 }
 
 void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
                       DeviceStats* stats, uint32_t bounce) {
-   k_shade_hit<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, im.reservoirs[2], ctl, stats, bounce);
-   k_count_misses<<<1, 1, 0, c.stream>>>(ctl, stats, bounce);
+   k_shade_hit<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, im.reservoirs[2], ctl, stats, bounce);
 }
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
                          uint32_t bounce, uint32_t cursor_slot, bool light) {
-   uint32_t* cursor = &ctl->cursor[cursor_slot];
    if (light) {
-      const uint32_t* count = &ctl->q_count[bounce * kQueueKinds + Q_LIGHT];
       if (c.count_visits)
-         k_trace_shadow<true, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ps.queue[4], count, cursor, stats);
+         k_trace_shadow<true, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
       else
-         k_trace_shadow<false, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ps.queue[4], count, cursor, stats);
+         k_trace_shadow<false, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
    } else {
-      const uint32_t* count = &ctl->q_count[(bounce + 1) * kQueueKinds + Q_RAY];
-      const uint32_t* queue = ps.queue[(bounce + 1) & 1];
       if (c.count_visits)
-         k_trace_shadow<true, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, queue, count, cursor, stats);
+         k_trace_shadow<true, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
       else
-         k_trace_shadow<false, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, queue, count, cursor, stats);
+         k_trace_shadow<false, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
    }
 }
 
@@ -779,11 +811,10 @@ void launch_resolve(const LaunchCfg& c, const Images& im, uint32_t W, uint32_t H
 
 void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
                     DeviceStats* stats) {
+   (void)ctl;
    const uint32_t n = fp.W * fp.H;
    k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps);
-   // identity queue, cursor = the last launch slot of the (already zeroed) control block
-   k_trace_closest<false, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, nullptr, nullptr, n, &ctl->cursor[kLaunchSlots - 1],
-                                                                       nullptr, nullptr, nullptr, nullptr, stats, UH_RAY_GBUFFER);
+   k_trace_closest_raw<<<dim3(c.num_cus * c.trace_blocks_per_cu), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, n);
    k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats);
 }
 
@@ -800,12 +831,11 @@ void launch_spatial_reuse(const LaunchCfg& c, const FrameParams& fp, const Scene
    k_spatial_reuse<<<dim3(c.num_cus * 4), kBlock, 0, c.stream>>>(fp, sc, im);
 }
 
-void launch_trace_closest_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n, uint32_t* cursor) {
-   k_trace_closest<false, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, hit, nullptr, nullptr, n, cursor, nullptr, nullptr, nullptr,
-                                                                       nullptr, nullptr, 0);
+void launch_trace_closest_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n) {
+   k_trace_closest_raw<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, hit, n);
 }
-void launch_trace_any_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n, uint32_t* cursor) {
-   k_trace_any_raw<false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, occluded, n, cursor);
+void launch_trace_any_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n) {
+   k_trace_any_raw<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, occluded, n);
 }
 
 void launch_pack_tiles(const LaunchCfg& c, const float4* acc, float4* out, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile) {

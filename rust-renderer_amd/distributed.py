@@ -1,0 +1,79 @@
+"""Multi-GPU composition: the framebuffer is partitioned into tile_size x tile_size tiles owned
+round-robin (tile id % world == rank); every rank path-traces only its tiles and ONE gather of the
+packed RGBA32F accumulation tiles to rank 0 composes the frame. The reference is single-device
+(utopian/src/device.rs:45); this is the build's own addition.
+
+The same index math runs in three places and is tested against each other: k_tiles (HIP,
+csrc/kernels.hip), pack_tiles_host / unpack_tiles_host here (numpy; CPU gloo tests and the oracle),
+and owns_pixel in both tracers.
+"""
+import numpy as np
+
+
+def tile_counts(W, H, tile, world):
+    tiles = -(-W // tile) * -(-H // tile)
+    return [(tiles - r + world - 1) // world if tiles > r else 0 for r in range(world)]
+
+
+def tile_pixel_index(W, H, tile, rank, world):
+    """(packed_count, flat image index per packed slot or -1 for padding outside the image)."""
+    tiles_x = -(-W // tile)
+    owned = tile_counts(W, H, tile, world)[rank]
+    t = rank + np.arange(owned, dtype=np.int64) * world
+    tx, ty = (t % tiles_x) * tile, (t // tiles_x) * tile
+    wy, wx = np.divmod(np.arange(tile * tile, dtype=np.int64), tile)
+    x = tx[:, None] + wx[None, :]
+    y = ty[:, None] + wy[None, :]
+    idx = np.where((x < W) & (y < H), y * W + x, -1)
+    return owned * tile * tile, idx.reshape(-1)
+
+
+def owner_map(W, H, tile, world):
+    tiles_x = -(-W // tile)
+    y, x = np.mgrid[0:H, 0:W]
+    return ((y // tile) * tiles_x + (x // tile)) % world
+
+
+def pack_tiles_host(acc, tile, rank, world):
+    H, W = acc.shape[:2]
+    n, idx = tile_pixel_index(W, H, tile, rank, world)
+    out = np.zeros((n, 4), dtype=np.float32)
+    valid = idx >= 0
+    out[valid] = acc.reshape(-1, 4)[idx[valid]]
+    return out
+
+
+def unpack_tiles_host(acc, packed, tile, rank, world):
+    H, W = acc.shape[:2]
+    _, idx = tile_pixel_index(W, H, tile, rank, world)
+    valid = idx >= 0
+    acc.reshape(-1, 4)[idx[valid]] = packed[: len(idx)][valid]
+    return acc
+
+
+def gather_and_compose(renderer, rank, world, tile, dist, torch, device):
+    """One collective per composed frame. HIP renderers pack on the device and hand RCCL a device
+    buffer; CPU (oracle / gloo) renderers go through the numpy restatement. Returns, on rank 0, the
+    composed (H, W, 4) accumulation as numpy for CPU renderers, or None after composing in place
+    on the device for HIP renderers."""
+    counts = [c * tile * tile for c in tile_counts(renderer.width, renderer.height, tile, world)]
+    if renderer.backend == "hip":
+        buf = torch.empty((max(counts), 4), dtype=torch.float32, device=device)
+        renderer.pack_tiles(buf.data_ptr(), buf.shape[0])
+        parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, parts, dst=0)
+        if rank == 0:
+            torch.cuda.synchronize()
+            for r in range(1, world):
+                renderer.unpack_tiles(r, parts[r].data_ptr(), counts[r])
+        return None
+    acc = renderer.read_accumulation()
+    buf = torch.zeros((max(counts), 4), dtype=torch.float32)
+    buf[: counts[rank]] = torch.from_numpy(pack_tiles_host(acc, tile, rank, world))
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, parts, dst=0)
+    if rank == 0:
+        for r in range(1, world):
+            unpack_tiles_host(acc, parts[r].numpy(), tile, r, world)
+        return acc
+    return None
