@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=3")
     ap.add_argument("--cpu-sample", type=str, default="960x540x3", help="WxHxframes rendered by the CPU oracle")
     return ap.parse_args()
 
@@ -72,6 +73,9 @@ def main():
     renderer = scene.upload(rr.Renderer(W, H, device=local_rank))
     if world > 1:
         renderer.set_tile_partition(rank, world, args.tile)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        renderer.set_option(k, int(v))
     pass_mask = rr.PASS_REFERENCE_PT if args.config == 1 else rr.PASS_ALL
     view = scene.make_view(W, H)
     loop = rr.FrameLoop(renderer, view)

@@ -28,6 +28,20 @@ struct alignas(16) Node4 {
 };
 static_assert(sizeof(Node4) == 128, "one node = one 128-byte line");
 
+// Device node: the same 4 children with boxes quantised to 8 bits per plane relative to the node's
+// own box (origin + 2^e * q), rounded outwards, so the slab test stays conservative and the hit
+// result does not change. 64 B = four dwordx4 loads per visit instead of seven, half the bytes:
+// the traversal kernels are bound by the L1/L2/Infinity-Cache gather of node lines, not by VALU.
+struct alignas(16) Node4Q {
+   float origin[3];    // lower corner of the node's own (padded) box
+   float scale_x;      // per-axis quantisation step, a power of two
+   float scale_yz[2];
+   uint32_t qlo[3];    // per axis: child k's quantised lower plane in byte k
+   uint32_t qhi[3];    // per axis: upper plane. Empty slot: qlo = 255, qhi = 0 (inverted box, never hit)
+   uint32_t child[4];
+};
+static_assert(sizeof(Node4Q) == 64, "quantised node = half a 128-byte line");
+
 struct alignas(16) TriPacket {
    float v0[3];
    float e1x;
@@ -54,7 +68,8 @@ struct BuildInput {
 };
 
 struct BuildOutput {
-   std::vector<Node4> nodes;         // BFS order, node 0 = root
+   std::vector<Node4> nodes;         // BFS order, node 0 = root (full-precision, padded child boxes)
+   std::vector<Node4Q> qnodes;       // the same tree, quantised (what the kernels traverse)
    std::vector<uint32_t> tri_order;  // packet i holds input triangle tri_order[i]
    uint32_t max_depth = 0;
 };

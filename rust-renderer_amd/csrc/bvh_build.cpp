@@ -188,6 +188,15 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads) {
       std::memset(&root, 0, sizeof(root));
       for (int k = 0; k < 4; k++) root.child[k] = kEmptyRef;
       out.nodes.push_back(root);
+      Node4Q q;  // empty scene: a root whose four slots are empty (every ray misses)
+      std::memset(&q, 0, sizeof(q));
+      q.scale_x = q.scale_yz[0] = q.scale_yz[1] = 1.0f;
+      for (int a = 0; a < 3; a++) {
+         q.qlo[a] = 0xffffffffu;
+         q.qhi[a] = 0u;
+      }
+      for (int k = 0; k < 4; k++) q.child[k] = kEmptyRef;
+      out.qnodes.push_back(q);
       return;
    }
    {
@@ -397,6 +406,60 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads) {
       }
       nd.meta[0] = (uint32_t)nc;
       out.nodes[qi] = nd;
+   }
+
+   // ---- quantise: per node, origin = min over its children, scale = 2^e with e minimal such that
+   // the node's extent fits 255 steps; lower planes round down, upper planes round up (in double)
+   out.qnodes.resize(out.nodes.size());
+   for (size_t i = 0; i < out.nodes.size(); i++) {
+      const Node4& nd = out.nodes[i];
+      Node4Q q;
+      std::memset(&q, 0, sizeof(q));
+      const float* lo[3] = {nd.lox, nd.loy, nd.loz};
+      const float* hi[3] = {nd.hix, nd.hiy, nd.hiz};
+      float scales[3];
+      for (int a = 0; a < 3; a++) {
+         double mn = INFINITY, mx = -INFINITY;
+         for (int k = 0; k < 4; k++)
+            if (nd.child[k] != kEmptyRef) {
+               mn = std::fmin(mn, (double)lo[a][k]);
+               mx = std::fmax(mx, (double)hi[a][k]);
+            }
+         if (!(mn <= mx)) mn = mx = 0.0;
+         float origin = (float)mn;
+         if ((double)origin > mn) origin = std::nextafterf(origin, -INFINITY);
+         double ext = mx - (double)origin;
+         int e = -100;
+         if (ext > 0) {
+            e = (int)std::ceil(std::log2(ext / 255.0));
+            while (std::ldexp(255.0, e) < ext) e++;
+            if (e < -100) e = -100;
+         }
+         double scale = std::ldexp(1.0, e);
+         uint32_t wlo = 0, whi = 0;
+         for (int k = 0; k < 4; k++) {
+            if (nd.child[k] == kEmptyRef) {
+               wlo |= 0xffu << (8 * k);  // inverted box: the slab test fails for every ray
+               continue;
+            }
+            double a0 = std::floor(((double)lo[a][k] - (double)origin) / scale);
+            double a1 = std::ceil(((double)hi[a][k] - (double)origin) / scale);
+            if (a0 < 0) a0 = 0;
+            if (a1 > 255) a1 = 255;  // cannot trigger: ext <= 255 * scale
+            if (a0 > 255) a0 = 255;
+            wlo |= (uint32_t)a0 << (8 * k);
+            whi |= (uint32_t)a1 << (8 * k);
+         }
+         q.origin[a] = origin;
+         q.qlo[a] = wlo;
+         q.qhi[a] = whi;
+         scales[a] = (float)scale;
+      }
+      q.scale_x = scales[0];
+      q.scale_yz[0] = scales[1];
+      q.scale_yz[1] = scales[2];
+      for (int k = 0; k < 4; k++) q.child[k] = nd.child[k];
+      out.qnodes[i] = q;
    }
 }
 

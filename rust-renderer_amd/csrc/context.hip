@@ -59,7 +59,7 @@ struct uh_ctx {
    hipStream_t stream = nullptr;
    uint32_t W = 0, H = 0;
    uint32_t num_cus = 256;
-   uint32_t trace_blocks_per_cu = 4;
+   uint32_t closest_blocks_per_cu = 8, shadow_blocks_per_cu = 6;
    std::string err;
 
    // host scene
@@ -92,6 +92,7 @@ struct uh_ctx {
 
    // options / stats
    bool count_visits = false, time_kernels = false, full_frame_restir = false;
+   int closest_variant = 0, shadow_variant = 3;  // measured fastest on MI355X (profiles/README.md)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
    float ms_by_kind[3] = {0, 0, 0};
@@ -154,7 +155,9 @@ void set_transform(HostMesh& m, const float* w) {
    }
 }
 
-LaunchCfg cfg(uh_ctx* c) { return LaunchCfg{c->stream, c->num_cus, c->trace_blocks_per_cu, c->count_visits}; }
+LaunchCfg cfg(uh_ctx* c) {
+   return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->closest_variant, c->shadow_variant};
+}
 
 void begin_timed(uh_ctx* c, int kind) {
    if (!c->time_kernels) return;
@@ -225,7 +228,11 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
    CREATE_TRY(hipEventCreate(&c->frame_start));
    CREATE_TRY(hipEventCreate(&c->frame_stop));
-   c->trace_blocks_per_cu = query_trace_occupancy();
+   {
+      uint32_t occ = query_trace_occupancy();  // blocks/CU the traversal kernels can keep resident
+      if (c->closest_blocks_per_cu > occ) c->closest_blocks_per_cu = occ;
+      if (c->shadow_blocks_per_cu > occ) c->shadow_blocks_per_cu = occ;
+   }
    const size_t n = (size_t)width * height;
    CREATE_TRY(c->ray_o.alloc(n));
    CREATE_TRY(c->ray_d.alloc(n));
@@ -470,14 +477,15 @@ int uh_build_acceleration(uh_ctx* c) {
    std::vector<TexInfo> tex(c->textures.size());
    for (size_t i = 0; i < tex.size(); i++) tex[i] = TexInfo{c->textures[i].dev, c->textures[i].w, c->textures[i].h};
 
+   if (bo.qnodes.empty()) return fail(c, UH_ERR_INVALID_ARGUMENT, "internal: BVH builder produced no root node");
    HIP_TRY(c, hipStreamSynchronize(c->stream));
-   HIP_TRY(c, c->d_nodes.alloc(bo.nodes.size() * 8));
+   HIP_TRY(c, c->d_nodes.alloc(bo.qnodes.size() * 4));
    HIP_TRY(c, c->d_tris.alloc(total * 3));
    HIP_TRY(c, c->d_shade.alloc(total * 4));
    HIP_TRY(c, c->d_meshes.alloc(ms.size()));
    HIP_TRY(c, c->d_lights.alloc(lights.size()));
    HIP_TRY(c, c->d_tex.alloc(tex.size()));
-   HIP_TRY(c, hipMemcpy(c->d_nodes.p, bo.nodes.data(), bo.nodes.size() * sizeof(Node4), hipMemcpyHostToDevice));
+   HIP_TRY(c, hipMemcpy(c->d_nodes.p, bo.qnodes.data(), bo.qnodes.size() * sizeof(Node4Q), hipMemcpyHostToDevice));
    if (total) {
       HIP_TRY(c, hipMemcpy(c->d_tris.p, tp.data(), total * sizeof(TriPacket), hipMemcpyHostToDevice));
       HIP_TRY(c, hipMemcpy(c->d_shade.p, sp.data(), total * sizeof(ShadePacket), hipMemcpyHostToDevice));
@@ -485,7 +493,7 @@ int uh_build_acceleration(uh_ctx* c) {
    if (!ms.empty()) HIP_TRY(c, hipMemcpy(c->d_meshes.p, ms.data(), ms.size() * sizeof(MeshShade), hipMemcpyHostToDevice));
    if (!lights.empty()) HIP_TRY(c, hipMemcpy(c->d_lights.p, lights.data(), lights.size() * sizeof(float4), hipMemcpyHostToDevice));
    if (!tex.empty()) HIP_TRY(c, hipMemcpy(c->d_tex.p, tex.data(), tex.size() * sizeof(TexInfo), hipMemcpyHostToDevice));
-   c->scene.nodes = c->d_nodes.p;
+   c->scene.nodes = reinterpret_cast<const uint4*>(c->d_nodes.p);
    c->scene.tris = c->d_tris.p;
    c->scene.shade = c->d_shade.p;
    c->scene.meshes = c->d_meshes.p;
@@ -773,9 +781,14 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->time_kernels = value != 0;
    } else if (n == "full_frame_restir")
       c->full_frame_restir = value != 0;
-   else if (n == "trace_blocks_per_cu") {
-      if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, "trace_blocks_per_cu must be 1..8");
-      c->trace_blocks_per_cu = (uint32_t)value;
+   else if (n == "trace_variant" || n == "closest_variant" || n == "shadow_variant") {
+      if (value < 0 || value > 16) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..16");
+      if (n != "shadow_variant") c->closest_variant = value;
+      if (n != "closest_variant") c->shadow_variant = value;
+   } else if (n == "trace_blocks_per_cu" || n == "closest_blocks_per_cu" || n == "shadow_blocks_per_cu") {
+      if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 1..8");
+      if (n != "shadow_blocks_per_cu") c->closest_blocks_per_cu = (uint32_t)value;
+      if (n != "closest_blocks_per_cu") c->shadow_blocks_per_cu = (uint32_t)value;
    } else
       return fail(c, UH_ERR_INVALID_ARGUMENT, "unknown option: " + n);
    return UH_OK;

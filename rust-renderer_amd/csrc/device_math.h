@@ -183,7 +183,7 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
    if (m < 0) m += period;
    return m < n ? m : period - 1 - m;
 }
-__device__ __forceinline__ V3 sample_texture(const SceneDev& sc, uint32_t index, float u, float v) {
+__device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __restrict__ lut, uint32_t index, float u, float v) {
    if (index >= sc.num_textures) return v3(1, 1, 1);
    TexInfo t = sc.textures[index];
    float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
@@ -192,7 +192,6 @@ __device__ __forceinline__ V3 sample_texture(const SceneDev& sc, uint32_t index,
    float ax = x - fx, ay = y - fy;
    int x0 = mirror_index((int)fx, (int)t.w), x1 = mirror_index((int)fx + 1, (int)t.w);
    int y0 = mirror_index((int)fy, (int)t.h), y1 = mirror_index((int)fy + 1, (int)t.h);
-   const float* lut = sc.unorm_lut;
    auto tx = [&](int xx, int yy) {
       uchar4 p = t.texels[(size_t)yy * t.w + xx];
       return v3(lut[p.x], lut[p.y], lut[p.z]);

@@ -56,7 +56,7 @@ struct TexInfo {
 };
 
 struct SceneDev {
-   const float4* nodes;   // 8 float4 per Node4
+   const uint4* nodes;    // 4 uint4 per Node4Q (quantised BVH4 node, 64 B)
    const float4* tris;    // 3 float4 per TriPacket
    const float4* shade;   // 4 float4 per ShadePacket
    const MeshShade* meshes;
@@ -102,8 +102,12 @@ struct Images {
 struct LaunchCfg {
    hipStream_t stream;
    uint32_t num_cus;
-   uint32_t trace_blocks_per_cu;
+   uint32_t closest_blocks_per_cu, shadow_blocks_per_cu;
    bool count_visits;
+   // traversal kernel variants (options "closest_variant" / "shadow_variant"; all bit-identical in
+   // results): 0 = batch if-if; 1..5 = v2 while-while with lane refill at 64/32/16/8/1 idle lanes;
+   // 6..10 = v2 + parked leaf; 11..16 = v3 vote scheduling. Defaults are what measured fastest.
+   int closest_variant, shadow_variant;
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);

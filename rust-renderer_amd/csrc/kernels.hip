@@ -18,8 +18,8 @@ namespace uh {
 
 constexpr int kBlock = 256;                 // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kLdsStack = 24;               // per-lane traversal stack entries kept in LDS
-constexpr int kSpillStack = 40;             // overflow entries in private memory (rarely touched)
+constexpr int kLdsStack = 16;               // per-lane traversal stack entries kept in LDS (16 KiB per 256-thread block -> 8 blocks/CU)
+constexpr int kSpillStack = 48;             // overflow entries in private memory (rarely touched)
 
 // ------------------------------------------------------------------------------------------
 // BVH4 traversal (thread per ray). Closest hit: min t over all triangles with tmin < t < tmax,
@@ -70,106 +70,162 @@ __device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, uint32
    }
 }
 
+constexpr uint32_t kChunk = 64;   // rays a wave takes from its shard's cursor per atomic (traversal v2)
+
 __device__ __forceinline__ float safe_rcp_dir(float x) {
    // the slab test only has to be conservative; a zero component becomes +-1e-30 so no inf/NaN appears
    return 1.0f / (fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x);
 }
 
-struct StackRef {
-   uint32_t* lds;  // this lane's column: entry k at lds[k * 64]
+struct Trav {
+   V3 o, d, idir;
+   float tmin, tlimit;
+   Hit best;
+   int sp;
+   uint32_t cur;
 };
 
+__device__ __forceinline__ void trav_init(Trav& t, float4 ro, float4 rd, float tlimit) {
+   t.o = v3(ro.x, ro.y, ro.z);
+   t.d = v3(rd.x, rd.y, rd.z);
+   t.idir = v3(safe_rcp_dir(t.d.x), safe_rcp_dir(t.d.y), safe_rcp_dir(t.d.z));
+   t.tmin = ro.w;
+   t.tlimit = tlimit;
+   t.best.t = rd.w;
+   t.best.u = t.best.v = 0.0f;
+   t.best.idx = kEmptyRef;
+   t.best.key = 0xffffffffu;
+   t.sp = 0;
+   t.cur = 0;
+}
+
+__device__ __forceinline__ void trav_push(Trav& t, uint32_t* lds_col, uint32_t* spill, uint32_t ref) {
+   if (t.sp < kLdsStack)
+      lds_col[t.sp * 64] = ref;
+   else if (t.sp < kLdsStack + kSpillStack)
+      spill[t.sp - kLdsStack] = ref;
+   else
+      return;
+   t.sp++;
+}
+__device__ __forceinline__ uint32_t trav_pop(Trav& t, const uint32_t* lds_col, const uint32_t* spill) {
+   if (t.sp == 0) return kEmptyRef;
+   t.sp--;
+   return t.sp < kLdsStack ? lds_col[t.sp * 64] : spill[t.sp - kLdsStack];
+}
+
+// one interior node (quantised, 64 B): slab-test the 4 children, continue with the nearest, push
+// the other hits. plane = origin + scale * q  =>  t = q * (scale * idir) + (origin - o) * idir.
+// Instruction diet (the kernel is VALU-issue bound, profiles/r01c_*): the near / far plane words
+// are picked once per axis by the sign of idir instead of min/max per plane; an empty slot is an
+// inverted box (no child != empty test); only the nearest child is fully ordered (3 comparators);
+// pushes are branch-free (write always, advance the stack pointer by the hit bit).
+template <bool ANY>
+__device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill) {
+   const uint4* n = nodes + 4 * (size_t)t.cur;
+   const uint4 w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
+   const float ax = __uint_as_float(w0.w) * t.idir.x, ay = __uint_as_float(w1.x) * t.idir.y, az = __uint_as_float(w1.y) * t.idir.z;
+   const float bx = (__uint_as_float(w0.x) - t.o.x) * t.idir.x, by = (__uint_as_float(w0.y) - t.o.y) * t.idir.y, bz = (__uint_as_float(w0.z) - t.o.z) * t.idir.z;
+   const bool nx = t.idir.x < 0.0f, ny = t.idir.y < 0.0f, nz = t.idir.z < 0.0f;
+   // qlo = (w1.z, w1.w, w2.x), qhi = (w2.y, w2.z, w2.w)
+   const uint32_t qnx = nx ? w2.y : w1.z, qfx = nx ? w1.z : w2.y;
+   const uint32_t qny = ny ? w2.z : w1.w, qfy = ny ? w1.w : w2.z;
+   const uint32_t qnz = nz ? w2.w : w2.x, qfz = nz ? w2.x : w2.w;
+   const float tcap = fminf(t.best.t, t.tlimit);
+   float tn[4];
+   uint32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+   for (int k = 0; k < 4; k++) {
+      const float t0x = fmaf((float)((qnx >> (8 * k)) & 0xffu), ax, bx), t1x = fmaf((float)((qfx >> (8 * k)) & 0xffu), ax, bx);
+      const float t0y = fmaf((float)((qny >> (8 * k)) & 0xffu), ay, by), t1y = fmaf((float)((qfy >> (8 * k)) & 0xffu), ay, by);
+      const float t0z = fmaf((float)((qnz >> (8 * k)) & 0xffu), az, bz), t1z = fmaf((float)((qfz >> (8 * k)) & 0xffu), az, bz);
+      const float tnear = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, t.tmin));
+      const float tfar = fminf(fminf(t1x, t1y), fminf(t1z, tcap));
+      tn[k] = (tnear <= tfar) ? tnear : INFINITY;
+   }
+   if (!ANY) {
+      // bring the nearest hit to slot 0 (3 comparators); slots 1..3 stay unordered
+      auto cswap = [&](int i, int j) {
+         bool s = tn[j] < tn[i];
+         float ta = s ? tn[j] : tn[i], tb = s ? tn[i] : tn[j];
+         uint32_t ca = s ? cr[j] : cr[i], cb = s ? cr[i] : cr[j];
+         tn[i] = ta;
+         tn[j] = tb;
+         cr[i] = ca;
+         cr[j] = cb;
+      };
+      cswap(0, 1);
+      cswap(2, 3);
+      cswap(0, 2);
+   } else {
+      // any-hit: order is irrelevant; just make slot 0 a hit if there is one
+      auto tofront = [&](int j) {
+         bool s = !(tn[0] < INFINITY) && (tn[j] < INFINITY);
+         float tj = tn[j];
+         uint32_t cj = cr[j];
+         tn[j] = s ? tn[0] : tj;
+         cr[j] = s ? cr[0] : cj;
+         tn[0] = s ? tj : tn[0];
+         cr[0] = s ? cj : cr[0];
+      };
+      tofront(1);
+      tofront(2);
+      tofront(3);
+   }
+   if (t.sp + 3 <= kLdsStack) {
+      // branch-free pushes of slots 3, 2, 1
+      uint32_t* p = lds_col + t.sp * 64;
+      int h3 = tn[3] < INFINITY ? 1 : 0, h2 = tn[2] < INFINITY ? 1 : 0, h1 = tn[1] < INFINITY ? 1 : 0;
+      p[0] = cr[3];
+      p += h3 * 64;
+      p[0] = cr[2];
+      p += h2 * 64;
+      p[0] = cr[1];
+      t.sp += h3 + h2 + h1;
+   } else {
+      if (tn[3] < INFINITY) trav_push(t, lds_col, spill, cr[3]);
+      if (tn[2] < INFINITY) trav_push(t, lds_col, spill, cr[2]);
+      if (tn[1] < INFINITY) trav_push(t, lds_col, spill, cr[1]);
+   }
+   t.cur = (tn[0] < INFINITY) ? cr[0] : trav_pop(t, lds_col, spill);
+}
+
+// one leaf: up to 4 triangle packets. Returns true when an any-hit walk found an occluder.
+template <bool ANY>
+__device__ __forceinline__ bool leaf_step(const float4* __restrict__ tris, Trav& t, uint32_t& n_tris) {
+   const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+   n_tris += cnt;
+   for (uint32_t k = 0; k < cnt; k++) {
+      bool h = tri_test<ANY>(tris, first + k, t.o, t.d, t.tmin, t.tlimit, t.best);
+      if (ANY && h) return true;
+   }
+   return false;
+}
+
+// batch (if-if) traversal of one ray: used by the stand-alone query kernels and trace variant 0
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, float tlimit, Hit& best, uint32_t* lds_col,
                                          uint32_t& n_nodes, uint32_t& n_tris) {
-   best.t = tmax;
-   best.u = best.v = 0.0f;
-   best.idx = kEmptyRef;
-   best.key = 0xffffffffu;
-   const float4* __restrict__ nodes = sc.nodes;
-   const float4* __restrict__ tris = sc.tris;
-   const V3 idir = v3(safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z));
-   const V3 ood = v3(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
+   Trav t;
+   trav_init(t, make_float4(o.x, o.y, o.z, tmin), make_float4(d.x, d.y, d.z, tmax), ANY ? tlimit : INFINITY);
    uint32_t spill[kSpillStack];
-   int sp = 0;
-   uint32_t cur = 0;  // root is always an interior node
-   auto push = [&](uint32_t ref) {
-      if (sp < kLdsStack)
-         lds_col[sp * 64] = ref;
-      else if (sp < kLdsStack + kSpillStack)
-         spill[sp - kLdsStack] = ref;
-      else
-         return;  // deeper than any tree the builder emits (depth cap 48 -> <= 3*depth entries is far above need)
-      sp++;
-   };
-   auto pop = [&]() -> uint32_t {
-      if (sp == 0) return kEmptyRef;
-      sp--;
-      return sp < kLdsStack ? lds_col[sp * 64] : spill[sp - kLdsStack];
-   };
-   while (cur != kEmptyRef) {
-      if (!(cur & kLeafBit)) {
-         const float4* n = nodes + 8 * (size_t)cur;
-         float4 lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
-         uint4 ch = *reinterpret_cast<const uint4*>(n + 6);
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   bool occluded = false;
+   while (t.cur != kEmptyRef) {
+      if (!(t.cur & kLeafBit)) {
          if (COUNT) n_nodes++;
-         float tn[4];
-         uint32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
-         const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
-         const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
-#pragma unroll
-         for (int k = 0; k < 4; k++) {
-            float t0x = fmaf(lx[k], idir.x, ood.x), t1x = fmaf(hx[k], idir.x, ood.x);
-            float t0y = fmaf(ly[k], idir.y, ood.y), t1y = fmaf(hy[k], idir.y, ood.y);
-            float t0z = fmaf(lz[k], idir.z, ood.z), t1z = fmaf(hz[k], idir.z, ood.z);
-            float tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-            float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
-            bool hit = (tnear <= tfar) && (cr[k] != kEmptyRef);
-            tn[k] = hit ? tnear : INFINITY;
-         }
-         if (!ANY) {
-            // 5-comparator sorting network, ascending by entry distance
-            auto cswap = [&](int i, int j) {
-               bool s = tn[j] < tn[i];
-               float ta = s ? tn[j] : tn[i], tb = s ? tn[i] : tn[j];
-               uint32_t ca = s ? cr[j] : cr[i], cb = s ? cr[i] : cr[j];
-               tn[i] = ta;
-               tn[j] = tb;
-               cr[i] = ca;
-               cr[j] = cb;
-            };
-            cswap(0, 1);
-            cswap(2, 3);
-            cswap(0, 2);
-            cswap(1, 3);
-            cswap(1, 2);
-            if (tn[3] < INFINITY) push(cr[3]);
-            if (tn[2] < INFINITY) push(cr[2]);
-            if (tn[1] < INFINITY) push(cr[1]);
-            cur = (tn[0] < INFINITY) ? cr[0] : pop();
-         } else {
-            uint32_t next = kEmptyRef;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-               if (tn[k] < INFINITY) {
-                  if (next == kEmptyRef)
-                     next = cr[k];
-                  else
-                     push(cr[k]);
-               }
-            cur = (next != kEmptyRef) ? next : pop();
-         }
+         node_step<ANY>(nodes, t, lds_col, spill);
       } else {
-         uint32_t first = cur & kLeafFirstMask, cnt = (cur >> kLeafCountShift) & 0xf;
-         if (COUNT) n_tris += cnt;
-         for (uint32_t k = 0; k < cnt; k++) {
-            bool h = tri_test<ANY>(tris, first + k, o, d, tmin, tlimit, best);
-            if (ANY && h) return true;
+         if (leaf_step<ANY>(tris, t, n_tris)) {
+            occluded = true;
+            break;
          }
-         cur = pop();
+         t.cur = trav_pop(t, lds_col, spill);
       }
    }
-   return ANY ? false : (best.idx != kEmptyRef);
+   best = t.best;
+   return ANY ? occluded : (best.idx != kEmptyRef);
 }
 
 // persistent-thread batch fetch: lane 0 pulls the next 64-item batch of its shard
@@ -195,7 +251,7 @@ __device__ __forceinline__ ShardCtx shard_ctx() {
 // trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes
 // ------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                                                           uint32_t cursor_slot, int ray_kind) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    const uint32_t lane = lane_id();
@@ -261,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_raw(SceneDev sc, const
 // Occluded <=> some triangle has tmin < t < tmax (sun) and additionally t <= distance_to_light.
 // ------------------------------------------------------------------------------------------
 template <bool COUNT, bool LIGHT>
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                                                          uint32_t cursor_slot) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    const uint32_t lane = lane_id();
@@ -322,6 +378,423 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_raw(SceneDev sc, const flo
       float4 ro = ray_o[i], rd = ray_d[i];
       Hit h;
       occluded[i] = traverse<true, false>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, INFINITY, h, lds_col, n_nodes, n_tris) ? 1u : 0u;
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Traversal v2 — persistent waves with per-lane ray replacement ("while-while" with dynamic fetch).
+// A wave keeps a pool of kChunk rays taken from its shard's cursor with ONE atomic; a lane whose ray
+// is finished goes idle, and as soon as kRefillIdle lanes are idle the wave (a) appends the finished
+// rays to the hit / miss queues with one ballot-aggregated atomic each and (b) hands every idle lane
+// the next ray of the pool. The inner structure is while-while: all lanes first descend interior
+// nodes until each holds a leaf (or is done), then the leaves are intersected together, so a wave
+// does not pay node + leaf cost in every iteration the way the if-if form of traverse() does.
+// ------------------------------------------------------------------------------------------
+// wave-uniform pool refill; returns false when the shard's queue is drained
+__device__ __forceinline__ bool pool_refill(uint32_t* cursor, uint32_t count, uint32_t& pool_pos, uint32_t& pool_end) {
+   uint32_t base = 0;
+   if (lane_id() == 0) base = atomicAdd(cursor, kChunk);
+   base = __builtin_amdgcn_readfirstlane(base);
+   if (base >= count) return false;
+   pool_pos = base;
+   pool_end = min(base + kChunk, count);
+   return true;
+}
+
+template <bool COUNT, int kRefillIdle, bool kPostpone>
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_v2(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+                                                             uint32_t cursor_slot, int ray_kind) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   const uint32_t lane = lane_id();
+   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
+   uint32_t* q_hit = ps.queue[2] + seg;
+   uint32_t* q_miss = ps.queue[3] + seg;
+   uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
+   uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
+   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   uint32_t spill[kSpillStack];
+   uint32_t pool_pos = 0, pool_end = 0;
+   bool drained = false;
+   bool active = false;
+   uint32_t pend = 0, id = 0;  // pend: 1 = finished with a hit, 2 = finished with a miss, not yet queued
+   Trav t;
+   t.cur = kEmptyRef;
+   t.sp = 0;
+   uint32_t n_nodes = 0, n_tris = 0;
+   for (;;) {
+      const unsigned long long idle_mask = __ballot(!active);
+      const int n_idle = __popcll(idle_mask);
+      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
+         // (a) queue the finished rays
+         uint32_t slot = wave_append(n_hit, pend == 1);
+         if (pend == 1) q_hit[slot] = id;
+         slot = wave_append(n_miss, pend == 2);
+         if (pend == 2) q_miss[slot] = id;
+         pend = 0;
+         // (b) hand out new rays
+         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
+         if (!drained) {
+            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+            const uint32_t idx = pool_pos + prefix;
+            if (!active && idx < pool_end) {
+               id = queue[idx];
+               trav_init(t, ps.ray_o[id], ps.ray_d[id], INFINITY);
+               active = true;
+            }
+            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
+         }
+         if (__ballot(active) == 0ull) {
+            if (drained) break;
+            continue;
+         }
+      }
+      if (active) {
+         if (kPostpone) {
+            // speculative while-while: a lane that reaches a leaf parks it and keeps descending from
+            // its stack, so it does not idle while the rest of the wave is still in interior nodes.
+            // (Hits are order-independent, so walking on with a stale tbest only costs a few visits.)
+            uint32_t parked = kEmptyRef;
+            for (;;) {
+               if (t.cur != kEmptyRef && (t.cur & kLeafBit) && parked == kEmptyRef) {
+                  parked = t.cur;
+                  t.cur = trav_pop(t, lds_col, spill);
+               }
+               if (t.cur == kEmptyRef || (t.cur & kLeafBit)) break;
+               if (COUNT) n_nodes++;
+               node_step<false>(nodes, t, lds_col, spill);
+            }
+            if (parked != kEmptyRef) {
+               const uint32_t keep = t.cur;
+               t.cur = parked;
+               leaf_step<false>(tris, t, n_tris);
+               t.cur = keep;
+            }
+         } else {
+            while (t.cur != kEmptyRef && !(t.cur & kLeafBit)) {
+               if (COUNT) n_nodes++;
+               node_step<false>(nodes, t, lds_col, spill);
+            }
+            if (t.cur != kEmptyRef) {
+               leaf_step<false>(tris, t, n_tris);
+               t.cur = trav_pop(t, lds_col, spill);
+            }
+         }
+         if (t.cur == kEmptyRef) {
+            ps.hit[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
+            pend = t.best.idx != kEmptyRef ? 1u : 2u;
+            active = false;
+         }
+      }
+   }
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
+   if (COUNT) {
+      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+   }
+}
+
+template <bool COUNT, bool LIGHT, int kRefillIdle, bool kPostpone>
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_shadow_v2(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats,
+                                                            uint32_t bounce, uint32_t cursor_slot) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   const uint32_t lane = lane_id();
+   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[4] : ps.queue[(bounce + 1) & 1]) + seg;
+   const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   uint32_t spill[kSpillStack];
+   uint32_t pool_pos = 0, pool_end = 0;
+   bool drained = false, active = false;
+   uint32_t id = 0;
+   float f = 1.0f;
+   Trav t;
+   t.cur = kEmptyRef;
+   t.sp = 0;
+   uint32_t n_nodes = 0, n_tris = 0;
+   for (;;) {
+      const unsigned long long idle_mask = __ballot(!active);
+      const int n_idle = __popcll(idle_mask);
+      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
+         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
+         if (!drained) {
+            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+            const uint32_t idx = pool_pos + prefix;
+            if (!active && idx < pool_end) {
+               id = queue[idx];
+               float4 ro = ps.ray_o[id];
+               ro.w = 0.001f;
+               float4 rd;
+               float tlimit = INFINITY;
+               if (LIGHT) {
+                  float4 thr = ps.thr[id], rad = ps.rad[id];
+                  int light_index = (int)__float_as_uint(rad.w);
+                  V3 lpos = v3(0, 0, 0);
+                  if (light_index >= 0 && (uint32_t)light_index < sc.num_lights) lpos = xyz(sc.lights[2 * light_index]);
+                  V3 o = v3(ro.x, ro.y, ro.z);
+                  V3 dir = normalize3(lpos - o);  // rgen:113
+                  tlimit = length3(lpos - o);     // rgen:114
+                  f = thr.w;
+                  rd = make_float4(dir.x, dir.y, dir.z, 10000.0f);
+               } else {
+                  rd = make_float4(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2], 10000.0f);  // rgen:64
+               }
+               trav_init(t, ro, rd, tlimit);
+               active = true;
+            }
+            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
+         }
+         if (__ballot(active) == 0ull) {
+            if (drained) break;
+            continue;
+         }
+      }
+      if (active) {
+         bool occluded = false;
+         if (kPostpone) {
+            uint32_t parked = kEmptyRef;
+            for (;;) {
+               if (t.cur != kEmptyRef && (t.cur & kLeafBit) && parked == kEmptyRef) {
+                  parked = t.cur;
+                  t.cur = trav_pop(t, lds_col, spill);
+               }
+               if (t.cur == kEmptyRef || (t.cur & kLeafBit)) break;
+               if (COUNT) n_nodes++;
+               node_step<true>(nodes, t, lds_col, spill);
+            }
+            if (parked != kEmptyRef) {
+               const uint32_t keep = t.cur;
+               t.cur = parked;
+               occluded = leaf_step<true>(tris, t, n_tris);
+               t.cur = occluded ? kEmptyRef : keep;
+            }
+         } else {
+            while (t.cur != kEmptyRef && !(t.cur & kLeafBit)) {
+               if (COUNT) n_nodes++;
+               node_step<true>(nodes, t, lds_col, spill);
+            }
+            if (t.cur != kEmptyRef) {
+               occluded = leaf_step<true>(tris, t, n_tris);
+               t.cur = occluded ? kEmptyRef : trav_pop(t, lds_col, spill);
+            }
+         }
+         if (t.cur == kEmptyRef) {
+            if (!occluded) {  // rgen:69-78 / :118-122
+               float4 thr = ps.thr[id], rad = ps.rad[id];
+               if (LIGHT)
+                  ps.rad[id] = make_float4(rad.x + thr.x * f, rad.y + thr.y * f, rad.z + thr.z * f, rad.w);
+               else
+                  ps.rad[id] = make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w);
+            }
+            active = false;
+         }
+      }
+   }
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
+   if (COUNT) {
+      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Traversal v3 — "vote" scheduling on top of the v2 refill. The v2 counters (profiles/r01c_*) show
+// the SIMDs ~70 % busy issuing VALU while only ~30 % of the lanes in those instructions are live:
+// lanes sit out whenever the wave is in the other phase (interior node vs triangle). Here every
+// loop iteration runs exactly ONE phase for the whole wave, chosen by ballot: a triangle step (one
+// triangle per lane that stands at a leaf) when at least kLeafVote lanes want one or nobody wants
+// a node step, else a node step. Lanes of the minority wait one iteration instead of dragging a
+// sparsely populated phase through the SIMD.
+// ------------------------------------------------------------------------------------------
+template <bool COUNT, int kRefillIdle, int kLeafVote>
+__global__ __launch_bounds__(kBlock) void k_trace_closest_v3(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+                                                             uint32_t cursor_slot, int ray_kind) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   const uint32_t lane = lane_id();
+   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
+   uint32_t* q_hit = ps.queue[2] + seg;
+   uint32_t* q_miss = ps.queue[3] + seg;
+   uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
+   uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
+   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   uint32_t spill[kSpillStack];
+   uint32_t pool_pos = 0, pool_end = 0;
+   bool drained = false, active = false;
+   uint32_t pend = 0, id = 0, tk = 0;
+   Trav t;
+   t.cur = kEmptyRef;
+   t.sp = 0;
+   uint32_t n_nodes = 0, n_tris = 0;
+   for (;;) {
+      const unsigned long long idle_mask = __ballot(!active);
+      const int n_idle = __popcll(idle_mask);
+      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
+         uint32_t slot = wave_append(n_hit, pend == 1);
+         if (pend == 1) q_hit[slot] = id;
+         slot = wave_append(n_miss, pend == 2);
+         if (pend == 2) q_miss[slot] = id;
+         pend = 0;
+         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
+         if (!drained) {
+            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+            const uint32_t idx = pool_pos + prefix;
+            if (!active && idx < pool_end) {
+               id = queue[idx];
+               trav_init(t, ps.ray_o[id], ps.ray_d[id], INFINITY);
+               tk = 0;
+               active = true;
+            }
+            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
+         }
+         if (__ballot(active) == 0ull) {
+            if (drained) break;
+            continue;
+         }
+      }
+      const bool at_leaf = active && (t.cur & kLeafBit);
+      const int n_leaf = __popcll(__ballot(at_leaf));
+      const int n_node = 64 - n_idle - n_leaf;  // n_idle is exact here: nothing changed `active` since the ballot unless we refilled
+      const bool tri_phase = (n_leaf >= kLeafVote) || (__ballot(active && !at_leaf) == 0ull);
+      (void)n_node;
+      if (tri_phase) {
+         if (at_leaf) {
+            const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+            if (COUNT) n_tris++;
+            tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
+            tk++;
+            if (tk >= cnt) {
+               tk = 0;
+               t.cur = trav_pop(t, lds_col, spill);
+            }
+         }
+      } else if (active && !at_leaf) {
+         if (COUNT) n_nodes++;
+         node_step<false>(nodes, t, lds_col, spill);
+      }
+      if (active && t.cur == kEmptyRef) {
+         ps.hit[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
+         pend = t.best.idx != kEmptyRef ? 1u : 2u;
+         active = false;
+      }
+   }
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
+   if (COUNT) {
+      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+   }
+}
+
+template <bool COUNT, bool LIGHT, int kRefillIdle, int kLeafVote>
+__global__ __launch_bounds__(kBlock) void k_trace_shadow_v3(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats,
+                                                            uint32_t bounce, uint32_t cursor_slot) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   const uint32_t lane = lane_id();
+   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[4] : ps.queue[(bounce + 1) & 1]) + seg;
+   const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   uint32_t spill[kSpillStack];
+   uint32_t pool_pos = 0, pool_end = 0;
+   bool drained = false, active = false;
+   uint32_t id = 0, tk = 0;
+   float f = 1.0f;
+   Trav t;
+   t.cur = kEmptyRef;
+   t.sp = 0;
+   uint32_t n_nodes = 0, n_tris = 0;
+   for (;;) {
+      const unsigned long long idle_mask = __ballot(!active);
+      const int n_idle = __popcll(idle_mask);
+      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
+         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
+         if (!drained) {
+            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+            const uint32_t idx = pool_pos + prefix;
+            if (!active && idx < pool_end) {
+               id = queue[idx];
+               float4 ro = ps.ray_o[id];
+               ro.w = 0.001f;
+               float4 rd;
+               float tlimit = INFINITY;
+               if (LIGHT) {
+                  float4 thr = ps.thr[id], rad = ps.rad[id];
+                  int light_index = (int)__float_as_uint(rad.w);
+                  V3 lpos = v3(0, 0, 0);
+                  if (light_index >= 0 && (uint32_t)light_index < sc.num_lights) lpos = xyz(sc.lights[2 * light_index]);
+                  V3 o = v3(ro.x, ro.y, ro.z);
+                  V3 dir = normalize3(lpos - o);  // rgen:113
+                  tlimit = length3(lpos - o);     // rgen:114
+                  f = thr.w;
+                  rd = make_float4(dir.x, dir.y, dir.z, 10000.0f);
+               } else {
+                  rd = make_float4(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2], 10000.0f);  // rgen:64
+               }
+               trav_init(t, ro, rd, tlimit);
+               tk = 0;
+               active = true;
+            }
+            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
+         }
+         if (__ballot(active) == 0ull) {
+            if (drained) break;
+            continue;
+         }
+      }
+      const bool at_leaf = active && (t.cur & kLeafBit);
+      const int n_leaf = __popcll(__ballot(at_leaf));
+      const bool tri_phase = (n_leaf >= kLeafVote) || (__ballot(active && !at_leaf) == 0ull);
+      bool occluded = false;
+      if (tri_phase) {
+         if (at_leaf) {
+            const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+            if (COUNT) n_tris++;
+            occluded = tri_test<true>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
+            tk++;
+            if (occluded) {
+               t.cur = kEmptyRef;
+            } else if (tk >= cnt) {
+               tk = 0;
+               t.cur = trav_pop(t, lds_col, spill);
+            }
+         }
+      } else if (active && !at_leaf) {
+         if (COUNT) n_nodes++;
+         node_step<true>(nodes, t, lds_col, spill);
+      }
+      if (active && t.cur == kEmptyRef) {
+         if (!occluded) {  // rgen:69-78 / :118-122
+            float4 thr = ps.thr[id], rad = ps.rad[id];
+            if (LIGHT)
+               ps.rad[id] = make_float4(rad.x + thr.x * f, rad.y + thr.y * f, rad.z + thr.z * f, rad.w);
+            else
+               ps.rad[id] = make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w);
+         }
+         active = false;
+      }
+   }
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
+   if (COUNT) {
+      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
    }
 }
 
@@ -405,6 +878,11 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
 
 __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, const UhReservoir* __restrict__ spatial_reservoirs,
                                                       Control* ctl, DeviceStats* stats, uint32_t bounce) {
+   // c / 255.0f table in LDS: the 12 per-fetch table gathers were texture-addresser traffic (the
+   // kernel ran 86 % TA-busy at 2 % VALU, profiles/r01c_*); LDS serves them at no TA cost
+   __shared__ float s_lut[256];
+   s_lut[threadIdx.x] = sc.unorm_lut[threadIdx.x];
+   __syncthreads();
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
@@ -441,7 +919,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
          if (dot3(world_normal, ray_dir) > 0.0f) world_normal = vneg(world_normal);   // rchit:35-37
          float uu = (uv0x * bx + uv1x * by) + uv2x * bz;                               // rchit:39
          float vv = (uv0y * bx + uv1y * by) + uv2y * bz;
-         V3 color = sample_texture(sc, ms.diffuse_map, uu, vv);                        // rchit:40
+         V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv);                        // rchit:40
          color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
 
          uint2 rng = ps.rng[id];
@@ -748,7 +1226,8 @@ static inline dim3 sharded_grid(uint32_t blocks) {
    uint32_t g = (blocks / kShards) * kShards;
    return dim3(g < kShards ? kShards : g);
 }
-static inline dim3 trace_grid(const LaunchCfg& c) { return sharded_grid(c.num_cus * c.trace_blocks_per_cu); }
+static inline dim3 closest_grid(const LaunchCfg& c) { return sharded_grid(c.num_cus * c.closest_blocks_per_cu); }
+static inline dim3 shadow_grid(const LaunchCfg& c) { return sharded_grid(c.num_cus * c.shadow_blocks_per_cu); }
 static inline dim3 shade_grid(const LaunchCfg& c, uint32_t n) {
    uint32_t blocks = (n + kBlock - 1) / kBlock, cap = c.num_cus * 8;
    return sharded_grid(blocks < cap ? blocks : cap);
@@ -770,10 +1249,52 @@ void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState&
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                           uint32_t cursor_slot, int ray_kind) {
-   if (c.count_visits)
-      k_trace_closest<true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
-   else
-      k_trace_closest<false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+   if (c.closest_variant == 0) {
+      if (c.count_visits)
+         k_trace_closest<true><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+      else
+         k_trace_closest<false><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+      return;
+   }
+   if (c.closest_variant >= 11) {
+#define UH_LAUNCH_V3(IDLE, VOTE)                                                                                                          \
+   do {                                                                                                                                   \
+      if (c.count_visits)                                                                                                                 \
+         k_trace_closest_v3<true, IDLE, VOTE><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);  \
+      else                                                                                                                                \
+         k_trace_closest_v3<false, IDLE, VOTE><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind); \
+   } while (0)
+      switch (c.closest_variant) {
+         case 11: UH_LAUNCH_V3(16, 16); break;
+         case 12: UH_LAUNCH_V3(16, 24); break;
+         case 13: UH_LAUNCH_V3(16, 32); break;
+         case 14: UH_LAUNCH_V3(8, 24); break;
+         case 15: UH_LAUNCH_V3(24, 24); break;
+         default: UH_LAUNCH_V3(16, 40); break;
+      }
+#undef UH_LAUNCH_V3
+      return;
+   }
+#define UH_LAUNCH_V2(IDLE, POST)                                                                                                          \
+   do {                                                                                                                                   \
+      if (c.count_visits)                                                                                                                 \
+         k_trace_closest_v2<true, IDLE, POST><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);  \
+      else                                                                                                                                \
+         k_trace_closest_v2<false, IDLE, POST><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind); \
+   } while (0)
+   switch (c.closest_variant) {
+      case 1: UH_LAUNCH_V2(64, false); break;
+      case 2: UH_LAUNCH_V2(32, false); break;
+      case 3: UH_LAUNCH_V2(16, false); break;
+      case 4: UH_LAUNCH_V2(8, false); break;
+      case 5: UH_LAUNCH_V2(1, false); break;
+      case 6: UH_LAUNCH_V2(64, true); break;
+      case 7: UH_LAUNCH_V2(32, true); break;
+      case 8: UH_LAUNCH_V2(16, true); break;
+      case 9: UH_LAUNCH_V2(8, true); break;
+      default: UH_LAUNCH_V2(1, true); break;
+   }
+#undef UH_LAUNCH_V2
 }
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
@@ -787,16 +1308,72 @@ void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev&
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
                          uint32_t bounce, uint32_t cursor_slot, bool light) {
+   if (c.shadow_variant >= 11) {
+#define UH_LAUNCH_S3(IDLE, VOTE)                                                                                                              \
+   do {                                                                                                                                       \
+      if (light) {                                                                                                                            \
+         if (c.count_visits)                                                                                                                  \
+            k_trace_shadow_v3<true, true, IDLE, VOTE><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);    \
+         else                                                                                                                                 \
+            k_trace_shadow_v3<false, true, IDLE, VOTE><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);   \
+      } else {                                                                                                                                \
+         if (c.count_visits)                                                                                                                  \
+            k_trace_shadow_v3<true, false, IDLE, VOTE><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);   \
+         else                                                                                                                                 \
+            k_trace_shadow_v3<false, false, IDLE, VOTE><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);  \
+      }                                                                                                                                       \
+   } while (0)
+      switch (c.shadow_variant) {
+         case 11: UH_LAUNCH_S3(16, 16); break;
+         case 12: UH_LAUNCH_S3(16, 24); break;
+         case 13: UH_LAUNCH_S3(16, 32); break;
+         case 14: UH_LAUNCH_S3(8, 24); break;
+         case 15: UH_LAUNCH_S3(24, 24); break;
+         default: UH_LAUNCH_S3(16, 40); break;
+      }
+#undef UH_LAUNCH_S3
+      return;
+   }
+   if (c.shadow_variant != 0) {
+#define UH_LAUNCH_S2(IDLE, POST)                                                                                                              \
+   do {                                                                                                                                 \
+      if (light) {                                                                                                                      \
+         if (c.count_visits)                                                                                                            \
+            k_trace_shadow_v2<true, true, IDLE, POST><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);    \
+         else                                                                                                                           \
+            k_trace_shadow_v2<false, true, IDLE, POST><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);   \
+      } else {                                                                                                                          \
+         if (c.count_visits)                                                                                                            \
+            k_trace_shadow_v2<true, false, IDLE, POST><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);   \
+         else                                                                                                                           \
+            k_trace_shadow_v2<false, false, IDLE, POST><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);  \
+      }                                                                                                                                 \
+   } while (0)
+      switch (c.shadow_variant) {
+         case 1: UH_LAUNCH_S2(64, false); break;
+         case 2: UH_LAUNCH_S2(32, false); break;
+         case 3: UH_LAUNCH_S2(16, false); break;
+         case 4: UH_LAUNCH_S2(8, false); break;
+         case 5: UH_LAUNCH_S2(1, false); break;
+         case 6: UH_LAUNCH_S2(64, true); break;
+         case 7: UH_LAUNCH_S2(32, true); break;
+         case 8: UH_LAUNCH_S2(16, true); break;
+         case 9: UH_LAUNCH_S2(8, true); break;
+         default: UH_LAUNCH_S2(1, true); break;
+      }
+#undef UH_LAUNCH_S2
+      return;
+   }
    if (light) {
       if (c.count_visits)
-         k_trace_shadow<true, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
+         k_trace_shadow<true, true><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
       else
-         k_trace_shadow<false, true><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
+         k_trace_shadow<false, true><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
    } else {
       if (c.count_visits)
-         k_trace_shadow<true, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
+         k_trace_shadow<true, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
       else
-         k_trace_shadow<false, false><<<trace_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
+         k_trace_shadow<false, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
    }
 }
 
@@ -814,7 +1391,7 @@ void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& s
    (void)ctl;
    const uint32_t n = fp.W * fp.H;
    k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps);
-   k_trace_closest_raw<<<dim3(c.num_cus * c.trace_blocks_per_cu), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, n);
+   k_trace_closest_raw<<<dim3(c.num_cus * c.closest_blocks_per_cu), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, n);
    k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats);
 }
 

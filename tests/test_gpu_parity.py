@@ -184,3 +184,18 @@ def test_instance_transform_rebuild(cornell):
         r.initialize_raytracing()
         run_frames(r, cornell, W, H, 1, rr.PASS_REFERENCE_PT)
     assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
+
+
+@pytest.mark.parametrize("variant", [1, 3, 5, 8, 11, 12, 14, 16])
+def test_traversal_variants_are_bit_identical(atrium, variant):
+    """every traversal kernel variant must produce the same image and the same ray counts"""
+    W, H = 160, 90
+    ref = atrium.upload(rr.Renderer(W, H))
+    alt = atrium.upload(rr.Renderer(W, H))
+    alt.set_option("trace_variant", variant)
+    for r in (ref, alt):
+        r.set_option("count_visits", 1)
+        run_frames(r, atrium, W, H, 2, rr.PASS_ALL)
+    assert np.array_equal(ref.read_accumulation().view(np.uint32), alt.read_accumulation().view(np.uint32))
+    a, b = ref.get_stats(), alt.get_stats()
+    assert list(a.rays) == list(b.rays) and a.closest_hits == b.closest_hits and a.misses == b.misses
