@@ -57,6 +57,11 @@ struct DevBuf {
 struct uh_ctx {
    int device = 0;
    hipStream_t stream = nullptr;
+   // second stream: shade_miss (pure VALU, touches only paths that left the scene) overlaps the
+   // memory-bound shade_hit and the shadow traversal of the same bounce
+   hipStream_t side = nullptr;
+   hipEvent_t ev_traced = nullptr, ev_side_done = nullptr;
+   bool overlap_miss = true;
    uint32_t W = 0, H = 0;
    uint32_t num_cus = 256;
    uint32_t closest_blocks_per_cu = 8, shadow_blocks_per_cu = 6;
@@ -92,7 +97,7 @@ struct uh_ctx {
 
    // options / stats
    bool count_visits = false, time_kernels = false, full_frame_restir = false;
-   int closest_variant = 0, shadow_variant = 3;  // measured fastest on MI355X (profiles/README.md)
+   int closest_variant = 0, shadow_variant = 19;  // measured fastest on MI355X (profiles/README.md)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
    float ms_by_kind[3] = {0, 0, 0};
@@ -226,6 +231,9 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    CREATE_TRY(hipGetDeviceProperties(&prop, device_ordinal));
    c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+   CREATE_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+   CREATE_TRY(hipEventCreateWithFlags(&c->ev_traced, hipEventDisableTiming));
+   CREATE_TRY(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
    CREATE_TRY(hipEventCreate(&c->frame_start));
    CREATE_TRY(hipEventCreate(&c->frame_stop));
    {
@@ -285,6 +293,7 @@ void uh_destroy(uh_ctx* c) {
    if (!c) return;
    (void)hipSetDevice(c->device);
    if (c->stream) (void)hipStreamSynchronize(c->stream);
+   if (c->side) (void)hipStreamSynchronize(c->side);
    for (auto& t : c->textures)
       if (t.dev) (void)hipFree(t.dev);
    for (auto& ep : c->pending) {
@@ -318,6 +327,9 @@ void uh_destroy(uh_ctx* c) {
    c->dstats.release();
    if (c->frame_start) (void)hipEventDestroy(c->frame_start);
    if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
+   if (c->ev_traced) (void)hipEventDestroy(c->ev_traced);
+   if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
+   if (c->side) (void)hipStreamDestroy(c->side);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
 }
@@ -578,8 +590,16 @@ int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask
             begin_timed(c, 0);
             launch_trace_closest(lc, c->scene, c->ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
             end_timed(c);
+            if (c->overlap_miss) {
+               // side stream: shade_miss(b) after trace_closest(b); joined before finish_sample
+               HIP_TRY(c, hipEventRecord(c->ev_traced, c->stream));
+               HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_traced, 0));
+               LaunchCfg ls = lc;
+               ls.stream = c->side;
+               launch_shade_miss(ls, fp, c->ps, ctl, st, b);
+            }
             begin_timed(c, 2);
-            launch_shade_miss(lc, fp, c->ps, ctl, st, b);
+            if (!c->overlap_miss) launch_shade_miss(lc, fp, c->ps, ctl, st, b);
             launch_shade_hit(lc, fp, c->scene, c->ps, c->im, ctl, st, b);
             end_timed(c);
             if (fp.sun_shadow_enabled == 1) {
@@ -592,6 +612,10 @@ int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask
                launch_trace_shadow(lc, fp, c->scene, c->ps, ctl, st, b, slot++, true);
                end_timed(c);
             }
+         }
+         if (c->overlap_miss && fp.num_bounces > 0) {
+            HIP_TRY(c, hipEventRecord(c->ev_side_done, c->side));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
          }
          launch_finish_sample(lc, fp, c->ps, c->im, s, s + 1 == fp.samples_per_frame);
       }
@@ -781,8 +805,10 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->time_kernels = value != 0;
    } else if (n == "full_frame_restir")
       c->full_frame_restir = value != 0;
+   else if (n == "overlap_miss")
+      c->overlap_miss = value != 0;
    else if (n == "trace_variant" || n == "closest_variant" || n == "shadow_variant") {
-      if (value < 0 || value > 16) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..16");
+      if (value < 0 || value > 21) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..21");
       if (n != "shadow_variant") c->closest_variant = value;
       if (n != "closest_variant") c->shadow_variant = value;
    } else if (n == "trace_blocks_per_cu" || n == "closest_blocks_per_cu" || n == "shadow_blocks_per_cu") {

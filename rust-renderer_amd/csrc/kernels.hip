@@ -212,16 +212,26 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
    bool occluded = false;
+   // if-if with ONE triangle per iteration: in a divergent wave both branches run every iteration,
+   // so the leaf branch must be as short as the node branch's partner can afford (a whole-leaf
+   // loop made every iteration pay up to 4 triangle tests for the few lanes standing at a leaf)
+   uint32_t tk = 0;
    while (t.cur != kEmptyRef) {
       if (!(t.cur & kLeafBit)) {
          if (COUNT) n_nodes++;
          node_step<ANY>(nodes, t, lds_col, spill);
       } else {
-         if (leaf_step<ANY>(tris, t, n_tris)) {
+         const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+         if (COUNT) n_tris++;
+         if (tri_test<ANY>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
             occluded = true;
             break;
          }
-         t.cur = trav_pop(t, lds_col, spill);
+         tk++;
+         if (tk >= cnt) {
+            tk = 0;
+            t.cur = trav_pop(t, lds_col, spill);
+         }
       }
    }
    best = t.best;
@@ -401,7 +411,7 @@ __device__ __forceinline__ bool pool_refill(uint32_t* cursor, uint32_t count, ui
    return true;
 }
 
-template <bool COUNT, int kRefillIdle, bool kPostpone>
+template <bool COUNT, int kRefillIdle, int kMode>
 __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_v2(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                                                              uint32_t cursor_slot, int ray_kind) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
@@ -423,6 +433,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    bool drained = false;
    bool active = false;
    uint32_t pend = 0, id = 0;  // pend: 1 = finished with a hit, 2 = finished with a miss, not yet queued
+   uint32_t tk = 0;            // next triangle of the current leaf (kMode 2)
    Trav t;
    t.cur = kEmptyRef;
    t.sp = 0;
@@ -445,6 +456,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
             if (!active && idx < pool_end) {
                id = queue[idx];
                trav_init(t, ps.ray_o[id], ps.ray_d[id], INFINITY);
+               tk = 0;
                active = true;
             }
             pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
@@ -455,7 +467,22 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
          }
       }
       if (active) {
-         if (kPostpone) {
+         if (kMode == 2) {
+            // if-if, one node OR one triangle per iteration (see traverse())
+            if (!(t.cur & kLeafBit)) {
+               if (COUNT) n_nodes++;
+               node_step<false>(nodes, t, lds_col, spill);
+            } else {
+               const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+               if (COUNT) n_tris++;
+               tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
+               tk++;
+               if (tk >= cnt) {
+                  tk = 0;
+                  t.cur = trav_pop(t, lds_col, spill);
+               }
+            }
+         } else if (kMode == 1) {
             // speculative while-while: a lane that reaches a leaf parks it and keeps descending from
             // its stack, so it does not idle while the rest of the wave is still in interior nodes.
             // (Hits are order-independent, so walking on with a stale tbest only costs a few visits.)
@@ -499,7 +526,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    }
 }
 
-template <bool COUNT, bool LIGHT, int kRefillIdle, bool kPostpone>
+template <bool COUNT, bool LIGHT, int kRefillIdle, int kMode>
 __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_shadow_v2(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats,
                                                             uint32_t bounce, uint32_t cursor_slot) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
@@ -515,7 +542,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    uint32_t spill[kSpillStack];
    uint32_t pool_pos = 0, pool_end = 0;
    bool drained = false, active = false;
-   uint32_t id = 0;
+   uint32_t id = 0, tk = 0;
    float f = 1.0f;
    Trav t;
    t.cur = kEmptyRef;
@@ -549,6 +576,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
                   rd = make_float4(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2], 10000.0f);  // rgen:64
                }
                trav_init(t, ro, rd, tlimit);
+               tk = 0;
                active = true;
             }
             pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
@@ -560,7 +588,23 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
       }
       if (active) {
          bool occluded = false;
-         if (kPostpone) {
+         if (kMode == 2) {
+            if (!(t.cur & kLeafBit)) {
+               if (COUNT) n_nodes++;
+               node_step<true>(nodes, t, lds_col, spill);
+            } else {
+               const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+               if (COUNT) n_tris++;
+               occluded = tri_test<true>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
+               tk++;
+               if (occluded) {
+                  t.cur = kEmptyRef;
+               } else if (tk >= cnt) {
+                  tk = 0;
+                  t.cur = trav_pop(t, lds_col, spill);
+               }
+            }
+         } else if (kMode == 1) {
             uint32_t parked = kEmptyRef;
             for (;;) {
                if (t.cur != kEmptyRef && (t.cur & kLeafBit) && parked == kEmptyRef) {
@@ -803,15 +847,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow_v3(SceneDev sc, FramePa
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState ps, Control* ctl, uint32_t sample) {
    const uint32_t n = fp.W * fp.H;
-   const ShardCtx sx = shard_ctx();
-   uint32_t* queue = ps.queue[0] + sx.shard * ps.shard_cap;
-   uint32_t* n_ray = &ctl->q_count[qc_index(0, Q_RAY, sx.shard)];
    const uint32_t lane = lane_id();
-   const uint32_t waves_in_shard = sx.nb * kWavesPerBlock;
-   // shard s owns the 64-pixel runs r = s, s + kShards, ...; one wave per run
-   for (uint32_t j = sx.lb * kWavesPerBlock + (threadIdx.x >> 6);; j += waves_in_shard) {
-      uint32_t run = sx.shard + kShards * j;
-      if (run * 64u >= n) break;
+   const uint32_t runs = (n + 63) / 64;
+   // one wave per 64-pixel run, runs streamed in linear order (plain coalesced 1-KiB stores per
+   // array); the run's shard (run % kShards) only decides which queue segment receives the ids
+   for (uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); run < runs; run += gridDim.x * kWavesPerBlock) {
+      const uint32_t shard = run % kShards;
+      uint32_t* queue = ps.queue[0] + shard * ps.shard_cap;
+      uint32_t* n_ray = &ctl->q_count[qc_index(0, Q_RAY, shard)];
       uint32_t id = run * 64u + lane;
       bool own = false;
       if (id < n) {
@@ -1244,7 +1287,7 @@ uint32_t query_trace_occupancy() {
 }
 
 void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, uint32_t sample) {
-   k_generate<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ctl, sample);
+   k_generate<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ctl, sample);
 }
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
@@ -1256,7 +1299,7 @@ void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathStat
          k_trace_closest<false><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
       return;
    }
-   if (c.closest_variant >= 11) {
+   if (c.closest_variant >= 11 && c.closest_variant <= 16) {
 #define UH_LAUNCH_V3(IDLE, VOTE)                                                                                                          \
    do {                                                                                                                                   \
       if (c.count_visits)                                                                                                                 \
@@ -1283,16 +1326,21 @@ void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathStat
          k_trace_closest_v2<false, IDLE, POST><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind); \
    } while (0)
    switch (c.closest_variant) {
-      case 1: UH_LAUNCH_V2(64, false); break;
-      case 2: UH_LAUNCH_V2(32, false); break;
-      case 3: UH_LAUNCH_V2(16, false); break;
-      case 4: UH_LAUNCH_V2(8, false); break;
-      case 5: UH_LAUNCH_V2(1, false); break;
-      case 6: UH_LAUNCH_V2(64, true); break;
-      case 7: UH_LAUNCH_V2(32, true); break;
-      case 8: UH_LAUNCH_V2(16, true); break;
-      case 9: UH_LAUNCH_V2(8, true); break;
-      default: UH_LAUNCH_V2(1, true); break;
+      case 1: UH_LAUNCH_V2(64, 0); break;
+      case 2: UH_LAUNCH_V2(32, 0); break;
+      case 3: UH_LAUNCH_V2(16, 0); break;
+      case 4: UH_LAUNCH_V2(8, 0); break;
+      case 5: UH_LAUNCH_V2(1, 0); break;
+      case 6: UH_LAUNCH_V2(64, 1); break;
+      case 7: UH_LAUNCH_V2(32, 1); break;
+      case 8: UH_LAUNCH_V2(16, 1); break;
+      case 9: UH_LAUNCH_V2(8, 1); break;
+      case 10: UH_LAUNCH_V2(1, 1); break;
+      case 17: UH_LAUNCH_V2(48, 2); break;
+      case 18: UH_LAUNCH_V2(32, 2); break;
+      case 19: UH_LAUNCH_V2(16, 2); break;
+      case 20: UH_LAUNCH_V2(8, 2); break;
+      default: UH_LAUNCH_V2(1, 2); break;
    }
 #undef UH_LAUNCH_V2
 }
@@ -1308,7 +1356,7 @@ void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev&
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
                          uint32_t bounce, uint32_t cursor_slot, bool light) {
-   if (c.shadow_variant >= 11) {
+   if (c.shadow_variant >= 11 && c.shadow_variant <= 16) {
 #define UH_LAUNCH_S3(IDLE, VOTE)                                                                                                              \
    do {                                                                                                                                       \
       if (light) {                                                                                                                            \
@@ -1350,16 +1398,21 @@ void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneD
       }                                                                                                                                 \
    } while (0)
       switch (c.shadow_variant) {
-         case 1: UH_LAUNCH_S2(64, false); break;
-         case 2: UH_LAUNCH_S2(32, false); break;
-         case 3: UH_LAUNCH_S2(16, false); break;
-         case 4: UH_LAUNCH_S2(8, false); break;
-         case 5: UH_LAUNCH_S2(1, false); break;
-         case 6: UH_LAUNCH_S2(64, true); break;
-         case 7: UH_LAUNCH_S2(32, true); break;
-         case 8: UH_LAUNCH_S2(16, true); break;
-         case 9: UH_LAUNCH_S2(8, true); break;
-         default: UH_LAUNCH_S2(1, true); break;
+         case 1: UH_LAUNCH_S2(64, 0); break;
+         case 2: UH_LAUNCH_S2(32, 0); break;
+         case 3: UH_LAUNCH_S2(16, 0); break;
+         case 4: UH_LAUNCH_S2(8, 0); break;
+         case 5: UH_LAUNCH_S2(1, 0); break;
+         case 6: UH_LAUNCH_S2(64, 1); break;
+         case 7: UH_LAUNCH_S2(32, 1); break;
+         case 8: UH_LAUNCH_S2(16, 1); break;
+         case 9: UH_LAUNCH_S2(8, 1); break;
+         case 10: UH_LAUNCH_S2(1, 1); break;
+         case 17: UH_LAUNCH_S2(48, 2); break;
+         case 18: UH_LAUNCH_S2(32, 2); break;
+         case 19: UH_LAUNCH_S2(16, 2); break;
+         case 20: UH_LAUNCH_S2(8, 2); break;
+         default: UH_LAUNCH_S2(1, 2); break;
       }
 #undef UH_LAUNCH_S2
       return;

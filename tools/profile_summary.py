@@ -27,7 +27,7 @@ def short(name):
 
 
 def per_kernel(dirname, counter):
-    files = glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True)
+    files = sorted(glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]  # newest run only
     agg = collections.defaultdict(lambda: [0, 0.0])
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -49,9 +49,9 @@ def main():
     args = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    ks = glob.glob(os.path.join(args.kt, "**", "*_kernel_stats.csv"), recursive=True)
+    ks = sorted(glob.glob(os.path.join(args.kt, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if ks:
-        shutil.copy(ks[0], os.path.join(out, f"{args.tag}_kernel_stats.csv"))
+        shutil.copy(ks[-1], os.path.join(out, f"{args.tag}_kernel_stats.csv"))
     fetch, write = per_kernel(args.fetch, "FETCH_SIZE"), per_kernel(args.write, "WRITE_SIZE")
     pmc = {"units": "KiB per dispatch as reported by rocprofv3; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction)", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
