@@ -60,8 +60,8 @@ struct uh_ctx {
    // second stream: shade_miss (pure VALU, touches only paths that left the scene) overlaps the
    // memory-bound shade_hit and the shadow traversal of the same bounce
    hipStream_t side = nullptr;
-   hipEvent_t ev_traced = nullptr, ev_side_done = nullptr;
-   bool overlap_miss = true;
+   hipEvent_t ev_traced = nullptr, ev_missed = nullptr, ev_shaded = nullptr, ev_shadowed = nullptr, ev_side_done = nullptr;
+   bool overlap_miss = true, overlap_shadow = true;
    uint32_t W = 0, H = 0;
    uint32_t num_cus = 256;
    uint32_t closest_blocks_per_cu = 8, shadow_blocks_per_cu = 6;
@@ -164,7 +164,8 @@ LaunchCfg cfg(uh_ctx* c) {
    return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->closest_variant, c->shadow_variant};
 }
 
-void begin_timed(uh_ctx* c, int kind) {
+void begin_timed(uh_ctx* c, int kind, hipStream_t stream = nullptr) {
+   if (!stream) stream = c->stream;
    if (!c->time_kernels) return;
    EventPair ep;
    if (!c->free_events.empty()) {
@@ -175,12 +176,12 @@ void begin_timed(uh_ctx* c, int kind) {
       (void)hipEventCreate(&ep.stop);
    }
    ep.kind = kind;
-   (void)hipEventRecord(ep.start, c->stream);
+   (void)hipEventRecord(ep.start, stream);
    c->pending.push_back(ep);
 }
-void end_timed(uh_ctx* c) {
+void end_timed(uh_ctx* c, hipStream_t stream = nullptr) {
    if (!c->time_kernels) return;
-   (void)hipEventRecord(c->pending.back().stop, c->stream);
+   (void)hipEventRecord(c->pending.back().stop, stream ? stream : c->stream);
 }
 void drain_timed(uh_ctx* c) {
    for (EventPair& ep : c->pending) {
@@ -234,6 +235,9 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    CREATE_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
    CREATE_TRY(hipEventCreateWithFlags(&c->ev_traced, hipEventDisableTiming));
    CREATE_TRY(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
+   CREATE_TRY(hipEventCreateWithFlags(&c->ev_shaded, hipEventDisableTiming));
+   CREATE_TRY(hipEventCreateWithFlags(&c->ev_missed, hipEventDisableTiming));
+   CREATE_TRY(hipEventCreateWithFlags(&c->ev_shadowed, hipEventDisableTiming));
    CREATE_TRY(hipEventCreate(&c->frame_start));
    CREATE_TRY(hipEventCreate(&c->frame_stop));
    {
@@ -329,6 +333,9 @@ void uh_destroy(uh_ctx* c) {
    if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
    if (c->ev_traced) (void)hipEventDestroy(c->ev_traced);
    if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
+   if (c->ev_shaded) (void)hipEventDestroy(c->ev_shaded);
+   if (c->ev_missed) (void)hipEventDestroy(c->ev_missed);
+   if (c->ev_shadowed) (void)hipEventDestroy(c->ev_shadowed);
    if (c->side) (void)hipStreamDestroy(c->side);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
@@ -587,6 +594,8 @@ int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask
          uint32_t slot = 0;
          launch_generate(lc, fp, c->ps, ctl, s);
          for (uint32_t b = 0; b < fp.num_bounces; b++) {
+            // trace_closest(b) refills the miss queue that shade_miss(b-1) reads on the side stream
+            if (c->overlap_miss && b > 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_missed, 0));
             begin_timed(c, 0);
             launch_trace_closest(lc, c->scene, c->ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
             end_timed(c);
@@ -597,23 +606,38 @@ int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask
                LaunchCfg ls = lc;
                ls.stream = c->side;
                launch_shade_miss(ls, fp, c->ps, ctl, st, b);
+               HIP_TRY(c, hipEventRecord(c->ev_missed, c->side));
             }
+            const bool side_shadow = c->overlap_shadow && (fp.sun_shadow_enabled == 1 || fp.lights_enabled == 1);
+            // shade_hit(b) rewrites ray_o / thr / rad of the paths shadow(b-1) still reads on the side stream
+            if (side_shadow && b > 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_shadowed, 0));
             begin_timed(c, 2);
             if (!c->overlap_miss) launch_shade_miss(lc, fp, c->ps, ctl, st, b);
             launch_shade_hit(lc, fp, c->scene, c->ps, c->im, ctl, st, b);
             end_timed(c);
+            // shadow traversals of bounce b are independent of trace_closest(b+1) (both only read what
+            // shade_hit(b) wrote): on the side stream their blocks fill the tail of the other kernel
+            LaunchCfg lsh = lc;
+            hipStream_t sh_stream = c->stream;
+            if (side_shadow) {
+               HIP_TRY(c, hipEventRecord(c->ev_shaded, c->stream));
+               HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_shaded, 0));
+               lsh.stream = c->side;
+               sh_stream = c->side;
+            }
             if (fp.sun_shadow_enabled == 1) {
-               begin_timed(c, 1);
-               launch_trace_shadow(lc, fp, c->scene, c->ps, ctl, st, b, slot++, false);
-               end_timed(c);
+               begin_timed(c, 1, sh_stream);
+               launch_trace_shadow(lsh, fp, c->scene, c->ps, ctl, st, b, slot++, false);
+               end_timed(c, sh_stream);
             }
             if (fp.lights_enabled == 1) {
-               begin_timed(c, 1);
-               launch_trace_shadow(lc, fp, c->scene, c->ps, ctl, st, b, slot++, true);
-               end_timed(c);
+               begin_timed(c, 1, sh_stream);
+               launch_trace_shadow(lsh, fp, c->scene, c->ps, ctl, st, b, slot++, true);
+               end_timed(c, sh_stream);
             }
+            if (side_shadow) HIP_TRY(c, hipEventRecord(c->ev_shadowed, c->side));
          }
-         if (c->overlap_miss && fp.num_bounces > 0) {
+         if ((c->overlap_miss || c->overlap_shadow) && fp.num_bounces > 0) {
             HIP_TRY(c, hipEventRecord(c->ev_side_done, c->side));
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
          }
@@ -807,6 +831,8 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->full_frame_restir = value != 0;
    else if (n == "overlap_miss")
       c->overlap_miss = value != 0;
+   else if (n == "overlap_shadow")
+      c->overlap_shadow = value != 0;
    else if (n == "trace_variant" || n == "closest_variant" || n == "shadow_variant") {
       if (value < 0 || value > 21) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..21");
       if (n != "shadow_variant") c->closest_variant = value;
