@@ -70,12 +70,13 @@ def main():
 
     W, H = args.width, args.height
     scene = rr.scenes.scene_for_config(args.config, detail=args.detail, tex_size=args.tex_size)
-    renderer = scene.upload(rr.Renderer(W, H, device=local_rank))
-    if world > 1:
-        renderer.set_tile_partition(rank, world, args.tile)
+    renderer = rr.Renderer(W, H, device=local_rank)
     for kv in args.opt:
         k, v = kv.split("=")
         renderer.set_option(k, int(v))
+    scene.upload(renderer)
+    if world > 1:
+        renderer.set_tile_partition(rank, world, args.tile)
     pass_mask = rr.PASS_REFERENCE_PT if args.config == 1 else rr.PASS_ALL
     view = scene.make_view(W, H)
     loop = rr.FrameLoop(renderer, view)

@@ -14,7 +14,7 @@ namespace uh {
 
 constexpr uint32_t kLeafBit = 0x80000000u;    // child ref: bit31 = leaf
 constexpr uint32_t kEmptyRef = 0xffffffffu;   // unused child slot / empty stack
-constexpr uint32_t kLeafCountShift = 27;      // leaf ref: bits 27..30 = triangle count (1..4)
+constexpr uint32_t kLeafCountShift = 27;      // leaf ref: bits 27..30 = triangle count (1..15)
 constexpr uint32_t kLeafFirstMask = 0x07ffffffu;
 constexpr uint32_t kMaxLeafTris = 4;
 constexpr uint32_t kPrimBits = 22;            // key = mesh << 22 | prim  (mesh < 1024, prim < 4 Mi)
@@ -75,6 +75,6 @@ struct BuildOutput {
 };
 
 // Binned-SAH BVH2 build, collapsed to BVH4, emitted breadth-first. Host-side, multi-threaded.
-void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads);
+void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_t max_leaf_tris = kMaxLeafTris, float sah_traversal_cost = 1.0f);
 
 }  // namespace uh

@@ -52,6 +52,8 @@ struct Builder {
    std::vector<uint32_t>& idx;
    std::vector<Node2> nodes;
    uint32_t max_depth = 0;
+   uint32_t max_leaf = kMaxLeafTris;
+   float sah_traversal_cost = 1.0f;
 
    Builder(const std::vector<Box>& tb_, const std::vector<float>& cen_, std::vector<uint32_t>& idx_) : tb(tb_), cen(cen_), idx(idx_) {}
 
@@ -68,12 +70,13 @@ struct Builder {
       }
       nodes[me].box = box;
       max_depth = std::max(max_depth, depth);
-      if (count <= kMaxLeafTris) {
+      auto make_leaf = [&]() {
          nodes[me].left = nodes[me].right = -1;
          nodes[me].first = first;
          nodes[me].count = count;
          return me;
-      }
+      };
+      if (count == 1) return make_leaf();
       constexpr int NB = 16;
       float best_cost = INFINITY;
       int best_axis = -1, best_split = -1;
@@ -119,6 +122,13 @@ struct Builder {
             }
          }
       }
+      if (count <= max_leaf) {
+         // SAH termination: split only when a traversal step plus the area-weighted triangle tests of
+         // the two sides is cheaper than testing all `count` triangles here (unit = one triangle test;
+         // a node step costs about sah_traversal_cost of them on this kernel)
+         float area = box.half_area();
+         if (best_axis < 0 || !(area > 0) || sah_traversal_cost + best_cost / area >= (float)count) return make_leaf();
+      }
       uint32_t mid;
       if (best_axis < 0 || depth > 48) {
          // degenerate centroids (or runaway depth): split the range in half along the widest axis
@@ -160,7 +170,9 @@ inline void padded(const Box& b, float* lo, float* hi) {
 
 }  // namespace
 
-void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads) {
+void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_t max_leaf_tris, float sah_traversal_cost) {
+   if (max_leaf_tris < 1) max_leaf_tris = 1;
+   if (max_leaf_tris > 15) max_leaf_tris = 15;
    out.nodes.clear();
    out.tri_order.clear();
    out.max_depth = 0;
@@ -201,6 +213,8 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads) {
    }
    {
       Builder top(tb, cen, out.tri_order);
+      top.max_leaf = max_leaf_tris;
+      top.sah_traversal_cost = sah_traversal_cost;
       if (num_threads <= 1 || n < 65536) {
          top.build(0, n, 0);
          n2.swap(top.nodes);
@@ -319,6 +333,8 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads) {
                size_t j = next.fetch_add(1);
                if (j >= jobs.size()) break;
                Builder b(tb, cen, out.tri_order);
+               b.max_leaf = max_leaf_tris;
+               b.sah_traversal_cost = sah_traversal_cost;
                b.build(jobs[j].first, jobs[j].count, jobs[j].depth);
                sub[j].swap(b.nodes);
                sub_depth[j] = b.max_depth;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -38,16 +39,23 @@ struct EventPair {
 template <typename T>
 struct DevBuf {
    T* p = nullptr;
+   void* base = nullptr;
    size_t n = 0;
-   hipError_t alloc(size_t count) {
+   // stagger_bytes shifts the array inside its allocation: the per-pixel SoA arrays are all the same
+   // size, and kernels touch the same index of several of them at once; without a stagger those
+   // accesses are an exact multiple of the array size apart
+   hipError_t alloc(size_t count, size_t stagger_bytes = 0) {
       release();
       n = count;
       if (count == 0) return hipSuccess;
-      return hipMalloc((void**)&p, count * sizeof(T));
+      hipError_t e = hipMalloc(&base, count * sizeof(T) + stagger_bytes);
+      if (e == hipSuccess) p = reinterpret_cast<T*>(static_cast<char*>(base) + stagger_bytes);
+      return e;
    }
    void release() {
-      if (p) (void)hipFree(p);
+      if (base) (void)hipFree(base);
       p = nullptr;
+      base = nullptr;
       n = 0;
    }
 };
@@ -97,6 +105,8 @@ struct uh_ctx {
 
    // options / stats
    bool count_visits = false, time_kernels = false, full_frame_restir = false;
+   uint32_t bvh_max_leaf = kMaxLeafTris;
+   float bvh_sah_cost = 0.5f;  // SAH leaf termination: a node step costs about half a triangle test here (swept on MI355X)
    int closest_variant = 0, shadow_variant = 19;  // measured fastest on MI355X (profiles/README.md)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
@@ -246,15 +256,16 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
       if (c->shadow_blocks_per_cu > occ) c->shadow_blocks_per_cu = occ;
    }
    const size_t n = (size_t)width * height;
-   CREATE_TRY(c->ray_o.alloc(n));
-   CREATE_TRY(c->ray_d.alloc(n));
-   CREATE_TRY(c->hit.alloc(n));
-   CREATE_TRY(c->thr.alloc(n));
-   CREATE_TRY(c->rad.alloc(n));
-   CREATE_TRY(c->pixcol.alloc(n));
-   CREATE_TRY(c->accumulation.alloc(n));
-   CREATE_TRY(c->gbuffer.alloc(n));
-   CREATE_TRY(c->rng.alloc(n));
+   const size_t stagger = getenv("UH_NO_STAGGER") ? 0 : 4352;  // 4 KiB + 256 B per array slot
+   CREATE_TRY(c->ray_o.alloc(n, 0 * stagger));
+   CREATE_TRY(c->ray_d.alloc(n, 1 * stagger));
+   CREATE_TRY(c->hit.alloc(n, 2 * stagger));
+   CREATE_TRY(c->thr.alloc(n, 3 * stagger));
+   CREATE_TRY(c->rad.alloc(n, 4 * stagger));
+   CREATE_TRY(c->pixcol.alloc(n, 5 * stagger));
+   CREATE_TRY(c->accumulation.alloc(n, 6 * stagger));
+   CREATE_TRY(c->gbuffer.alloc(n, 7 * stagger));
+   CREATE_TRY(c->rng.alloc(n, 8 * stagger));
    // sharded queues: capacity per shard = the pixels (64-pixel runs) a shard can own
    const uint32_t runs = (uint32_t)((n + 63) / 64);
    const uint32_t shard_cap = ((runs + kShards - 1) / kShards) * 64;
@@ -441,7 +452,7 @@ int uh_build_acceleration(uh_ctx* c) {
    int threads = (int)std::thread::hardware_concurrency();
    if (threads < 1) threads = 1;
    if (threads > 32) threads = 32;
-   build_bvh4(in, bo, threads);
+   build_bvh4(in, bo, threads, c->bvh_max_leaf, c->bvh_sah_cost);
 
    // packets in leaf order
    std::vector<TriPacket> tp(total);
@@ -829,7 +840,15 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->time_kernels = value != 0;
    } else if (n == "full_frame_restir")
       c->full_frame_restir = value != 0;
-   else if (n == "overlap_miss")
+   else if (n == "bvh_max_leaf") {
+      if (value < 1 || value > 15) return fail(c, UH_ERR_INVALID_ARGUMENT, "bvh_max_leaf must be 1..15");
+      c->bvh_max_leaf = (uint32_t)value;
+      c->built = false;
+   } else if (n == "bvh_sah_cost_x100") {
+      if (value < 0 || value > 1000) return fail(c, UH_ERR_INVALID_ARGUMENT, "bvh_sah_cost_x100 must be 0..1000");
+      c->bvh_sah_cost = (float)value / 100.0f;
+      c->built = false;
+   } else if (n == "overlap_miss")
       c->overlap_miss = value != 0;
    else if (n == "overlap_shadow")
       c->overlap_shadow = value != 0;

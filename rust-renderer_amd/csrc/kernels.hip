@@ -868,10 +868,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
             primary_ray(fp, px, py, jx, jy, o, d);
             ps.ray_o[id] = make_float4(o.x, o.y, o.z, 0.001f);
             ps.ray_d[id] = make_float4(d.x, d.y, d.z, 10000.0f);
-            ps.thr[id] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            ps.rad[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // throughput = 1 / radiance = 0 / pixelColor = 0 (rgen:26,39-40) are not materialised: the
+            // bounce-0 shading kernels and the first finish_sample use the constants directly
             ps.rng[id] = make_uint2(rng, seed);
-            if (sample == 0) ps.pixcol[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
          }
       }
       uint32_t slot = wave_append(n_ray, own);
@@ -894,7 +893,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState
          V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
          sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
       }
-      float4 thr = ps.thr[id], rad = ps.rad[id];
+      float4 thr = make_float4(1.0f, 1.0f, 1.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (bounce != 0) {
+         thr = ps.thr[id];
+         rad = ps.rad[id];
+      }
       V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
       ps.rad[id] = make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w);   // rgen:55
    }
@@ -998,7 +1001,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
          }
          rng.y = seed;                                                                 // rchit:91
 
-         float4 thr4 = ps.thr[id], rad4 = ps.rad[id];
+         float4 thr4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+         if (bounce != 0) {
+            thr4 = ps.thr[id];
+            rad4 = ps.rad[id];
+         }
          V3 thr = v3(thr4.x, thr4.y, thr4.z) * color;                                  // rgen:48
          if (!scattered) {                                                             // rgen:53-57
             ps.rad[id] = make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, rad4.w);
@@ -1052,12 +1059,14 @@ __device__ __forceinline__ uchar4 resolve_color(float4 acc, uint32_t total_sampl
    return make_uchar4((unsigned char)unorm8(c.z), (unsigned char)unorm8(c.y), (unsigned char)unorm8(c.x), 0);  // B8G8R8A8, alpha 0
 }
 
-__global__ __launch_bounds__(kBlock) void k_finish_sample(FrameParams fp, PathState ps, Images im, bool last) {
+__global__ __launch_bounds__(kBlock) void k_finish_sample(FrameParams fp, PathState ps, Images im, uint32_t sample, bool last) {
    const uint32_t n = fp.W * fp.H;
    for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
       uint32_t px = id % fp.W, py = id / fp.W;
       if (!owns_pixel(fp, px, py)) continue;
-      float4 pc = ps.pixcol[id], rad = ps.rad[id];
+      float4 pc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (sample != 0) pc = ps.pixcol[id];
+      if (fp.num_bounces != 0) rad = ps.rad[id];  // with zero bounces no kernel ever wrote a radiance
       pc = make_float4(pc.x + rad.x, pc.y + rad.y, pc.z + rad.z, 0.0f);                  // rgen:127
       if (!last) {
          ps.pixcol[id] = pc;
@@ -1431,8 +1440,7 @@ void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneD
 }
 
 void launch_finish_sample(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, const Images& im, uint32_t sample, bool last) {
-   (void)sample;
-   k_finish_sample<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, im, last);
+   k_finish_sample<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, im, sample, last);
 }
 
 void launch_resolve(const LaunchCfg& c, const Images& im, uint32_t W, uint32_t H, uint32_t total_samples, uint32_t limit) {
