@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=3")
     ap.add_argument("--cpu-sample", type=str, default="960x540x3", help="WxHxframes rendered by the CPU oracle")
     return ap.parse_args()
@@ -61,7 +62,10 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         import torch
         import torch.distributed as dist
 
@@ -75,7 +79,7 @@ def main():
         k, v = kv.split("=")
         renderer.set_option(k, int(v))
     scene.upload(renderer)
-    if world > 1:
+    if use_dist:
         renderer.set_tile_partition(rank, world, args.tile)
     pass_mask = rr.PASS_REFERENCE_PT if args.config == 1 else rr.PASS_ALL
     view = scene.make_view(W, H)
@@ -83,7 +87,7 @@ def main():
 
     def sync_all():
         renderer.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
 
@@ -109,7 +113,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loop.frame(pass_mask)
-    if world > 1:
+    if use_dist:
         # the ONE collective of the data path: RCCL gather of the packed accumulation tiles to rank 0
         rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}")
         if rank == 0:
@@ -120,7 +124,7 @@ def main():
     st = renderer.get_stats()
     my_rays = float(st.path_rays)
     my_closest = float(st.rays[rr.RAY_PRIMARY] + st.rays[rr.RAY_BOUNCE])
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, my_rays, my_closest, st.trace_closest_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -179,10 +183,10 @@ def main():
                 "shade_ms": st.shade_ms,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, scene)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

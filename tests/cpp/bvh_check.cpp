@@ -1,0 +1,158 @@
+// bvh_check.cpp — host-side invariants of the BVH4 builder (csrc/bvh_build.cpp), built with
+// -fsanitize=address,undefined by tests/test_bvh_builder.py. Triangle soups come from a seeded LCG,
+// including degenerate cases (zero-area, duplicated, coincident centroids, huge coordinates).
+//   every input triangle sits in exactly one leaf; leaf counts are 1..max_leaf; child refs are in
+//   range and form a tree (each interior node referenced once); every full-precision child box
+//   contains its subtree's triangles; every quantised box contains the full-precision box; empty
+//   slots are inverted boxes.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "bvh.h"
+
+using namespace uh;
+
+static uint32_t g_state = 1;
+static float rnd() {
+   g_state = g_state * 747796405u + 1u;
+   uint32_t w = ((g_state >> ((g_state >> 28) + 4u)) ^ g_state) * 277803737u;
+   w = (w >> 22) ^ w;
+   return (float)w / 4294967296.0f;
+}
+
+static int check(const std::vector<float>& corners, uint32_t max_leaf, int threads, const char* name) {
+   const uint32_t n = (uint32_t)(corners.size() / 9);
+   std::vector<uint32_t> keys(n);
+   for (uint32_t i = 0; i < n; i++) keys[i] = i;
+   BuildInput in{corners.data(), keys.data(), n};
+   BuildOutput out;
+   build_bvh4(in, out, threads, max_leaf, 0.5f);
+   int errors = 0;
+   auto fail = [&](const char* what, uint32_t a, uint32_t b) {
+      if (errors++ < 5) std::printf("FAIL[%s]: %s (%u, %u)\n", name, what, a, b);
+   };
+   if (out.nodes.empty() || out.nodes.size() != out.qnodes.size()) fail("node arrays", (uint32_t)out.nodes.size(), (uint32_t)out.qnodes.size());
+   if (out.tri_order.size() != n) fail("tri_order size", (uint32_t)out.tri_order.size(), n);
+   std::vector<uint32_t> seen(n, 0), node_refs(out.nodes.size(), 0);
+   std::vector<uint32_t> packet_use(n, 0);
+   for (uint32_t i = 0; i < out.tri_order.size(); i++) {
+      if (out.tri_order[i] >= n) fail("tri_order entry out of range", i, out.tri_order[i]);
+      else seen[out.tri_order[i]]++;
+   }
+   for (uint32_t i = 0; i < n; i++)
+      if (seen[i] != 1) fail("triangle not exactly once in tri_order", i, seen[i]);
+   // recursive subtree bounds
+   struct Frame {
+      uint32_t node;
+   };
+   std::vector<Frame> st{{0}};
+   while (!st.empty()) {
+      uint32_t ni = st.back().node;
+      st.pop_back();
+      const Node4& nd = out.nodes[ni];
+      const Node4Q& q = out.qnodes[ni];
+      const float scale[3] = {q.scale_x, q.scale_yz[0], q.scale_yz[1]};
+      for (int k = 0; k < 4; k++) {
+         uint32_t c = nd.child[k];
+         if (q.child[k] != c) fail("quantised child ref differs", ni, (uint32_t)k);
+         if (c == kEmptyRef) {
+            for (int a = 0; a < 3; a++)
+               if (((q.qlo[a] >> (8 * k)) & 0xff) != 0xff || ((q.qhi[a] >> (8 * k)) & 0xff) != 0) fail("empty slot is not an inverted box", ni, (uint32_t)k);
+            continue;
+         }
+         const float lo[3] = {nd.lox[k], nd.loy[k], nd.loz[k]}, hi[3] = {nd.hix[k], nd.hiy[k], nd.hiz[k]};
+         for (int a = 0; a < 3; a++) {
+            float qlo = q.origin[a] + scale[a] * (float)((q.qlo[a] >> (8 * k)) & 0xff);
+            float qhi = q.origin[a] + scale[a] * (float)((q.qhi[a] >> (8 * k)) & 0xff);
+            // the kernel evaluates origin + scale*q in t-space; in world space allow one ulp of the sum
+            float slack = 4e-7f * std::fmax(std::fabs(lo[a]), std::fabs(hi[a])) + 1e-30f;
+            if (!(qlo <= lo[a] + slack) || !(qhi >= hi[a] - slack)) fail("quantised box does not contain the full box", ni, (uint32_t)(k * 3 + a));
+         }
+         if (c & kLeafBit) {
+            uint32_t first = c & kLeafFirstMask, cnt = (c >> kLeafCountShift) & 0xf;
+            if (cnt < 1 || cnt > max_leaf || first + cnt > n) {
+               fail("leaf range", first, cnt);
+               continue;
+            }
+            for (uint32_t p = first; p < first + cnt; p++) {
+               packet_use[p]++;
+               const float* t = &corners[9 * (size_t)out.tri_order[p]];
+               for (int v = 0; v < 3; v++)
+                  for (int a = 0; a < 3; a++)
+                     if (!(t[3 * v + a] >= lo[a]) || !(t[3 * v + a] <= hi[a])) fail("triangle outside its leaf box", ni, p);
+            }
+         } else {
+            if (c >= out.nodes.size()) {
+               fail("child index out of range", ni, c);
+               continue;
+            }
+            node_refs[c]++;
+            // child's own children must lie inside this slot's box (boxes are padded outwards at every level)
+            const Node4& ch = out.nodes[c];
+            for (int j = 0; j < 4; j++)
+               if (ch.child[j] != kEmptyRef) {
+                  const float clo[3] = {ch.lox[j], ch.loy[j], ch.loz[j]}, chi[3] = {ch.hix[j], ch.hiy[j], ch.hiz[j]};
+                  for (int a = 0; a < 3; a++) {
+                     float pad = 2e-4f + 2e-5f * std::fmax(std::fabs(clo[a]), std::fabs(chi[a]));
+                     if (!(clo[a] >= lo[a] - pad) || !(chi[a] <= hi[a] + pad)) fail("grandchild box escapes its parent slot", ni, c);
+                  }
+               }
+            st.push_back({c});
+         }
+      }
+   }
+   for (uint32_t p = 0; p < n; p++)
+      if (packet_use[p] != 1) fail("packet not referenced by exactly one leaf", p, packet_use[p]);
+   for (size_t i = 1; i < node_refs.size(); i++)
+      if (node_refs[i] != 1) fail("interior node not referenced exactly once", (uint32_t)i, node_refs[i]);
+   std::printf("%s: %u tris -> %zu nodes, depth %u, %s\n", name, n, out.nodes.size(), out.max_depth, errors ? "FAILED" : "ok");
+   return errors;
+}
+
+int main() {
+   int errors = 0;
+   for (uint32_t max_leaf : {1u, 3u, 4u, 8u}) {
+      for (int threads : {1, 4}) {
+         std::vector<float> soup;
+         g_state = 12345 + max_leaf;
+         for (int i = 0; i < 200000; i++) {
+            float c[3] = {rnd() * 40 - 20, rnd() * 15, rnd() * 16 - 8};
+            for (int v = 0; v < 3; v++)
+               for (int a = 0; a < 3; a++) soup.push_back(c[a] + (rnd() - 0.5f) * 0.4f);
+         }
+         errors += check(soup, max_leaf, threads, "random soup");
+      }
+   }
+   {
+      std::vector<float> empty;
+      errors += check(empty, 4, 1, "empty");
+      std::vector<float> one = {0, 0, 0, 1, 0, 0, 0, 1, 0};
+      errors += check(one, 4, 1, "single triangle");
+      std::vector<float> dup;
+      for (int i = 0; i < 1000; i++) dup.insert(dup.end(), one.begin(), one.end());
+      errors += check(dup, 4, 4, "1000 identical triangles");
+      std::vector<float> degenerate;
+      g_state = 7;
+      for (int i = 0; i < 5000; i++) {
+         float p[3] = {rnd(), rnd(), rnd()};
+         for (int v = 0; v < 3; v++)
+            for (int a = 0; a < 3; a++) degenerate.push_back(p[a]);  // zero-area (point) triangles
+      }
+      errors += check(degenerate, 4, 2, "point triangles");
+      std::vector<float> huge;
+      for (int i = 0; i < 3000; i++)
+         for (int k = 0; k < 9; k++) huge.push_back((rnd() - 0.5f) * 2e6f);
+      errors += check(huge, 4, 2, "huge coordinates");
+      std::vector<float> planar;
+      for (int i = 0; i < 20000; i++) {
+         float x = rnd() * 10, z = rnd() * 10;
+         float t[9] = {x, 0, z, x + 0.1f, 0, z, x, 0, z + 0.1f};
+         planar.insert(planar.end(), t, t + 9);
+      }
+      errors += check(planar, 4, 4, "coplanar sheet");
+   }
+   std::printf(errors ? "BVH CHECK FAILED (%d)\n" : "BVH CHECK OK\n", errors);
+   return errors ? 1 : 0;
+}
