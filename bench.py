@@ -73,7 +73,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W, H = args.width, args.height
-    scene = rr.scenes.scene_for_config(args.config, detail=args.detail, tex_size=args.tex_size)
+    kw = dict(tex_size=args.tex_size)
+    if args.detail != 1.0 or args.config != 3:
+        kw["detail"] = args.detail
+    scene = rr.scenes.scene_for_config(args.config, **kw)
     renderer = rr.Renderer(W, H, device=local_rank)
     for kv in args.opt:
         k, v = kv.split("=")
@@ -81,7 +84,7 @@ def main():
     scene.upload(renderer)
     if use_dist:
         renderer.set_tile_partition(rank, world, args.tile)
-    pass_mask = rr.PASS_REFERENCE_PT if args.config == 1 else rr.PASS_ALL
+    pass_mask = rr.PASS_ALL if args.config == 2 else rr.PASS_REFERENCE_PT
     view = scene.make_view(W, H)
     loop = rr.FrameLoop(renderer, view)
 
@@ -161,8 +164,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE.json configs[{args.config}]: Sponza-class procedural atrium ({scene.num_triangles} tris, {scene.num_meshes} meshes, 25 textured Lambertian materials), "
-                f"{W}x{H}, 1 spp/frame x {args.steps} frames, 5 bounces, sky + sun shadow rays" + (", 1024 lights ReSTIR DI" if args.config == 2 else ", lights off"),
+                "workload": f"BASELINE.json configs[{args.config}]: {scene.name} procedural atrium ({scene.num_triangles} tris, {scene.num_meshes} meshes, textured materials), "
+                f"{W}x{H}, 1 spp/frame x {args.steps} frames, 5 bounces, sky + sun shadow rays"
+                + (f", {len(scene.lights)} lights " + ("ReSTIR DI" if view.use_ris_light_sampling else "uniform sampling") if view.lights_enabled else ", lights off"),
                 "rays_per_frame": total_rays / args.steps,
                 "partition": f"{args.tile}x{args.tile} tiles round-robin over {world} rank(s), 1 RCCL gather" if world > 1 else "single GPU",
             },
@@ -215,7 +219,7 @@ def cpu_baseline(args, scene):
     loop = rr.FrameLoop(o, scene.make_view(w, h))
     t0 = time.perf_counter()
     for _ in range(frames):
-        loop.frame(rr.PASS_REFERENCE_PT if args.config == 1 else rr.PASS_ALL)
+        loop.frame(rr.PASS_ALL if args.config == 2 else rr.PASS_REFERENCE_PT)
     dt = time.perf_counter() - t0
     s = o.get_stats()
     return {

@@ -341,10 +341,11 @@ TESS = 1.327  # base tessellation factor: detail=1.0 gives 262,432 triangles (Sp
 LIGHTS_SEED = 0x4C495445
 
 
-def sponza_class_scene(detail=1.0, tex_size=1024, with_spheres=False, num_lights=0, sphere_subdivisions=4):
+def sponza_class_scene(detail=1.0, tex_size=1024, with_spheres=False, num_lights=0, sphere_subdivisions=4, target_meshes=103, num_materials=25,
+                       num_textures=25, material_mix=False, seed=None, scene_name="sponza_class"):
     """detail scales every tessellation factor linearly (triangles ~ detail^2). detail=1.0 gives
     the headline ~262 k-triangle scene; tests use detail ~0.1."""
-    seed = SPONZA_SEED
+    seed = SPONZA_SEED if seed is None else seed
     rnd = hash_floats(seed, 4096, stream=7).astype(np.float64)
     ri = [0]
 
@@ -428,7 +429,6 @@ def sponza_class_scene(detail=1.0, tex_size=1024, with_spheres=False, num_lights
 
     # group the parts into exactly 103 meshes (Sponza.gltf has 103 primitives): columns, arches and
     # curtains are merged in runs so that the count lands on 103
-    target_meshes = 103
     groups = []
     by_name = {}
     for name, v, i in parts:
@@ -453,13 +453,19 @@ def sponza_class_scene(detail=1.0, tex_size=1024, with_spheres=False, num_lights
         v, i = merge([p[1] for p in run])
         groups.append((run[0][0], v, i))
 
-    num_materials = 25
-    textures = [procedural_texture(seed, k, tex_size) for k in range(num_materials)]
+    textures = [procedural_texture(seed, k, tex_size) for k in range(num_textures)]
     meshes = []
-    for gi, (name, v, i) in enumerate(groups):
+    for gi, (mname, v, i) in enumerate(groups):
         k = (gi * 7 + 3) % num_materials
         col = 0.75 + 0.25 * hash_floats(seed, 3, stream=5000 + k).astype(np.float64)
-        meshes.append(Mesh(v, i, LAMBERTIAN, 0.0, (float(col[0]), float(col[1]), float(col[2]), 1.0), k, identity3x4(), name=name))
+        mtype, prop = LAMBERTIAN, 0.0
+        if material_mix:  # "full PBR" of config 4 = the reference's four RT material types
+            pick = hash_floats(seed, 2, stream=9000 + k).astype(np.float64)
+            if mname in ("vase", "column") and pick[0] < 0.35:
+                mtype, prop = METAL, float(0.05 + 0.4 * pick[1])
+            elif mname in ("vase", "curtain") and pick[0] > 0.8:
+                mtype, prop = DIELECTRIC, 1.5
+        meshes.append(Mesh(v, i, mtype, prop, (float(col[0]), float(col[1]), float(col[2]), 1.0), k % num_textures, identity3x4(), name=mname))
     models = [(Model(meshes, textures), None)]
 
     if with_spheres:  # scenes.rs:116-149
@@ -480,7 +486,7 @@ def sponza_class_scene(detail=1.0, tex_size=1024, with_spheres=False, num_lights
 
     cam = Camera((-10.28, 2.10, -0.18), (0.0, 0.5, 0.0), 60.0, 16.0 / 9.0, 0.01, 1000.0)
     flags = dict(sky_enabled=1, sun_shadow_enabled=1, lights_enabled=1 if num_lights else 0, use_ris_light_sampling=1 if num_lights else 0)
-    return Scene("sponza_class", models, lights, cam, flags)
+    return Scene(scene_name, models, lights, cam, flags)
 
 
 def scene_for_config(config, **kw):
@@ -491,4 +497,19 @@ def scene_for_config(config, **kw):
         return sponza_class_scene(num_lights=0, **kw)
     if config == 2:
         return sponza_class_scene(num_lights=1024, **kw)
+    if config == 3:
+        return bistro_class_scene(**kw)
     raise ValueError(f"config {config} is not built in this round")
+
+
+BISTRO_SEED = 0x42495354
+
+
+def bistro_class_scene(detail=3.27, tex_size=1024, num_lights=64):
+    """config 4 of BASELINE.json ("Bistro Exterior full PBR, 3840x2160"): the same generator at
+    ~3.3x tessellation (~2.8 M triangles), 130 meshes / materials with Metal and Dielectric mixed
+    in, point lights on (uniform sampling). Bistro itself is not part of the reference checkout."""
+    sc = sponza_class_scene(detail=detail, tex_size=tex_size, with_spheres=True, num_lights=num_lights, sphere_subdivisions=5, target_meshes=130,
+                            num_materials=130, num_textures=25, material_mix=True, seed=BISTRO_SEED, scene_name="bistro_class")
+    sc.view_flags.update(dict(lights_enabled=1, use_ris_light_sampling=0))
+    return sc
