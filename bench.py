@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only rank 0's tiles of an N-rank partition (what one rank sees at --gpus N)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=3")
     ap.add_argument("--cpu-sample", type=str, default="960x540x3", help="WxHxframes rendered by the CPU oracle")
@@ -84,6 +85,8 @@ def main():
     scene.upload(renderer)
     if use_dist:
         renderer.set_tile_partition(rank, world, args.tile)
+    elif args.emulate_world > 1:
+        renderer.set_tile_partition(0, args.emulate_world, args.tile)
     pass_mask = rr.PASS_ALL if args.config == 2 else rr.PASS_REFERENCE_PT
     view = scene.make_view(W, H)
     loop = rr.FrameLoop(renderer, view)
@@ -105,8 +108,7 @@ def main():
     renderer.set_option("count_visits", 0)
 
     # ---- warmup
-    for _ in range(args.warmup):
-        loop.frame(pass_mask)
+    loop.frames(args.warmup, pass_mask)
     loop.reset()
     renderer.reset_stats()
     renderer.set_option("time_kernels", 1)
@@ -114,8 +116,7 @@ def main():
     # ---- timed region: exactly K steps (+ the composition gather for N > 1)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loop.frame(pass_mask)
+    loop.frames(args.steps, pass_mask)  # static camera: the library may batch / overlap frames (uh_render_frames)
     if use_dist:
         # the ONE collective of the data path: RCCL gather of the packed accumulation tiles to rank 0
         rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}")

@@ -17,6 +17,7 @@
  *   uh_render_frame           the 6 graph passes gbuffer→reset→initial_ris→temporal→spatial→pt
  *                             (utopian/src/renderers/mod.rs:246-358), one ViewUniformData memcpy
  *                             per frame (prototype/src/main.rs:477-478)
+ *   uh_render_frames          the same node for N consecutive frames of a static camera (batched)
  *   uh_reset_accumulation     total_samples = 0 semantics       (prototype/src/main.rs:400-413)
  *   uh_read_*                 pt_accumulation_image / pt_output_image / reservoir SSBO read-back
  *   uh_set_tile_partition,
@@ -197,6 +198,14 @@ int uh_build_acceleration(uh_ctx* ctx);
 
 /* ---- per frame ------------------------------------------------------------------------- */
 int uh_render_frame(uh_ctx* ctx, const UhViewUniformData* view, uint32_t pass_mask);
+/* `count` consecutive frames of the reference_pt pass with an unchanged camera: frame i is rendered
+ * with total_samples = view->total_samples + i * samples_per_frame, exactly what `count` calls of
+ * uh_render_frame under the application's frame protocol (prototype/src/main.rs:467-469) produce,
+ * bit for bit; internally up to option "batch_frames" frames share one wavefront (path id =
+ * frame * W*H + pixel) so that a rank owning few pixels still launches full-size kernels.
+ * Only UH_PASS_REFERENCE_PT without reservoir light sampling can be batched (each ReSTIR frame
+ * depends on the previous one); otherwise UH_ERR_INVALID_ARGUMENT. */
+int uh_render_frames(uh_ctx* ctx, const UhViewUniformData* view, uint32_t pass_mask, uint32_t count);
 int uh_reset_accumulation(uh_ctx* ctx);
 int uh_synchronize(uh_ctx* ctx);
 

@@ -48,6 +48,7 @@ class CApi:
             "set_instance_transform": [vp, u32, p(C.c_float)],
             "build_acceleration": [vp],
             "render_frame": [vp, p(ViewUniformData), u32],
+            "render_frames": [vp, p(ViewUniformData), u32, u32],
             "reset_accumulation": [vp],
             "read_accumulation": [vp, vp],
             "read_output_bgra8": [vp, vp],
@@ -63,6 +64,8 @@ class CApi:
             "resolve_output": [vp, u32, u32],
         }
         for name, argtypes in sig.items():
+            if not hasattr(lib, prefix + name) and name == "render_frames":
+                continue  # the oracle renders frame by frame
             fn = getattr(lib, prefix + name)
             fn.argtypes, fn.restype = argtypes, C.c_int
             setattr(self, name, fn)
@@ -272,6 +275,10 @@ class Renderer:
     def render_frame(self, view, pass_mask=PASS_ALL):
         self._check(self._api.render_frame(self._ctx, C.byref(view), pass_mask))
 
+    def render_frames(self, view, pass_mask, count):
+        """`count` consecutive path-tracing frames of a static camera (uh_render_frames)."""
+        self._check(self._api.render_frames(self._ctx, C.byref(view), pass_mask, count))
+
     def reset_accumulation(self):
         self._check(self._api.reset_accumulation(self._ctx))
 
@@ -411,6 +418,29 @@ class FrameLoop:
         v.total_samples += v.samples_per_frame
         v.num_lights = self.renderer.get_num_lights()
         self.renderer.render_frame(v, pass_mask)
+        proj = np.array(v.projection[:], dtype=np.float32).reshape(4, 4).T
+        view = np.array(v.view[:], dtype=np.float32).reshape(4, 4).T
+        v.prev_frame_projection_view[:] = cam.to_glam((proj @ view).astype(np.float32)).tolist()
+
+    def frames(self, count, pass_mask=PASS_ALL):
+        """`count` frames of the loop. The path-tracing pass of a static camera is handed to
+        uh_render_frames in one call (the library batches frames into shared wavefronts); anything
+        involving the ReSTIR chain runs frame by frame."""
+        from .types import PASS_REFERENCE_PT
+
+        v = self.view
+        batchable = (
+            self.renderer.backend == "hip" and count > 1 and pass_mask == PASS_REFERENCE_PT
+            and not (v.lights_enabled == 1 and v.use_ris_light_sampling == 1)
+        )
+        if not batchable:
+            for _ in range(count):
+                self.frame(pass_mask)
+            return
+        v.num_lights = self.renderer.get_num_lights()
+        v.total_samples += v.samples_per_frame  # first frame of the run
+        self.renderer.render_frames(v, pass_mask, count)
+        v.total_samples += (count - 1) * v.samples_per_frame
         proj = np.array(v.projection[:], dtype=np.float32).reshape(4, 4).T
         view = np.array(v.view[:], dtype=np.float32).reshape(4, 4).T
         v.prev_frame_projection_view[:] = cam.to_glam((proj @ view).astype(np.float32)).tolist()

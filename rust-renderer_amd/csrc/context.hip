@@ -62,13 +62,104 @@ struct DevBuf {
 
 }  // namespace
 
-struct uh_ctx {
-   int device = 0;
+// One frame in flight: its own stream pair, hazard events, path state and queue control block.
+// Frames of the path-tracing pass are independent except for the order of the accumulation
+// read-modify-write (reference.rgen:131-143), so up to `frames_in_flight` of them overlap on the
+// GPU: one frame's memory-bound shading and kernel tails are filled by another frame's traversal,
+// and a rank that owns only 1/N of the pixels still keeps the chip busy.
+constexpr uint32_t kMaxSlots = 8;
+struct Slot {
    hipStream_t stream = nullptr;
-   // second stream: shade_miss (pure VALU, touches only paths that left the scene) overlaps the
-   // memory-bound shade_hit and the shadow traversal of the same bounce
+   // second stream: shade_miss (pure VALU, touches only paths that left the scene) and the shadow
+   // traversals overlap the main stream's shade_hit / next closest-hit traversal
    hipStream_t side = nullptr;
    hipEvent_t ev_traced = nullptr, ev_missed = nullptr, ev_shaded = nullptr, ev_shadowed = nullptr, ev_side_done = nullptr;
+   hipEvent_t ev_acc = nullptr;  // recorded after the frame's accumulate / store tail
+   hipEvent_t frame_start = nullptr, frame_stop = nullptr;
+   DevBuf<float4> ray_o, ray_d, hit, thr, rad, pixcol;
+   DevBuf<uint2> rng;
+   DevBuf<uint32_t> queues[5];
+   DevBuf<Control> control;
+   PathState ps{};
+   bool ready = false;
+   size_t capacity = 0;  // path ids this slot can hold (pixels x frames per batch)
+
+   hipError_t create(size_t n, uint32_t shard_cap) {
+      capacity = n;
+      if (shard_cap == 0) {  // exact: the largest number of 64-path runs one shard receives (shard_of_run)
+         const uint32_t runs = (uint32_t)((n + 63) / 64);
+         uint32_t per_shard[kShards] = {0};
+         for (uint32_t r = 0; r < runs; r++) per_shard[shard_of_run(r)]++;
+         for (uint32_t s = 0; s < kShards; s++) shard_cap = per_shard[s] * 64 > shard_cap ? per_shard[s] * 64 : shard_cap;
+      }
+      hipError_t e;
+#define SLOT_TRY(expr)                 \
+   if ((e = (expr)) != hipSuccess) return e
+      SLOT_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      SLOT_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      for (hipEvent_t* ev : {&ev_traced, &ev_missed, &ev_shaded, &ev_shadowed, &ev_side_done, &ev_acc}) SLOT_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+      SLOT_TRY(hipEventCreate(&frame_start));
+      SLOT_TRY(hipEventCreate(&frame_stop));
+      const size_t stagger = 4352;  // 4 KiB + 256 B per array slot
+      SLOT_TRY(ray_o.alloc(n, 0 * stagger));
+      SLOT_TRY(ray_d.alloc(n, 1 * stagger));
+      SLOT_TRY(hit.alloc(n, 2 * stagger));
+      SLOT_TRY(thr.alloc(n, 3 * stagger));
+      SLOT_TRY(rad.alloc(n, 4 * stagger));
+      SLOT_TRY(pixcol.alloc(n, 5 * stagger));
+      SLOT_TRY(rng.alloc(n, 6 * stagger));
+      // sharded queues: capacity per shard = the pixels (64-pixel runs) a shard can own
+      for (auto& q : queues) SLOT_TRY(q.alloc((size_t)shard_cap * kShards));
+      SLOT_TRY(control.alloc(1));
+      SLOT_TRY(hipMemsetAsync(control.p, 0, sizeof(Control), stream));
+      SLOT_TRY(hipStreamSynchronize(stream));
+#undef SLOT_TRY
+      ps.ray_o = ray_o.p;
+      ps.ray_d = ray_d.p;
+      ps.hit = hit.p;
+      ps.thr = thr.p;
+      ps.rad = rad.p;
+      ps.pixcol = pixcol.p;
+      ps.rng = rng.p;
+      for (int i = 0; i < 5; i++) ps.queue[i] = queues[i].p;
+      ps.shard_cap = shard_cap;
+      ready = true;
+      return hipSuccess;
+   }
+   void destroy() {
+      if (stream) (void)hipStreamSynchronize(stream);
+      if (side) (void)hipStreamSynchronize(side);
+      ray_o.release();
+      ray_d.release();
+      hit.release();
+      thr.release();
+      rad.release();
+      pixcol.release();
+      rng.release();
+      for (auto& q : queues) q.release();
+      control.release();
+      for (hipEvent_t ev : {ev_traced, ev_missed, ev_shaded, ev_shadowed, ev_side_done, ev_acc, frame_start, frame_stop})
+         if (ev) (void)hipEventDestroy(ev);
+      if (side) (void)hipStreamDestroy(side);
+      if (stream) (void)hipStreamDestroy(stream);
+      stream = side = nullptr;
+      ready = false;
+   }
+};
+
+struct uh_ctx {
+   int device = 0;
+   Slot slots[kMaxSlots];
+   uint32_t frames_in_flight = 3;     // slots used round-robin by path-tracing-only frames (swept: 3 is best)
+   uint32_t batch_frames = 0;         // frames one uh_render_frames launch chain carries (option "batch_frames"); 0 = auto
+   uint32_t next_slot = 0;
+   uint32_t shard_cap = 0;
+   hipEvent_t last_acc = nullptr;     // ev_acc of the most recent frame (accumulation order)
+   hipEvent_t serial_barrier = nullptr;  // set by a frame that ran ReSTIR / G-buffer passes: the next frame waits for it
+   Slot* last_slot = nullptr;
+   hipStream_t& stream = slots[0].stream;  // slot 0 also serves every non-frame operation
+   PathState& ps = slots[0].ps;
+   DevBuf<Control>& control = slots[0].control;
    bool overlap_miss = true, overlap_shadow = true;
    uint32_t W = 0, H = 0;
    uint32_t num_cus = 256;
@@ -92,15 +183,11 @@ struct uh_ctx {
    DevBuf<float> d_lut;
    SceneDev scene{};
 
-   // per-pixel state
-   DevBuf<float4> ray_o, ray_d, hit, thr, rad, pixcol, accumulation, gbuffer;
-   DevBuf<uint2> rng;
-   DevBuf<uint32_t> queues[5];
+   // frame-persistent per-pixel images (graph resources of renderers/mod.rs:199-244)
+   DevBuf<float4> accumulation, gbuffer;
    DevBuf<uchar4> output;
    DevBuf<UhReservoir> reservoirs[3];
-   DevBuf<Control> control;
    DevBuf<DeviceStats> dstats;
-   PathState ps{};
    Images im{};
 
    // options / stats
@@ -112,13 +199,14 @@ struct uh_ctx {
    float build_ms = 0.0f, last_frame_ms = 0.0f;
    float ms_by_kind[3] = {0, 0, 0};
    uint32_t trace_closest_launches = 0;
-   hipEvent_t frame_start = nullptr, frame_stop = nullptr;
    bool frame_timed = false;
    std::vector<EventPair> pending, free_events;
    uint32_t bvh_nodes = 0, bvh_tris = 0;
 
    // tile partition
    uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
+   DevBuf<uint32_t> owned_pixels;  // ascending pixel ids this rank owns (empty = the whole frame)
+   uint32_t n_owned = 0;
 };
 
 namespace {
@@ -241,46 +329,23 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    hipDeviceProp_t prop;
    CREATE_TRY(hipGetDeviceProperties(&prop, device_ordinal));
    c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
-   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-   CREATE_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-   CREATE_TRY(hipEventCreateWithFlags(&c->ev_traced, hipEventDisableTiming));
-   CREATE_TRY(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
-   CREATE_TRY(hipEventCreateWithFlags(&c->ev_shaded, hipEventDisableTiming));
-   CREATE_TRY(hipEventCreateWithFlags(&c->ev_missed, hipEventDisableTiming));
-   CREATE_TRY(hipEventCreateWithFlags(&c->ev_shadowed, hipEventDisableTiming));
-   CREATE_TRY(hipEventCreate(&c->frame_start));
-   CREATE_TRY(hipEventCreate(&c->frame_stop));
    {
       uint32_t occ = query_trace_occupancy();  // blocks/CU the traversal kernels can keep resident
       if (c->closest_blocks_per_cu > occ) c->closest_blocks_per_cu = occ;
       if (c->shadow_blocks_per_cu > occ) c->shadow_blocks_per_cu = occ;
    }
    const size_t n = (size_t)width * height;
-   const size_t stagger = getenv("UH_NO_STAGGER") ? 0 : 4352;  // 4 KiB + 256 B per array slot
-   CREATE_TRY(c->ray_o.alloc(n, 0 * stagger));
-   CREATE_TRY(c->ray_d.alloc(n, 1 * stagger));
-   CREATE_TRY(c->hit.alloc(n, 2 * stagger));
-   CREATE_TRY(c->thr.alloc(n, 3 * stagger));
-   CREATE_TRY(c->rad.alloc(n, 4 * stagger));
-   CREATE_TRY(c->pixcol.alloc(n, 5 * stagger));
-   CREATE_TRY(c->accumulation.alloc(n, 6 * stagger));
-   CREATE_TRY(c->gbuffer.alloc(n, 7 * stagger));
-   CREATE_TRY(c->rng.alloc(n, 8 * stagger));
-   // sharded queues: capacity per shard = the pixels (64-pixel runs) a shard can own
-   const uint32_t runs = (uint32_t)((n + 63) / 64);
-   const uint32_t shard_cap = ((runs + kShards - 1) / kShards) * 64;
-   for (auto& q : c->queues) CREATE_TRY(q.alloc((size_t)shard_cap * kShards));
-   c->ps.shard_cap = shard_cap;
+   CREATE_TRY(c->slots[0].create(n, 0));
+   CREATE_TRY(c->accumulation.alloc(n));
+   CREATE_TRY(c->gbuffer.alloc(n));
    CREATE_TRY(c->output.alloc(n));
    for (auto& r : c->reservoirs) CREATE_TRY(r.alloc(n));
-   CREATE_TRY(c->control.alloc(1));
    CREATE_TRY(c->dstats.alloc(1));
    CREATE_TRY(hipMemsetAsync(c->accumulation.p, 0, n * sizeof(float4), c->stream));
    CREATE_TRY(hipMemsetAsync(c->output.p, 0, n * sizeof(uchar4), c->stream));
    CREATE_TRY(hipMemsetAsync(c->gbuffer.p, 0, n * sizeof(float4), c->stream));
    for (auto& r : c->reservoirs) CREATE_TRY(hipMemsetAsync(r.p, 0, n * sizeof(UhReservoir), c->stream));
    CREATE_TRY(hipMemsetAsync(c->dstats.p, 0, sizeof(DeviceStats), c->stream));
-   CREATE_TRY(hipMemsetAsync(c->control.p, 0, sizeof(Control), c->stream));
    // c / 255.0f table (exact host division; replaces 12 IEEE divides per bilinear fetch)
    float lut[256];
    for (int i = 0; i < 256; i++) lut[i] = (float)i / 255.0f;
@@ -288,14 +353,6 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    CREATE_TRY(hipMemcpy(c->d_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice));
    CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
-   c->ps.ray_o = c->ray_o.p;
-   c->ps.ray_d = c->ray_d.p;
-   c->ps.hit = c->hit.p;
-   c->ps.thr = c->thr.p;
-   c->ps.rad = c->rad.p;
-   c->ps.pixcol = c->pixcol.p;
-   c->ps.rng = c->rng.p;
-   for (int i = 0; i < 5; i++) c->ps.queue[i] = c->queues[i].p;
    c->im.accumulation = c->accumulation.p;
    c->im.output = c->output.p;
    c->im.gbuffer_pos = c->gbuffer.p;
@@ -307,8 +364,10 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
 void uh_destroy(uh_ctx* c) {
    if (!c) return;
    (void)hipSetDevice(c->device);
-   if (c->stream) (void)hipStreamSynchronize(c->stream);
-   if (c->side) (void)hipStreamSynchronize(c->side);
+   for (auto& s : c->slots) {
+      if (s.stream) (void)hipStreamSynchronize(s.stream);
+      if (s.side) (void)hipStreamSynchronize(s.side);
+   }
    for (auto& t : c->textures)
       if (t.dev) (void)hipFree(t.dev);
    for (auto& ep : c->pending) {
@@ -326,29 +385,13 @@ void uh_destroy(uh_ctx* c) {
    c->d_meshes.release();
    c->d_tex.release();
    c->d_lut.release();
-   c->ray_o.release();
-   c->ray_d.release();
-   c->hit.release();
-   c->thr.release();
-   c->rad.release();
-   c->pixcol.release();
    c->accumulation.release();
    c->gbuffer.release();
-   c->rng.release();
-   for (auto& q : c->queues) q.release();
    c->output.release();
    for (auto& r : c->reservoirs) r.release();
-   c->control.release();
    c->dstats.release();
-   if (c->frame_start) (void)hipEventDestroy(c->frame_start);
-   if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
-   if (c->ev_traced) (void)hipEventDestroy(c->ev_traced);
-   if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
-   if (c->ev_shaded) (void)hipEventDestroy(c->ev_shaded);
-   if (c->ev_missed) (void)hipEventDestroy(c->ev_missed);
-   if (c->ev_shadowed) (void)hipEventDestroy(c->ev_shadowed);
-   if (c->side) (void)hipStreamDestroy(c->side);
-   if (c->stream) (void)hipStreamDestroy(c->stream);
+   for (auto& s : c->slots) s.destroy();
+   c->owned_pixels.release();
    delete c;
 }
 
@@ -412,6 +455,8 @@ int uh_set_instance_transform(uh_ctx* c, uint32_t mesh_index, const float world3
    c->built = false;
    return UH_OK;
 }
+
+static int sync_all(uh_ctx* c);
 
 int uh_build_acceleration(uh_ctx* c) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
@@ -508,7 +553,7 @@ int uh_build_acceleration(uh_ctx* c) {
    for (size_t i = 0; i < tex.size(); i++) tex[i] = TexInfo{c->textures[i].dev, c->textures[i].w, c->textures[i].h};
 
    if (bo.qnodes.empty()) return fail(c, UH_ERR_INVALID_ARGUMENT, "internal: BVH builder produced no root node");
-   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   if (int st = sync_all(c)) return st;
    HIP_TRY(c, c->d_nodes.alloc(bo.qnodes.size() * 4));
    HIP_TRY(c, c->d_tris.alloc(total * 3));
    HIP_TRY(c, c->d_shade.alloc(total * 4));
@@ -556,6 +601,9 @@ static FrameParams make_params(uh_ctx* c, const UhViewUniformData& v) {
    fp.H = c->H;
    // reference.rgen:24: int(float(total_samples) + time * 10000.0)
    fp.frame_number = (uint32_t)(int32_t)((float)v.total_samples + v.time * 10000.0f);
+   fp.batch_frames = 1;
+   fp.frame_numbers[0] = fp.frame_number;
+   fp.total_samples_of[0] = v.total_samples;
    fp.samples_per_frame = v.samples_per_frame;
    fp.total_samples = v.total_samples;
    fp.num_bounces = v.num_bounces;
@@ -572,10 +620,114 @@ static FrameParams make_params(uh_ctx* c, const UhViewUniformData& v) {
    fp.tp_world = c->tp_world;
    fp.tp_tile = c->tp_tile;
    fp.tiles_x = (c->W + c->tp_tile - 1) / c->tp_tile;
+   fp.owned_pixels = c->tp_world > 1 ? c->owned_pixels.p : nullptr;
+   fp.n_owned = c->tp_world > 1 ? c->n_owned : c->W * c->H;
    return fp;
 }
 
-int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask) {
+// every stream of every slot idle (read-backs, scene rebuilds, stats)
+static int sync_all(uh_ctx* c) {
+   for (auto& s : c->slots) {
+      if (!s.ready) continue;
+      HIP_TRY(c, hipStreamSynchronize(s.stream));
+      HIP_TRY(c, hipStreamSynchronize(s.side));
+   }
+   return UH_OK;
+}
+
+// slot i exists and can hold `batch` frames worth of paths
+static int ensure_slot(uh_ctx* c, uint32_t i, uint32_t batch = 1) {
+   const size_t need = (size_t)c->W * c->H * batch;
+   Slot& s = c->slots[i];
+   if (s.ready && s.capacity >= need) return UH_OK;
+   if (s.ready) {
+      HIP_TRY(c, hipStreamSynchronize(s.stream));
+      HIP_TRY(c, hipStreamSynchronize(s.side));
+      if (c->last_acc == s.ev_acc) c->last_acc = nullptr;
+      if (c->serial_barrier == s.ev_acc) c->serial_barrier = nullptr;
+      if (c->last_slot == &s) c->last_slot = nullptr;
+      s.destroy();
+   }
+   HIP_TRY(c, s.create(need, 0));
+   return UH_OK;
+}
+
+// reference_pt_pass of one frame on one slot (reference.rgen:22-145 as a kernel chain)
+static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
+   LaunchCfg lc = cfg(c);
+   lc.stream = s.stream;
+   Control* ctl = s.control.p;
+   DeviceStats* st = c->dstats.p;
+   // reference.rgen:28: samples of one frame run back to back (the raygen RNG state carries over)
+   for (uint32_t smp = 0; smp < fp.samples_per_frame; smp++) {
+      HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(Control), s.stream));
+      uint32_t slot = 0;
+      launch_generate(lc, fp, s.ps, ctl, smp);
+      for (uint32_t b = 0; b < fp.num_bounces; b++) {
+         // trace_closest(b) refills the miss queue that shade_miss(b-1) reads on the side stream
+         if (c->overlap_miss && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_missed, 0));
+         begin_timed(c, 0, s.stream);
+         launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
+         end_timed(c, s.stream);
+         if (c->overlap_miss) {
+            // side stream: shade_miss(b) after trace_closest(b); joined before finish_sample
+            HIP_TRY(c, hipEventRecord(s.ev_traced, s.stream));
+            HIP_TRY(c, hipStreamWaitEvent(s.side, s.ev_traced, 0));
+            LaunchCfg ls = lc;
+            ls.stream = s.side;
+            launch_shade_miss(ls, fp, s.ps, ctl, st, b);
+            HIP_TRY(c, hipEventRecord(s.ev_missed, s.side));
+         }
+         const bool side_shadow = c->overlap_shadow && (fp.sun_shadow_enabled == 1 || fp.lights_enabled == 1);
+         // shade_hit(b) rewrites ray_o / thr / rad of the paths shadow(b-1) still reads on the side stream
+         if (side_shadow && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_shadowed, 0));
+         begin_timed(c, 2, s.stream);
+         if (!c->overlap_miss) launch_shade_miss(lc, fp, s.ps, ctl, st, b);
+         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b);
+         end_timed(c, s.stream);
+         // shadow traversals of bounce b are independent of trace_closest(b+1) (both only read what
+         // shade_hit(b) wrote): on the side stream their blocks fill the tail of the other kernel
+         LaunchCfg lsh = lc;
+         hipStream_t sh_stream = s.stream;
+         if (side_shadow) {
+            HIP_TRY(c, hipEventRecord(s.ev_shaded, s.stream));
+            HIP_TRY(c, hipStreamWaitEvent(s.side, s.ev_shaded, 0));
+            lsh.stream = s.side;
+            sh_stream = s.side;
+         }
+         if (fp.sun_shadow_enabled == 1) {
+            begin_timed(c, 1, sh_stream);
+            launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, false);
+            end_timed(c, sh_stream);
+         }
+         if (fp.lights_enabled == 1) {
+            begin_timed(c, 1, sh_stream);
+            launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, true);
+            end_timed(c, sh_stream);
+         }
+         if (side_shadow) HIP_TRY(c, hipEventRecord(s.ev_shadowed, s.side));
+      }
+      if ((c->overlap_miss || c->overlap_shadow) && fp.num_bounces > 0) {
+         HIP_TRY(c, hipEventRecord(s.ev_side_done, s.side));
+         HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_side_done, 0));
+      }
+      const bool last = smp + 1 == fp.samples_per_frame;
+      // the accumulate / store tail (rgen:130-144) is a read-modify-write on the accumulation image:
+      // frames must apply it in order, everything before it may overlap with other frames in flight
+      if (last && c->last_acc && c->last_acc != s.ev_acc) HIP_TRY(c, hipStreamWaitEvent(s.stream, c->last_acc, 0));
+      launch_finish_sample(lc, fp, s.ps, c->im, smp, last);
+   }
+   if (fp.samples_per_frame == 0) {
+      // zero samples: the raygen still runs its accumulate / store tail
+      if (c->last_acc && c->last_acc != s.ev_acc) HIP_TRY(c, hipStreamWaitEvent(s.stream, c->last_acc, 0));
+      launch_resolve(lc, c->im, c->W, c->H, fp.total_samples, fp.accumulation_limit);
+   }
+   HIP_TRY(c, hipEventRecord(s.ev_acc, s.stream));
+   c->last_acc = s.ev_acc;
+   return UH_OK;
+}
+
+static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t batch) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (!view) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frame: null view");
    if (!c->built) return fail(c, UH_ERR_NOT_BUILT, "uh_render_frame before uh_build_acceleration");
@@ -583,15 +735,46 @@ int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask
    if (view->num_lights > c->lights.size() && (view->lights_enabled == 1 || (pass_mask & UH_PASS_RESTIR)))
       return fail(c, UH_ERR_INVALID_ARGUMENT, "view.num_lights exceeds the lights added with uh_add_light");
    HIP_TRY(c, hipSetDevice(c->device));
-   const FrameParams fp = make_params(c, *view);
-   const LaunchCfg lc = cfg(c);
-   Control* ctl = c->control.p;
-   DeviceStats* st = c->dstats.p;
-   HIP_TRY(c, hipEventRecord(c->frame_start, c->stream));
+   FrameParams fp = make_params(c, *view);
+   fp.batch_frames = batch;
+   for (uint32_t f = 0; f < batch; f++) {
+      // frame f of the batch: total_samples advanced by the application once per frame (main.rs:467-469)
+      const uint32_t total = view->total_samples + f * view->samples_per_frame;
+      fp.total_samples_of[f] = total;
+      fp.frame_numbers[f] = (uint32_t)(int32_t)((float)total + view->time * 10000.0f);
+   }
+   const bool restir_frame = (pass_mask & UH_PASS_RESTIR) != 0;
+   // the path tracer reads spatial_reuse_reservoirs when it samples lights from them (rgen:98)
+   const bool reads_reservoirs = (pass_mask & UH_PASS_REFERENCE_PT) && fp.lights_enabled == 1 && fp.use_ris == 1;
 
+   uint32_t si = 0;
+   if (!restir_frame && (pass_mask & UH_PASS_REFERENCE_PT)) {
+      si = c->next_slot;
+      c->next_slot = (c->next_slot + 1) % (c->frames_in_flight ? c->frames_in_flight : 1);
+   }
+   int st = ensure_slot(c, si, batch);
+   if (st != UH_OK) return st;
+   Slot& s = c->slots[si];
+   if (batch > 1 && (restir_frame || reads_reservoirs || !(pass_mask & UH_PASS_REFERENCE_PT)))
+      return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: only the path-tracing pass without reservoir light sampling can be batched");
+
+   if (restir_frame) {
+      // G-buffer / reservoir passes write buffers that frames in flight may still read, and the
+      // temporal pass consumes the previous frame's spatial reservoirs: run after everything else
+      for (auto& o : c->slots)
+         if (o.ready && &o != &s) HIP_TRY(c, hipStreamWaitEvent(s.stream, o.ev_acc, 0));
+   } else if (c->serial_barrier) {
+      // the previous frame produced reservoirs / G-buffer this frame may read
+      HIP_TRY(c, hipStreamWaitEvent(s.stream, c->serial_barrier, 0));
+      if (!reads_reservoirs) c->serial_barrier = nullptr;
+   }
+   HIP_TRY(c, hipEventRecord(s.frame_start, s.stream));
+
+   LaunchCfg lc = cfg(c);
+   lc.stream = s.stream;
    if (pass_mask & UH_PASS_GBUFFER) {
-      HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(Control), c->stream));
-      launch_gbuffer(lc, fp, c->scene, c->ps, c->im, ctl, st);
+      HIP_TRY(c, hipMemsetAsync(s.control.p, 0, sizeof(Control), s.stream));
+      launch_gbuffer(lc, fp, c->scene, s.ps, c->im, s.control.p, c->dstats.p);
    }
    if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(lc, fp, c->im);
    if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(lc, fp, c->scene, c->im);
@@ -599,76 +782,46 @@ int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask
    if (pass_mask & UH_PASS_SPATIAL_REUSE) launch_spatial_reuse(lc, fp, c->scene, c->im);
 
    if (pass_mask & UH_PASS_REFERENCE_PT) {
-      // reference.rgen:28: samples of one frame run back to back (the raygen RNG state carries over)
-      for (uint32_t s = 0; s < fp.samples_per_frame; s++) {
-         HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(Control), c->stream));
-         uint32_t slot = 0;
-         launch_generate(lc, fp, c->ps, ctl, s);
-         for (uint32_t b = 0; b < fp.num_bounces; b++) {
-            // trace_closest(b) refills the miss queue that shade_miss(b-1) reads on the side stream
-            if (c->overlap_miss && b > 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_missed, 0));
-            begin_timed(c, 0);
-            launch_trace_closest(lc, c->scene, c->ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
-            end_timed(c);
-            if (c->overlap_miss) {
-               // side stream: shade_miss(b) after trace_closest(b); joined before finish_sample
-               HIP_TRY(c, hipEventRecord(c->ev_traced, c->stream));
-               HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_traced, 0));
-               LaunchCfg ls = lc;
-               ls.stream = c->side;
-               launch_shade_miss(ls, fp, c->ps, ctl, st, b);
-               HIP_TRY(c, hipEventRecord(c->ev_missed, c->side));
-            }
-            const bool side_shadow = c->overlap_shadow && (fp.sun_shadow_enabled == 1 || fp.lights_enabled == 1);
-            // shade_hit(b) rewrites ray_o / thr / rad of the paths shadow(b-1) still reads on the side stream
-            if (side_shadow && b > 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_shadowed, 0));
-            begin_timed(c, 2);
-            if (!c->overlap_miss) launch_shade_miss(lc, fp, c->ps, ctl, st, b);
-            launch_shade_hit(lc, fp, c->scene, c->ps, c->im, ctl, st, b);
-            end_timed(c);
-            // shadow traversals of bounce b are independent of trace_closest(b+1) (both only read what
-            // shade_hit(b) wrote): on the side stream their blocks fill the tail of the other kernel
-            LaunchCfg lsh = lc;
-            hipStream_t sh_stream = c->stream;
-            if (side_shadow) {
-               HIP_TRY(c, hipEventRecord(c->ev_shaded, c->stream));
-               HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_shaded, 0));
-               lsh.stream = c->side;
-               sh_stream = c->side;
-            }
-            if (fp.sun_shadow_enabled == 1) {
-               begin_timed(c, 1, sh_stream);
-               launch_trace_shadow(lsh, fp, c->scene, c->ps, ctl, st, b, slot++, false);
-               end_timed(c, sh_stream);
-            }
-            if (fp.lights_enabled == 1) {
-               begin_timed(c, 1, sh_stream);
-               launch_trace_shadow(lsh, fp, c->scene, c->ps, ctl, st, b, slot++, true);
-               end_timed(c, sh_stream);
-            }
-            if (side_shadow) HIP_TRY(c, hipEventRecord(c->ev_shadowed, c->side));
-         }
-         if ((c->overlap_miss || c->overlap_shadow) && fp.num_bounces > 0) {
-            HIP_TRY(c, hipEventRecord(c->ev_side_done, c->side));
-            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
-         }
-         launch_finish_sample(lc, fp, c->ps, c->im, s, s + 1 == fp.samples_per_frame);
-      }
-      if (fp.samples_per_frame == 0) {
-         // zero samples: the raygen still runs its accumulate / store tail
-         launch_resolve(lc, c->im, c->W, c->H, fp.total_samples, fp.accumulation_limit);
-      }
+      st = enqueue_path_trace(c, s, fp);
+      if (st != UH_OK) return st;
+   } else {
+      HIP_TRY(c, hipEventRecord(s.ev_acc, s.stream));
    }
-   HIP_TRY(c, hipEventRecord(c->frame_stop, c->stream));
+   if (restir_frame) c->serial_barrier = s.ev_acc;
+   HIP_TRY(c, hipEventRecord(s.frame_stop, s.stream));
+   c->last_slot = &s;
    c->frame_timed = true;
-   c->frames++;
+   c->frames += batch;
    HIP_TRY(c, hipGetLastError());
+   return UH_OK;
+}
+
+int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask) { return render_batch(c, view, pass_mask, 1); }
+
+int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t count) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!view || count == 0) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: null view or zero frames");
+   UhViewUniformData v = *view;
+   uint32_t done = 0;
+   // auto: keep launches about the size of two full frames - a rank that owns 1/world of the pixels
+   // carries 2 * world frames per wavefront, capped at 8 so that a 64-frame run still pipelines
+   // several wavefronts through the frames-in-flight slots (swept on MI355X: profiles/README.md)
+   uint32_t batch = c->batch_frames ? c->batch_frames : (2 * c->tp_world > 8 ? 8 : 2 * c->tp_world);
+   if (batch > kMaxBatchFrames) batch = kMaxBatchFrames;
+   while (done < count) {
+      uint32_t b = count - done < batch ? count - done : batch;
+      int st = render_batch(c, &v, pass_mask, b);
+      if (st != UH_OK) return st;
+      done += b;
+      v.total_samples += b * v.samples_per_frame;
+   }
    return UH_OK;
 }
 
 int uh_reset_accumulation(uh_ctx* c) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
    HIP_TRY(c, hipMemsetAsync(c->accumulation.p, 0, c->accumulation.n * sizeof(float4), c->stream));
    HIP_TRY(c, hipMemsetAsync(c->output.p, 0, c->output.n * sizeof(uchar4), c->stream));
    return UH_OK;
@@ -677,14 +830,14 @@ int uh_reset_accumulation(uh_ctx* c) {
 int uh_synchronize(uh_ctx* c) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    HIP_TRY(c, hipSetDevice(c->device));
-   HIP_TRY(c, hipStreamSynchronize(c->stream));
-   return UH_OK;
+   return sync_all(c);
 }
 
 static int read_back(uh_ctx* c, void* dst, const void* src, size_t bytes) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (!dst) return fail(c, UH_ERR_INVALID_ARGUMENT, "null destination");
    HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    return UH_OK;
@@ -702,6 +855,7 @@ int uh_write_reservoirs(uh_ctx* c, int which, const UhReservoir* in) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (which < 0 || which > 2 || !in) return fail(c, UH_ERR_INVALID_ARGUMENT, "reservoir buffer index must be 0..2");
    HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
    HIP_TRY(c, hipMemcpyAsync(c->reservoirs[which].p, in, c->reservoirs[which].n * sizeof(UhReservoir), hipMemcpyHostToDevice, c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    return UH_OK;
@@ -786,13 +940,13 @@ int uh_trace_any(uh_ctx* c, const float* rays, uint32_t n, uint8_t* out_occluded
 int uh_get_stats(uh_ctx* c, UhStats* out) {
    if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
    HIP_TRY(c, hipSetDevice(c->device));
-   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   if (int st = sync_all(c)) return st;
    DeviceStats ds;
    HIP_TRY(c, hipMemcpy(&ds, c->dstats.p, sizeof(ds), hipMemcpyDeviceToHost));
    drain_timed(c);
    if (c->frame_timed) {
       float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, c->frame_start, c->frame_stop) == hipSuccess) c->last_frame_ms = ms;
+      if (c->last_slot && hipEventElapsedTime(&ms, c->last_slot->frame_start, c->last_slot->frame_stop) == hipSuccess) c->last_frame_ms = ms;
    }
    std::memset(out, 0, sizeof(*out));
    for (int i = 0; i < UH_RAY_KINDS; i++) out->rays[i] = ds.rays[i];
@@ -817,7 +971,7 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
 int uh_reset_stats(uh_ctx* c) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    HIP_TRY(c, hipSetDevice(c->device));
-   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   if (int st = sync_all(c)) return st;
    drain_timed(c);
    HIP_TRY(c, hipMemset(c->dstats.p, 0, sizeof(DeviceStats)));
    c->frames = 0;
@@ -834,7 +988,7 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->count_visits = value != 0;
    else if (n == "time_kernels") {
       if (c->time_kernels && !value) {
-         (void)hipStreamSynchronize(c->stream);
+         (void)sync_all(c);
          drain_timed(c);
       }
       c->time_kernels = value != 0;
@@ -852,10 +1006,19 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->overlap_miss = value != 0;
    else if (n == "overlap_shadow")
       c->overlap_shadow = value != 0;
+   else if (n == "batch_frames") {
+      if (value < 0 || value > (int)kMaxBatchFrames) return fail(c, UH_ERR_INVALID_ARGUMENT, "batch_frames must be 0 (auto) .. 16");
+      c->batch_frames = (uint32_t)value;
+   } else if (n == "frames_in_flight") {
+      if (value < 1 || value > (int)kMaxSlots) return fail(c, UH_ERR_INVALID_ARGUMENT, "frames_in_flight must be 1..8");
+      (void)sync_all(c);
+      c->frames_in_flight = (uint32_t)value;
+      c->next_slot = 0;
+   }
    else if (n == "trace_variant" || n == "closest_variant" || n == "shadow_variant") {
-      if (value < 0 || value > 21) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..21");
+      if (value < 0 || value > 25) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..25");
       if (n != "shadow_variant") c->closest_variant = value;
-      if (n != "closest_variant") c->shadow_variant = value;
+      if (n != "closest_variant") c->shadow_variant = value > 21 ? 19 : value;
    } else if (n == "trace_blocks_per_cu" || n == "closest_blocks_per_cu" || n == "shadow_blocks_per_cu") {
       if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 1..8");
       if (n != "shadow_blocks_per_cu") c->closest_blocks_per_cu = (uint32_t)value;
@@ -868,9 +1031,24 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
 int uh_set_tile_partition(uh_ctx* c, uint32_t rank, uint32_t world, uint32_t tile_size) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (world == 0 || rank >= world || tile_size == 0) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_set_tile_partition: need rank < world, tile_size > 0");
+   HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
    c->tp_rank = rank;
    c->tp_world = world;
    c->tp_tile = tile_size;
+   c->n_owned = c->W * c->H;
+   c->owned_pixels.release();
+   if (world > 1) {
+      const uint32_t tiles_x = (c->W + tile_size - 1) / tile_size;
+      std::vector<uint32_t> own;
+      own.reserve((size_t)c->W * c->H / world + 1);
+      for (uint32_t y = 0; y < c->H; y++)
+         for (uint32_t x = 0; x < c->W; x++)
+            if (((y / tile_size) * tiles_x + x / tile_size) % world == rank) own.push_back(y * c->W + x);
+      c->n_owned = (uint32_t)own.size();
+      HIP_TRY(c, c->owned_pixels.alloc(own.size() ? own.size() : 1));
+      if (!own.empty()) HIP_TRY(c, hipMemcpy(c->owned_pixels.p, own.data(), own.size() * 4, hipMemcpyHostToDevice));
+   }
    return UH_OK;
 }
 
@@ -889,6 +1067,7 @@ int uh_pack_tiles(uh_ctx* c, void* device_out, uint64_t capacity_pixels) {
    uh_tile_pack_count(c, c->tp_rank, &need);
    if (!device_out || capacity_pixels < need) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_pack_tiles: buffer too small");
    HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
    launch_pack_tiles(cfg(c), c->accumulation.p, (float4*)device_out, c->W, c->H, c->tp_rank, c->tp_world, c->tp_tile);
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    return UH_OK;
@@ -900,6 +1079,7 @@ int uh_unpack_tiles(uh_ctx* c, uint32_t from_rank, const void* device_in, uint64
    if (uh_tile_pack_count(c, from_rank, &need) != UH_OK) return UH_ERR_INVALID_ARGUMENT;
    if (!device_in || num_pixels < need) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_unpack_tiles: buffer too small");
    HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
    launch_unpack_tiles(cfg(c), c->accumulation.p, (const float4*)device_in, c->W, c->H, from_rank, c->tp_world, c->tp_tile);
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    return UH_OK;
@@ -908,6 +1088,7 @@ int uh_unpack_tiles(uh_ctx* c, uint32_t from_rank, const void* device_in, uint64
 int uh_resolve_output(uh_ctx* c, uint32_t total_samples, uint32_t accumulation_limit) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
    launch_resolve(cfg(c), c->im, c->W, c->H, total_samples, accumulation_limit);
    HIP_TRY(c, hipGetLastError());
    return UH_OK;

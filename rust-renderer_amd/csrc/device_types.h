@@ -15,7 +15,7 @@ constexpr uint32_t kQueueKinds = 4;  // per bounce: RAY, HIT, MISS, LIGHT
 enum { Q_RAY = 0, Q_HIT = 1, Q_MISS = 2, Q_LIGHT = 3 };
 constexpr uint32_t kLaunchSlots = kMaxBounces * 3 + 4;
 
-// Queues are sharded: pixel p lives in shard (p / 64) % kShards for its whole life, every queue
+// Queues are sharded: path p lives in shard shard_of_run(p / 64) for its whole life, every queue
 // has one segment (capacity PathState::shard_cap) and one counter per shard, and the blocks of a
 // launch are bound to shards by blockIdx % kShards. A single device-wide counter saturates at
 // ~88 atomics/us on MI355X (MI355X_MICROARCH.md "dequeue"), which capped every queue-building
@@ -23,6 +23,10 @@ constexpr uint32_t kLaunchSlots = kMaxBounces * 3 + 4;
 // Blocks b and b + 8 share an XCD under the observed round-robin dispatch, so shard s is served by
 // XCD s % 8 and its queue segments stay in that XCD's L2 between producer and consumer launches.
 constexpr uint32_t kShards = 32;
+// Fibonacci hash of the 64-path run index (top 5 bits). A plain `run % 32` aliases with the tile
+// partition: with 64-pixel-wide tiles every run a rank owns is even, which left half of the shards
+// (and half of the traversal blocks) empty on every rank of a multi-GPU job.
+__host__ __device__ inline uint32_t shard_of_run(uint32_t run) { return (run * 0x9E3779B1u) >> 27; }
 
 // Zeroed once per sample pass by one hipMemsetAsync.
 struct Control {
@@ -66,7 +70,16 @@ struct SceneDev {
    uint32_t num_nodes, num_tris, num_meshes, num_textures, num_lights;
 };
 
+constexpr uint32_t kMaxBatchFrames = 16;
+
 struct FrameParams {
+   // A launch chain may carry `batch_frames` consecutive frames of the path-tracing pass as one
+   // wavefront: path id = f * (W*H) + pixel. Frames differ only in their RNG frame number and in
+   // total_samples (prototype/src/main.rs:467-469 adds samples_per_frame per frame); the
+   // accumulate / store tail applies them in frame order, so results equal one-by-one rendering.
+   uint32_t batch_frames;
+   uint32_t frame_numbers[kMaxBatchFrames];
+   uint32_t total_samples_of[kMaxBatchFrames];
    float inv_view[16], inv_proj[16], prev_pv[16];
    float sun_dir[3];  // normalize(view.sun_dir), computed on the host with the contract's normalize
    uint32_t W, H, frame_number;
@@ -75,6 +88,10 @@ struct FrameParams {
    uint32_t num_lights_used;  // min(view.num_lights, view.max_num_lights_used)
    uint32_t temporal_enabled, spatial_enabled;
    uint32_t tp_rank, tp_world, tp_tile, tiles_x;
+   // pixels this rank owns under the tile partition, ascending; nullptr = all W*H pixels. The
+   // per-pixel kernels (generate, finish_sample) walk this list, so their cost shrinks with 1/world.
+   const uint32_t* owned_pixels;
+   uint32_t n_owned;
 };
 
 // Path / ray state, SoA over pixels (path id == pixel id). 16-byte records so that every lane

@@ -651,6 +651,118 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 }
 
 // ------------------------------------------------------------------------------------------
+// Traversal v5 (closest hit) — if-if one-node / one-triangle steps + per-lane refill, with the
+// finished ray ids staged in two per-wave LDS lists (hit / miss) that are flushed to the global
+// queues 64 ids at a time. The refill path therefore contains no global atomic (the v2 refill lost
+// to two returning atomics per refill); queue atomics stay at the batch kernel's rate of one per
+// 64 rays per queue.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flush_list(uint32_t* list, uint32_t& n, uint32_t take, uint32_t* counter, uint32_t* queue) {
+   const uint32_t lane = lane_id();
+   uint32_t base = 0;
+   if (lane == 0) base = atomicAdd(counter, take);
+   base = __builtin_amdgcn_readfirstlane(base);
+   if (lane < take) queue[base + lane] = list[lane];
+   // move the tail (at most 63 entries) to the front; one wave, LDS ops in order: read, then write
+   const uint32_t rest = n - take;
+   uint32_t tmp = 0;
+   if (lane < rest) tmp = list[take + lane];
+   if (lane < rest) list[lane] = tmp;
+   n = rest;
+}
+
+template <bool COUNT, int kRefillIdle>
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_v5(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats,
+                                                                                                  uint32_t bounce, uint32_t cursor_slot, int ray_kind) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   __shared__ uint32_t s_out[kWavesPerBlock][2][128];
+   const uint32_t lane = lane_id();
+   const uint32_t wave = threadIdx.x >> 6;
+   uint32_t* lds_col = &s_stack[wave][0][lane];
+   uint32_t* hit_list = s_out[wave][0];
+   uint32_t* miss_list = s_out[wave][1];
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
+   uint32_t* q_hit = ps.queue[2] + seg;
+   uint32_t* q_miss = ps.queue[3] + seg;
+   uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
+   uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
+   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   uint32_t spill[kSpillStack];
+   uint32_t pool_pos = 0, pool_end = 0;
+   bool drained = false, active = false;
+   uint32_t id = 0, tk = 0;
+   uint32_t n_hq = 0, n_mq = 0;  // wave-uniform fill of the two LDS lists
+   Trav t;
+   t.cur = kEmptyRef;
+   t.sp = 0;
+   uint32_t n_nodes = 0, n_tris = 0;
+   for (;;) {
+      const unsigned long long idle_mask = __ballot(!active);
+      const int n_idle = __popcll(idle_mask);
+      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
+         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
+         if (!drained) {
+            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+            const uint32_t idx = pool_pos + prefix;
+            if (!active && idx < pool_end) {
+               id = queue[idx];
+               trav_init(t, ps.ray_o[id], ps.ray_d[id], INFINITY);
+               tk = 0;
+               active = true;
+            }
+            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
+         }
+         if (__ballot(active) == 0ull) {
+            if (drained) break;
+            continue;
+         }
+      }
+      if (active) {
+         if (!(t.cur & kLeafBit)) {
+            if (COUNT) n_nodes++;
+            node_step<false>(nodes, t, lds_col, spill);
+         } else {
+            const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+            if (COUNT) n_tris++;
+            tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
+            tk++;
+            if (tk >= cnt) {
+               tk = 0;
+               t.cur = trav_pop(t, lds_col, spill);
+            }
+         }
+      }
+      const bool fin = active && t.cur == kEmptyRef;
+      if (__ballot(fin) != 0ull) {
+         const bool is_hit = fin && t.best.idx != kEmptyRef, is_miss = fin && t.best.idx == kEmptyRef;
+         if (fin) {
+            ps.hit[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
+            active = false;
+         }
+         const unsigned long long hm = __ballot(is_hit), mm = __ballot(is_miss);
+         if (is_hit) hit_list[n_hq + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u))] = id;
+         if (is_miss) miss_list[n_mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = id;
+         n_hq += (uint32_t)__popcll(hm);
+         n_mq += (uint32_t)__popcll(mm);
+         if (n_hq >= 64u) flush_list(hit_list, n_hq, 64u, n_hit, q_hit);
+         if (n_mq >= 64u) flush_list(miss_list, n_mq, 64u, n_miss, q_miss);
+      }
+   }
+   if (n_hq) flush_list(hit_list, n_hq, n_hq, n_hit, q_hit);
+   if (n_mq) flush_list(miss_list, n_mq, n_mq, n_miss, q_miss);
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
+   if (COUNT) {
+      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+   }
+}
+
+// ------------------------------------------------------------------------------------------
 // Traversal v3 — "vote" scheduling on top of the v2 refill. The v2 counters (profiles/r01c_*) show
 // the SIMDs ~70 % busy issuing VALU while only ~30 % of the lanes in those instructions are live:
 // lanes sit out whenever the wave is in the other phase (interior node vs triangle). Here every
@@ -846,35 +958,45 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow_v3(SceneDev sc, FramePa
 // generate — reference.rgen:24-40: RNG init, payload seed copy, jitter, primary ray
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState ps, Control* ctl, uint32_t sample) {
-   const uint32_t n = fp.W * fp.H;
+   const uint32_t npix = fp.W * fp.H;
+   const uint32_t n = fp.n_owned * fp.batch_frames;  // owned pixels x frames of the batch
    const uint32_t lane = lane_id();
-   const uint32_t runs = (n + 63) / 64;
-   // one wave per 64-pixel run, runs streamed in linear order (plain coalesced 1-KiB stores per
-   // array); the run's shard (run % kShards) only decides which queue segment receives the ids
-   for (uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); run < runs; run += gridDim.x * kWavesPerBlock) {
-      const uint32_t shard = run % kShards;
-      uint32_t* queue = ps.queue[0] + shard * ps.shard_cap;
-      uint32_t* n_ray = &ctl->q_count[qc_index(0, Q_RAY, shard)];
-      uint32_t id = run * 64u + lane;
-      bool own = false;
-      if (id < n) {
-         uint32_t px = id % fp.W, py = id / fp.W;
-         own = owns_pixel(fp, px, py);
-         if (own) {
-            uint32_t rng = sample == 0 ? init_rng(px, py, fp.W, fp.frame_number) : ps.rng[id].x;  // rgen:24
-            uint32_t seed = rng;                                                                 // rgen:30
-            float jx = random_float(rng), jy = random_float(rng);                                // rgen:31
-            V3 o, d;
-            primary_ray(fp, px, py, jx, jy, o, d);
-            ps.ray_o[id] = make_float4(o.x, o.y, o.z, 0.001f);
-            ps.ray_d[id] = make_float4(d.x, d.y, d.z, 10000.0f);
-            // throughput = 1 / radiance = 0 / pixelColor = 0 (rgen:26,39-40) are not materialised: the
-            // bounce-0 shading kernels and the first finish_sample use the constants directly
-            ps.rng[id] = make_uint2(rng, seed);
-         }
+   const uint32_t groups = (n + 63) / 64;
+   // one wave per 64 owned pixels, streamed in order (plain coalesced 1-KiB stores per array for
+   // whole tile rows); a path's shard (shard_of_run of its 64-path run) decides which queue segment
+   // receives its id
+   for (uint32_t g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); g < groups; g += gridDim.x * kWavesPerBlock) {
+      const uint32_t q = g * 64u + lane;
+      bool own = q < n;
+      uint32_t id = 0;
+      if (own) {
+         const uint32_t f = q / fp.n_owned, k = q - f * fp.n_owned;
+         const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
+         id = f * npix + pix;
+         uint32_t px = pix % fp.W, py = pix / fp.W;
+         uint32_t rng = sample == 0 ? init_rng(px, py, fp.W, fp.frame_numbers[f]) : ps.rng[id].x;  // rgen:24
+         uint32_t seed = rng;                                                                   // rgen:30
+         float jx = random_float(rng), jy = random_float(rng);                                  // rgen:31
+         V3 o, d;
+         primary_ray(fp, px, py, jx, jy, o, d);
+         ps.ray_o[id] = make_float4(o.x, o.y, o.z, 0.001f);
+         ps.ray_d[id] = make_float4(d.x, d.y, d.z, 10000.0f);
+         // throughput = 1 / radiance = 0 / pixelColor = 0 (rgen:26,39-40) are not materialised: the
+         // bounce-0 shading kernels and the first finish_sample use the constants directly
+         ps.rng[id] = make_uint2(rng, seed);
       }
-      uint32_t slot = wave_append(n_ray, own);
-      if (own) queue[slot] = id;
+      // the 64 paths of a wave normally share one run (hence one shard); at tile edges that are not
+      // 64-aligned they may not, so append shard by shard
+      uint32_t shard = own ? shard_of_run(id >> 6) : 0xffffffffu;
+      unsigned long long todo = __ballot(own);
+      while (todo) {
+         const int leader = __ffsll((long long)todo) - 1;
+         const uint32_t s = __shfl(shard, leader);
+         const bool mine = own && shard == s;
+         uint32_t slot = wave_append(&ctl->q_count[qc_index(0, Q_RAY, s)], mine);
+         if (mine) ps.queue[0][s * ps.shard_cap + slot] = id;
+         todo &= ~__ballot(mine);
+      }
    }
 }
 
@@ -1019,10 +1141,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
             int light_index = 0;
             if (fp.lights_enabled == 1) {                                              // rgen:81-110
                float light_sample_weight = 0.0f, total_weights = 1.0f;
-               uint32_t px = id % fp.W;
+               const uint32_t pix = id % (fp.W * fp.H);
+               uint32_t px = pix % fp.W;
                bool use_reservoir = (px > fp.W / 2 || fp.full_frame_restir) && fp.use_ris == 1;  // rgen:87
                if (use_reservoir) {
-                  UhReservoir rs = spatial_reservoirs[id];                             // rgen:98
+                  UhReservoir rs = spatial_reservoirs[pix];                            // rgen:98
                   light_sample_weight = rs.W_X;
                   total_weights = rs.W_sum;
                   light_index = rs.Y;
@@ -1060,24 +1183,36 @@ __device__ __forceinline__ uchar4 resolve_color(float4 acc, uint32_t total_sampl
 }
 
 __global__ __launch_bounds__(kBlock) void k_finish_sample(FrameParams fp, PathState ps, Images im, uint32_t sample, bool last) {
-   const uint32_t n = fp.W * fp.H;
-   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
-      uint32_t px = id % fp.W, py = id / fp.W;
-      if (!owns_pixel(fp, px, py)) continue;
-      float4 pc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (sample != 0) pc = ps.pixcol[id];
-      if (fp.num_bounces != 0) rad = ps.rad[id];  // with zero bounces no kernel ever wrote a radiance
-      pc = make_float4(pc.x + rad.x, pc.y + rad.y, pc.z + rad.z, 0.0f);                  // rgen:127
-      if (!last) {
-         ps.pixcol[id] = pc;
-         continue;
-      }
+   const uint32_t npix = fp.W * fp.H;
+   for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < fp.n_owned; k += gridDim.x * kBlock) {
+      const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
       float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (fp.total_samples != fp.samples_per_frame) acc = im.accumulation[id];          // rgen:131-134
-      if (fp.total_samples <= fp.accumulation_limit) acc = make_float4(acc.x + pc.x, acc.y + pc.y, acc.z + pc.z, 0.0f);  // rgen:136-138
-      acc.w = 0.0f;
-      im.accumulation[id] = acc;                                                         // rgen:143
-      im.output[id] = resolve_color(acc, fp.total_samples, fp.accumulation_limit);       // rgen:144
+      bool acc_loaded = false;
+      uint32_t total = fp.total_samples;
+      // frames of the batch in order: each applies the reference's accumulate tail with ITS total_samples
+      for (uint32_t f = 0; f < fp.batch_frames; f++) {
+         const uint32_t id = f * npix + pix;
+         float4 pc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+         if (sample != 0) pc = ps.pixcol[id];
+         if (fp.num_bounces != 0) rad = ps.rad[id];  // with zero bounces no kernel ever wrote a radiance
+         pc = make_float4(pc.x + rad.x, pc.y + rad.y, pc.z + rad.z, 0.0f);                  // rgen:127
+         if (!last) {
+            ps.pixcol[id] = pc;
+            continue;
+         }
+         total = fp.total_samples_of[f];
+         if (total != fp.samples_per_frame) {                                               // rgen:131-134
+            if (!acc_loaded) acc = im.accumulation[pix];
+         } else {
+            acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+         }
+         acc_loaded = true;
+         if (total <= fp.accumulation_limit) acc = make_float4(acc.x + pc.x, acc.y + pc.y, acc.z + pc.z, 0.0f);  // rgen:136-138
+         acc.w = 0.0f;
+      }
+      if (!last) continue;
+      im.accumulation[pix] = acc;                                                            // rgen:143
+      im.output[pix] = resolve_color(acc, total, fp.accumulation_limit);                     // rgen:144
    }
 }
 
@@ -1296,7 +1431,7 @@ uint32_t query_trace_occupancy() {
 }
 
 void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, uint32_t sample) {
-   k_generate<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ctl, sample);
+   k_generate<<<stream_grid(c, fp.n_owned * fp.batch_frames), kBlock, 0, c.stream>>>(fp, ps, ctl, sample);
 }
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
@@ -1306,6 +1441,23 @@ void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathStat
          k_trace_closest<true><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
       else
          k_trace_closest<false><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+      return;
+   }
+   if (c.closest_variant >= 22) {
+#define UH_LAUNCH_V5(IDLE)                                                                                                           \
+   do {                                                                                                                              \
+      if (c.count_visits)                                                                                                            \
+         k_trace_closest_v5<true, IDLE><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);  \
+      else                                                                                                                           \
+         k_trace_closest_v5<false, IDLE><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind); \
+   } while (0)
+      switch (c.closest_variant) {
+         case 22: UH_LAUNCH_V5(32); break;
+         case 23: UH_LAUNCH_V5(16); break;
+         case 24: UH_LAUNCH_V5(8); break;
+         default: UH_LAUNCH_V5(4); break;
+      }
+#undef UH_LAUNCH_V5
       return;
    }
    if (c.closest_variant >= 11 && c.closest_variant <= 16) {
@@ -1365,7 +1517,7 @@ void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev&
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
                          uint32_t bounce, uint32_t cursor_slot, bool light) {
-   if (c.shadow_variant >= 11 && c.shadow_variant <= 16) {
+   if (c.shadow_variant >= 11 && c.shadow_variant <= 16) {  // (22..25 are closest-only kernels; shadow falls back to the 17..21 family)
 #define UH_LAUNCH_S3(IDLE, VOTE)                                                                                                              \
    do {                                                                                                                                       \
       if (light) {                                                                                                                            \
@@ -1440,7 +1592,7 @@ void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneD
 }
 
 void launch_finish_sample(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, const Images& im, uint32_t sample, bool last) {
-   k_finish_sample<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, im, sample, last);
+   k_finish_sample<<<stream_grid(c, fp.n_owned), kBlock, 0, c.stream>>>(fp, ps, im, sample, last);
 }
 
 void launch_resolve(const LaunchCfg& c, const Images& im, uint32_t W, uint32_t H, uint32_t total_samples, uint32_t limit) {

@@ -186,7 +186,7 @@ def test_instance_transform_rebuild(cornell):
     assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
 
 
-@pytest.mark.parametrize("variant", [1, 3, 5, 8, 11, 14, 17, 19, 21])
+@pytest.mark.parametrize("variant", [1, 3, 5, 8, 11, 14, 17, 19, 21, 22, 23, 25])
 def test_traversal_variants_are_bit_identical(atrium, variant):
     """every traversal kernel variant must produce the same image and the same ray counts"""
     W, H = 160, 90
@@ -199,3 +199,51 @@ def test_traversal_variants_are_bit_identical(atrium, variant):
     assert np.array_equal(ref.read_accumulation().view(np.uint32), alt.read_accumulation().view(np.uint32))
     a, b = ref.get_stats(), alt.get_stats()
     assert list(a.rays) == list(b.rays) and a.closest_hits == b.closest_hits and a.misses == b.misses
+
+
+@pytest.mark.parametrize("batch,in_flight,spp,limit", [(3, 2, 1, 999999), (8, 3, 1, 999999), (4, 1, 2, 999999), (3, 3, 1, 4)])
+def test_batched_frames_equal_frame_by_frame(cornell, batch, in_flight, spp, limit):
+    """uh_render_frames (several frames per wavefront, several wavefronts in flight) must equal the
+    frame-by-frame protocol bit for bit, including the accumulation-limit freeze and partial batches"""
+    W, H, frames = 96, 80, 7
+    ref = cornell.upload(rr.Renderer(W, H))
+    ref.set_option("frames_in_flight", 1)
+    loop = run_frames(ref, cornell, W, H, frames, rr.PASS_REFERENCE_PT, samples_per_frame=spp, accumulation_limit=limit)
+    alt = cornell.upload(rr.Renderer(W, H))
+    alt.set_option("batch_frames", batch)
+    alt.set_option("frames_in_flight", in_flight)
+    loop2 = rr.FrameLoop(alt, cornell.make_view(W, H, samples_per_frame=spp, accumulation_limit=limit))
+    loop2.frames(frames, rr.PASS_REFERENCE_PT)
+    assert loop2.view.total_samples == loop.view.total_samples == frames * spp
+    assert np.array_equal(ref.read_accumulation().view(np.uint32), alt.read_accumulation().view(np.uint32))
+    assert np.array_equal(ref.read_output_bgra8(), alt.read_output_bgra8())
+    assert list(ref.get_stats().rays) == list(alt.get_stats().rays)
+    # and continuing frame by frame after a batched run keeps matching
+    loop.frame(rr.PASS_REFERENCE_PT)
+    loop2.frame(rr.PASS_REFERENCE_PT)
+    assert np.array_equal(ref.read_accumulation().view(np.uint32), alt.read_accumulation().view(np.uint32))
+
+
+def test_batched_frames_with_tile_partition(cornell):
+    W, H, frames = 96, 80, 5
+    ref = cornell.upload(rr.Renderer(W, H))
+    ref.set_tile_partition(1, 3, 16)
+    run_frames(ref, cornell, W, H, frames, rr.PASS_REFERENCE_PT)
+    alt = cornell.upload(rr.Renderer(W, H))
+    alt.set_tile_partition(1, 3, 16)
+    alt.set_option("batch_frames", 4)
+    rr.FrameLoop(alt, cornell.make_view(W, H)).frames(frames, rr.PASS_REFERENCE_PT)
+    assert np.array_equal(ref.read_accumulation().view(np.uint32), alt.read_accumulation().view(np.uint32))
+
+
+def test_restir_frames_cannot_be_batched(atrium):
+    r = atrium.upload(rr.Renderer(64, 36))
+    r.set_option("batch_frames", 4)
+    v = atrium.make_view(64, 36)
+    v.total_samples = 1
+    with pytest.raises(rr.UtopianError, match="batched"):
+        r.render_frames(v, rr.PASS_ALL, 4)
+    # the host loop falls back to frame-by-frame for the ReSTIR chain
+    loop = rr.FrameLoop(r, atrium.make_view(64, 36))
+    loop.frames(3, rr.PASS_ALL)
+    assert loop.view.total_samples == 3 and (r.read_reservoirs(2)["M"] > 1).any()
