@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone", action="store_true", help="skip the untimed standalone-kernel calibration frames (profiling runs: every launch in the trace is then in the timed regime)")
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only rank 0's tiles of an N-rank partition (what one rank sees at --gpus N)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=3")
@@ -106,6 +107,25 @@ def main():
     nodes_per_ray = cs.nodes_visited / max(closest_rays, 1)
     tris_per_ray = cs.tris_tested / max(closest_rays, 1)
     renderer.set_option("count_visits", 0)
+
+    # ---- untimed: the dominant kernel alone on the GPU (no frame overlap, no second stream), so its
+    # launch duration can be read without co-scheduled kernels sharing the chip
+    renderer.set_option("time_kernels", 1)
+    saved = {}
+    for k, v in (("frames_in_flight", 1), ("overlap_miss", 0), ("overlap_shadow", 0), ("batch_frames", 1)):
+        renderer.set_option(k, v)
+    renderer.reset_stats()
+    for _ in range(0 if args.no_alone else 4):
+        loop.frame(pass_mask)
+    alone = renderer.get_stats()
+    alone_ms = alone.trace_closest_ms / max(alone.trace_closest_launches, 1)
+    alone_rays = float(alone.rays[rr.RAY_PRIMARY] + alone.rays[rr.RAY_BOUNCE]) / max(alone.trace_closest_launches, 1)
+    renderer.set_option("time_kernels", 0)
+    for k, v in (("frames_in_flight", 3), ("overlap_miss", 1), ("overlap_shadow", 1), ("batch_frames", 0)):
+        renderer.set_option(k, v)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        renderer.set_option(k, int(v))
 
     # ---- warmup
     loop.frames(args.warmup, pass_mask)
@@ -183,6 +203,12 @@ def main():
                 "launches": st.trace_closest_launches,
                 "nodes_per_ray": nodes_per_ray,
                 "tris_per_ray": tris_per_ray,
+                "note": "timed-region launches overlap with up to 2 other frames in flight and the shadow traversals on a second stream; `alone` is the same kernel with the GPU to itself (untimed calibration frames)",
+                "alone": {
+                    "avg_launch_ms": alone_ms,
+                    "achieved": (alone_rays * (48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0)) / (alone_ms * 1e-3) / 1e9 if alone_ms > 0 else 0.0,
+                    "frac": ((alone_rays * (48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0)) / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms > 0 else 0.0,
+                },
                 "kernel_share_of_step": st.trace_closest_ms / (elapsed * 1e3),
                 "trace_shadow_ms": st.trace_shadow_ms,
                 "shade_ms": st.shade_ms,
