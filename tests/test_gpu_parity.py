@@ -247,3 +247,47 @@ def test_restir_frames_cannot_be_batched(atrium):
     loop = rr.FrameLoop(r, atrium.make_view(64, 36))
     loop.frames(3, rr.PASS_ALL)
     assert loop.view.total_samples == 3 and (r.read_reservoirs(2)["M"] > 1).any()
+
+
+@pytest.mark.parametrize("W,H,world,tile,batch", [(97, 61, 1, 64, 3), (97, 61, 3, 20, 4), (65, 3, 2, 7, 2), (1, 1, 1, 64, 2), (130, 70, 8, 64, 8)])
+def test_awkward_sizes_match_oracle(cornell, W, H, world, tile, batch):
+    """widths that are not multiples of the 64-path run, tiles that do not divide the frame, 1x1:
+    every rank's pixels equal the oracle's full frame bit for bit (no sky in view => exact)"""
+    frames = 3
+    cpu = cornell.upload(oa.OracleRenderer(W, H))
+    run_frames(cpu, cornell, W, H, frames, rr.PASS_REFERENCE_PT, sky_enabled=0)
+    ref = cpu.read_accumulation()
+    owner = rr.distributed.owner_map(W, H, tile, world)
+    total_rays = 0
+    for rank in range(world):
+        gpu = cornell.upload(rr.Renderer(W, H))
+        if world > 1:
+            gpu.set_tile_partition(rank, world, tile)
+        gpu.set_option("batch_frames", batch)
+        rr.FrameLoop(gpu, cornell.make_view(W, H, sky_enabled=0)).frames(frames, rr.PASS_REFERENCE_PT)
+        acc = gpu.read_accumulation()
+        mine = owner == rank
+        assert np.array_equal(acc[mine].view(np.uint32), ref[mine].view(np.uint32)), f"rank {rank}"
+        assert (acc[~mine] == 0).all()
+        total_rays += gpu.get_stats().path_rays
+    assert total_rays == cpu.get_stats().path_rays
+
+
+@pytest.mark.parametrize("overrides", [dict(num_bounces=0), dict(samples_per_frame=0), dict(num_bounces=1), dict(num_bounces=17),
+                                       dict(lights_enabled=1, num_lights=0), dict(sun_shadow_enabled=0, lights_enabled=0)])
+def test_degenerate_view_settings_match_oracle(cornell, overrides):
+    W, H = 64, 48
+    gpu, cpu = make_pair(cornell, W, H)
+    ov = dict(overrides)
+    if ov.pop("num_lights", None) == 0:
+        # a scene without lights: lights_enabled with zero lights samples index 0 of an empty table
+        scene = rr.scenes.Scene("nolights", cornell.models, [], cornell.camera, dict(cornell.view_flags))
+        gpu, cpu = make_pair(scene, W, H)
+    else:
+        scene = cornell
+    for r in (gpu, cpu):
+        run_frames(r, scene, W, H, 2, rr.PASS_REFERENCE_PT, **ov)
+    a, b = gpu.read_accumulation(), cpu.read_accumulation()
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert per_pixel_l2(np.nan_to_num(a), np.nan_to_num(b)) <= L2_TOL
+    assert list(gpu.get_stats().rays)[:4] == list(cpu.get_stats().rays)[:4]
