@@ -172,6 +172,7 @@ struct uh_ctx {
    struct HostTex {
       uint32_t w, h;
       uchar4* dev;
+      uint32_t tiles_x;  // 0 = row-major
    };
    std::vector<HostTex> textures;
    bool built = false;
@@ -401,12 +402,25 @@ int uh_add_texture_rgba8(uh_ctx* c, const uint8_t* pixels, uint32_t w, uint32_t 
    HIP_TRY(c, hipSetDevice(c->device));
    uchar4* dev = nullptr;
    HIP_TRY(c, hipMalloc((void**)&dev, (size_t)w * h * 4));
-   hipError_t e = hipMemcpy(dev, pixels, (size_t)w * h * 4, hipMemcpyHostToDevice);
+   // 8x8-texel tiles when the size allows (device_types.h TexInfo)
+   const uint32_t tiles_x = (w % 8 == 0 && h % 8 == 0) ? w / 8 : 0;
+   std::vector<uint8_t> tiled;
+   const uint8_t* src = pixels;
+   if (tiles_x) {
+      tiled.resize((size_t)w * h * 4);
+      for (uint32_t y = 0; y < h; y++)
+         for (uint32_t x = 0; x < w; x++) {
+            size_t at = ((size_t)((y >> 3) * tiles_x + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7);
+            std::memcpy(&tiled[at * 4], &pixels[((size_t)y * w + x) * 4], 4);
+         }
+      src = tiled.data();
+   }
+   hipError_t e = hipMemcpy(dev, src, (size_t)w * h * 4, hipMemcpyHostToDevice);
    if (e != hipSuccess) {
       (void)hipFree(dev);
       return fail(c, UH_ERR_HIP, std::string("texture upload: ") + hipGetErrorString(e));
    }
-   c->textures.push_back(uh_ctx::HostTex{w, h, dev});
+   c->textures.push_back(uh_ctx::HostTex{w, h, dev, tiles_x});
    c->built = false;
    if (out_index) *out_index = (uint32_t)c->textures.size() - 1;
    return UH_OK;
@@ -550,7 +564,7 @@ int uh_build_acceleration(uh_ctx* c) {
       lights[2 * i + 1] = make_float4(l.intensity[0], l.intensity[1], l.intensity[2], 0.0f);
    }
    std::vector<TexInfo> tex(c->textures.size());
-   for (size_t i = 0; i < tex.size(); i++) tex[i] = TexInfo{c->textures[i].dev, c->textures[i].w, c->textures[i].h};
+   for (size_t i = 0; i < tex.size(); i++) tex[i] = TexInfo{c->textures[i].dev, c->textures[i].w, c->textures[i].h, c->textures[i].tiles_x, 0};
 
    if (bo.qnodes.empty()) return fail(c, UH_ERR_INVALID_ARGUMENT, "internal: BVH builder produced no root node");
    if (int st = sync_all(c)) return st;

@@ -193,7 +193,8 @@ __device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __
    int x0 = mirror_index((int)fx, (int)t.w), x1 = mirror_index((int)fx + 1, (int)t.w);
    int y0 = mirror_index((int)fy, (int)t.h), y1 = mirror_index((int)fy + 1, (int)t.h);
    auto tx = [&](int xx, int yy) {
-      uchar4 p = t.texels[(size_t)yy * t.w + xx];
+      const size_t at = t.tiles_x ? ((size_t)((yy >> 3) * t.tiles_x + (xx >> 3)) << 6) + ((yy & 7) << 3) + (xx & 7) : (size_t)yy * t.w + xx;
+      uchar4 p = t.texels[at];
       return v3(lut[p.x], lut[p.y], lut[p.z]);
    };
    V3 t00 = tx(x0, y0), t10 = tx(x1, y0), t01 = tx(x0, y1), t11 = tx(x1, y1);

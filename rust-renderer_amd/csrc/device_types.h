@@ -57,6 +57,11 @@ static_assert(sizeof(MeshShade) == 64, "mesh shading record");
 struct TexInfo {
    const uchar4* texels;
    uint32_t w, h;
+   // tiles_x > 0: texels are stored in 8x8-texel tiles (256 B, row-major inside the tile, tiles
+   // row-major), so the 2x2 bilinear footprint usually sits in one 128-B line instead of two rows.
+   // 0: plain row-major (sizes that are not multiples of 8).
+   uint32_t tiles_x;
+   uint32_t pad;
 };
 
 struct SceneDev {

@@ -1123,13 +1123,14 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
          }
          rng.y = seed;                                                                 // rchit:91
 
-         float4 thr4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-         if (bounce != 0) {
-            thr4 = ps.thr[id];
-            rad4 = ps.rad[id];
-         }
+         float4 thr4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+         if (bounce != 0) thr4 = ps.thr[id];
          V3 thr = v3(thr4.x, thr4.y, thr4.z) * color;                                  // rgen:48
+         // the radiance record is only touched when this path ends here (rgen:53-57) or a light sample
+         // has to be parked in its w component; a scattered path with lights off leaves it alone
          if (!scattered) {                                                             // rgen:53-57
+            float4 rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (bounce != 0) rad4 = ps.rad[id];
             ps.rad[id] = make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, rad4.w);
             ps.rng[id] = rng;
          } else {
@@ -1159,7 +1160,13 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
                }
             }
             ps.thr[id] = make_float4(thr.x, thr.y, thr.z, f);
-            ps.rad[id] = make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index));
+            if (bounce == 0) {
+               // first write of this path's radiance record (generate does not materialise the zero)
+               ps.rad[id] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)light_index));
+            } else if (fp.lights_enabled == 1) {
+               float4 rad4 = ps.rad[id];
+               ps.rad[id] = make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index));
+            }
             ps.rng[id] = rng;
          }
       }
