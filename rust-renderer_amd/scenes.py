@@ -499,7 +499,98 @@ def scene_for_config(config, **kw):
         return sponza_class_scene(num_lights=1024, **kw)
     if config == 3:
         return bistro_class_scene(**kw)
-    raise ValueError(f"config {config} is not built in this round")
+    if config == 4:
+        kw.pop("tex_size", None)
+        kw.pop("detail", None)
+        return isosurface_scene(**kw)
+    raise ValueError(f"config {config} is not defined in BASELINE.json")
+
+
+# ---------------------------------------------------------------------------------------------
+# config 5 - isosurface of the reference's marching-cubes density field
+# ---------------------------------------------------------------------------------------------
+def reference_density(p):
+    """marching_cubes.comp:83-103 at view.time = 0 (sphere radius 0): density = max(-1, -sdTorus,
+    -sdBox) with the torus (R 5, r 3, axis y) above the box (half size 5); positive inside."""
+    q = p - np.array([16.0, 20.0, 16.0])
+    torus = np.sqrt((np.sqrt(q[..., 0] ** 2 + q[..., 2] ** 2) - 5.0) ** 2 + q[..., 1] ** 2) - 3.0
+    d = np.abs(p - np.array([16.0, 10.0, 16.0])) - 5.0
+    box = np.minimum(np.maximum(d[..., 0], np.maximum(d[..., 1], d[..., 2])), 0.0) + np.sqrt((np.maximum(d, 0.0) ** 2).sum(-1))
+    return np.maximum(np.maximum(-torus, -box), -1.0)
+
+
+# the 6 tetrahedra of a cube around its 0-6 diagonal (corner numbering of marching_cubes.rs:23-32)
+_CUBE_CORNERS = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]])
+_TETS = np.array([[0, 5, 1, 6], [0, 1, 2, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 7, 4, 6], [0, 4, 5, 6]])
+
+
+def extract_isosurface(density, lo, hi, resolution, slab=16):
+    """triangle soup of {density = 0} on a resolution^3 grid over [lo, hi]^3 by marching tetrahedra
+    (host-side stand-in for the GPU marching-cubes extraction of SURVEY.md section 8f N3)."""
+    h = (hi - lo) / resolution
+    tris = []
+    ax = lo + h * np.arange(resolution + 1)
+    for z0 in range(0, resolution, slab):
+        z1 = min(z0 + slab, resolution)
+        X, Y, Z = np.meshgrid(ax, ax, ax[z0 : z1 + 1], indexing="ij")
+        P = np.stack([X, Y, Z], -1)
+        D = density(P)
+        inside = D > 0
+        c = inside[:-1, :-1, :-1]
+        mixed = np.zeros_like(c)
+        cnt = np.zeros(c.shape, dtype=np.int8)
+        for dx, dy, dz in _CUBE_CORNERS:
+            cnt += inside[dx : dx + resolution, dy : dy + resolution, dz : dz + (z1 - z0)]
+        mixed = (cnt > 0) & (cnt < 8)
+        ix, iy, iz = np.nonzero(mixed)
+        if len(ix) == 0:
+            continue
+        cp = np.stack([P[ix + dx, iy + dy, iz + dz] for dx, dy, dz in _CUBE_CORNERS], 1)  # (n, 8, 3)
+        cv = np.stack([D[ix + dx, iy + dy, iz + dz] for dx, dy, dz in _CUBE_CORNERS], 1)  # (n, 8)
+        for tet in _TETS:
+            p, v = cp[:, tet], cv[:, tet]
+            ins = v > 0
+            k = ins.sum(1)
+            order = np.argsort(~ins, axis=1, kind="stable")  # inside vertices first
+            p = np.take_along_axis(p, order[..., None], 1)
+            v = np.take_along_axis(v, order[:, :], 1)
+
+            def cut(a, b, sel):
+                t = (v[sel, a] / (v[sel, a] - v[sel, b]))[:, None]
+                return p[sel, a] + t * (p[sel, b] - p[sel, a])
+
+            s1, s2, s3 = k == 1, k == 2, k == 3
+            if s1.any():
+                tris.append(np.stack([cut(0, 1, s1), cut(0, 2, s1), cut(0, 3, s1)], 1))
+            if s3.any():
+                tris.append(np.stack([cut(0, 3, s3), cut(1, 3, s3), cut(2, 3, s3)], 1))
+            if s2.any():
+                a, b, c2, d2 = cut(0, 2, s2), cut(0, 3, s2), cut(1, 3, s2), cut(1, 2, s2)
+                tris.append(np.stack([a, b, c2], 1))
+                tris.append(np.stack([a, c2, d2], 1))
+    return np.concatenate(tris) if tris else np.zeros((0, 3, 3))
+
+
+def isosurface_scene(resolution=512):
+    """BASELINE.json configs[4]: the 512^3 isosurface of the reference's density field (torus above a
+    box, marching_cubes.comp:83-103 scaled to a 32-unit domain), one Lambertian mesh on a ground
+    plane, sky + sun. ~1.3 M triangles at 512^3."""
+    T = extract_isosurface(reference_density, 0.0, 32.0, resolution)
+    # drop degenerate slivers (zero area), keep the soup unindexed
+    n = np.cross(T[:, 1] - T[:, 0], T[:, 2] - T[:, 0])
+    T = T[np.linalg.norm(n, axis=1) > 1e-12]
+    pos = T.reshape(-1, 3)
+    eps = 1e-3
+    g = np.stack([reference_density(pos + e) - reference_density(pos - e) for e in (np.array([eps, 0, 0]), np.array([0, eps, 0]), np.array([0, 0, eps]))], -1)
+    nrm = -g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-20)  # density grows inwards
+    uv = pos[:, [0, 2]] / 32.0
+    verts = _pack_vertices(pos.astype(f32), nrm.astype(f32), uv.astype(f32))
+    idx = np.arange(len(pos), dtype=u32)
+    meshes = [Mesh(verts, idx, LAMBERTIAN, 0.0, (0.8, 0.8, 0.8, 1.0), None, identity3x4(), "isosurface"),
+              Mesh(*quad((-64, 4.99, -64), (0, 0, 160), (160, 0, 0), 32, 32, uv_scale=(8, 8)), base_color=(0.6, 0.6, 0.6, 1.0), name="ground")]
+    cam = Camera((27.0, 19.0, 33.0), (16.0, 14.0, 16.0), 60.0, 16.0 / 9.0, 0.01, 1000.0)
+    flags = dict(sky_enabled=1, sun_shadow_enabled=1, lights_enabled=0, use_ris_light_sampling=0)
+    return Scene("isosurface", [(Model(meshes, []), None)], [], cam, flags)
 
 
 BISTRO_SEED = 0x42495354
