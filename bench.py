@@ -197,7 +197,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE.json configs[{args.config}]: {scene.name} procedural atrium ({scene.num_triangles} tris, {scene.num_meshes} meshes, textured materials), "
+                "workload": f"BASELINE.json configs[{args.config}]: {scene.name} synthetic scene ({scene.num_triangles} tris, {scene.num_meshes} meshes, textured materials), "
                 f"{W}x{H}, 1 spp/frame x {args.steps} frames, 5 bounces, sky + sun shadow rays"
                 + (f", {len(scene.lights)} lights " + ("ReSTIR DI" if view.use_ris_light_sampling else "uniform sampling") if view.lights_enabled else ", lights off"),
                 "rays_per_frame": total_rays / args.steps,
