@@ -168,7 +168,7 @@ typedef struct UhStats {
    uint64_t frames;
    uint32_t bvh_nodes;          /* BVH4 node count */
    uint32_t bvh_triangles;
-   float build_ms;              /* last uh_build_acceleration, host wall time */
+   float build_ms;              /* last uh_build_acceleration / uh_refit_acceleration, host wall time */
    float last_frame_ms;         /* hipEvent time of the last uh_render_frame (all passes) */
    float trace_closest_ms;      /* summed hipEvent time of closest-hit traversal launches since reset (option "time_kernels") */
    float trace_shadow_ms;
@@ -195,6 +195,13 @@ int uh_add_light(uh_ctx* ctx, const UhGpuLight* light, uint32_t* out_index);
 int uh_get_num_lights(uh_ctx* ctx, uint32_t* out); /* Renderer::get_num_lights (renderer.rs:412) */
 int uh_set_instance_transform(uh_ctx* ctx, uint32_t mesh_index, const float world3x4[12]);
 int uh_build_acceleration(uh_ctx* ctx);
+/* Raytracing::rebuild_tlas (raytracing.rs:400-459): after uh_set_instance_transform calls, re-bakes the
+ * triangles and recomputes every box of the existing tree ON THE DEVICE (no host rebuild; topology kept).
+ * Results equal a full uh_build_acceleration bit for bit - hits do not depend on the boxes - only the
+ * traversal cost grows while instances drift from where the tree was built. UH_ERR_NOT_BUILT when meshes
+ * or lights were added since the last build. uh_render_frame calls it by itself when transforms are
+ * pending and view->rebuild_tlas == 1 (the flag the application sets, main.rs:392,526). */
+int uh_refit_acceleration(uh_ctx* ctx);
 
 /* ---- per frame ------------------------------------------------------------------------- */
 int uh_render_frame(uh_ctx* ctx, const UhViewUniformData* view, uint32_t pass_mask);

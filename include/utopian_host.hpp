@@ -281,7 +281,7 @@ class Renderer {
       auto w = world.to_3x4();
       check(uh_set_instance_transform(ctx_, gpu_mesh, w.data()), "set_instance_transform");
    }
-   void rebuild_tlas() { initialize_raytracing(); }
+   void rebuild_tlas() { check(uh_refit_acceleration(ctx_), "Raytracing::rebuild_tlas"); }
 
    std::vector<float> read_accumulation() {
       std::vector<float> out((size_t)width_ * height_ * 4);

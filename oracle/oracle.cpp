@@ -321,7 +321,7 @@ struct Oracle {
    std::vector<Tri> tris;
    std::vector<BNode> nodes;
    std::vector<uint32_t> tri_order;
-   bool built = false;
+   bool built = false, ever_built = false;
    bool brute_force = false;
    bool full_frame_restir = false;
    int num_threads = 0;
@@ -1045,7 +1045,7 @@ int orc_add_mesh(orc_ctx* c, const UhVertex* v, uint32_t nv, const uint32_t* idx
       invert3x3(m.o2w, m.w2o);
    m.first_tri = 0;
    c->o.meshes.push_back(std::move(m));
-   c->o.built = false;
+   c->o.built = c->o.ever_built = false;
    if (out_mesh_index) *out_mesh_index = (uint32_t)c->o.meshes.size() - 1;
    return UH_OK;
 }
@@ -1072,8 +1072,14 @@ int orc_build_acceleration(orc_ctx* c) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    bake_triangles(c->o);
    build_bvh(c->o);
-   c->o.built = true;
+   c->o.built = c->o.ever_built = true;
    return UH_OK;
+}
+// raytracing.rs:400-459 rebuild_tlas. The oracle simply rebuilds: results do not depend on the tree.
+int orc_refit_acceleration(orc_ctx* c) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!c->o.ever_built) return UH_ERR_NOT_BUILT;
+   return orc_build_acceleration(c);
 }
 // option names: "brute_force", "threads", "full_frame_restir"
 int orc_set_option(orc_ctx* c, const char* name, int value) {
@@ -1103,6 +1109,7 @@ int orc_set_tile_partition(orc_ctx* c, uint32_t rank, uint32_t world, uint32_t t
 int orc_render_frame(orc_ctx* c, const UhViewUniformData* view, uint32_t pass_mask) {
    if (!c || !view) return UH_ERR_INVALID_ARGUMENT;
    Oracle& o = c->o;
+   if (!o.built && o.ever_built && view->rebuild_tlas == 1) orc_build_acceleration(c);  // main.rs:392,526
    if (!o.built) return UH_ERR_NOT_BUILT;
    const UhViewUniformData v = *view;
    if (pass_mask & UH_PASS_GBUFFER) parallel_rows(o, [&](uint32_t x, uint32_t y) { gbuffer_pixel(o, v, x, y); });

@@ -47,6 +47,7 @@ class CApi:
             "add_light": [vp, p(GpuLight), p(u32)],
             "set_instance_transform": [vp, u32, p(C.c_float)],
             "build_acceleration": [vp],
+            "refit_acceleration": [vp],
             "render_frame": [vp, p(ViewUniformData), u32],
             "render_frames": [vp, p(ViewUniformData), u32, u32],
             "reset_accumulation": [vp],
@@ -270,6 +271,12 @@ class Renderer:
         self._check(self._api.build_acceleration(self._ctx))
 
     build_acceleration = initialize_raytracing
+
+    def rebuild_tlas(self):
+        """Raytracing::rebuild_tlas (raytracing.rs:400): on-device refit after set_instance_transform."""
+        self._check(self._api.refit_acceleration(self._ctx))
+
+    refit_acceleration = rebuild_tlas
 
     # -- per frame ------------------------------------------------------------------------
     def render_frame(self, view, pass_mask=PASS_ALL):

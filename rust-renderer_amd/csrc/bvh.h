@@ -72,6 +72,7 @@ struct BuildOutput {
    std::vector<Node4Q> qnodes;       // the same tree, quantised (what the kernels traverse)
    std::vector<uint32_t> tri_order;  // packet i holds input triangle tri_order[i]
    uint32_t max_depth = 0;
+   std::vector<uint32_t> level_start;  // BFS level l = nodes [level_start[l], level_start[l+1]); children always lie in a later level
 };
 
 // Binned-SAH BVH2 build, collapsed to BVH4, emitted breadth-first. Host-side, multi-threaded.

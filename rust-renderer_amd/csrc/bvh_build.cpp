@@ -175,6 +175,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
    if (max_leaf_tris > 15) max_leaf_tris = 15;
    out.nodes.clear();
    out.tri_order.clear();
+   out.level_start.assign({0u, 1u});
    out.max_depth = 0;
    const uint32_t n = in.count;
    std::vector<Box> tb(n);
@@ -422,6 +423,20 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
       }
       nd.meta[0] = (uint32_t)nc;
       out.nodes[qi] = nd;
+   }
+
+   // ---- BFS levels (for the on-device refit, which walks them deepest first)
+   {
+      std::vector<uint32_t> depth(out.nodes.size(), 0);
+      for (size_t i = 0; i < out.nodes.size(); i++)
+         for (int k = 0; k < 4; k++) {
+            uint32_t ch = out.nodes[i].child[k];
+            if (ch != kEmptyRef && !(ch & kLeafBit)) depth[ch] = depth[i] + 1;
+         }
+      out.level_start.clear();
+      for (size_t i = 0; i < out.nodes.size(); i++)
+         if (i == 0 || depth[i] != depth[i - 1]) out.level_start.push_back((uint32_t)i);
+      out.level_start.push_back((uint32_t)out.nodes.size());
    }
 
    // ---- quantise: per node, origin = min over its children, scale = 2^e with e minimal such that

@@ -180,6 +180,13 @@ struct uh_ctx {
    // device scene
    DevBuf<float4> d_nodes, d_tris, d_shade, d_lights;
    DevBuf<MeshShade> d_meshes;
+   // on-device refit (refit.hip), allocated by the first uh_refit_acceleration
+   DevBuf<float> d_obj_corners, d_world_corners, d_node_box;
+   DevBuf<RefitMesh> d_refit_meshes;
+   std::vector<uint32_t> packet_keys;  // key of triangle packet i (leaf order)
+   std::vector<uint32_t> level_start;  // BFS levels of the node array
+   bool topology_valid = false;        // the device tree matches the mesh list (transforms may differ)
+   float refit_ms = 0.0f;
    DevBuf<TexInfo> d_tex;
    DevBuf<float> d_lut;
    SceneDev scene{};
@@ -192,7 +199,7 @@ struct uh_ctx {
    Images im{};
 
    // options / stats
-   bool count_visits = false, time_kernels = false, full_frame_restir = false;
+   bool count_visits = false, time_kernels = false, full_frame_restir = false, raw_visit_counts = false;
    uint32_t bvh_max_leaf = kMaxLeafTris;
    float bvh_sah_cost = 0.5f;  // SAH leaf termination: a node step costs about half a triangle test here (swept on MI355X)
    int closest_variant = 0, shadow_variant = 19;  // measured fastest on MI355X (profiles/README.md)
@@ -260,7 +267,7 @@ void set_transform(HostMesh& m, const float* w) {
 }
 
 LaunchCfg cfg(uh_ctx* c) {
-   return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->closest_variant, c->shadow_variant};
+   return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->closest_variant, c->shadow_variant, c->raw_visit_counts};
 }
 
 void begin_timed(uh_ctx* c, int kind, hipStream_t stream = nullptr) {
@@ -384,6 +391,10 @@ void uh_destroy(uh_ctx* c) {
    c->d_shade.release();
    c->d_lights.release();
    c->d_meshes.release();
+   c->d_obj_corners.release();
+   c->d_world_corners.release();
+   c->d_node_box.release();
+   c->d_refit_meshes.release();
    c->d_tex.release();
    c->d_lut.release();
    c->accumulation.release();
@@ -442,6 +453,7 @@ int uh_add_mesh(uh_ctx* c, const UhVertex* vertices, uint32_t num_vertices, cons
    set_transform(m, world3x4);
    c->meshes.push_back(std::move(m));
    c->built = false;
+   c->topology_valid = false;
    if (out_mesh_index) *out_mesh_index = (uint32_t)c->meshes.size() - 1;
    return UH_OK;
 }
@@ -452,6 +464,7 @@ int uh_add_light(uh_ctx* c, const UhGpuLight* light, uint32_t* out_index) {
    if (c->lights.size() >= UH_MAX_GPU_LIGHTS) return fail(c, UH_ERR_CAPACITY, "uh_add_light: more than 1024 lights (MAX_NUM_GPU_LIGHTS)");
    c->lights.push_back(*light);
    c->built = false;
+   c->topology_valid = false;
    if (out_index) *out_index = (uint32_t)c->lights.size() - 1;
    return UH_OK;
 }
@@ -596,8 +609,69 @@ int uh_build_acceleration(uh_ctx* c) {
    c->scene.num_lights = (uint32_t)c->lights.size();
    c->bvh_nodes = c->scene.num_nodes;
    c->bvh_tris = c->scene.num_tris;
+   c->packet_keys.resize(total);
+   for (size_t i = 0; i < total; i++) c->packet_keys[i] = tp[i].key;
+   c->level_start = bo.level_start;
+   c->d_obj_corners.release();  // leaf order changed: the next refit re-creates its inputs
+   c->topology_valid = true;
    c->built = true;
    c->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+   return UH_OK;
+}
+
+// Raytracing::rebuild_tlas (raytracing.rs:400-459) for a flattened tree: see refit.hip
+int uh_refit_acceleration(uh_ctx* c) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!c->topology_valid)
+      return fail(c, UH_ERR_NOT_BUILT, "uh_refit_acceleration: meshes or lights were added since the last uh_build_acceleration (or it never ran)");
+   HIP_TRY(c, hipSetDevice(c->device));
+   auto t0 = std::chrono::steady_clock::now();
+   if (int st = sync_all(c)) return st;  // frames in flight still traverse the old boxes
+   const size_t total = c->packet_keys.size();
+   if (total && !c->d_obj_corners.p) {
+      std::vector<float> oc(9 * total);
+      for (size_t i = 0; i < total; i++) {
+         const HostMesh& m = c->meshes[c->packet_keys[i] >> kPrimBits];
+         const uint32_t p = c->packet_keys[i] & kPrimMask;
+         for (int k = 0; k < 3; k++) {
+            const UhVertex& vx = m.vertices[m.indices[3 * (size_t)p + k]];
+            for (int a = 0; a < 3; a++) oc[9 * i + 3 * k + a] = vx.pos[a];
+         }
+      }
+      HIP_TRY(c, c->d_obj_corners.alloc(9 * total));
+      HIP_TRY(c, c->d_world_corners.alloc(9 * total));
+      HIP_TRY(c, c->d_node_box.alloc(6 * (size_t)c->scene.num_nodes));
+      HIP_TRY(c, c->d_refit_meshes.alloc(c->meshes.size()));
+      HIP_TRY(c, hipMemcpy(c->d_obj_corners.p, oc.data(), oc.size() * sizeof(float), hipMemcpyHostToDevice));
+   }
+   std::vector<RefitMesh> rm(c->meshes.size());
+   std::vector<MeshShade> ms(c->meshes.size());
+   HIP_TRY(c, hipMemcpy(ms.data(), c->d_meshes.p, ms.size() * sizeof(MeshShade), hipMemcpyDeviceToHost));
+   for (size_t i = 0; i < c->meshes.size(); i++) {
+      std::memset(&rm[i], 0, sizeof(RefitMesh));
+      std::memcpy(rm[i].o2w, c->meshes[i].o2w, sizeof(rm[i].o2w));
+      rm[i].identity = is_identity3x4(c->meshes[i].o2w) ? 1u : 0u;
+      std::memcpy(ms[i].w2o, c->meshes[i].w2o, sizeof(ms[i].w2o));
+   }
+   if (!ms.empty()) HIP_TRY(c, hipMemcpy(c->d_meshes.p, ms.data(), ms.size() * sizeof(MeshShade), hipMemcpyHostToDevice));
+   if (total) {
+      HIP_TRY(c, hipMemcpy(c->d_refit_meshes.p, rm.data(), rm.size() * sizeof(RefitMesh), hipMemcpyHostToDevice));
+      RefitArgs a;
+      a.obj_corners = c->d_obj_corners.p;
+      a.meshes = c->d_refit_meshes.p;
+      a.tris = c->d_tris.p;
+      a.world_corners = c->d_world_corners.p;
+      a.nodes = reinterpret_cast<uint4*>(c->d_nodes.p);
+      a.node_box = c->d_node_box.p;
+      a.level_start = c->level_start.data();
+      a.num_levels = (uint32_t)c->level_start.size() - 1;
+      a.num_tris = (uint32_t)total;
+      launch_refit(cfg(c), a);
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+   }
+   c->built = true;
+   c->build_ms = c->refit_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
    return UH_OK;
 }
 
@@ -744,6 +818,10 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
 static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t batch) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (!view) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frame: null view");
+   if (!c->built && c->topology_valid && view->rebuild_tlas == 1) {
+      // the application moved instances and asks for the per-frame rebuild (main.rs:392,526; graph.rs:715-741)
+      if (int st = uh_refit_acceleration(c)) return st;
+   }
    if (!c->built) return fail(c, UH_ERR_NOT_BUILT, "uh_render_frame before uh_build_acceleration");
    if (view->num_bounces > kMaxBounces) return fail(c, UH_ERR_INVALID_ARGUMENT, "num_bounces > 64");
    if (view->num_lights > c->lights.size() && (view->lights_enabled == 1 || (pass_mask & UH_PASS_RESTIR)))
@@ -893,7 +971,9 @@ int uh_trace_closest(uh_ctx* c, const float* rays, uint32_t n, float* out_tuv, u
    HIP_TRY(c, dh.alloc(n));
    HIP_TRY(c, hipMemcpyAsync(d_o.p, o.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
    HIP_TRY(c, hipMemcpyAsync(dd.p, d.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+   begin_timed(c, 0);
    launch_trace_closest_raw(cfg(c), c->scene, d_o.p, dd.p, dh.p, n);
+   end_timed(c);
    std::vector<float4> h(n);
    HIP_TRY(c, hipMemcpyAsync(h.data(), dh.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -940,7 +1020,9 @@ int uh_trace_any(uh_ctx* c, const float* rays, uint32_t n, uint8_t* out_occluded
    HIP_TRY(c, occ.alloc(n));
    HIP_TRY(c, hipMemcpyAsync(d_o.p, o.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
    HIP_TRY(c, hipMemcpyAsync(dd.p, d.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+   begin_timed(c, 1);
    launch_trace_any_raw(cfg(c), c->scene, d_o.p, dd.p, occ.p, n);
+   end_timed(c);
    std::vector<uint32_t> h(n);
    HIP_TRY(c, hipMemcpyAsync(h.data(), occ.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1000,6 +1082,8 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
    std::string n(name);
    if (n == "count_visits")
       c->count_visits = value != 0;
+   else if (n == "raw_visit_counts")
+      c->raw_visit_counts = value != 0;
    else if (n == "time_kernels") {
       if (c->time_kernels && !value) {
          (void)sync_all(c);

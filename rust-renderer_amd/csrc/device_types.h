@@ -130,6 +130,7 @@ struct LaunchCfg {
    // results): 0 = batch if-if; 1..5 = v2 while-while with lane refill at 64/32/16/8/1 idle lanes;
    // 6..10 = v2 + parked leaf; 11..16 = v3 vote scheduling. Defaults are what measured fastest.
    int closest_variant, shadow_variant;
+   bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);
@@ -151,6 +152,25 @@ void launch_spatial_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&,
 void launch_trace_closest_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n);
 void launch_trace_any_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n);
 // tiles
+// on-device refit (refit.hip): per-mesh object->world rows, and what one refit pass touches
+struct RefitMesh {
+   float o2w[12];
+   uint32_t identity;
+   uint32_t pad[3];
+};
+struct RefitArgs {
+   const float* obj_corners;   // 9 floats per triangle packet, object space, leaf order
+   const RefitMesh* meshes;
+   float4* tris;               // TriPacket array, rewritten
+   float* world_corners;       // scratch, 9 floats per packet
+   uint4* nodes;               // Node4Q array, boxes rewritten, child refs kept
+   float* node_box;            // scratch, 6 floats per node (unpadded)
+   const uint32_t* level_start;  // HOST array: BFS level l = nodes [level_start[l], level_start[l+1])
+   uint32_t num_levels;
+   uint32_t num_tris;
+};
+void launch_refit(const LaunchCfg&, const RefitArgs&);
+
 void launch_pack_tiles(const LaunchCfg&, const float4* acc, float4* out, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);
 void launch_unpack_tiles(const LaunchCfg&, float4* acc, const float4* in, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);
 uint32_t query_trace_occupancy();

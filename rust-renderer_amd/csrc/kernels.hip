@@ -295,6 +295,8 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 }
 
 // stand-alone closest-hit query over n rays (identity queue): uh_trace_closest and the G-buffer cast
+// DIAG (option "raw_visit_counts"): u,v of the result carry the ray's node / triangle visit counts instead
+template <bool DIAG>
 __global__ __launch_bounds__(kBlock) void k_trace_closest_raw(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                               float4* __restrict__ hit_out, uint32_t count) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
@@ -303,8 +305,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_raw(SceneDev sc, const
    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
       float4 ro = ray_o[i], rd = ray_d[i];
       Hit h;
-      traverse<false, false>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
-      hit_out[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
+      if (DIAG) n_nodes = n_tris = 0;
+      traverse<false, DIAG>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
+      hit_out[i] = DIAG ? make_float4(h.t, (float)n_nodes, (float)n_tris, __uint_as_float(h.idx)) : make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
    }
 }
 
@@ -1599,7 +1602,7 @@ void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& s
    (void)ctl;
    const uint32_t n = fp.W * fp.H;
    k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps);
-   k_trace_closest_raw<<<dim3(c.num_cus * c.closest_blocks_per_cu), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, n);
+   k_trace_closest_raw<false><<<dim3(c.num_cus * c.closest_blocks_per_cu), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, n);
    k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats);
 }
 
@@ -1617,7 +1620,10 @@ void launch_spatial_reuse(const LaunchCfg& c, const FrameParams& fp, const Scene
 }
 
 void launch_trace_closest_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n) {
-   k_trace_closest_raw<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, hit, n);
+   if (c.raw_visit_counts)
+      k_trace_closest_raw<true><<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, hit, n);
+   else
+      k_trace_closest_raw<false><<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, hit, n);
 }
 void launch_trace_any_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n) {
    k_trace_any_raw<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, occluded, n);

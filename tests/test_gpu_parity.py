@@ -291,3 +291,85 @@ def test_degenerate_view_settings_match_oracle(cornell, overrides):
     assert np.array_equal(np.isnan(a), np.isnan(b))
     assert per_pixel_l2(np.nan_to_num(a), np.nan_to_num(b)) <= L2_TOL
     assert list(gpu.get_stats().rays)[:4] == list(cpu.get_stats().rays)[:4]
+
+
+# ---- on-device refit (uh_refit_acceleration; raytracing.rs:400-459 rebuild_tlas) ---------------------
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    mx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    my = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    mz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return (mz @ my @ mx).astype(np.float32)
+
+
+def _moved(scene, renderer_factory, W, H, moves, how):
+    """how = 'build': transforms set before the one and only build; 'refit': built at the scene's
+    own transforms, then moved and refitted on the device; 'flag': as refit, but requested through
+    view.rebuild_tlas like the application does."""
+    r = renderer_factory()
+    if how == "build":
+        for model, transform in scene.models:
+            r.add_model(model, transform)
+        for p in scene.lights:
+            r.add_light(p, (1.0, 1.0, 1.0), 1.0)
+        for mesh, w in moves:
+            r.set_instance_transform(mesh, w)
+        r.initialize_raytracing()
+    else:
+        scene.upload(r)
+        run_frames(r, scene, W, H, 1, rr.PASS_REFERENCE_PT)  # frames in flight on the old tree
+        for mesh, w in moves:
+            r.set_instance_transform(mesh, w)
+        if how == "refit":
+            r.rebuild_tlas()
+        r.reset_accumulation()
+        r.reset_stats()
+    return r
+
+
+@pytest.mark.parametrize("how", ["refit", "flag"])
+def test_refit_equals_rebuild_bit_for_bit(atrium, how):
+    W, H = 96, 64
+    n_mesh = atrium.num_meshes
+    moves = [(n_mesh - 1, rr.transform3x4((0.8, 1.1, 0.9), (1.5, 0.7, -0.4), _rot(0.3, 1.0, -0.2))),
+             (n_mesh - 2, rr.transform3x4((1.0, 1.0, 1.0), (-2.0, 1.2, 0.6))),
+             (3, rr.transform3x4((1.02, 0.97, 1.0), (0.05, 0.0, -0.03), _rot(0.0, 0.02, 0.0)))]
+    built = _moved(atrium, lambda: rr.Renderer(W, H), W, H, moves, "build")
+    refit = _moved(atrium, lambda: rr.Renderer(W, H), W, H, moves, how)
+    rays = random_rays(((-14, -1, -7), (14, 12, 7)), 20000, seed=77)
+    overrides = dict(rebuild_tlas=1) if how == "flag" else {}
+    for r in (built, refit):
+        run_frames(r, atrium, W, H, 2, rr.PASS_ALL, **overrides)
+    a, b = built.trace_closest(rays), refit.trace_closest(rays)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert np.array_equal(built.trace_any(rays), refit.trace_any(rays))
+    assert np.array_equal(built.read_accumulation().view(np.uint32), refit.read_accumulation().view(np.uint32))
+    assert np.array_equal(built.read_gbuffer_position().view(np.uint32), refit.read_gbuffer_position().view(np.uint32))
+    assert list(built.get_stats().rays) == list(refit.get_stats().rays)
+
+
+def test_refit_matches_oracle(cornell):
+    W, H = 64, 48
+    moves = [(6, rr.transform3x4((0.25, 0.35, 0.25), (-0.3, 0.5, 0.1), _rot(0.0, 0.6, 0.0)))]
+    gpu = _moved(cornell, lambda: rr.Renderer(W, H), W, H, moves, "refit")
+    cpu = _moved(cornell, lambda: oa.OracleRenderer(W, H, threads=3), W, H, moves, "refit")
+    for r in (gpu, cpu):
+        run_frames(r, cornell, W, H, 2, rr.PASS_ALL)
+    assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
+    assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays)
+
+
+def test_refit_needs_a_built_tree(cornell):
+    r = rr.Renderer(32, 32)
+    with pytest.raises(rr.UtopianError):
+        r.rebuild_tlas()
+    cornell.upload(r)
+    r.rebuild_tlas()  # nothing moved: a refit of the tree onto itself
+    m = cornell.models[0][0].meshes[0]
+    r.add_mesh(m.vertices, m.indices, m.material_struct(), None)
+    with pytest.raises(rr.UtopianError):
+        r.rebuild_tlas()
+    v = cornell.make_view(32, 32, rebuild_tlas=1)
+    with pytest.raises(rr.UtopianError):
+        r.render_frame(v, rr.PASS_REFERENCE_PT)
