@@ -256,6 +256,41 @@ int uh_device_pointer(uh_ctx* ctx, int which, void** out);
 /* the HIP stream all work of this context is enqueued on (hipStream_t as void*) */
 int uh_stream(uh_ctx* ctx, void** out);
 
+/* ---- several GPUs behind ONE application process (SURVEY.md section 8b "multi-GPU", 8e) ------------
+ * The reference application is a single process with one render thread (prototype/src/main.rs:86-570);
+ * a maintainer who wants N GPUs behind it binds this group instead of one uh_ctx. Every verb above has a
+ * uh_mgpu_ twin with the same meaning: scene verbs replicate the scene on every GPU, frame verbs make GPU i
+ * path-trace the tiles t % N == i (tile_size x tile_size, row-major ids; ReSTIR / G-buffer passes run
+ * full-frame on every GPU, identical results), nothing is exchanged per frame, and the read-backs (or
+ * uh_mgpu_compose) gather the packed RGBA32F tiles onto GPU 0 with peer copies over xGMI and recompute
+ * pt_output_image there. Pixels are bit-identical to a single-GPU render (RNG keyed on absolute pixel
+ * coordinates, random.glsl:14-18). device_ordinals == NULL means GPUs 0..ngpus-1; the same ordinal may
+ * appear several times (how the 1-GPU tests exercise this layer). */
+typedef struct uh_mgpu uh_mgpu;
+int uh_mgpu_create(int ngpus, const int* device_ordinals, uint32_t width, uint32_t height, uint32_t tile_size, uh_mgpu** out);
+void uh_mgpu_destroy(uh_mgpu* group);
+const char* uh_mgpu_last_error(uh_mgpu* group); /* NULL: the last creation error */
+int uh_mgpu_num_devices(uh_mgpu* group);
+uh_ctx* uh_mgpu_context(uh_mgpu* group, int index); /* GPU i's context (options, stats, queries); owned by the group */
+int uh_mgpu_add_texture_rgba8(uh_mgpu* group, const uint8_t* pixels, uint32_t w, uint32_t h, uint32_t* out_index);
+int uh_mgpu_add_mesh(uh_mgpu* group, const UhVertex* vertices, uint32_t num_vertices, const uint32_t* indices, uint32_t num_indices,
+                     const UhGpuMaterial* material, const float world3x4[12], uint32_t* out_mesh_index);
+int uh_mgpu_add_light(uh_mgpu* group, const UhGpuLight* light, uint32_t* out_index);
+int uh_mgpu_get_num_lights(uh_mgpu* group, uint32_t* out);
+int uh_mgpu_set_instance_transform(uh_mgpu* group, uint32_t mesh_index, const float world3x4[12]);
+int uh_mgpu_build_acceleration(uh_mgpu* group);  /* the N host builds run concurrently */
+int uh_mgpu_refit_acceleration(uh_mgpu* group);
+int uh_mgpu_render_frame(uh_mgpu* group, const UhViewUniformData* view, uint32_t pass_mask);   /* enqueues on every GPU, does not wait */
+int uh_mgpu_render_frames(uh_mgpu* group, const UhViewUniformData* view, uint32_t pass_mask, uint32_t count);
+int uh_mgpu_reset_accumulation(uh_mgpu* group);
+int uh_mgpu_synchronize(uh_mgpu* group);
+int uh_mgpu_compose(uh_mgpu* group);             /* gather tiles to GPU 0 + resolve; a no-op until the next frame */
+int uh_mgpu_read_accumulation(uh_mgpu* group, float* rgba32f /* W*H*4 */);  /* compose, then read GPU 0 */
+int uh_mgpu_read_output_bgra8(uh_mgpu* group, uint8_t* bgra /* W*H*4 */);
+int uh_mgpu_get_stats(uh_mgpu* group, UhStats* out); /* counters summed over GPUs, times = slowest GPU */
+int uh_mgpu_reset_stats(uh_mgpu* group);
+int uh_mgpu_set_option(uh_mgpu* group, const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@ HIP kernels + C ABI in csrc/ (built to libutopian_hip.so by build.py)."""
 from . import camera, distributed, gltf, scenes, types  # noqa: F401
 from .api import (  # noqa: F401
     FrameLoop,
+    MultiGpuRenderer,
     Renderer,
     UtopianError,
     default_view,

@@ -65,8 +65,8 @@ class CApi:
             "resolve_output": [vp, u32, u32],
         }
         for name, argtypes in sig.items():
-            if not hasattr(lib, prefix + name) and name == "render_frames":
-                continue  # the oracle renders frame by frame
+            if not hasattr(lib, prefix + name) and (name == "render_frames" or prefix == "uh_mgpu_"):
+                continue  # the oracle renders frame by frame; the GPU group has no per-context queries
             fn = getattr(lib, prefix + name)
             fn.argtypes, fn.restype = argtypes, C.c_int
             setattr(self, name, fn)
@@ -376,6 +376,51 @@ class Renderer:
         return out.value
 
 
+class MultiGpuRenderer(Renderer):
+    """uh_mgpu_*: the same host interface over several GPUs driven by ONE process (tiles t % N == i
+    per GPU, composition on GPU 0 at read-back). `devices` may repeat an ordinal."""
+
+    backend = "hip-group"
+
+    def __init__(self, width, height, devices, tile_size=64):
+        lib = load_library()
+        lib.uh_mgpu_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.uh_mgpu_create.restype = C.c_int
+        lib.uh_mgpu_last_error.argtypes, lib.uh_mgpu_last_error.restype = [C.c_void_p], C.c_char_p
+        lib.uh_mgpu_context.argtypes, lib.uh_mgpu_context.restype = [C.c_void_p, C.c_int], C.c_void_p
+        lib.uh_mgpu_num_devices.argtypes, lib.uh_mgpu_num_devices.restype = [C.c_void_p], C.c_int
+        for name, extra in (("get_num_lights", [C.POINTER(C.c_uint32)]), ("synchronize", []), ("compose", []), ("refit_acceleration", [])):
+            fn = getattr(lib, "uh_mgpu_" + name)
+            fn.argtypes, fn.restype = [C.c_void_p] + extra, C.c_int
+        devices = [int(d) for d in devices]
+        arr = (C.c_int * len(devices))(*devices)
+
+        def factory(w, h):
+            ctx = C.c_void_p()
+            st = lib.uh_mgpu_create(len(devices), arr, w, h, int(tile_size), C.byref(ctx))
+            if st != 0:
+                raise UtopianError(f"uh_mgpu_create failed: {ERR_NAMES.get(st, st)}: {(lib.uh_mgpu_last_error(None) or b'').decode()}")
+            return ctx
+
+        super().__init__(width, height, _api=CApi(lib, "uh_mgpu_"), _ctx_factory=factory)
+        self.devices = devices
+
+    def _check(self, st):
+        if st != 0:
+            raise UtopianError(f"{ERR_NAMES.get(st, st)}: {(self._lib.uh_mgpu_last_error(self._ctx) or b'').decode()}")
+
+    def get_num_lights(self):
+        out = C.c_uint32()
+        self._check(self._lib.uh_mgpu_get_num_lights(self._ctx, C.byref(out)))
+        return out.value
+
+    def synchronize(self):
+        self._check(self._lib.uh_mgpu_synchronize(self._ctx))
+
+    def compose(self):
+        self._check(self._lib.uh_mgpu_compose(self._ctx))
+
+
 def compose3x4(a, b):
     """a * b for row-major 3x4 affine matrices (instance.transform * model.transforms[i])."""
     A = np.vstack([np.asarray(a, dtype=np.float32).reshape(3, 4), [0, 0, 0, 1]]).astype(np.float32)
@@ -437,7 +482,7 @@ class FrameLoop:
 
         v = self.view
         batchable = (
-            self.renderer.backend == "hip" and count > 1 and pass_mask == PASS_REFERENCE_PT
+            self.renderer.backend.startswith("hip") and count > 1 and pass_mask == PASS_REFERENCE_PT
             and not (v.lights_enabled == 1 and v.use_ris_light_sampling == 1)
         )
         if not batchable:

@@ -1,0 +1,276 @@
+// mgpu.hip — uh_mgpu_*: one application process driving several GPUs.
+// The reference application is a single process with one render thread (prototype/src/main.rs); a
+// maintainer who wants N MI355X behind it binds this group instead of a single uh_ctx. It is a thin
+// layer over the public uh_* calls: one context per GPU, a full scene replica on each, the
+// framebuffer split into tiles t % N == i, no data-path exchange per frame, and one gather of packed
+// RGBA32F tiles to GPU 0 (hipMemcpyPeer: a direct xGMI copy, 7 peers land on 7 distinct links) per
+// COMPOSED image. (bench.py / the driver's scaling run use the one-process-per-GPU + RCCL form of
+// the same partition, distributed.py.)
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "utopian_hip.h"
+
+struct uh_mgpu {
+   std::vector<uh_ctx*> ctx;
+   std::vector<int> device;
+   std::vector<void*> packed;  // on device[i]: this GPU's tiles, packed
+   std::vector<void*> staged;  // on device[0]: the copy of packed[i] (i > 0)
+   std::vector<uint64_t> pack_pixels;
+   uint32_t W = 0, H = 0, tile = 0;
+   uint32_t total_samples = 1, accumulation_limit = 999999;  // of the last frame, for the resolve
+   bool composed = false;
+   std::string error;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(uh_mgpu* m, int st, const std::string& what, uh_ctx* from = nullptr) {
+   if (m) {
+      m->error = what;
+      if (from) {
+         const char* e = uh_last_error(from);
+         if (e && *e) m->error += std::string(": ") + e;
+      }
+   }
+   return st;
+}
+
+// run f(i) for every GPU concurrently (host-side work such as the BVH build or blocking copies)
+template <typename F>
+int for_all(uh_mgpu* m, F f) {
+   std::vector<int> st(m->ctx.size(), UH_OK);
+   std::vector<std::thread> th;
+   for (size_t i = 1; i < m->ctx.size(); i++) th.emplace_back([&, i]() { st[i] = f((int)i); });
+   st[0] = f(0);
+   for (auto& t : th) t.join();
+   for (size_t i = 0; i < st.size(); i++)
+      if (st[i] != UH_OK) return fail(m, st[i], "GPU " + std::to_string(m->device[i]), m->ctx[i]);
+   return UH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uh_mgpu_create(int ngpus, const int* device_ordinals, uint32_t width, uint32_t height, uint32_t tile_size, uh_mgpu** out) {
+   if (!out || ngpus < 1 || ngpus > 64 || tile_size == 0) {
+      g_create_error = "uh_mgpu_create: bad argument";
+      return UH_ERR_INVALID_ARGUMENT;
+   }
+   *out = nullptr;
+   uh_mgpu* m = new uh_mgpu();
+   m->W = width;
+   m->H = height;
+   m->tile = tile_size;
+   for (int i = 0; i < ngpus; i++) {
+      const int dev = device_ordinals ? device_ordinals[i] : i;
+      uh_ctx* c = nullptr;
+      int st = uh_create(dev, width, height, &c);
+      if (st == UH_OK) st = uh_set_tile_partition(c, (uint32_t)i, (uint32_t)ngpus, tile_size);
+      if (st != UH_OK) {
+         const char* e = uh_last_error(c);
+         g_create_error = std::string("uh_mgpu_create: GPU ") + std::to_string(dev) + ": " + (e ? e : "");
+         if (c) uh_destroy(c);
+         for (uh_ctx* o : m->ctx) uh_destroy(o);
+         delete m;
+         return st;
+      }
+      m->ctx.push_back(c);
+      m->device.push_back(dev);
+   }
+   m->packed.assign(ngpus, nullptr);
+   m->staged.assign(ngpus, nullptr);
+   m->pack_pixels.assign(ngpus, 0);
+   for (int i = 0; i < ngpus; i++) {
+      uh_tile_pack_count(m->ctx[i], (uint32_t)i, &m->pack_pixels[i]);
+      if (i == 0 || m->pack_pixels[i] == 0) continue;
+      const size_t bytes = m->pack_pixels[i] * 16;
+      hipError_t e = hipSetDevice(m->device[i]);
+      if (e == hipSuccess) e = hipMalloc(&m->packed[i], bytes);
+      if (e == hipSuccess) e = hipSetDevice(m->device[0]);
+      if (e == hipSuccess) e = hipMalloc(&m->staged[i], bytes);
+      if (e == hipSuccess && m->device[i] != m->device[0]) {
+         // direct xGMI copies; "already enabled" / "not supported" leave hipMemcpyPeer to stage by itself
+         (void)hipDeviceEnablePeerAccess(m->device[i], 0);
+         (void)hipGetLastError();
+      }
+      if (e != hipSuccess) {
+         g_create_error = std::string("uh_mgpu_create: ") + hipGetErrorString(e);
+         *out = m;
+         uh_mgpu_destroy(m);
+         *out = nullptr;
+         return e == hipErrorOutOfMemory ? UH_ERR_OUT_OF_MEMORY : UH_ERR_HIP;
+      }
+   }
+   *out = m;
+   return UH_OK;
+}
+
+void uh_mgpu_destroy(uh_mgpu* m) {
+   if (!m) return;
+   for (size_t i = 0; i < m->ctx.size(); i++) {
+      if (m->packed[i]) {
+         (void)hipSetDevice(m->device[i]);
+         (void)hipFree(m->packed[i]);
+      }
+      if (m->staged[i]) {
+         (void)hipSetDevice(m->device[0]);
+         (void)hipFree(m->staged[i]);
+      }
+   }
+   for (uh_ctx* c : m->ctx) uh_destroy(c);
+   delete m;
+}
+
+const char* uh_mgpu_last_error(uh_mgpu* m) { return m ? m->error.c_str() : g_create_error.c_str(); }
+int uh_mgpu_num_devices(uh_mgpu* m) { return m ? (int)m->ctx.size() : 0; }
+uh_ctx* uh_mgpu_context(uh_mgpu* m, int index) { return (m && index >= 0 && index < (int)m->ctx.size()) ? m->ctx[index] : nullptr; }
+
+// ---- scene verbs: replicated on every GPU (full scene replica per GPU) ------------
+int uh_mgpu_add_texture_rgba8(uh_mgpu* m, const uint8_t* pixels, uint32_t w, uint32_t h, uint32_t* out_index) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_add_texture_rgba8(c, pixels, w, h, out_index)) return fail(m, st, "uh_mgpu_add_texture_rgba8", c);
+   return UH_OK;
+}
+int uh_mgpu_add_mesh(uh_mgpu* m, const UhVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const UhGpuMaterial* mat, const float world3x4[12],
+                     uint32_t* out_mesh_index) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_add_mesh(c, v, nv, idx, ni, mat, world3x4, out_mesh_index)) return fail(m, st, "uh_mgpu_add_mesh", c);
+   return UH_OK;
+}
+int uh_mgpu_add_light(uh_mgpu* m, const UhGpuLight* light, uint32_t* out_index) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_add_light(c, light, out_index)) return fail(m, st, "uh_mgpu_add_light", c);
+   return UH_OK;
+}
+int uh_mgpu_get_num_lights(uh_mgpu* m, uint32_t* out) { return m ? uh_get_num_lights(m->ctx[0], out) : UH_ERR_INVALID_ARGUMENT; }
+int uh_mgpu_set_instance_transform(uh_mgpu* m, uint32_t mesh_index, const float world3x4[12]) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_set_instance_transform(c, mesh_index, world3x4)) return fail(m, st, "uh_mgpu_set_instance_transform", c);
+   return UH_OK;
+}
+int uh_mgpu_build_acceleration(uh_mgpu* m) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   return for_all(m, [&](int i) { return uh_build_acceleration(m->ctx[i]); });
+}
+int uh_mgpu_refit_acceleration(uh_mgpu* m) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   return for_all(m, [&](int i) { return uh_refit_acceleration(m->ctx[i]); });
+}
+int uh_mgpu_set_option(uh_mgpu* m, const char* name, int value) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_set_option(c, name, value)) return fail(m, st, "uh_mgpu_set_option", c);
+   return UH_OK;
+}
+
+// ---- frames: every GPU enqueues its tiles of the frame; the calls return without waiting ----
+int uh_mgpu_render_frame(uh_mgpu* m, const UhViewUniformData* view, uint32_t pass_mask) {
+   if (!m || !view) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_render_frame(c, view, pass_mask)) return fail(m, st, "uh_mgpu_render_frame", c);
+   m->total_samples = view->total_samples;
+   m->accumulation_limit = view->accumulation_limit;
+   m->composed = false;
+   return UH_OK;
+}
+int uh_mgpu_render_frames(uh_mgpu* m, const UhViewUniformData* view, uint32_t pass_mask, uint32_t count) {
+   if (!m || !view || count == 0) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_render_frames(c, view, pass_mask, count)) return fail(m, st, "uh_mgpu_render_frames", c);
+   m->total_samples = view->total_samples + (count - 1) * view->samples_per_frame;
+   m->accumulation_limit = view->accumulation_limit;
+   m->composed = false;
+   return UH_OK;
+}
+int uh_mgpu_reset_accumulation(uh_mgpu* m) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_reset_accumulation(c)) return fail(m, st, "uh_mgpu_reset_accumulation", c);
+   m->composed = false;
+   return UH_OK;
+}
+int uh_mgpu_synchronize(uh_mgpu* m) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_synchronize(c)) return fail(m, st, "uh_mgpu_synchronize", c);
+   return UH_OK;
+}
+
+// gather every GPU's tiles into GPU 0's accumulation image and recompute pt_output_image there
+int uh_mgpu_compose(uh_mgpu* m) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   if (m->composed) return UH_OK;
+   int st = for_all(m, [&](int i) -> int {
+      if (i == 0) return uh_synchronize(m->ctx[0]);
+      if (!m->pack_pixels[i]) return UH_OK;
+      if (int s = uh_pack_tiles(m->ctx[i], m->packed[i], m->pack_pixels[i])) return s;
+      hipError_t e = hipMemcpyPeer(m->staged[i], m->device[0], m->packed[i], m->device[i], m->pack_pixels[i] * 16);
+      return e == hipSuccess ? UH_OK : UH_ERR_HIP;
+   });
+   if (st != UH_OK) return st;
+   for (size_t i = 1; i < m->ctx.size(); i++)
+      if (m->pack_pixels[i])
+         if (int s = uh_unpack_tiles(m->ctx[0], (uint32_t)i, m->staged[i], m->pack_pixels[i])) return fail(m, s, "uh_mgpu_compose: unpack", m->ctx[0]);
+   if (int s = uh_resolve_output(m->ctx[0], m->total_samples, m->accumulation_limit)) return fail(m, s, "uh_mgpu_compose: resolve", m->ctx[0]);
+   m->composed = true;
+   return UH_OK;
+}
+int uh_mgpu_read_accumulation(uh_mgpu* m, float* rgba32f) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   if (int st = uh_mgpu_compose(m)) return st;
+   if (int st = uh_read_accumulation(m->ctx[0], rgba32f)) return fail(m, st, "uh_mgpu_read_accumulation", m->ctx[0]);
+   return UH_OK;
+}
+int uh_mgpu_read_output_bgra8(uh_mgpu* m, uint8_t* bgra) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   if (int st = uh_mgpu_compose(m)) return st;
+   if (int st = uh_read_output_bgra8(m->ctx[0], bgra)) return fail(m, st, "uh_mgpu_read_output_bgra8", m->ctx[0]);
+   return UH_OK;
+}
+
+// counters summed over the GPUs (each traces only its tiles); times are the slowest GPU's
+int uh_mgpu_get_stats(uh_mgpu* m, UhStats* out) {
+   if (!m || !out) return UH_ERR_INVALID_ARGUMENT;
+   std::memset(out, 0, sizeof(*out));
+   for (size_t i = 0; i < m->ctx.size(); i++) {
+      UhStats s;
+      if (int st = uh_get_stats(m->ctx[i], &s)) return fail(m, st, "uh_mgpu_get_stats", m->ctx[i]);
+      for (int k = 0; k < UH_RAY_KINDS; k++) out->rays[k] += (k == UH_RAY_GBUFFER && i > 0) ? 0 : s.rays[k];  // the G-buffer cast is replicated
+      out->nodes_visited += s.nodes_visited;
+      out->tris_tested += s.tris_tested;
+      out->shadow_nodes_visited += s.shadow_nodes_visited;
+      out->shadow_tris_tested += s.shadow_tris_tested;
+      out->closest_hits += s.closest_hits;
+      out->misses += s.misses;
+      out->frames = s.frames;
+      out->bvh_nodes = s.bvh_nodes;
+      out->bvh_triangles = s.bvh_triangles;
+      if (s.build_ms > out->build_ms) out->build_ms = s.build_ms;
+      if (s.last_frame_ms > out->last_frame_ms) out->last_frame_ms = s.last_frame_ms;
+      if (s.trace_closest_ms > out->trace_closest_ms) out->trace_closest_ms = s.trace_closest_ms;
+      if (s.trace_shadow_ms > out->trace_shadow_ms) out->trace_shadow_ms = s.trace_shadow_ms;
+      if (s.shade_ms > out->shade_ms) out->shade_ms = s.shade_ms;
+      out->trace_closest_launches += s.trace_closest_launches;
+   }
+   return UH_OK;
+}
+int uh_mgpu_reset_stats(uh_mgpu* m) {
+   if (!m) return UH_ERR_INVALID_ARGUMENT;
+   for (uh_ctx* c : m->ctx)
+      if (int st = uh_reset_stats(c)) return fail(m, st, "uh_mgpu_reset_stats", c);
+   return UH_OK;
+}
+
+}  // extern "C"

@@ -373,3 +373,36 @@ def test_refit_needs_a_built_tree(cornell):
     v = cornell.make_view(32, 32, rebuild_tlas=1)
     with pytest.raises(rr.UtopianError):
         r.render_frame(v, rr.PASS_REFERENCE_PT)
+
+
+# ---- uh_mgpu_*: several GPUs behind one process (here: several contexts on the one GPU) ---------------
+@pytest.mark.parametrize("ngpus,tile", [(3, 16), (2, 64), (5, 8)])
+def test_gpu_group_equals_single_context(cornell, ngpus, tile):
+    W, H = 80, 56
+    single = cornell.upload(rr.Renderer(W, H))
+    group = cornell.upload(rr.MultiGpuRenderer(W, H, devices=[0] * ngpus, tile_size=tile))
+    assert group.get_num_lights() == single.get_num_lights()
+    for r in (single, group):
+        loop = run_frames(r, cornell, W, H, 2, rr.PASS_ALL)       # G-buffer + ReSTIR + path tracing, frame by frame
+        loop.view.use_ris_light_sampling = 0
+        loop.frames(5, rr.PASS_REFERENCE_PT)                       # batched progressive frames
+    assert np.array_equal(single.read_accumulation().view(np.uint32), group.read_accumulation().view(np.uint32))
+    assert np.array_equal(single.read_output_bgra8(), group.read_output_bgra8())
+    a, b = single.get_stats(), group.get_stats()
+    assert list(a.rays) == list(b.rays) and a.closest_hits == b.closest_hits and a.misses == b.misses
+    # a moved instance reaches every GPU; the group refits on all of them
+    moved = rr.transform3x4((0.25, 0.35, 0.25), (-0.3, 0.5, 0.1))
+    for r in (single, group):
+        r.set_instance_transform(6, moved)
+        r.rebuild_tlas()
+        r.reset_accumulation()
+        run_frames(r, cornell, W, H, 2, rr.PASS_REFERENCE_PT)
+    assert np.array_equal(single.read_accumulation().view(np.uint32), group.read_accumulation().view(np.uint32))
+
+
+def test_gpu_group_errors():
+    with pytest.raises(rr.UtopianError):
+        rr.MultiGpuRenderer(32, 32, devices=[0, 4096])
+    g = rr.MultiGpuRenderer(32, 32, devices=[0, 0])
+    with pytest.raises(rr.UtopianError):
+        g.render_frame(rr.types.ViewUniformData(), rr.PASS_REFERENCE_PT)  # nothing built
