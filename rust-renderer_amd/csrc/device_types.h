@@ -128,7 +128,8 @@ struct LaunchCfg {
    bool count_visits;
    // traversal kernel variants (options "closest_variant" / "shadow_variant"; all bit-identical in
    // results): 0 = batch if-if; 1..5 = v2 while-while with lane refill at 64/32/16/8/1 idle lanes;
-   // 6..10 = v2 + parked leaf; 11..16 = v3 vote scheduling. Defaults are what measured fastest.
+   // 6..10 = v2 + parked leaf; 11..16 = v3 vote scheduling; 17..21 if-if + refill; 22..25 v5 (closest only:
+   // LDS-staged result lists); 26 (closest only) = variant 0 + entry-distance culling. Defaults measured fastest.
    int closest_variant, shadow_variant;
    bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
 };

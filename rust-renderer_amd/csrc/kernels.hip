@@ -226,6 +226,112 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
    return ANY ? occluded : (best.idx != kEmptyRef);
 }
 
+// ------------------------------------------------------------------------------------------
+// Closest-hit traversal with ENTRY-DISTANCE culling: a stack entry is (child ref, tnear) and an
+// entry whose box starts beyond the best hit found since it was pushed is dropped at pop time
+// instead of costing a whole node step. 8-byte entries: the LDS part of the stack holds half as
+// many (same 16 KiB per block), the rest spills to private memory as before.
+// ------------------------------------------------------------------------------------------
+constexpr int kLdsStack2 = kLdsStack / 2;
+
+__device__ __forceinline__ void push2(Trav& t, uint2* col, uint2* spill, uint32_t ref, float tn) {
+   if (t.sp < kLdsStack2)
+      col[t.sp * 64] = make_uint2(ref, __float_as_uint(tn));
+   else if (t.sp < kLdsStack2 + kSpillStack)
+      spill[t.sp - kLdsStack2] = make_uint2(ref, __float_as_uint(tn));
+   else
+      return;
+   t.sp++;
+}
+__device__ __forceinline__ uint32_t pop2(Trav& t, const uint2* col, const uint2* spill) {
+   while (t.sp > 0) {
+      t.sp--;
+      const uint2 e = t.sp < kLdsStack2 ? col[t.sp * 64] : spill[t.sp - kLdsStack2];
+      // strict: a triangle at exactly best.t with a smaller key must still be found
+      if (!(__uint_as_float(e.y) > t.best.t)) return e.x;
+   }
+   return kEmptyRef;
+}
+
+__device__ __forceinline__ void node_step_cull(const uint4* __restrict__ nodes, Trav& t, uint2* col, uint2* spill) {
+   const uint4* n = nodes + 4 * (size_t)t.cur;
+   const uint4 w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
+   const float ax = __uint_as_float(w0.w) * t.idir.x, ay = __uint_as_float(w1.x) * t.idir.y, az = __uint_as_float(w1.y) * t.idir.z;
+   const float bx = (__uint_as_float(w0.x) - t.o.x) * t.idir.x, by = (__uint_as_float(w0.y) - t.o.y) * t.idir.y, bz = (__uint_as_float(w0.z) - t.o.z) * t.idir.z;
+   const bool nx = t.idir.x < 0.0f, ny = t.idir.y < 0.0f, nz = t.idir.z < 0.0f;
+   const uint32_t qnx = nx ? w2.y : w1.z, qfx = nx ? w1.z : w2.y;
+   const uint32_t qny = ny ? w2.z : w1.w, qfy = ny ? w1.w : w2.z;
+   const uint32_t qnz = nz ? w2.w : w2.x, qfz = nz ? w2.x : w2.w;
+   const float tcap = t.best.t;
+   float tn[4];
+   uint32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+   for (int k = 0; k < 4; k++) {
+      const float t0x = fmaf((float)((qnx >> (8 * k)) & 0xffu), ax, bx), t1x = fmaf((float)((qfx >> (8 * k)) & 0xffu), ax, bx);
+      const float t0y = fmaf((float)((qny >> (8 * k)) & 0xffu), ay, by), t1y = fmaf((float)((qfy >> (8 * k)) & 0xffu), ay, by);
+      const float t0z = fmaf((float)((qnz >> (8 * k)) & 0xffu), az, bz), t1z = fmaf((float)((qfz >> (8 * k)) & 0xffu), az, bz);
+      const float tnear = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, t.tmin));
+      const float tfar = fminf(fminf(t1x, t1y), fminf(t1z, tcap));
+      tn[k] = (tnear <= tfar) ? tnear : INFINITY;
+   }
+   auto cswap = [&](int i, int j) {
+      bool s = tn[j] < tn[i];
+      float ta = s ? tn[j] : tn[i], tb = s ? tn[i] : tn[j];
+      uint32_t ca = s ? cr[j] : cr[i], cb = s ? cr[i] : cr[j];
+      tn[i] = ta;
+      tn[j] = tb;
+      cr[i] = ca;
+      cr[j] = cb;
+   };
+   cswap(0, 1);
+   cswap(2, 3);
+   cswap(0, 2);
+   if (t.sp + 3 <= kLdsStack2) {
+      uint2* p = col + t.sp * 64;
+      int h3 = tn[3] < INFINITY ? 1 : 0, h2 = tn[2] < INFINITY ? 1 : 0, h1 = tn[1] < INFINITY ? 1 : 0;
+      p[0] = make_uint2(cr[3], __float_as_uint(tn[3]));
+      p += h3 * 64;
+      p[0] = make_uint2(cr[2], __float_as_uint(tn[2]));
+      p += h2 * 64;
+      p[0] = make_uint2(cr[1], __float_as_uint(tn[1]));
+      t.sp += h3 + h2 + h1;
+   } else {
+      if (tn[3] < INFINITY) push2(t, col, spill, cr[3], tn[3]);
+      if (tn[2] < INFINITY) push2(t, col, spill, cr[2], tn[2]);
+      if (tn[1] < INFINITY) push2(t, col, spill, cr[1], tn[1]);
+   }
+   t.cur = (tn[0] < INFINITY) ? cr[0] : pop2(t, col, spill);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool traverse_cull(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, Hit& best, uint32_t* lds_col, uint32_t& n_nodes, uint32_t& n_tris) {
+   Trav t;
+   trav_init(t, make_float4(o.x, o.y, o.z, tmin), make_float4(d.x, d.y, d.z, tmax), INFINITY);
+   uint2 spill[kSpillStack];
+   // the wave's [kLdsStack][64] dwords seen as [kLdsStack2][64] entry pairs
+   uint2* col = reinterpret_cast<uint2*>(lds_col - lane_id()) + lane_id();
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   uint32_t tk = 0;
+   while (t.cur != kEmptyRef) {
+      if (!(t.cur & kLeafBit)) {
+         if (COUNT) n_nodes++;
+         node_step_cull(nodes, t, col, spill);
+      } else {
+         const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+         if (COUNT) n_tris++;
+         tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
+         tk++;
+         if (tk >= cnt) {
+            tk = 0;
+            t.cur = pop2(t, col, spill);
+         }
+      }
+   }
+   best = t.best;
+   return best.idx != kEmptyRef;
+}
+
 // persistent-thread batch fetch: lane 0 pulls the next 64-item batch of its shard
 __device__ __forceinline__ uint32_t next_batch(uint32_t* cursor) {
    uint32_t base = 0;
@@ -248,7 +354,7 @@ __device__ __forceinline__ ShardCtx shard_ctx() {
 // ------------------------------------------------------------------------------------------
 // trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes
 // ------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool CULL>
 __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                                                           uint32_t cursor_slot, int ray_kind) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
@@ -278,7 +384,10 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
       if (active) {
          id = queue[i];
          float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
-         traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
+         if (CULL)
+            traverse_cull<COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, h, lds_col, n_nodes, n_tris);
+         else
+            traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
          ps.hit[id] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
       }
       bool is_hit = active && h.idx != kEmptyRef, is_miss = active && h.idx == kEmptyRef;
@@ -1420,7 +1529,7 @@ static inline dim3 shade_grid(const LaunchCfg& c, uint32_t n) {
 
 uint32_t query_trace_occupancy() {
    int a = 0, b = 0;
-   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<false>, kBlock, 0) != hipSuccess) a = 4;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<false, false>, kBlock, 0) != hipSuccess) a = 4;
    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kBlock, 0) != hipSuccess) b = 4;
    int m = a < b ? a : b;
    if (m < 1) m = 1;
@@ -1436,9 +1545,16 @@ void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathStat
                           uint32_t cursor_slot, int ray_kind) {
    if (c.closest_variant == 0) {
       if (c.count_visits)
-         k_trace_closest<true><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+         k_trace_closest<true, false><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
       else
-         k_trace_closest<false><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+         k_trace_closest<false, false><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+      return;
+   }
+   if (c.closest_variant == 26) {  // entry-distance culling
+      if (c.count_visits)
+         k_trace_closest<true, true><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+      else
+         k_trace_closest<false, true><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
       return;
    }
    if (c.closest_variant >= 22) {
