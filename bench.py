@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only rank 0's tiles of an N-rank partition (what one rank sees at --gpus N)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=3")
-    ap.add_argument("--cpu-sample", type=str, default="960x540x3", help="WxHxframes rendered by the CPU oracle")
+    ap.add_argument("--cpu-sample", type=str, default="1920x1080x8", help="WxHx(max frames) rendered by the CPU oracle")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline stops after the first frame that ends beyond this many seconds")
     return ap.parse_args()
 
 
@@ -257,8 +258,11 @@ def cpu_baseline(args, scene):
     o = scene.upload(oa.OracleRenderer(w, h, threads=cores))
     loop = rr.FrameLoop(o, scene.make_view(w, h))
     t0 = time.perf_counter()
-    for _ in range(frames):
+    done = 0
+    while done < frames and (done == 0 or time.perf_counter() - t0 < args.cpu_seconds):
         loop.frame(rr.PASS_ALL if args.config == 2 else rr.PASS_REFERENCE_PT)
+        done += 1
+    frames = done
     dt = time.perf_counter() - t0
     s = o.get_stats()
     return {
