@@ -1114,7 +1114,7 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->next_slot = 0;
    }
    else if (n == "trace_variant" || n == "closest_variant" || n == "shadow_variant") {
-      if (value < 0 || value > 26) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..26");
+      if (value < 0 || value > 29) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..29");
       if (n != "shadow_variant") c->closest_variant = value;
       if (n != "closest_variant") c->shadow_variant = value > 21 ? 19 : value;
    } else if (n == "trace_blocks_per_cu" || n == "closest_blocks_per_cu" || n == "shadow_blocks_per_cu") {

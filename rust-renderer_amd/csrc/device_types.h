@@ -129,7 +129,8 @@ struct LaunchCfg {
    // traversal kernel variants (options "closest_variant" / "shadow_variant"; all bit-identical in
    // results): 0 = batch if-if; 1..5 = v2 while-while with lane refill at 64/32/16/8/1 idle lanes;
    // 6..10 = v2 + parked leaf; 11..16 = v3 vote scheduling; 17..21 if-if + refill; 22..25 v5 (closest only:
-   // LDS-staged result lists); 26 (closest only) = variant 0 + entry-distance culling. Defaults measured fastest.
+   // LDS-staged result lists); 26 (closest only) = variant 0 + entry-distance culling; 27..29 (closest only) = variant 0 with
+   // the top 32 / 64 / 128 nodes of the tree staged in LDS. Defaults measured fastest.
    int closest_variant, shadow_variant;
    bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
 };

@@ -121,8 +121,11 @@ __device__ __forceinline__ uint32_t trav_pop(Trav& t, const uint32_t* lds_col, c
 // inverted box (no child != empty test); only the nearest child is fully ordered (3 comparators);
 // pushes are branch-free (write always, advance the stack pointer by the hit bit).
 template <bool ANY>
-__device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill) {
-   const uint4* n = nodes + 4 * (size_t)t.cur;
+__device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill, const uint4* lds_nodes = nullptr,
+                                          uint32_t n_lds = 0) {
+   // n_lds > 0: the first n_lds nodes (BFS order = the top of the tree) are also staged in LDS; one flat
+   // load serves both address spaces per lane
+   const uint4* n = (n_lds && t.cur < n_lds) ? lds_nodes + 4 * t.cur : nodes + 4 * (size_t)t.cur;
    const uint4 w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
    const float ax = __uint_as_float(w0.w) * t.idir.x, ay = __uint_as_float(w1.x) * t.idir.y, az = __uint_as_float(w1.y) * t.idir.z;
    const float bx = (__uint_as_float(w0.x) - t.o.x) * t.idir.x, by = (__uint_as_float(w0.y) - t.o.y) * t.idir.y, bz = (__uint_as_float(w0.z) - t.o.z) * t.idir.z;
@@ -193,7 +196,7 @@ __device__ __forceinline__ bool leaf_step(const float4* __restrict__ tris, Trav&
 // batch (if-if) traversal of one ray: used by the stand-alone query kernels and trace variant 0
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, float tlimit, Hit& best, uint32_t* lds_col,
-                                         uint32_t& n_nodes, uint32_t& n_tris) {
+                                         uint32_t& n_nodes, uint32_t& n_tris, const uint4* lds_nodes = nullptr, uint32_t n_lds = 0) {
    Trav t;
    trav_init(t, make_float4(o.x, o.y, o.z, tmin), make_float4(d.x, d.y, d.z, tmax), ANY ? tlimit : INFINITY);
    uint32_t spill[kSpillStack];
@@ -207,7 +210,7 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
    while (t.cur != kEmptyRef) {
       if (!(t.cur & kLeafBit)) {
          if (COUNT) n_nodes++;
-         node_step<ANY>(nodes, t, lds_col, spill);
+         node_step<ANY>(nodes, t, lds_col, spill, lds_nodes, n_lds);
       } else {
          const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
          if (COUNT) n_tris++;
@@ -354,7 +357,8 @@ __device__ __forceinline__ ShardCtx shard_ctx() {
 // ------------------------------------------------------------------------------------------
 // trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes
 // ------------------------------------------------------------------------------------------
-template <bool COUNT, bool CULL>
+// MODE 0: plain; 1: entry-distance culling; >= 32: the top MODE nodes of the tree staged in LDS
+template <bool COUNT, int MODE>
 __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                                                           uint32_t cursor_slot, int ray_kind) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
@@ -371,6 +375,12 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
    uint32_t n_nodes = 0, n_tris = 0;
+   __shared__ uint4 s_top[MODE >= 32 ? 4 * MODE : 1];
+   const uint32_t n_top = MODE >= 32 ? (sc.num_nodes < (uint32_t)MODE ? sc.num_nodes : (uint32_t)MODE) : 0;
+   if (MODE >= 32) {
+      for (uint32_t k = threadIdx.x; k < 4 * n_top; k += kBlock) s_top[k] = sc.nodes[k];
+      __syncthreads();
+   }
    for (;;) {
       uint32_t base = next_batch(cursor);
       if (base >= count) break;
@@ -384,8 +394,10 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
       if (active) {
          id = queue[i];
          float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
-         if (CULL)
+         if (MODE == 1)
             traverse_cull<COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, h, lds_col, n_nodes, n_tris);
+         else if (MODE >= 32)
+            traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris, s_top, n_top);
          else
             traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
          ps.hit[id] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
@@ -1529,7 +1541,7 @@ static inline dim3 shade_grid(const LaunchCfg& c, uint32_t n) {
 
 uint32_t query_trace_occupancy() {
    int a = 0, b = 0;
-   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<false, false>, kBlock, 0) != hipSuccess) a = 4;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<false, 0>, kBlock, 0) != hipSuccess) a = 4;
    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kBlock, 0) != hipSuccess) b = 4;
    int m = a < b ? a : b;
    if (m < 1) m = 1;
@@ -1545,16 +1557,30 @@ void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathStat
                           uint32_t cursor_slot, int ray_kind) {
    if (c.closest_variant == 0) {
       if (c.count_visits)
-         k_trace_closest<true, false><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+         k_trace_closest<true, 0><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
       else
-         k_trace_closest<false, false><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+         k_trace_closest<false, 0><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+      return;
+   }
+   if (c.closest_variant >= 27 && c.closest_variant <= 29) {  // top of the tree staged in LDS: 32 / 64 / 128 nodes
+#define UH_LAUNCH_TOP(N)                                                                                                          \
+   do {                                                                                                                           \
+      if (c.count_visits)                                                                                                         \
+         k_trace_closest<true, N><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);     \
+      else                                                                                                                        \
+         k_trace_closest<false, N><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);    \
+   } while (0)
+      if (c.closest_variant == 27) UH_LAUNCH_TOP(32);
+      else if (c.closest_variant == 28) UH_LAUNCH_TOP(64);
+      else UH_LAUNCH_TOP(128);
+#undef UH_LAUNCH_TOP
       return;
    }
    if (c.closest_variant == 26) {  // entry-distance culling
       if (c.count_visits)
-         k_trace_closest<true, true><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+         k_trace_closest<true, 1><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
       else
-         k_trace_closest<false, true><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
+         k_trace_closest<false, 1><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
       return;
    }
    if (c.closest_variant >= 22) {
