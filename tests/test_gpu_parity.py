@@ -7,7 +7,7 @@ import pytest
 
 import oracle_api as oa
 import rust_renderer_amd as rr
-from util import L2_TOL, make_pair, per_pixel_l2, random_rays, run_frames
+from util import L2_TOL, make_pair, per_pixel_l2, random_rays, run_frames, torture_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -406,3 +406,31 @@ def test_gpu_group_errors():
     g = rr.MultiGpuRenderer(32, 32, devices=[0, 0])
     with pytest.raises(rr.UtopianError):
         g.render_frame(rr.types.ViewUniformData(), rr.PASS_REFERENCE_PT)  # nothing built
+
+
+# ---- geometric torture: the intersection contract (min t, ties -> smaller mesh<<22|prim) -------------
+def test_intersection_contract_on_torture_geometry():
+    scene = torture_scene()
+    gpu, cpu = make_pair(scene, 8, 8, brute_force=True)
+    rng = np.random.default_rng(5)
+    n = 60_000
+    o = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(3, 6, n)], 1)
+    tgt = np.stack([rng.uniform(-1.2, 1.2, n), rng.uniform(-1.2, 1.2, n), np.zeros(n)], 1)
+    # a third of the rays aim exactly at vertices / edges / the shared diagonal
+    special = np.array([[-1, -1, 0], [1, 1, 0], [0, 0, 0], [1, -1, 0], [0.5, 0.5, 0], [0, 0, 2], [0.25, 0.25, 0.5], [1, 0, 0]], dtype=np.float64)
+    tgt[::3] = special[rng.integers(0, len(special), len(tgt[::3]))]
+    o[::6, :2] = tgt[::6, :2]  # and some of those straight down the z axis
+    rays = np.empty((n, 8), dtype=np.float32)
+    rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o, 0.001, tgt - o, 10000.0
+    tg, mg, pg = gpu.trace_closest(rays)
+    tc, mc, pc = cpu.trace_closest(rays)
+    assert np.array_equal(mg, mc) and np.array_equal(pg, pc)
+    assert np.array_equal(tg.view(np.uint32), tc.view(np.uint32))
+    hit0 = mg == 0
+    assert hit0.sum() > 1000 and not (mg == 1).any() and not (mg == 2).any(), "coincident surfaces: the smaller key must win every tie"
+    assert not (mg == 3).any(), "zero-area triangles are never hit (det == 0)"
+    assert np.array_equal(gpu.trace_any(rays).astype(bool), mc != 0xFFFFFFFF)
+    # the same contract through the whole path tracer
+    for r in (gpu, cpu):
+        run_frames(r, scene, 8, 8, 2, rr.PASS_ALL)
+    assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL

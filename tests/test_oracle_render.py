@@ -186,3 +186,22 @@ def test_oracle_rebuild_tlas_protocol():
     b.initialize_raytracing()
     b.render_frame(v, rr.PASS_REFERENCE_PT)
     assert np.array_equal(a.read_accumulation(), b.read_accumulation())
+
+
+def test_oracle_bvh_equals_brute_force_on_torture_geometry():
+    """coincident surfaces (t ties -> smaller key), zero-area, huge, tiny and instanced triangles"""
+    from util import torture_scene
+    scene = torture_scene()
+    bvh = scene.upload(oa.OracleRenderer(8, 8))
+    brute = scene.upload(oa.OracleRenderer(8, 8, brute_force=True))
+    rng = np.random.default_rng(9)
+    n = 30_000
+    o = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(3, 6, n)], 1)
+    tgt = np.stack([rng.uniform(-1.2, 1.2, n), rng.uniform(-1.2, 1.2, n), np.zeros(n)], 1)
+    tgt[::4] = np.array([[-1, -1, 0], [1, 1, 0], [0, 0, 0], [0.25, 0.25, 0.5]])[rng.integers(0, 4, len(tgt[::4]))]
+    rays = np.empty((n, 8), dtype=np.float32)
+    rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o, 0.001, tgt - o, 10000.0
+    a, b = bvh.trace_closest(rays), brute.trace_closest(rays)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert (a[1] == 0).sum() > 500 and not (a[1] == 1).any() and not (a[1] == 2).any() and not (a[1] == 3).any()
