@@ -1,0 +1,119 @@
+"""-m gpu, at BASELINE.json's full frame size (1920x1080, the config-2 / config-3 scenes): parity against
+the oracle on a sample of framebuffer tiles (the oracle renders only those tiles - its tile partition
+is the multi-GPU one), full-frame reservoir parity, and size-independent properties of the frame."""
+import numpy as np
+import pytest
+
+import oracle_api as oa
+import rust_renderer_amd as rr
+from util import L2_TOL, per_pixel_l2, run_frames
+
+pytestmark = pytest.mark.gpu
+W, H, TILE = 1920, 1080, 64
+
+
+@pytest.fixture(scope="module")
+def sponza():
+    return rr.scenes.scene_for_config(1, tex_size=64)
+
+
+@pytest.fixture(scope="module")
+def sponza_lights():
+    return rr.scenes.scene_for_config(2, tex_size=64)
+
+
+def sampled(world, rank):
+    return rr.distributed.owner_map(W, H, TILE, world) == rank
+
+
+def test_sampled_tiles_match_oracle_config2(sponza):
+    gpu = sponza.upload(rr.Renderer(W, H))
+    cpu = sponza.upload(oa.OracleRenderer(W, H))
+    cpu.set_tile_partition(11, 53, TILE)  # 9-10 of the 510 tiles, spread over the frame
+    for r in (gpu, cpu):
+        run_frames(r, sponza, W, H, 2, rr.PASS_REFERENCE_PT)
+    mask = sampled(53, 11)
+    assert mask.sum() >= 30_000
+    a, b = gpu.read_accumulation()[mask], cpu.read_accumulation()[mask]
+    assert per_pixel_l2(a, b) <= L2_TOL
+    assert np.abs(a - b).max() <= 1e-4  # only the sky integral (device exp/pow vs libm) differs
+
+
+def test_restir_frame_matches_oracle_config3(sponza_lights):
+    gpu = sponza_lights.upload(rr.Renderer(W, H))
+    cpu = sponza_lights.upload(oa.OracleRenderer(W, H))
+    cpu.set_tile_partition(5, 47, TILE)
+    for r in (gpu, cpu):
+        run_frames(r, sponza_lights, W, H, 2, rr.PASS_ALL)
+    # G-buffer and all three reservoir buffers: full frame, bit for bit
+    assert np.array_equal(gpu.read_gbuffer_position().view(np.uint32), cpu.read_gbuffer_position().view(np.uint32))
+    for which in range(3):
+        g, c = gpu.read_reservoirs(which), cpu.read_reservoirs(which)
+        for f in ("Y", "M"):
+            assert np.array_equal(g[f], c[f]), (which, f)
+        for f in ("W_sum", "W_X"):
+            assert np.array_equal(g[f].view(np.uint32), c[f].view(np.uint32)), (which, f)
+    mask = sampled(47, 5)
+    a, b = gpu.read_accumulation()[mask], cpu.read_accumulation()[mask]
+    assert per_pixel_l2(a, b) <= L2_TOL
+    # both halves of the reference's split screen (x > W/2 reads reservoirs) are in the sample
+    xs = np.nonzero(mask)[1]
+    assert (xs > W // 2).any() and (xs < W // 2).any()
+
+
+def test_frame_invariants_and_determinism(sponza):
+    frames = 3
+    out = []
+    for _ in range(2):
+        r = sponza.upload(rr.Renderer(W, H))
+        run_frames(r, sponza, W, H, frames, rr.PASS_REFERENCE_PT)
+        out.append((r.read_accumulation(), r.get_stats()))
+    (a, s), (b, t) = out
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "two runs of the same frames must agree bit for bit"
+    assert list(s.rays) == list(t.rays)
+    assert s.rays[0] == W * H * frames                       # one primary ray per pixel and sample
+    assert s.closest_hits + s.misses == s.rays[0] + s.rays[1]  # every path ray ends in exactly one shader
+    # a sun ray leaves every scattered hit (rgen:63-79), a bounce ray every scattered hit but the last bounce's
+    assert s.rays[1] <= s.rays[2] <= s.closest_hits
+    assert s.rays[3] == 0                                    # no lights in config 2
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and (a[..., 3] == 0).all()
+
+
+def test_batched_in_flight_frames_equal_frame_by_frame(sponza):
+    ref = sponza.upload(rr.Renderer(W, H))
+    ref.set_option("frames_in_flight", 1)
+    run_frames(ref, sponza, W, H, 7, rr.PASS_REFERENCE_PT)
+    alt = sponza.upload(rr.Renderer(W, H))
+    alt.set_option("batch_frames", 3)
+    rr.FrameLoop(alt, sponza.make_view(W, H)).frames(7, rr.PASS_REFERENCE_PT)
+    assert np.array_equal(ref.read_accumulation().view(np.uint32), alt.read_accumulation().view(np.uint32))
+    assert list(ref.get_stats().rays) == list(alt.get_stats().rays)
+
+
+def test_gpu_group_composes_the_full_frame(sponza):
+    single = sponza.upload(rr.Renderer(W, H))
+    group = sponza.upload(rr.MultiGpuRenderer(W, H, devices=[0, 0, 0, 0], tile_size=TILE))
+    for r in (single, group):
+        rr.FrameLoop(r, sponza.make_view(W, H)).frames(4, rr.PASS_REFERENCE_PT)
+    assert np.array_equal(single.read_accumulation().view(np.uint32), group.read_accumulation().view(np.uint32))
+    assert np.array_equal(single.read_output_bgra8(), group.read_output_bgra8())
+    assert list(single.get_stats().rays) == list(group.get_stats().rays)
+
+
+def test_moved_instances_refit_equals_rebuild(sponza):
+    n = sponza.num_meshes
+    moves = [(n - 1, rr.transform3x4((1, 1, 1), (3.0, 0.5, 1.0))), (n - 2, rr.transform3x4((1.3, 0.7, 1.0), (-4.0, 1.5, -1.0)))]
+    refit = sponza.upload(rr.Renderer(W, H))
+    for mesh, w in moves:
+        refit.set_instance_transform(mesh, w)
+    refit.rebuild_tlas()
+    built = rr.Renderer(W, H)
+    for model, transform in sponza.models:
+        built.add_model(model, transform)
+    for mesh, w in moves:
+        built.set_instance_transform(mesh, w)
+    built.initialize_raytracing()
+    for r in (refit, built):
+        run_frames(r, sponza, W, H, 2, rr.PASS_REFERENCE_PT)
+    assert np.array_equal(refit.read_accumulation().view(np.uint32), built.read_accumulation().view(np.uint32))
+    assert list(refit.get_stats().rays) == list(built.get_stats().rays)
