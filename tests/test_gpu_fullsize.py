@@ -117,3 +117,24 @@ def test_moved_instances_refit_equals_rebuild(sponza):
         run_frames(r, sponza, W, H, 2, rr.PASS_REFERENCE_PT)
     assert np.array_equal(refit.read_accumulation().view(np.uint32), built.read_accumulation().view(np.uint32))
     assert list(refit.get_stats().rays) == list(built.get_stats().rays)
+
+
+def test_config4_scene_class_at_4k_sampled_tiles_and_group():
+    """BASELINE configs[3]: the Bistro-class scene (2.88 M triangles, all four material types, 64 lights)
+    at 3840x2160 - the largest frame and scene the configs name"""
+    W4, H4 = 3840, 2160
+    scene = rr.scenes.scene_for_config(3, tex_size=64)
+    gpu = scene.upload(rr.Renderer(W4, H4))
+    cpu = scene.upload(oa.OracleRenderer(W4, H4))
+    cpu.set_tile_partition(7, 211, TILE)  # 9-10 of the 2040 tiles
+    for r in (gpu, cpu):
+        run_frames(r, scene, W4, H4, 2, rr.PASS_REFERENCE_PT, use_ris_light_sampling=0)
+    mask = rr.distributed.owner_map(W4, H4, TILE, 211) == 7
+    assert mask.sum() >= 30_000
+    a, b = gpu.read_accumulation()[mask], cpu.read_accumulation()[mask]
+    assert per_pixel_l2(a, b) <= L2_TOL
+    s = gpu.get_stats()
+    assert s.rays[0] == 2 * W4 * H4 and s.rays[3] > 0 and s.closest_hits + s.misses == s.rays[0] + s.rays[1]
+    group = scene.upload(rr.MultiGpuRenderer(W4, H4, devices=[0, 0], tile_size=TILE))
+    run_frames(group, scene, W4, H4, 2, rr.PASS_REFERENCE_PT, use_ris_light_sampling=0)
+    assert np.array_equal(gpu.read_accumulation().view(np.uint32), group.read_accumulation().view(np.uint32))
