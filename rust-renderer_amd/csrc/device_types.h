@@ -19,7 +19,8 @@ constexpr uint32_t kLaunchSlots = kMaxBounces * 3 + 4;
 // has one segment (capacity PathState::shard_cap) and one counter per shard, and the blocks of a
 // launch are bound to shards by blockIdx % kShards. A single device-wide counter saturates at
 // ~88 atomics/us on MI355X (MI355X_MICROARCH.md "dequeue"), which capped every queue-building
-// kernel of the unsharded first version (profiles/r01a_*): 32 shards lift that ceiling 32x.
+// kernel of the unsharded first version (profiles/r01a_*): 32 shards lift that ceiling 32x - provided
+// the 32 counters live in 32 different 128-byte lines (see Control below).
 // Blocks b and b + 8 share an XCD under the observed round-robin dispatch, so shard s is served by
 // XCD s % 8 and its queue segments stay in that XCD's L2 between producer and consumer launches.
 constexpr uint32_t kShards = 32;
@@ -29,11 +30,18 @@ constexpr uint32_t kShards = 32;
 __host__ __device__ inline uint32_t shard_of_run(uint32_t run) { return (run * 0x9E3779B1u) >> 27; }
 
 // Zeroed once per sample pass by one hipMemsetAsync.
+// Counter layout: the words that one launch hammers concurrently (the same bounce and queue kind, or
+// the same launch slot, of all 32 shards) must not share a 128-byte line - atomics to one LINE
+// serialise in its L2 channel just like atomics to one word. So the shard (and queue kind) select
+// the line and the bounce / launch slot the word inside it.
+constexpr uint32_t kBounceStride = ((kMaxBounces + 1 + 31) / 32) * 32;  // words, whole lines
+constexpr uint32_t kSlotStride = ((kLaunchSlots + 31) / 32) * 32;
 struct Control {
-   uint32_t q_count[(kMaxBounces + 1) * kQueueKinds * kShards];
-   uint32_t cursor[kLaunchSlots * kShards];  // persistent-thread work cursors, one row per launch of the pass
+   uint32_t q_count[kShards * kQueueKinds * kBounceStride];
+   uint32_t cursor[kShards * kSlotStride];  // persistent-thread work cursors, one per (shard, launch of the pass)
 };
-__host__ __device__ inline uint32_t qc_index(uint32_t bounce, uint32_t kind, uint32_t shard) { return (bounce * kQueueKinds + kind) * kShards + shard; }
+__host__ __device__ inline uint32_t qc_index(uint32_t bounce, uint32_t kind, uint32_t shard) { return (shard * kQueueKinds + kind) * kBounceStride + bounce; }
+__host__ __device__ inline uint32_t cursor_index(uint32_t slot, uint32_t shard) { return shard * kSlotStride + slot; }
 
 // Persistent across frames; read back by uh_get_stats.
 struct DeviceStats {

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    uint32_t* q_miss = ps.queue[3] + seg;
    uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
    uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
    uint32_t n_nodes = 0, n_tris = 0;
    __shared__ uint4 s_top[MODE >= 32 ? 4 * MODE : 1];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    // sun rays leave from every scattered path = the next bounce's ray queue; light rays from Q_LIGHT
    const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[4] : ps.queue[(bounce + 1) & 1]) + seg;
    const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const float tmin = 0.001f, tmax = 10000.0f;
    uint32_t n_nodes = 0, n_tris = 0;
    for (;;) {
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    uint32_t* q_miss = ps.queue[3] + seg;
    uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
    uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    const uint32_t seg = sx.shard * ps.shard_cap;
    const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[4] : ps.queue[(bounce + 1) & 1]) + seg;
    const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
    uint32_t spill[kSpillStack];
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    uint32_t* q_miss = ps.queue[3] + seg;
    uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
    uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_v3(SceneDev sc, PathSt
    uint32_t* q_miss = ps.queue[3] + seg;
    uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
    uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow_v3(SceneDev sc, FramePa
    const uint32_t seg = sx.shard * ps.shard_cap;
    const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[4] : ps.queue[(bounce + 1) & 1]) + seg;
    const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_slot * kShards + sx.shard];
+   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
    uint32_t spill[kSpillStack];
