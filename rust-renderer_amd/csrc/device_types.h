@@ -24,10 +24,12 @@ constexpr uint32_t kLaunchSlots = kMaxBounces * 3 + 4;
 // Blocks b and b + 8 share an XCD under the observed round-robin dispatch, so shard s is served by
 // XCD s % 8 and its queue segments stay in that XCD's L2 between producer and consumer launches.
 constexpr uint32_t kShards = 32;
+constexpr uint32_t kShardBits = 5;
+static_assert((1u << kShardBits) == kShards, "kShards is a power of two");
 // Fibonacci hash of the 64-path run index (top 5 bits). A plain `run % 32` aliases with the tile
 // partition: with 64-pixel-wide tiles every run a rank owns is even, which left half of the shards
 // (and half of the traversal blocks) empty on every rank of a multi-GPU job.
-__host__ __device__ inline uint32_t shard_of_run(uint32_t run) { return (run * 0x9E3779B1u) >> 27; }
+__host__ __device__ inline uint32_t shard_of_run(uint32_t run) { return (run * 0x9E3779B1u) >> (32 - kShardBits); }
 
 // Zeroed once per sample pass by one hipMemsetAsync.
 // Counter layout: the words that one launch hammers concurrently (the same bounce and queue kind, or
