@@ -895,11 +895,15 @@ int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mas
    if (!view || count == 0) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: null view or zero frames");
    UhViewUniformData v = *view;
    uint32_t done = 0;
-   // auto: keep launches about the size of two full frames - a rank that owns 1/world of the pixels
-   // carries 2 * world frames per wavefront, capped at 8 so that a 64-frame run still pipelines
-   // several wavefronts through the frames-in-flight slots (swept on MI355X: profiles/README.md)
-   uint32_t batch = c->batch_frames ? c->batch_frames : (2 * c->tp_world > 8 ? 8 : 2 * c->tp_world);
+   // auto: 4 frames per wavefront (swept on MI355X for 1, 2, 4 and 8 ranks' shares of the frame,
+   // tools/world_sweep.sh, profiles/README.md)
+   uint32_t batch = c->batch_frames ? c->batch_frames : 4;
    if (batch > kMaxBatchFrames) batch = kMaxBatchFrames;
+   // create every frames-in-flight slot now: the first call (an application's first frames, a benchmark's
+   // warm-up) pays for the allocations and stream creation, not whichever later wavefront first reaches a slot
+   if (!(pass_mask & UH_PASS_RESTIR) && (pass_mask & UH_PASS_REFERENCE_PT))
+      for (uint32_t i = 0; i < (c->frames_in_flight ? c->frames_in_flight : 1); i++)
+         if (int st = ensure_slot(c, i, batch)) return st;
    while (done < count) {
       uint32_t b = count - done < batch ? count - done : batch;
       int st = render_batch(c, &v, pass_mask, b);
