@@ -27,6 +27,7 @@
 #include <cstring>
 #include <algorithm>
 #include <string>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -967,9 +968,22 @@ static void flush_counters(Oracle& o) {
    tl_ctr = LocalCounters();
 }
 
+// the cores this process may actually run on (a container's CPU set), not every core of the host
+static int default_threads() {
+   int n = (int)std::thread::hardware_concurrency();
+#ifdef __linux__
+   cpu_set_t set;
+   if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+      int c = CPU_COUNT(&set);
+      if (c > 0 && c < n) n = c;
+   }
+#endif
+   return n > 64 ? 64 : n;
+}
+
 template <typename F>
 static void parallel_rows(Oracle& o, F f) {
-   int nt = o.num_threads > 0 ? o.num_threads : (int)std::thread::hardware_concurrency();
+   int nt = o.num_threads > 0 ? o.num_threads : default_threads();
    if (nt < 1) nt = 1;
    std::atomic<uint32_t> next(0);
    auto worker = [&]() {
@@ -1162,7 +1176,7 @@ int orc_resolve_output(orc_ctx* c, uint32_t total_samples, uint32_t limit) {
 int orc_trace_closest(orc_ctx* c, const float* rays, uint32_t n, float* out_tuv, uint32_t* out_mesh, uint32_t* out_prim) {
    if (!c || !c->o.built) return UH_ERR_NOT_BUILT;
    Oracle& o = c->o;
-   int nt = o.num_threads > 0 ? o.num_threads : (int)std::thread::hardware_concurrency();
+   int nt = o.num_threads > 0 ? o.num_threads : default_threads();
    std::atomic<uint32_t> next(0);
    auto worker = [&]() {
       for (;;) {

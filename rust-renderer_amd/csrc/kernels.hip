@@ -203,15 +203,18 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
    bool occluded = false;
-   // if-if with ONE triangle per iteration: in a divergent wave both branches run every iteration,
-   // so the leaf branch must be as short as the node branch's partner can afford (a whole-leaf
-   // loop made every iteration pay up to 4 triangle tests for the few lanes standing at a leaf)
+   // if-if with ONE triangle per iteration: in a divergent wave both branches are issued every
+   // iteration, so (a) the leaf branch must be short (a whole-leaf loop made every iteration pay up
+   // to 4 triangle tests for the few lanes standing at a leaf) and (b) a lane that the node step has
+   // just sent to a leaf uses this iteration's leaf branch too instead of idling through it
    uint32_t tk = 0;
    while (t.cur != kEmptyRef) {
       if (!(t.cur & kLeafBit)) {
          if (COUNT) n_nodes++;
          node_step<ANY>(nodes, t, lds_col, spill, lds_nodes, n_lds);
-      } else {
+      }
+      // a lane that the node step just sent to a leaf tests that leaf's first triangle in the same iteration
+      if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
          const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
          if (COUNT) n_tris++;
          if (tri_test<ANY>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
@@ -320,7 +323,8 @@ __device__ __forceinline__ bool traverse_cull(const SceneDev& sc, V3 o, V3 d, fl
       if (!(t.cur & kLeafBit)) {
          if (COUNT) n_nodes++;
          node_step_cull(nodes, t, col, spill);
-      } else {
+      }
+      if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
          const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
          if (COUNT) n_tris++;
          tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
@@ -580,11 +584,12 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
       }
       if (active) {
          if (kMode == 2) {
-            // if-if, one node OR one triangle per iteration (see traverse())
+            // if-if: one node step, then one triangle if the lane stands at a leaf (see traverse())
             if (!(t.cur & kLeafBit)) {
                if (COUNT) n_nodes++;
                node_step<false>(nodes, t, lds_col, spill);
-            } else {
+            }
+            if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
                const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
                if (COUNT) n_tris++;
                tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
@@ -704,7 +709,8 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
             if (!(t.cur & kLeafBit)) {
                if (COUNT) n_nodes++;
                node_step<true>(nodes, t, lds_col, spill);
-            } else {
+            }
+            if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {  // also the leaf the node step just descended to
                const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
                if (COUNT) n_tris++;
                occluded = tri_test<true>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
@@ -838,7 +844,8 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
          if (!(t.cur & kLeafBit)) {
             if (COUNT) n_nodes++;
             node_step<false>(nodes, t, lds_col, spill);
-         } else {
+         }
+         if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
             const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
             if (COUNT) n_tris++;
             tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
