@@ -1098,12 +1098,12 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->full_frame_restir = value != 0;
    else if (n == "bvh_max_leaf") {
       if (value < 1 || value > 15) return fail(c, UH_ERR_INVALID_ARGUMENT, "bvh_max_leaf must be 1..15");
+      if (c->bvh_max_leaf != (uint32_t)value) c->built = c->topology_valid = false;  // needs a rebuild, not a refit
       c->bvh_max_leaf = (uint32_t)value;
-      c->built = false;
    } else if (n == "bvh_sah_cost_x100") {
       if (value < 0 || value > 1000) return fail(c, UH_ERR_INVALID_ARGUMENT, "bvh_sah_cost_x100 must be 0..1000");
+      if (c->bvh_sah_cost != (float)value / 100.0f) c->built = c->topology_valid = false;
       c->bvh_sah_cost = (float)value / 100.0f;
-      c->built = false;
    } else if (n == "overlap_miss")
       c->overlap_miss = value != 0;
    else if (n == "overlap_shadow")
