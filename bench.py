@@ -177,6 +177,10 @@ def main():
         launches = max(st.trace_closest_launches, 1)
         avg_ms = st.trace_closest_ms / launches
         achieved = (algo_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # the bytes this build's layout actually requests for the same visits: 4 B queue id + 32 B ray + 16 B hit
+        # record + 4 B hit/miss queue entry per ray, 64-byte quantised nodes, 48-byte triangle packets
+        layout_bytes = my_closest * (56.0 + nodes_per_ray * 64.0 + tris_per_ray * 48.0)
+        requested = (layout_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_trace_closest.json")
         if os.path.exists(pmc):
@@ -212,6 +216,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "requested_by_layout": {"GB/s": requested, "frac": requested / HBM_PEAK_GBS,
+                                        "note": "same visits priced with this build's 64-byte nodes and actual record sizes instead of SURVEY 8d's 128-byte node"},
                 "avg_launch_ms": avg_ms,
                 "launches": st.trace_closest_launches,
                 "nodes_per_ray": nodes_per_ray,
