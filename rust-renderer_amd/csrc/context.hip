@@ -155,7 +155,16 @@ struct uh_ctx {
    uint32_t next_slot = 0;
    uint32_t shard_cap = 0;
    hipEvent_t last_acc = nullptr;     // ev_acc of the most recent frame (accumulation order)
-   hipEvent_t serial_barrier = nullptr;  // set by a frame that ran ReSTIR / G-buffer passes: the next frame waits for it
+   // G-buffer cast + reservoir passes run in call order on their own stream, beside path-tracing frames in flight.
+   // The path tracer of frame f reads spatial buffer `spatial_cur` while frame f+1's passes already run: its
+   // temporal pass reads the same buffer and its spatial pass writes the other one (after the last path-tracing
+   // frame that read THAT one has finished: spatial_reader[]).
+   hipStream_t restir_stream = nullptr;
+   hipEvent_t ev_restir = nullptr, rs_start = nullptr, rs_stop = nullptr;
+   bool restir_recorded = false;
+   int spatial_cur = 0;
+   hipEvent_t spatial_reader[2] = {nullptr, nullptr};
+   hipEvent_t t_start = nullptr, t_stop = nullptr;  // bracket of the last uh_render_frame call (last_frame_ms)
    Slot* last_slot = nullptr;
    hipStream_t& stream = slots[0].stream;  // slot 0 also serves every non-frame operation
    PathState& ps = slots[0].ps;
@@ -194,7 +203,8 @@ struct uh_ctx {
    // frame-persistent per-pixel images (graph resources of renderers/mod.rs:199-244)
    DevBuf<float4> accumulation, gbuffer;
    DevBuf<uchar4> output;
-   DevBuf<UhReservoir> reservoirs[3];
+   DevBuf<UhReservoir> reservoirs[3], spatial_alt;
+   DevBuf<float4> gb_ray_o, gb_ray_d, gb_hit;  // scratch of the G-buffer cast (allocated by the first G-buffer pass)
    DevBuf<DeviceStats> dstats;
    Images im{};
 
@@ -365,6 +375,7 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    c->im.output = c->output.p;
    c->im.gbuffer_pos = c->gbuffer.p;
    for (int i = 0; i < 3; i++) c->im.reservoirs[i] = c->reservoirs[i].p;
+   c->im.prev_spatial = c->reservoirs[2].p;
    *out = c;
    return UH_OK;
 }
@@ -372,6 +383,16 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
 void uh_destroy(uh_ctx* c) {
    if (!c) return;
    (void)hipSetDevice(c->device);
+   if (c->restir_stream) {
+      (void)hipStreamSynchronize(c->restir_stream);
+      for (hipEvent_t ev : {c->ev_restir, c->rs_start, c->rs_stop})
+         if (ev) (void)hipEventDestroy(ev);
+      (void)hipStreamDestroy(c->restir_stream);
+   }
+   c->spatial_alt.release();
+   c->gb_ray_o.release();
+   c->gb_ray_d.release();
+   c->gb_hit.release();
    for (auto& s : c->slots) {
       if (s.stream) (void)hipStreamSynchronize(s.stream);
       if (s.side) (void)hipStreamSynchronize(s.side);
@@ -715,6 +736,7 @@ static FrameParams make_params(uh_ctx* c, const UhViewUniformData& v) {
 
 // every stream of every slot idle (read-backs, scene rebuilds, stats)
 static int sync_all(uh_ctx* c) {
+   if (c->restir_stream) HIP_TRY(c, hipStreamSynchronize(c->restir_stream));
    for (auto& s : c->slots) {
       if (!s.ready) continue;
       HIP_TRY(c, hipStreamSynchronize(s.stream));
@@ -732,7 +754,10 @@ static int ensure_slot(uh_ctx* c, uint32_t i, uint32_t batch = 1) {
       HIP_TRY(c, hipStreamSynchronize(s.stream));
       HIP_TRY(c, hipStreamSynchronize(s.side));
       if (c->last_acc == s.ev_acc) c->last_acc = nullptr;
-      if (c->serial_barrier == s.ev_acc) c->serial_barrier = nullptr;
+      for (hipEvent_t& r : c->spatial_reader)
+         if (r == s.ev_acc) r = nullptr;
+      if (c->t_start == s.frame_start) c->t_start = nullptr;
+      if (c->t_stop == s.frame_stop) c->t_stop = nullptr;
       if (c->last_slot == &s) c->last_slot = nullptr;
       s.destroy();
    }
@@ -839,49 +864,77 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
    // the path tracer reads spatial_reuse_reservoirs when it samples lights from them (rgen:98)
    const bool reads_reservoirs = (pass_mask & UH_PASS_REFERENCE_PT) && fp.lights_enabled == 1 && fp.use_ris == 1;
 
-   uint32_t si = 0;
-   if (!restir_frame && (pass_mask & UH_PASS_REFERENCE_PT)) {
-      si = c->next_slot;
-      c->next_slot = (c->next_slot + 1) % (c->frames_in_flight ? c->frames_in_flight : 1);
-   }
-   int st = ensure_slot(c, si, batch);
-   if (st != UH_OK) return st;
-   Slot& s = c->slots[si];
    if (batch > 1 && (restir_frame || reads_reservoirs || !(pass_mask & UH_PASS_REFERENCE_PT)))
       return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: only the path-tracing pass without reservoir light sampling can be batched");
+   const size_t npix = (size_t)c->W * c->H;
+   auto spatial_buf = [&](int which) { return which ? c->spatial_alt.p : c->reservoirs[2].p; };
+   c->t_start = c->t_stop = nullptr;
 
    if (restir_frame) {
-      // G-buffer / reservoir passes write buffers that frames in flight may still read, and the
-      // temporal pass consumes the previous frame's spatial reservoirs: run after everything else
-      for (auto& o : c->slots)
-         if (o.ready && &o != &s) HIP_TRY(c, hipStreamWaitEvent(s.stream, o.ev_acc, 0));
-   } else if (c->serial_barrier) {
-      // the previous frame produced reservoirs / G-buffer this frame may read
-      HIP_TRY(c, hipStreamWaitEvent(s.stream, c->serial_barrier, 0));
-      if (!reads_reservoirs) c->serial_barrier = nullptr;
+      if (!c->restir_stream) {
+         HIP_TRY(c, hipStreamCreateWithFlags(&c->restir_stream, hipStreamNonBlocking));
+         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_restir, hipEventDisableTiming));
+         HIP_TRY(c, hipEventCreate(&c->rs_start));
+         HIP_TRY(c, hipEventCreate(&c->rs_stop));
+         HIP_TRY(c, c->spatial_alt.alloc(npix));
+         // both spatial buffers start from the same (zeroed or uh_write_reservoirs) history
+         HIP_TRY(c, hipStreamSynchronize(c->stream));
+         HIP_TRY(c, hipMemcpy(c->spatial_alt.p, c->reservoirs[2].p, npix * sizeof(UhReservoir), hipMemcpyDeviceToDevice));
+      }
+      LaunchCfg rc = cfg(c);
+      rc.stream = c->restir_stream;
+      HIP_TRY(c, hipEventRecord(c->rs_start, c->restir_stream));
+      c->t_start = c->rs_start;
+      Images im = c->im;  // reservoirs[2] = the current spatial buffer
+      im.prev_spatial = spatial_buf(c->spatial_cur);
+      if (pass_mask & UH_PASS_GBUFFER) {
+         if (!c->gb_hit.p) {
+            HIP_TRY(c, c->gb_ray_o.alloc(npix));
+            HIP_TRY(c, c->gb_ray_d.alloc(npix));
+            HIP_TRY(c, c->gb_hit.alloc(npix));
+         }
+         PathState gps;
+         std::memset(&gps, 0, sizeof(gps));
+         gps.ray_o = c->gb_ray_o.p;
+         gps.ray_d = c->gb_ray_d.p;
+         gps.hit = c->gb_hit.p;
+         launch_gbuffer(rc, fp, c->scene, gps, im, nullptr, c->dstats.p);
+      }
+      if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(rc, fp, im);
+      if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(rc, fp, c->scene, im);
+      if (pass_mask & UH_PASS_TEMPORAL_REUSE) launch_temporal_reuse(rc, fp, c->scene, im);
+      if (pass_mask & UH_PASS_SPATIAL_REUSE) {
+         // writes the OTHER spatial buffer: the path-tracing frame that still reads the current one keeps going
+         const int nxt = c->spatial_cur ^ 1;
+         if (c->spatial_reader[nxt]) HIP_TRY(c, hipStreamWaitEvent(c->restir_stream, c->spatial_reader[nxt], 0));
+         im.reservoirs[2] = spatial_buf(nxt);
+         launch_spatial_reuse(rc, fp, c->scene, im);
+         c->spatial_cur = nxt;
+         c->im.reservoirs[2] = spatial_buf(nxt);
+      }
+      HIP_TRY(c, hipEventRecord(c->ev_restir, c->restir_stream));
+      c->restir_recorded = true;
+      HIP_TRY(c, hipEventRecord(c->rs_stop, c->restir_stream));
+      c->t_stop = c->rs_stop;
    }
-   HIP_TRY(c, hipEventRecord(s.frame_start, s.stream));
-
-   LaunchCfg lc = cfg(c);
-   lc.stream = s.stream;
-   if (pass_mask & UH_PASS_GBUFFER) {
-      HIP_TRY(c, hipMemsetAsync(s.control.p, 0, sizeof(Control), s.stream));
-      launch_gbuffer(lc, fp, c->scene, s.ps, c->im, s.control.p, c->dstats.p);
-   }
-   if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(lc, fp, c->im);
-   if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(lc, fp, c->scene, c->im);
-   if (pass_mask & UH_PASS_TEMPORAL_REUSE) launch_temporal_reuse(lc, fp, c->scene, c->im);
-   if (pass_mask & UH_PASS_SPATIAL_REUSE) launch_spatial_reuse(lc, fp, c->scene, c->im);
 
    if (pass_mask & UH_PASS_REFERENCE_PT) {
+      const uint32_t si = c->next_slot;
+      c->next_slot = (c->next_slot + 1) % (c->frames_in_flight ? c->frames_in_flight : 1);
+      int st = ensure_slot(c, si, batch);
+      if (st != UH_OK) return st;
+      Slot& s = c->slots[si];
+      // rgen:98 reads this frame's spatial_reuse_reservoirs
+      if (reads_reservoirs && c->restir_recorded) HIP_TRY(c, hipStreamWaitEvent(s.stream, c->ev_restir, 0));
+      HIP_TRY(c, hipEventRecord(s.frame_start, s.stream));
+      if (!c->t_start) c->t_start = s.frame_start;
       st = enqueue_path_trace(c, s, fp);
       if (st != UH_OK) return st;
-   } else {
-      HIP_TRY(c, hipEventRecord(s.ev_acc, s.stream));
+      if (reads_reservoirs) c->spatial_reader[c->spatial_cur] = s.ev_acc;
+      HIP_TRY(c, hipEventRecord(s.frame_stop, s.stream));
+      c->t_stop = s.frame_stop;
+      c->last_slot = &s;
    }
-   if (restir_frame) c->serial_barrier = s.ev_acc;
-   HIP_TRY(c, hipEventRecord(s.frame_stop, s.stream));
-   c->last_slot = &s;
    c->frame_timed = true;
    c->frames += batch;
    HIP_TRY(c, hipGetLastError());
@@ -945,14 +998,17 @@ int uh_read_gbuffer_position(uh_ctx* c, float* out) { return read_back(c, out, c
 int uh_read_reservoirs(uh_ctx* c, int which, UhReservoir* out) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (which < 0 || which > 2) return fail(c, UH_ERR_INVALID_ARGUMENT, "reservoir buffer index must be 0..2");
-   return read_back(c, out, c->reservoirs[which].p, c->reservoirs[which].n * sizeof(UhReservoir));
+   // spatial_reuse_reservoirs is double-buffered (render_batch): the current one is what the reference's single buffer holds
+   const UhReservoir* src = which == 2 ? c->im.reservoirs[2] : c->reservoirs[which].p;
+   return read_back(c, out, src, c->reservoirs[which].n * sizeof(UhReservoir));
 }
 int uh_write_reservoirs(uh_ctx* c, int which, const UhReservoir* in) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (which < 0 || which > 2 || !in) return fail(c, UH_ERR_INVALID_ARGUMENT, "reservoir buffer index must be 0..2");
    HIP_TRY(c, hipSetDevice(c->device));
    if (int st = sync_all(c)) return st;
-   HIP_TRY(c, hipMemcpyAsync(c->reservoirs[which].p, in, c->reservoirs[which].n * sizeof(UhReservoir), hipMemcpyHostToDevice, c->stream));
+   UhReservoir* dst = which == 2 ? c->im.reservoirs[2] : c->reservoirs[which].p;
+   HIP_TRY(c, hipMemcpyAsync(dst, in, c->reservoirs[which].n * sizeof(UhReservoir), hipMemcpyHostToDevice, c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    return UH_OK;
 }
@@ -1046,7 +1102,7 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    drain_timed(c);
    if (c->frame_timed) {
       float ms = 0.0f;
-      if (c->last_slot && hipEventElapsedTime(&ms, c->last_slot->frame_start, c->last_slot->frame_stop) == hipSuccess) c->last_frame_ms = ms;
+      if (c->t_start && c->t_stop && hipEventElapsedTime(&ms, c->t_start, c->t_stop) == hipSuccess) c->last_frame_ms = ms;
    }
    std::memset(out, 0, sizeof(*out));
    for (int i = 0; i < UH_RAY_KINDS; i++) out->rays[i] = ds.rays[i];

@@ -127,7 +127,8 @@ struct Images {
    float4* accumulation;  // pt_accumulation_image RGBA32F
    uchar4* output;        // pt_output_image B8G8R8A8_UNORM
    float4* gbuffer_pos;   // gbuffer_position RGBA32F, un-filtered texels
-   UhReservoir* reservoirs[3];
+   UhReservoir* reservoirs[3];          // initial, temporal, spatial (the buffer this frame's spatial pass writes / the path tracer reads)
+   const UhReservoir* prev_spatial;     // last frame's spatial_reuse_reservoirs, read by the temporal pass (renderers/mod.rs:294)
 };
 
 // launch wrappers implemented in kernels.hip --------------------------------------------------

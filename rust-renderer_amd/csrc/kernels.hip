@@ -1459,7 +1459,7 @@ __global__ __launch_bounds__(kBlock) void k_temporal_reuse(FrameParams fp, Scene
          int ix = (int)(ux * (float)fp.W + 0.5f), iy = (int)(uy * (float)fp.H + 0.5f);
          uint32_t ti = (uint32_t)iy * fp.W + (uint32_t)ix;  // may be one past the end in the reference (y == H)
          if (ti > n - 1) ti = n - 1;
-         pr = im.reservoirs[2][ti];  // last frame's spatial_reuse_reservoirs (renderers/mod.rs:294)
+         pr = im.prev_spatial[ti];  // last frame's spatial_reuse_reservoirs (renderers/mod.rs:294)
       }
       p_hat = pr.Y == -1 ? 0.0f : target_function(s_lights, sc.num_lights, pr.Y, hit_position);
       pr.M = min(20 * ir.M, pr.M);
