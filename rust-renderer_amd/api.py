@@ -470,6 +470,11 @@ class FrameLoop:
         v.total_samples += v.samples_per_frame
         v.num_lights = self.renderer.get_num_lights()
         self.renderer.render_frame(v, pass_mask)
+        self.end_frame()
+
+    def end_frame(self):
+        """main.rs:545-546: prev_frame_projection_view = projection * view, after the frame."""
+        v = self.view
         proj = np.array(v.projection[:], dtype=np.float32).reshape(4, 4).T
         view = np.array(v.view[:], dtype=np.float32).reshape(4, 4).T
         v.prev_frame_projection_view[:] = cam.to_glam((proj @ view).astype(np.float32)).tolist()
