@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 // stand-alone closest-hit query over n rays (identity queue): uh_trace_closest and the G-buffer cast
 // DIAG (option "raw_visit_counts"): u,v of the result carry the ray's node / triangle visit counts instead
 template <bool DIAG>
-__global__ __launch_bounds__(kBlock) void k_trace_closest_raw(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+__global__ __launch_bounds__(kBlock, 8) void k_trace_closest_raw(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                               float4* __restrict__ hit_out, uint32_t count) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane_id()];
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    uint32_t pool_pos = 0, pool_end = 0;
    bool drained = false, active = false;
    uint32_t id = 0, tk = 0;
-   float f = 1.0f;
+   float4 lit = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
    Trav t;
    t.cur = kEmptyRef;
    t.sp = 0;
@@ -679,17 +679,22 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
                ro.w = 0.001f;
                float4 rd;
                float tlimit = INFINITY;
+               // the radiance this path gets if the ray turns out unoccluded (rgen:69-78 / :118-122) is formed
+               // NOW, beside the ray fetch: a load at the moment a lane finishes would stall the whole wave
+               // in almost every iteration (some lane finishes in nearly each one)
+               const float4 thr = ps.thr[id], rad = ps.rad[id];
                if (LIGHT) {
-                  float4 thr = ps.thr[id], rad = ps.rad[id];
                   int light_index = (int)__float_as_uint(rad.w);
                   V3 lpos = v3(0, 0, 0);
                   if (light_index >= 0 && (uint32_t)light_index < sc.num_lights) lpos = xyz(sc.lights[2 * light_index]);
                   V3 o = v3(ro.x, ro.y, ro.z);
                   V3 dir = normalize3(lpos - o);  // rgen:113
                   tlimit = length3(lpos - o);     // rgen:114
-                  f = thr.w;
+                  const float f = thr.w;
+                  lit = make_float4(rad.x + thr.x * f, rad.y + thr.y * f, rad.z + thr.z * f, rad.w);
                   rd = make_float4(dir.x, dir.y, dir.z, 10000.0f);
                } else {
+                  lit = make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w);
                   rd = make_float4(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2], 10000.0f);  // rgen:64
                }
                trav_init(t, ro, rd, tlimit);
@@ -750,13 +755,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
             }
          }
          if (t.cur == kEmptyRef) {
-            if (!occluded) {  // rgen:69-78 / :118-122
-               float4 thr = ps.thr[id], rad = ps.rad[id];
-               if (LIGHT)
-                  ps.rad[id] = make_float4(rad.x + thr.x * f, rad.y + thr.y * f, rad.z + thr.z * f, rad.w);
-               else
-                  ps.rad[id] = make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w);
-            }
+            if (!occluded) ps.rad[id] = lit;
             active = false;
          }
       }
