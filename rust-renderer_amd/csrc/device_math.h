@@ -101,6 +101,12 @@ __device__ __forceinline__ V3 C_MIE() { return v3(3.996f, 3.996f, 3.996f) * 1e-6
 __device__ __forceinline__ V3 C_OZONE() { return v3(0.650f, 1.881f, 0.085f) * 1e-6f; }
 __device__ __forceinline__ V3 PLANET_CENTER() { return v3(0.0f, -PLANET_RADIUS, 0.0f); }
 
+// The sky is the one part of the path that is compared with a tolerance instead of bit for bit (device exp / pow
+// already differ from libm by an ulp): inside it, divisions by constants are reciprocal multiplications and square
+// roots / reciprocals use the 1-ulp hardware instructions. ~2.5x fewer instructions in k_shade_miss; the result moves
+// by ~1e-6 relative (tests: per-pixel L2 <= 1e-3, sampled max |diff| <= 1e-4).
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ void atmosphere_intersection(V3 s, V3 d, float& t0, float& t1) {  // atmosphere.glsl:53-77
    const float radius = PLANET_RADIUS + ATMOSPHERE_HEIGHT;
    s = s - PLANET_CENTER();
@@ -112,16 +118,20 @@ __device__ __forceinline__ void atmosphere_intersection(V3 s, V3 d, float& t0, f
       t0 = -1.0f;
       t1 = -1.0f;
    } else {
-      disc = sqrtf(disc);
-      t0 = (-b - disc) / (2.0f * a);
-      t1 = (-b + disc) / (2.0f * a);
+      disc = fast_sqrt(disc);
+      const float inv = fast_rcp(2.0f * a);
+      t0 = (-b - disc) * inv;
+      t1 = (-b + disc) * inv;
    }
 }
-__device__ __forceinline__ float atmosphere_height(V3 p) { return length3(p - PLANET_CENTER()) - PLANET_RADIUS; }  // :95-98
-__device__ __forceinline__ V3 atmosphere_density(float h) {                                                        // :99-115
-   float r = __expf(-fmaxf(0.0f, h / RAYLEIGH_HEIGHT));
-   float m = __expf(-fmaxf(0.0f, h / MIE_HEIGHT));
-   float o = fmaxf(0.0f, 1.0f - fabsf(h - 25000.0f) / 15000.0f);
+__device__ __forceinline__ float atmosphere_height(V3 p) {  // :95-98
+   V3 q = p - PLANET_CENTER();
+   return fast_sqrt(dot3(q, q)) - PLANET_RADIUS;
+}
+__device__ __forceinline__ V3 atmosphere_density(float h) {  // :99-115
+   float r = __expf(-fmaxf(0.0f, h * (1.0f / RAYLEIGH_HEIGHT)));
+   float m = __expf(-fmaxf(0.0f, h * (1.0f / MIE_HEIGHT)));
+   float o = fmaxf(0.0f, 1.0f - fabsf(h - 25000.0f) * (1.0f / 15000.0f));
    return v3(r, m, o);
 }
 __device__ __forceinline__ V3 absorb(V3 od) {  // :146-150
@@ -142,7 +152,7 @@ __device__ __forceinline__ V3 integrate_optical_depth(V3 start, V3 dir) {  // :1
 }
 __device__ __noinline__ V3 integrate_scattering(V3 start, V3 dir, float ray_length, V3 light_dir) {  // :154-214 (lightColor = 1)
    float ray_height = atmosphere_height(start);
-   float c = 1.0f - ray_height / ATMOSPHERE_HEIGHT;
+   float c = 1.0f - ray_height * (1.0f / ATMOSPHERE_HEIGHT);
    c = fminf(fmaxf(c, 0.0f), 1.0f);
    float exponent = 1.0f + c * 8.0f;
    float i0, i1;
