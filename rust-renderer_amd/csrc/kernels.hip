@@ -73,8 +73,9 @@ __device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, uint32
 constexpr uint32_t kChunk = 64;   // rays a wave takes from its shard's cursor per atomic (traversal v2)
 
 __device__ __forceinline__ float safe_rcp_dir(float x) {
-   // the slab test only has to be conservative; a zero component becomes +-1e-30 so no inf/NaN appears
-   return 1.0f / (fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x);
+   // the slab test only has to be conservative (boxes are padded by >= 1e-5 relative, the 1-ulp hardware
+   // reciprocal is 1e-7): no IEEE division here; a zero component becomes +-1e-30 so no inf/NaN appears
+   return __builtin_amdgcn_rcpf(fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x);
 }
 
 struct Trav {
@@ -134,7 +135,7 @@ __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav&
    const uint32_t qnx = nx ? w2.y : w1.z, qfx = nx ? w1.z : w2.y;
    const uint32_t qny = ny ? w2.z : w1.w, qfy = ny ? w1.w : w2.z;
    const uint32_t qnz = nz ? w2.w : w2.x, qfz = nz ? w2.x : w2.w;
-   const float tcap = fminf(t.best.t, t.tlimit);
+   const float tcap = ANY ? fminf(t.best.t, t.tlimit) : t.best.t;  // closest: tlimit is +inf
    float tn[4];
    uint32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
 #pragma unroll
