@@ -138,6 +138,7 @@ __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav&
    const float tcap = ANY ? fminf(t.best.t, t.tlimit) : t.best.t;  // closest: tlimit is +inf
    float tn[4];
    uint32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
+   bool hit[4];
 #pragma unroll
    for (int k = 0; k < 4; k++) {
       const float t0x = fmaf((float)((qnx >> (8 * k)) & 0xffu), ax, bx), t1x = fmaf((float)((qfx >> (8 * k)) & 0xffu), ax, bx);
@@ -145,12 +146,34 @@ __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav&
       const float t0z = fmaf((float)((qnz >> (8 * k)) & 0xffu), az, bz), t1z = fmaf((float)((qfz >> (8 * k)) & 0xffu), az, bz);
       const float tnear = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, t.tmin));
       const float tfar = fminf(fminf(t1x, t1y), fminf(t1z, tcap));
-      tn[k] = (tnear <= tfar) ? tnear : INFINITY;
+      hit[k] = tnear <= tfar;
+      tn[k] = hit[k] ? tnear : INFINITY;
+   }
+   if (ANY) {
+      // visibility walk: the order of the children does not matter to an unoccluded ray (it visits them all) and
+      // hardly to an occluded one (measured, profiles/README.md): no ordering network, the first hit child in
+      // slot order is next, the other hits are pushed
+      const bool any = hit[0] || hit[1] || hit[2] || hit[3];
+      const uint32_t next = hit[0] ? cr[0] : hit[1] ? cr[1] : hit[2] ? cr[2] : cr[3];
+      const bool p1 = hit[1] && hit[0], p2 = hit[2] && (hit[0] || hit[1]), p3 = hit[3] && (hit[0] || hit[1] || hit[2]);
+      if (t.sp + 3 <= kLdsStack) {
+         uint32_t* p = lds_col + t.sp * 64;
+         p[0] = cr[3];
+         p += (p3 ? 1 : 0) * 64;
+         p[0] = cr[2];
+         p += (p2 ? 1 : 0) * 64;
+         p[0] = cr[1];
+         t.sp += (p3 ? 1 : 0) + (p2 ? 1 : 0) + (p1 ? 1 : 0);
+      } else {
+         if (p3) trav_push(t, lds_col, spill, cr[3]);
+         if (p2) trav_push(t, lds_col, spill, cr[2]);
+         if (p1) trav_push(t, lds_col, spill, cr[1]);
+      }
+      t.cur = any ? next : trav_pop(t, lds_col, spill);
+      return;
    }
    {
-      // bring the nearest hit to slot 0 (3 comparators); slots 1..3 stay unordered. Any-hit walks use
-      // the same order: an occluder close to the shaded point is the likeliest one (12.3 -> see
-      // tools/traversal_stats.py for nodes per shadow ray), and the network is cheaper than compacting
+      // closest hit: bring the nearest hit to slot 0 (3 comparators); slots 1..3 stay unordered
       auto cswap = [&](int i, int j) {
          bool s = tn[j] < tn[i];
          float ta = s ? tn[j] : tn[i], tb = s ? tn[i] : tn[j];
