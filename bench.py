@@ -122,7 +122,7 @@ def main():
     alone_ms = alone.trace_closest_ms / max(alone.trace_closest_launches, 1)
     alone_rays = float(alone.rays[rr.RAY_PRIMARY] + alone.rays[rr.RAY_BOUNCE]) / max(alone.trace_closest_launches, 1)
     renderer.set_option("time_kernels", 0)
-    for k, v in (("frames_in_flight", 3), ("overlap_miss", 1), ("overlap_shadow", 1), ("batch_frames", 0)):
+    for k, v in (("frames_in_flight", 4), ("overlap_miss", 1), ("overlap_shadow", 1), ("batch_frames", 0)):
         renderer.set_option(k, v)
     for kv in args.opt:
         k, v = kv.split("=")

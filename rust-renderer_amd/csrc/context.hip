@@ -150,7 +150,7 @@ struct Slot {
 struct uh_ctx {
    int device = 0;
    Slot slots[kMaxSlots];
-   uint32_t frames_in_flight = 3;     // slots used round-robin by path-tracing-only frames (swept: 3 is best)
+   uint32_t frames_in_flight = 4;     // slots used round-robin by path-tracing frames (swept: profiles/README.md)
    uint32_t batch_frames = 0;         // frames one uh_render_frames launch chain carries (option "batch_frames"); 0 = auto
    uint32_t next_slot = 0;
    uint32_t shard_cap = 0;
@@ -212,7 +212,7 @@ struct uh_ctx {
    bool count_visits = false, time_kernels = false, full_frame_restir = false, raw_visit_counts = false;
    uint32_t bvh_max_leaf = kMaxLeafTris;
    float bvh_sah_cost = 0.5f;  // SAH leaf termination: a node step costs about half a triangle test here (swept on MI355X)
-   int closest_variant = 0, shadow_variant = 19;  // measured fastest on MI355X (profiles/README.md)
+   int closest_variant = 0, shadow_variant = 18;  // measured fastest on MI355X (profiles/README.md)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
    float ms_by_kind[3] = {0, 0, 0};
@@ -1176,7 +1176,7 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
    else if (n == "trace_variant" || n == "closest_variant" || n == "shadow_variant") {
       if (value < 0 || value > 29) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..29");
       if (n != "shadow_variant") c->closest_variant = value;
-      if (n != "closest_variant") c->shadow_variant = value > 21 ? 19 : value;
+      if (n != "closest_variant") c->shadow_variant = value > 21 ? 18 : value;
    } else if (n == "trace_blocks_per_cu" || n == "closest_blocks_per_cu" || n == "shadow_blocks_per_cu") {
       if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 1..8");
       if (n != "shadow_blocks_per_cu") c->closest_blocks_per_cu = (uint32_t)value;
