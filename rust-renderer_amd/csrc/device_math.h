@@ -193,9 +193,11 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
    if (m < 0) m += period;
    return m < n ? m : period - 1 - m;
 }
-__device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __restrict__ lut, uint32_t index, float u, float v) {
+// lds_tex (may be null): the first n_lds_tex texture descriptors staged in LDS by the caller
+__device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __restrict__ lut, uint32_t index, float u, float v, const TexInfo* lds_tex = nullptr,
+                                             uint32_t n_lds_tex = 0) {
    if (index >= sc.num_textures) return v3(1, 1, 1);
-   TexInfo t = sc.textures[index];
+   TexInfo t = (index < n_lds_tex) ? lds_tex[index] : sc.textures[index];
    float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
    if (!(fabsf(x) < 1e9f) || !(fabsf(y) < 1e9f)) return v3(0, 0, 0);
    float fx = floorf(x), fy = floorf(y);

@@ -1192,6 +1192,15 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
    // kernel ran 86 % TA-busy at 2 % VALU, profiles/r01c_*); LDS serves them at no TA cost
    __shared__ float s_lut[256];
    s_lut[threadIdx.x] = sc.unorm_lut[threadIdx.x];
+   // per-mesh shading records and texture descriptors of the first kLdsMeshes / kLdsTextures entries: every hit
+   // gathers 64 + 24 bytes of them per lane, and the kernel is bound by its gather traffic (texture addresser)
+   constexpr uint32_t kLdsMeshes = 192, kLdsTextures = 64;
+   __shared__ MeshShade s_mesh[kLdsMeshes];
+   __shared__ TexInfo s_tex[kLdsTextures];
+   const uint32_t n_lds_mesh = sc.num_meshes < kLdsMeshes ? sc.num_meshes : kLdsMeshes;
+   const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
+   if (threadIdx.x < n_lds_mesh) s_mesh[threadIdx.x] = sc.meshes[threadIdx.x];
+   if (threadIdx.x < n_lds_tex) s_tex[threadIdx.x] = sc.textures[threadIdx.x];
    __syncthreads();
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
@@ -1219,7 +1228,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
          const V3 n0 = v3(s0.x, s0.y, s0.z), n1 = v3(s0.w, s1.x, s1.y), n2 = v3(s1.z, s1.w, s2.x);
          const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
          const uint32_t mesh_index = __float_as_uint(s3.w);
-         const MeshShade ms = sc.meshes[mesh_index];                                   // rchit:22-23
+         const MeshShade ms = (mesh_index < n_lds_mesh) ? s_mesh[mesh_index] : sc.meshes[mesh_index];  // rchit:22-23
          const float bx = 1.0f - bu - bv, by = bu, bz = bv;                            // rchit:30
          V3 normal = (n0 * bx + n1 * by) + n2 * bz;                                    // rchit:31
          V3 wn = v3((normal.x * ms.w2o[0] + normal.y * ms.w2o[3]) + normal.z * ms.w2o[6],
@@ -1229,7 +1238,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
          if (dot3(world_normal, ray_dir) > 0.0f) world_normal = vneg(world_normal);   // rchit:35-37
          float uu = (uv0x * bx + uv1x * by) + uv2x * bz;                               // rchit:39
          float vv = (uv0y * bx + uv1y * by) + uv2y * bz;
-         V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv);                        // rchit:40
+         V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);       // rchit:40
          color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
 
          uint2 rng = ps.rng[id];
