@@ -235,7 +235,11 @@ int uh_trace_any(uh_ctx* ctx, const float* rays, uint32_t n, uint8_t* out_occlud
 int uh_get_stats(uh_ctx* ctx, UhStats* out);
 int uh_reset_stats(uh_ctx* ctx);
 /* options: "count_visits" (0/1), "time_kernels" (0/1), "full_frame_restir" (0/1; 1 = documented
- * divergence: use the reservoir for every pixel instead of the reference's x > W/2 split) */
+ * divergence: use the reservoir for every pixel instead of the reference's x > W/2 split),
+ * "device_build" (0/1; 1 = uh_build_acceleration builds a Morton-order tree ON THE DEVICE in a few ms instead
+ * of the host SAH tree in tens to hundreds: same hits bit for bit, about 30 % more traversal work per ray -
+ * for geometry that changes every few frames), tuning knobs documented in DESIGN.md ("frames_in_flight",
+ * "batch_frames", "closest_variant", "shadow_variant", "*_blocks_per_cu", "bvh_max_leaf", "bvh_sah_cost_x100") */
 int uh_set_option(uh_ctx* ctx, const char* name, int value);
 
 /* ---- multi-GPU framebuffer tile partition (one process per GPU) ------------------------ */

@@ -195,6 +195,12 @@ struct uh_ctx {
    std::vector<uint32_t> packet_keys;  // key of triangle packet i (leaf order)
    std::vector<uint32_t> level_start;  // BFS levels of the node array
    bool topology_valid = false;        // the device tree matches the mesh list (transforms may differ)
+   // on-device build (lbvh.hip, option "device_build"): per-triangle sources in mesh order, kept on the device
+   // until a mesh is added, so that a rebuild after moved instances or changed parameters uploads nothing
+   bool device_build = false, src_valid = false;
+   DevBuf<float> d_src_corners;
+   DevBuf<uint32_t> d_src_keys;
+   DevBuf<float4> d_src_shade;
    float refit_ms = 0.0f;
    DevBuf<TexInfo> d_tex;
    DevBuf<float> d_lut;
@@ -416,6 +422,9 @@ void uh_destroy(uh_ctx* c) {
    c->d_world_corners.release();
    c->d_node_box.release();
    c->d_refit_meshes.release();
+   c->d_src_corners.release();
+   c->d_src_keys.release();
+   c->d_src_shade.release();
    c->d_tex.release();
    c->d_lut.release();
    c->accumulation.release();
@@ -475,6 +484,7 @@ int uh_add_mesh(uh_ctx* c, const UhVertex* vertices, uint32_t num_vertices, cons
    c->meshes.push_back(std::move(m));
    c->built = false;
    c->topology_valid = false;
+   c->src_valid = false;
    if (out_mesh_index) *out_mesh_index = (uint32_t)c->meshes.size() - 1;
    return UH_OK;
 }
@@ -506,9 +516,49 @@ int uh_set_instance_transform(uh_ctx* c, uint32_t mesh_index, const float world3
 
 static int sync_all(uh_ctx* c);
 
+// per-mesh shading records, light table, texture descriptors: everything of the scene except the geometry
+static int upload_scene_tables(uh_ctx* c) {
+   std::vector<MeshShade> ms(c->meshes.size());
+   for (size_t i = 0; i < c->meshes.size(); i++) {
+      const HostMesh& m = c->meshes[i];
+      std::memcpy(ms[i].w2o, m.w2o, sizeof(m.w2o));
+      ms[i].diffuse_map = m.material.diffuse_map;
+      for (int a = 0; a < 3; a++) ms[i].base_color[a] = m.material.base_color_factor[a];
+      ms[i].type = m.material.raytrace_properties[0];
+      ms[i].property = m.material.raytrace_properties[1];
+      ms[i].pad = 0;
+   }
+   std::vector<float4> lights(2 * c->lights.size());
+   for (size_t i = 0; i < c->lights.size(); i++) {
+      const UhGpuLight& l = c->lights[i];
+      lights[2 * i] = make_float4(l.position[0], l.position[1], l.position[2], 0.0f);
+      lights[2 * i + 1] = make_float4(l.intensity[0], l.intensity[1], l.intensity[2], 0.0f);
+   }
+   std::vector<TexInfo> tex(c->textures.size());
+   for (size_t i = 0; i < tex.size(); i++) tex[i] = TexInfo{c->textures[i].dev, c->textures[i].w, c->textures[i].h, c->textures[i].tiles_x, 0};
+
+   HIP_TRY(c, c->d_meshes.alloc(ms.size()));
+   HIP_TRY(c, c->d_lights.alloc(lights.size()));
+   HIP_TRY(c, c->d_tex.alloc(tex.size()));
+   if (!ms.empty()) HIP_TRY(c, hipMemcpy(c->d_meshes.p, ms.data(), ms.size() * sizeof(MeshShade), hipMemcpyHostToDevice));
+   if (!lights.empty()) HIP_TRY(c, hipMemcpy(c->d_lights.p, lights.data(), lights.size() * sizeof(float4), hipMemcpyHostToDevice));
+   if (!tex.empty()) HIP_TRY(c, hipMemcpy(c->d_tex.p, tex.data(), tex.size() * sizeof(TexInfo), hipMemcpyHostToDevice));
+   c->scene.meshes = c->d_meshes.p;
+   c->scene.textures = c->d_tex.p;
+   c->scene.lights = c->d_lights.p;
+   c->scene.unorm_lut = c->d_lut.p;
+   c->scene.num_meshes = (uint32_t)ms.size();
+   c->scene.num_textures = (uint32_t)tex.size();
+   c->scene.num_lights = (uint32_t)c->lights.size();
+   return UH_OK;
+}
+
+static int build_on_device(uh_ctx* c);
+
 int uh_build_acceleration(uh_ctx* c) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    HIP_TRY(c, hipSetDevice(c->device));
+   if (c->device_build) return build_on_device(c);
    auto t0 = std::chrono::steady_clock::now();
    // bake instance transforms: world = ((m0*x + m1*y) + m2*z) + m3 per row (identity: verbatim)
    size_t total = 0;
@@ -581,53 +631,22 @@ int uh_build_acceleration(uh_ctx* c) {
       }
       s.mesh = mi;
    }
-   std::vector<MeshShade> ms(c->meshes.size());
-   for (size_t i = 0; i < c->meshes.size(); i++) {
-      const HostMesh& m = c->meshes[i];
-      std::memcpy(ms[i].w2o, m.w2o, sizeof(m.w2o));
-      ms[i].diffuse_map = m.material.diffuse_map;
-      for (int a = 0; a < 3; a++) ms[i].base_color[a] = m.material.base_color_factor[a];
-      ms[i].type = m.material.raytrace_properties[0];
-      ms[i].property = m.material.raytrace_properties[1];
-      ms[i].pad = 0;
-   }
-   std::vector<float4> lights(2 * c->lights.size());
-   for (size_t i = 0; i < c->lights.size(); i++) {
-      const UhGpuLight& l = c->lights[i];
-      lights[2 * i] = make_float4(l.position[0], l.position[1], l.position[2], 0.0f);
-      lights[2 * i + 1] = make_float4(l.intensity[0], l.intensity[1], l.intensity[2], 0.0f);
-   }
-   std::vector<TexInfo> tex(c->textures.size());
-   for (size_t i = 0; i < tex.size(); i++) tex[i] = TexInfo{c->textures[i].dev, c->textures[i].w, c->textures[i].h, c->textures[i].tiles_x, 0};
-
    if (bo.qnodes.empty()) return fail(c, UH_ERR_INVALID_ARGUMENT, "internal: BVH builder produced no root node");
    if (int st = sync_all(c)) return st;
+   if (int st = upload_scene_tables(c)) return st;
    HIP_TRY(c, c->d_nodes.alloc(bo.qnodes.size() * 4));
    HIP_TRY(c, c->d_tris.alloc(total * 3));
    HIP_TRY(c, c->d_shade.alloc(total * 4));
-   HIP_TRY(c, c->d_meshes.alloc(ms.size()));
-   HIP_TRY(c, c->d_lights.alloc(lights.size()));
-   HIP_TRY(c, c->d_tex.alloc(tex.size()));
    HIP_TRY(c, hipMemcpy(c->d_nodes.p, bo.qnodes.data(), bo.qnodes.size() * sizeof(Node4Q), hipMemcpyHostToDevice));
    if (total) {
       HIP_TRY(c, hipMemcpy(c->d_tris.p, tp.data(), total * sizeof(TriPacket), hipMemcpyHostToDevice));
       HIP_TRY(c, hipMemcpy(c->d_shade.p, sp.data(), total * sizeof(ShadePacket), hipMemcpyHostToDevice));
    }
-   if (!ms.empty()) HIP_TRY(c, hipMemcpy(c->d_meshes.p, ms.data(), ms.size() * sizeof(MeshShade), hipMemcpyHostToDevice));
-   if (!lights.empty()) HIP_TRY(c, hipMemcpy(c->d_lights.p, lights.data(), lights.size() * sizeof(float4), hipMemcpyHostToDevice));
-   if (!tex.empty()) HIP_TRY(c, hipMemcpy(c->d_tex.p, tex.data(), tex.size() * sizeof(TexInfo), hipMemcpyHostToDevice));
    c->scene.nodes = reinterpret_cast<const uint4*>(c->d_nodes.p);
    c->scene.tris = c->d_tris.p;
    c->scene.shade = c->d_shade.p;
-   c->scene.meshes = c->d_meshes.p;
-   c->scene.textures = c->d_tex.p;
-   c->scene.lights = c->d_lights.p;
-   c->scene.unorm_lut = c->d_lut.p;
    c->scene.num_nodes = (uint32_t)bo.nodes.size();
    c->scene.num_tris = (uint32_t)total;
-   c->scene.num_meshes = (uint32_t)ms.size();
-   c->scene.num_textures = (uint32_t)tex.size();
-   c->scene.num_lights = (uint32_t)c->lights.size();
    c->bvh_nodes = c->scene.num_nodes;
    c->bvh_tris = c->scene.num_tris;
    c->packet_keys.resize(total);
@@ -693,6 +712,133 @@ int uh_refit_acceleration(uh_ctx* c) {
    }
    c->built = true;
    c->build_ms = c->refit_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+   return UH_OK;
+}
+
+// uh_build_acceleration with option "device_build": Morton-order tree built by lbvh.hip, boxes by refit.hip
+static int build_on_device(uh_ctx* c) {
+   auto t0 = std::chrono::steady_clock::now();
+   size_t total = 0;
+   for (const HostMesh& m : c->meshes) total += m.indices.size() / 3;
+   if (total > kLeafFirstMask) return fail(c, UH_ERR_CAPACITY, "scene has more than 2^27 triangles");
+   if (int st = sync_all(c)) return st;
+   if (int st = upload_scene_tables(c)) return st;
+   if (!c->src_valid) {
+      std::vector<float> corners(9 * total);
+      std::vector<uint32_t> keys(total);
+      std::vector<ShadePacket> sp(total);
+      size_t t = 0;
+      for (uint32_t mi = 0; mi < c->meshes.size(); mi++) {
+         const HostMesh& m = c->meshes[mi];
+         const uint32_t nt = (uint32_t)m.indices.size() / 3;
+         for (uint32_t p = 0; p < nt; p++, t++) {
+            const UhVertex* v[3] = {&m.vertices[m.indices[3 * (size_t)p]], &m.vertices[m.indices[3 * (size_t)p + 1]], &m.vertices[m.indices[3 * (size_t)p + 2]]};
+            ShadePacket& s = sp[t];
+            for (int k = 0; k < 3; k++)
+               for (int a = 0; a < 3; a++) corners[9 * t + 3 * k + a] = v[k]->pos[a];
+            for (int a = 0; a < 3; a++) {
+               s.n0[a] = v[0]->normal[a];
+               s.n1[a] = v[1]->normal[a];
+               s.n2[a] = v[2]->normal[a];
+            }
+            for (int a = 0; a < 2; a++) {
+               s.uv0[a] = v[0]->uv[a];
+               s.uv1[a] = v[1]->uv[a];
+               s.uv2[a] = v[2]->uv[a];
+            }
+            s.mesh = mi;
+            keys[t] = (mi << kPrimBits) | p;
+         }
+      }
+      HIP_TRY(c, c->d_src_corners.alloc(9 * total));
+      HIP_TRY(c, c->d_src_keys.alloc(total));
+      HIP_TRY(c, c->d_src_shade.alloc(4 * total));
+      if (total) {
+         HIP_TRY(c, hipMemcpy(c->d_src_corners.p, corners.data(), corners.size() * sizeof(float), hipMemcpyHostToDevice));
+         HIP_TRY(c, hipMemcpy(c->d_src_keys.p, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+         HIP_TRY(c, hipMemcpy(c->d_src_shade.p, sp.data(), sp.size() * sizeof(ShadePacket), hipMemcpyHostToDevice));
+      }
+      c->src_valid = true;
+   }
+   // per-mesh rows + a box that holds every centroid: the 8 corners of each mesh's object-space box, transformed
+   std::vector<RefitMesh> rm(c->meshes.size());
+   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+   for (size_t i = 0; i < c->meshes.size(); i++) {
+      const HostMesh& m = c->meshes[i];
+      std::memset(&rm[i], 0, sizeof(RefitMesh));
+      std::memcpy(rm[i].o2w, m.o2w, sizeof(rm[i].o2w));
+      rm[i].identity = is_identity3x4(m.o2w) ? 1u : 0u;
+      float olo[3] = {INFINITY, INFINITY, INFINITY}, ohi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (const UhVertex& v : m.vertices)
+         for (int a = 0; a < 3; a++) {
+            olo[a] = std::fmin(olo[a], v.pos[a]);
+            ohi[a] = std::fmax(ohi[a], v.pos[a]);
+         }
+      if (m.vertices.empty()) continue;
+      for (int k = 0; k < 8; k++) {
+         const float x = (k & 1) ? ohi[0] : olo[0], y = (k & 2) ? ohi[1] : olo[1], z = (k & 4) ? ohi[2] : olo[2];
+         for (int a = 0; a < 3; a++) {
+            const float w = m.o2w[4 * a] * x + m.o2w[4 * a + 1] * y + m.o2w[4 * a + 2] * z + m.o2w[4 * a + 3];
+            lo[a] = std::fmin(lo[a], w);
+            hi[a] = std::fmax(hi[a], w);
+         }
+      }
+   }
+   for (int a = 0; a < 3; a++)
+      if (!(lo[a] <= hi[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a])) lo[a] = hi[a] = 0.0f;
+   const size_t node_cap = total > 1 ? total : 1;
+   HIP_TRY(c, c->d_nodes.alloc(node_cap * 4));
+   HIP_TRY(c, c->d_tris.alloc(total * 3));
+   HIP_TRY(c, c->d_shade.alloc(total * 4));
+   HIP_TRY(c, c->d_obj_corners.alloc(9 * total));
+   HIP_TRY(c, c->d_world_corners.alloc(9 * total));
+   HIP_TRY(c, c->d_node_box.alloc(6 * node_cap));
+   HIP_TRY(c, c->d_refit_meshes.alloc(rm.size()));
+   if (!rm.empty()) HIP_TRY(c, hipMemcpy(c->d_refit_meshes.p, rm.data(), rm.size() * sizeof(RefitMesh), hipMemcpyHostToDevice));
+   LbvhArgs la;
+   la.src_corners = c->d_src_corners.p;
+   la.src_keys = c->d_src_keys.p;
+   la.src_shade = c->d_src_shade.p;
+   la.meshes = c->d_refit_meshes.p;
+   for (int a = 0; a < 3; a++) {
+      la.bounds_lo[a] = lo[a];
+      la.bounds_hi[a] = hi[a];
+   }
+   la.num_tris = (uint32_t)total;
+   la.nodes = reinterpret_cast<uint4*>(c->d_nodes.p);
+   la.node_capacity = (uint32_t)node_cap;
+   la.tris = c->d_tris.p;
+   la.shade = c->d_shade.p;
+   la.obj_corners = c->d_obj_corners.p;
+   uint32_t num_nodes = 1;
+   hipError_t e = lbvh_build(la, c->stream, c->level_start, &num_nodes);
+   if (e != hipSuccess) return fail(c, UH_ERR_HIP, std::string("device BVH build: ") + hipGetErrorString(e));
+   if (total) {
+      RefitArgs a;
+      a.obj_corners = c->d_obj_corners.p;
+      a.meshes = c->d_refit_meshes.p;
+      a.tris = c->d_tris.p;
+      a.world_corners = c->d_world_corners.p;
+      a.nodes = reinterpret_cast<uint4*>(c->d_nodes.p);
+      a.node_box = c->d_node_box.p;
+      a.level_start = c->level_start.data();
+      a.num_levels = (uint32_t)c->level_start.size() - 1;
+      a.num_tris = (uint32_t)total;
+      launch_refit(cfg(c), a);
+      HIP_TRY(c, hipGetLastError());
+   }
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   c->scene.nodes = reinterpret_cast<const uint4*>(c->d_nodes.p);
+   c->scene.tris = c->d_tris.p;
+   c->scene.shade = c->d_shade.p;
+   c->scene.num_nodes = num_nodes;
+   c->scene.num_tris = (uint32_t)total;
+   c->bvh_nodes = num_nodes;
+   c->bvh_tris = (uint32_t)total;
+   c->packet_keys.assign(total, 0u);  // only its size is used once d_obj_corners exists (uh_refit_acceleration)
+   c->topology_valid = true;
+   c->built = true;
+   c->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
    return UH_OK;
 }
 
@@ -1144,6 +1290,10 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->count_visits = value != 0;
    else if (n == "raw_visit_counts")
       c->raw_visit_counts = value != 0;
+   else if (n == "device_build") {
+      if (c->device_build != (value != 0)) c->built = c->topology_valid = false;
+      c->device_build = value != 0;
+   }
    else if (n == "time_kernels") {
       if (c->time_kernels && !value) {
          (void)sync_all(c);

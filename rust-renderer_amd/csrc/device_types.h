@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 #include "bvh.h"
 #include "utopian_hip.h"
@@ -183,6 +184,22 @@ struct RefitArgs {
    uint32_t num_tris;
 };
 void launch_refit(const LaunchCfg&, const RefitArgs&);
+
+// on-device LBVH build (lbvh.hip): topology + packets in Morton order; boxes come from launch_refit afterwards
+struct LbvhArgs {
+   const float* src_corners;     // 9 floats per triangle, object space, mesh order
+   const uint32_t* src_keys;     // mesh << 22 | primitive, mesh order
+   const float4* src_shade;      // ShadePacket (4 float4) per triangle, mesh order
+   const RefitMesh* meshes;
+   float bounds_lo[3], bounds_hi[3];  // world-space box containing every centroid (Morton normalisation)
+   uint32_t num_tris;
+   uint4* nodes;                 // out: Node4Q array (child refs valid, boxes to be refitted)
+   uint32_t node_capacity;       // nodes the array can hold
+   float4* tris;                 // out: TriPacket array in leaf order (keys; refit writes the geometry)
+   float4* shade;                // out: ShadePacket array in leaf order
+   float* obj_corners;           // out: object-space corners in leaf order (the refit input)
+};
+hipError_t lbvh_build(const LbvhArgs&, hipStream_t, std::vector<uint32_t>& level_start, uint32_t* out_nodes);
 
 void launch_pack_tiles(const LaunchCfg&, const float4* acc, float4* out, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);
 void launch_unpack_tiles(const LaunchCfg&, float4* acc, const float4* in, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);

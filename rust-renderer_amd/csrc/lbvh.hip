@@ -1,0 +1,250 @@
+// lbvh.hip — on-device build of the flattened BVH4 ("on-device LBVH build + refit").
+// Option "device_build" makes uh_build_acceleration take this path instead of the host SAH builder
+// (bvh_build.cpp). It replaces the driver's vkCmdBuildAccelerationStructuresKHR on the path
+// utopian/src/raytracing.rs:113-217 (BLAS) / :279-398 (TLAS) for scenes whose geometry changes too
+// often for a host rebuild.
+//
+//   1. bake: object-space corners -> world centroid -> 30-bit Morton code in the scene bounds; the sort key is
+//      (morton << 32 | triangle) so keys are unique and the payload rides in the low word
+//   2. radix sort of the 64-bit keys (hipcub / rocPRIM)
+//   3. binary radix tree over the sorted keys (Karras 2012: every internal node finds its range and split
+//      from the common-prefix lengths, all nodes in parallel)
+//   4. collapse to 4-wide nodes, breadth-first, one launch per level: a subtree of at most kLeafTris
+//      triangles becomes a leaf (a contiguous run of the sorted order), other children get node slots of
+//      the next level from one atomic counter
+//   5. boxes + quantisation: the refit kernels (refit.hip) - a device build is "topology here, boxes by refit"
+// The tree is a Morton-order tree, not a SAH one: it builds in about a millisecond instead of tens and costs
+// more node visits per ray (measured in profiles/README.md). Hits do not depend on the tree (bvh.h), so a
+// device-built scene renders bit for bit what a host-built one does (tests/test_gpu_parity.py).
+#include <hip/hip_runtime.h>
+
+#include <hipcub/hipcub.hpp>
+
+#include "bvh.h"
+#include "device_types.h"
+
+namespace uh {
+
+namespace {
+
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kLeafTris = 2;  // subtrees of at most this many triangles become leaves
+
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {  // 10 bits -> every third bit
+   v = (v * 0x00010001u) & 0xFF0000FFu;
+   v = (v * 0x00000101u) & 0x0F00F00Fu;
+   v = (v * 0x00000011u) & 0xC30C30C3u;
+   v = (v * 0x00000005u) & 0x49249249u;
+   return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_lbvh_keys(const float* __restrict__ src_corners, const uint32_t* __restrict__ src_keys, const RefitMesh* __restrict__ meshes,
+                                                      float3 lo, float3 inv_ext, unsigned long long* __restrict__ keys, uint32_t n) {
+   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+   if (i >= n) return;
+   const RefitMesh m = meshes[src_keys[i] >> kPrimBits];
+   const float* oc = src_corners + 9 * (size_t)i;
+   float c[3] = {0.0f, 0.0f, 0.0f};
+   for (int k = 0; k < 3; k++) {
+      const float x = oc[3 * k], y = oc[3 * k + 1], z = oc[3 * k + 2];
+      if (m.identity) {
+         c[0] += x;
+         c[1] += y;
+         c[2] += z;
+      } else {
+         c[0] += ((m.o2w[0] * x + m.o2w[1] * y) + m.o2w[2] * z) + m.o2w[3];
+         c[1] += ((m.o2w[4] * x + m.o2w[5] * y) + m.o2w[6] * z) + m.o2w[7];
+         c[2] += ((m.o2w[8] * x + m.o2w[9] * y) + m.o2w[10] * z) + m.o2w[11];
+      }
+   }
+   auto q = [](float v, float l, float s) {
+      float t = (v * (1.0f / 3.0f) - l) * s;
+      t = fminf(fmaxf(t, 0.0f), 1.0f);  // NaN -> 0
+      return (uint32_t)fminf(t * 1024.0f, 1023.0f);
+   };
+   const uint32_t morton = (expand10(q(c[0], lo.x, inv_ext.x)) << 2) | (expand10(q(c[1], lo.y, inv_ext.y)) << 1) | expand10(q(c[2], lo.z, inv_ext.z));
+   keys[i] = ((unsigned long long)morton << 32) | i;
+}
+
+// common-prefix length of sorted keys i and j; -1 outside the array
+__device__ __forceinline__ int delta(const unsigned long long* __restrict__ k, int n, int i, int j) {
+   if (j < 0 || j >= n) return -1;
+   return __clzll((long long)(k[i] ^ k[j]));
+}
+
+// internal node i of the binary radix tree over n >= 2 sorted unique keys (Karras 2012, section 3)
+__global__ __launch_bounds__(kBlock) void k_lbvh_tree(const unsigned long long* __restrict__ keys, uint4* __restrict__ node2, uint32_t n) {
+   const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+   const int N = (int)n;
+   if (i >= N - 1) return;
+   const int d = (delta(keys, N, i, i + 1) - delta(keys, N, i, i - 1)) >= 0 ? 1 : -1;
+   const int dmin = delta(keys, N, i, i - d);
+   int lmax = 2;
+   while (delta(keys, N, i, i + lmax * d) > dmin) lmax *= 2;
+   int l = 0;
+   for (int t = lmax / 2; t >= 1; t /= 2)
+      if (delta(keys, N, i, i + (l + t) * d) > dmin) l += t;
+   const int j = i + l * d;
+   const int dnode = delta(keys, N, i, j);
+   int s = 0, t = l;
+   do {
+      t = (t + 1) / 2;
+      if (delta(keys, N, i, i + (s + t) * d) > dnode) s += t;
+   } while (t > 1);
+   const int gamma = i + s * d + (d < 0 ? d : 0);
+   const int first = i < j ? i : j, last = i < j ? j : i;
+   const uint32_t left = (first == gamma) ? (kLeafBit | (uint32_t)gamma) : (uint32_t)gamma;
+   const uint32_t right = (last == gamma + 1) ? (kLeafBit | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+   node2[i] = make_uint4(left, right, (uint32_t)first, (uint32_t)(last - first + 1));
+}
+
+// one BFS level of the 4-wide tree: level node `idx` (global index level_first + idx) collapses the
+// binary subtree rooted at internal node src[idx]
+__global__ __launch_bounds__(kBlock) void k_lbvh_collapse(const uint4* __restrict__ node2, const uint32_t* __restrict__ src, uint32_t level_first, uint32_t level_count,
+                                                          uint32_t next_first, uint32_t* __restrict__ next_src, uint32_t* __restrict__ next_count, uint4* __restrict__ nodes) {
+   const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+   if (idx >= level_count) return;
+   auto count_of = [&](uint32_t ref) { return (ref & kLeafBit) ? 1u : node2[ref].w; };
+   auto first_of = [&](uint32_t ref) { return (ref & kLeafBit) ? (ref & ~kLeafBit) : node2[ref].z; };
+   const uint4 root = node2[src[idx]];
+   uint32_t ch[4] = {root.x, root.y, kEmptyRef, kEmptyRef};
+   int nc = 2;
+   while (nc < 4) {
+      int pick = -1;
+      uint32_t best = kLeafTris;
+      for (int k = 0; k < nc; k++) {
+         const uint32_t c = count_of(ch[k]);
+         if (c > best) {
+            best = c;
+            pick = k;
+         }
+      }
+      if (pick < 0) break;
+      const uint4 e = node2[ch[pick]];
+      ch[pick] = e.x;
+      ch[nc++] = e.y;
+   }
+   uint32_t out[4] = {kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef};
+   for (int k = 0; k < nc; k++) {
+      const uint32_t c = count_of(ch[k]);
+      if (c <= kLeafTris) {
+         out[k] = kLeafBit | (c << kLeafCountShift) | (first_of(ch[k]) & kLeafFirstMask);
+      } else {
+         const uint32_t slot = atomicAdd(next_count, 1u);
+         next_src[slot] = ch[k];
+         out[k] = next_first + slot;
+      }
+   }
+   uint4* nd = nodes + 4 * (size_t)(level_first + idx);
+   nd[0] = make_uint4(0u, 0u, 0u, __float_as_uint(1.0f));
+   nd[1] = make_uint4(__float_as_uint(1.0f), __float_as_uint(1.0f), 0xffffffffu, 0xffffffffu);
+   nd[2] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+   nd[3] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// a tree without internal binary nodes (n <= kLeafTris): one root whose first child is the only leaf
+__global__ void k_lbvh_tiny(uint4* __restrict__ nodes, uint32_t n) {
+   nodes[0] = make_uint4(0u, 0u, 0u, __float_as_uint(1.0f));
+   nodes[1] = make_uint4(__float_as_uint(1.0f), __float_as_uint(1.0f), 0xffffffffu, 0xffffffffu);
+   nodes[2] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+   nodes[3] = make_uint4(n ? (kLeafBit | (n << kLeafCountShift)) : kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef);
+}
+
+// packets in sorted order: object-space corners (refit input), key, shading packet
+__global__ __launch_bounds__(kBlock) void k_lbvh_gather(const unsigned long long* __restrict__ keys, const float* __restrict__ src_corners, const uint32_t* __restrict__ src_keys,
+                                                        const float4* __restrict__ src_shade, float* __restrict__ obj_corners, float4* __restrict__ tris,
+                                                        float4* __restrict__ shade, uint32_t n) {
+   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+   if (i >= n) return;
+   const uint32_t s = (uint32_t)(keys[i] & 0xffffffffull);
+   for (int k = 0; k < 9; k++) obj_corners[9 * (size_t)i + k] = src_corners[9 * (size_t)s + k];
+   for (int k = 0; k < 4; k++) shade[4 * (size_t)i + k] = src_shade[4 * (size_t)s + k];
+   tris[3 * (size_t)i + 2] = make_float4(0.0f, __uint_as_float(src_keys[s]), 0.0f, 0.0f);  // the key; refit writes the rest
+}
+
+}  // namespace
+
+// Builds topology + packets on `stream`. `level_start` (host) receives the BFS levels. Returns the node count.
+// Scratch (keys x2, sort temp, binary nodes, level lists, counters) is allocated and freed here.
+hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_t>& level_start, uint32_t* out_nodes) {
+   const uint32_t n = a.num_tris;
+   level_start.assign({0u, 1u});
+   *out_nodes = 1;
+   if (n <= kLeafTris) {
+      k_lbvh_tiny<<<1, 1, 0, stream>>>(a.nodes, n);
+      if (n) {
+         // identity order
+         unsigned long long* keys = nullptr;
+         hipError_t e = hipMalloc(&keys, n * sizeof(unsigned long long));
+         if (e != hipSuccess) return e;
+         std::vector<unsigned long long> h(n);
+         for (uint32_t i = 0; i < n; i++) h[i] = i;
+         e = hipMemcpyAsync(keys, h.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice, stream);
+         if (e == hipSuccess) k_lbvh_gather<<<1, kBlock, 0, stream>>>(keys, a.src_corners, a.src_keys, a.src_shade, a.obj_corners, a.tris, a.shade, n);
+         hipError_t e2 = hipStreamSynchronize(stream);
+         (void)hipFree(keys);
+         return e != hipSuccess ? e : e2;
+      }
+      return hipStreamSynchronize(stream);
+   }
+   unsigned long long *keys_in = nullptr, *keys_out = nullptr;
+   uint4* node2 = nullptr;
+   uint32_t *list_a = nullptr, *list_b = nullptr, *counter = nullptr;
+   void* temp = nullptr;
+   size_t temp_bytes = 0;
+   hipError_t e = hipSuccess;
+   auto cleanup = [&]() {
+      for (void* p : {(void*)keys_in, (void*)keys_out, (void*)node2, (void*)list_a, (void*)list_b, (void*)counter, temp})
+         if (p) (void)hipFree(p);
+   };
+#define LB_TRY(expr)            \
+   if ((e = (expr)) != hipSuccess) { \
+      cleanup();                \
+      return e;                 \
+   }
+   LB_TRY(hipMalloc(&keys_in, n * sizeof(unsigned long long)));
+   LB_TRY(hipMalloc(&keys_out, n * sizeof(unsigned long long)));
+   LB_TRY(hipMalloc(&node2, (size_t)n * sizeof(uint4)));
+   LB_TRY(hipMalloc(&list_a, (size_t)n * sizeof(uint32_t)));
+   LB_TRY(hipMalloc(&list_b, (size_t)n * sizeof(uint32_t)));
+   LB_TRY(hipMalloc(&counter, sizeof(uint32_t)));
+   const dim3 grid((n + kBlock - 1) / kBlock);
+   const float3 lo = make_float3(a.bounds_lo[0], a.bounds_lo[1], a.bounds_lo[2]);
+   auto inv = [](float l, float h) { return h > l ? 1.0f / (h - l) : 0.0f; };
+   const float3 inv_ext = make_float3(inv(a.bounds_lo[0], a.bounds_hi[0]), inv(a.bounds_lo[1], a.bounds_hi[1]), inv(a.bounds_lo[2], a.bounds_hi[2]));
+   k_lbvh_keys<<<grid, kBlock, 0, stream>>>(a.src_corners, a.src_keys, a.meshes, lo, inv_ext, keys_in, n);
+   LB_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_in, keys_out, (int)n, 0, 62, stream));
+   LB_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+   LB_TRY(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys_in, keys_out, (int)n, 0, 62, stream));
+   k_lbvh_tree<<<grid, kBlock, 0, stream>>>(keys_out, node2, n);
+   k_lbvh_gather<<<grid, kBlock, 0, stream>>>(keys_out, a.src_corners, a.src_keys, a.src_shade, a.obj_corners, a.tris, a.shade, n);
+   // breadth-first collapse, one launch per level; the level sizes come back through one counter
+   level_start.assign({0u});
+   uint32_t level_first = 0, level_count = 1;
+   const uint32_t zero = 0;
+   LB_TRY(hipMemcpyAsync(list_a, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, stream));  // level 0 = binary root 0
+   uint32_t *cur = list_a, *nxt = list_b;
+   while (level_count) {
+      const uint32_t next_first = level_first + level_count;
+      if ((size_t)next_first > (size_t)a.node_capacity) {
+         cleanup();
+         return hipErrorInvalidValue;
+      }
+      LB_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
+      k_lbvh_collapse<<<dim3((level_count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(node2, cur, level_first, level_count, next_first, nxt, counter, a.nodes);
+      uint32_t produced = 0;
+      LB_TRY(hipMemcpyAsync(&produced, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      LB_TRY(hipStreamSynchronize(stream));
+      level_start.push_back(next_first);
+      level_first = next_first;
+      level_count = produced;
+      std::swap(cur, nxt);
+   }
+   *out_nodes = level_first;
+   LB_TRY(hipGetLastError());
+#undef LB_TRY
+   cleanup();
+   return hipSuccess;
+}
+
+}  // namespace uh

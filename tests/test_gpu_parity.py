@@ -516,3 +516,48 @@ def test_random_soup_scenes_match_oracle(seed):
     assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays), overrides
     if not overrides["sky_enabled"]:
         assert np.array_equal(gpu.read_accumulation().view(np.uint32), cpu.read_accumulation().view(np.uint32)), "without the sky integral the image is bit-exact"
+
+
+# ---- on-device LBVH build (option "device_build"): same hits as the host SAH tree, bit for bit -----------
+def _single_triangle_scene():
+    from rust_renderer_amd.camera import Camera
+    from rust_renderer_amd.scenes import Mesh, Model, Scene, _pack_vertices
+    pos = np.float32([[-1, -1, 0], [1, -1, 0], [0, 1, 0]])
+    m = Mesh(_pack_vertices(pos, np.tile(np.float32([0, 0, 1]), (3, 1)), np.zeros((3, 2), np.float32)), np.arange(3, dtype=np.uint32))
+    return Scene("one", [(Model([m], []), None)], [(0.0, 0.0, 3.0)], Camera((0, 0, 4), (0, 0, 0), 60.0, 1.0, 0.01, 100.0))
+
+
+@pytest.mark.parametrize("which", ["cornell", "atrium", "torture", "soup", "one", "empty"])
+def test_device_build_equals_host_build(cornell, atrium, which):
+    from rust_renderer_amd.camera import Camera
+    from rust_renderer_amd.scenes import Model, Scene
+    scene = {"cornell": cornell, "atrium": atrium, "torture": torture_scene(), "soup": _soup_scene(11), "one": _single_triangle_scene(),
+             "empty": Scene("empty", [(Model([], []), None)], [], Camera((0, 0, 4), (0, 0, 0), 60.0, 1.0, 0.01, 100.0))}[which]
+    W, H = 72, 48
+    host = scene.upload(rr.Renderer(W, H))
+    dev = rr.Renderer(W, H)
+    dev.set_option("device_build", 1)
+    scene.upload(dev)
+    assert dev.get_stats().bvh_triangles == host.get_stats().bvh_triangles == scene.num_triangles
+    rays = random_rays(((-3, -1, -3), (3, 3, 3)) if which != "atrium" else ((-14, 0, -7), (14, 10, 7)), 30000, seed=21)
+    if scene.num_triangles:
+        for a, b in zip(host.trace_closest(rays), dev.trace_closest(rays)):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(host.trace_any(rays), dev.trace_any(rays))
+    for r in (host, dev):
+        run_frames(r, scene, W, H, 2, rr.PASS_ALL if scene.lights else rr.PASS_REFERENCE_PT)
+    assert np.array_equal(host.read_accumulation().view(np.uint32), dev.read_accumulation().view(np.uint32))
+    assert list(host.get_stats().rays) == list(dev.get_stats().rays)
+    if scene.num_meshes > 2:
+        # moved instances: device rebuild, then a refit of the device-built tree, against the host rebuild
+        w = rr.transform3x4((0.6, 0.8, 0.7), (0.2, 0.3, -0.1), _rot(0.1, 0.5, -0.2))
+        for r in (host, dev):
+            r.set_instance_transform(1, w)
+            r.initialize_raytracing()
+        w2 = rr.transform3x4((0.9, 0.9, 0.9), (-0.2, 0.1, 0.3))
+        host.set_instance_transform(2, w2)
+        host.initialize_raytracing()
+        dev.set_instance_transform(2, w2)
+        dev.rebuild_tlas()
+        for a, b in zip(host.trace_closest(rays), dev.trace_closest(rays)):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
