@@ -193,6 +193,7 @@ struct LbvhArgs {
    const RefitMesh* meshes;
    float bounds_lo[3], bounds_hi[3];  // world-space box containing every centroid (Morton normalisation)
    uint32_t num_tris;
+   uint32_t leaf_tris;           // subtrees of at most this many triangles become leaves
    uint4* nodes;                 // out: Node4Q array (child refs valid, boxes to be refitted)
    uint32_t node_capacity;       // nodes the array can hold
    float4* tris;                 // out: TriPacket array in leaf order (keys; refit writes the geometry)

@@ -13,8 +13,8 @@
 //      triangles becomes a leaf (a contiguous run of the sorted order), other children get node slots of
 //      the next level from one atomic counter
 //   5. boxes + quantisation: the refit kernels (refit.hip) - a device build is "topology here, boxes by refit"
-// The tree is a Morton-order tree, not a SAH one: it builds in about a millisecond instead of tens and costs
-// more node visits per ray (measured in profiles/README.md). Hits do not depend on the tree (bvh.h), so a
+// The tree is a Morton-order tree, not a SAH one: it builds in a few milliseconds instead of tens to hundreds and
+// costs about a quarter more traversal work per ray (DESIGN.md "On-device build"). Hits do not depend on the tree (bvh.h), so a
 // device-built scene renders bit for bit what a host-built one does (tests/test_gpu_parity.py).
 #include <hip/hip_runtime.h>
 
@@ -28,7 +28,6 @@ namespace uh {
 namespace {
 
 constexpr uint32_t kBlock = 256;
-constexpr uint32_t kLeafTris = 2;  // subtrees of at most this many triangles become leaves
 
 __device__ __forceinline__ uint32_t expand10(uint32_t v) {  // 10 bits -> every third bit
    v = (v * 0x00010001u) & 0xFF0000FFu;
@@ -101,7 +100,8 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_tree(const unsigned long long* 
 // one BFS level of the 4-wide tree: level node `idx` (global index level_first + idx) collapses the
 // binary subtree rooted at internal node src[idx]
 __global__ __launch_bounds__(kBlock) void k_lbvh_collapse(const uint4* __restrict__ node2, const uint32_t* __restrict__ src, uint32_t level_first, uint32_t level_count,
-                                                          uint32_t next_first, uint32_t* __restrict__ next_src, uint32_t* __restrict__ next_count, uint4* __restrict__ nodes) {
+                                                          uint32_t next_first, uint32_t* __restrict__ next_src, uint32_t* __restrict__ next_count, uint4* __restrict__ nodes,
+                                                          uint32_t kLeafTris) {
    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
    if (idx >= level_count) return;
    auto count_of = [&](uint32_t ref) { return (ref & kLeafBit) ? 1u : node2[ref].w; };
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_gather(const unsigned long long
 // Scratch (keys x2, sort temp, binary nodes, level lists, counters) is allocated and freed here.
 hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_t>& level_start, uint32_t* out_nodes) {
    const uint32_t n = a.num_tris;
+   const uint32_t kLeafTris = a.leaf_tris < 1 ? 1u : (a.leaf_tris > 15 ? 15u : a.leaf_tris);  // subtrees of at most this many triangles become leaves
    level_start.assign({0u, 1u});
    *out_nodes = 1;
    if (n <= kLeafTris) {
@@ -231,7 +232,7 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
          return hipErrorInvalidValue;
       }
       LB_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
-      k_lbvh_collapse<<<dim3((level_count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(node2, cur, level_first, level_count, next_first, nxt, counter, a.nodes);
+      k_lbvh_collapse<<<dim3((level_count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(node2, cur, level_first, level_count, next_first, nxt, counter, a.nodes, kLeafTris);
       uint32_t produced = 0;
       LB_TRY(hipMemcpyAsync(&produced, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       LB_TRY(hipStreamSynchronize(stream));
