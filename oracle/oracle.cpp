@@ -1047,6 +1047,10 @@ int orc_add_mesh(orc_ctx* c, const UhVertex* v, uint32_t nv, const uint32_t* idx
    if (c->o.meshes.size() >= UH_MAX_GPU_MESHES) return UH_ERR_CAPACITY;
    for (uint32_t i = 0; i < ni; i++)
       if (idx[i] >= nv) return UH_ERR_INVALID_ARGUMENT;
+   for (uint32_t i = 0; i < nv; i++)
+      if (!std::isfinite(v[i].pos[0]) || !std::isfinite(v[i].pos[1]) || !std::isfinite(v[i].pos[2])) return UH_ERR_INVALID_ARGUMENT;
+   for (int i = 0; i < 12; i++)
+      if (!std::isfinite(world3x4[i])) return UH_ERR_INVALID_ARGUMENT;
    MeshRec m;
    m.vertices.assign(v, v + nv);
    m.indices.assign(idx, idx + ni);
@@ -1071,7 +1075,9 @@ int orc_add_light(orc_ctx* c, const UhGpuLight* l, uint32_t* out_index) {
    return UH_OK;
 }
 int orc_set_instance_transform(orc_ctx* c, uint32_t mesh_index, const float world3x4[12]) {
-   if (!c || mesh_index >= c->o.meshes.size()) return UH_ERR_INVALID_ARGUMENT;
+   if (!c || mesh_index >= c->o.meshes.size() || !world3x4) return UH_ERR_INVALID_ARGUMENT;
+   for (int i = 0; i < 12; i++)
+      if (!std::isfinite(world3x4[i])) return UH_ERR_INVALID_ARGUMENT;
    MeshRec& m = c->o.meshes[mesh_index];
    std::memcpy(m.o2w, world3x4, sizeof(m.o2w));
    if (is_identity3x4(m.o2w)) {

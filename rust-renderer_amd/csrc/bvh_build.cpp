@@ -82,7 +82,7 @@ struct Builder {
       int best_axis = -1, best_split = -1;
       for (int a = 0; a < 3; a++) {
          float lo = cb.lo[a], ext = cb.hi[a] - cb.lo[a];
-         if (!(ext > 0)) continue;
+         if (!(ext > 0) || !std::isfinite(ext)) continue;
          Box bb[NB];
          uint32_t bc[NB];
          for (int b = 0; b < NB; b++) {
@@ -187,6 +187,14 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
       b.grow_pt(c);
       b.grow_pt(c + 3);
       b.grow_pt(c + 6);
+      // a triangle with a non-finite corner can never be hit (NaN fails every comparison of the slab and
+      // triangle tests, an infinite edge turns the barycentrics into NaN): it gets a point box at the origin so
+      // that the split search below only ever sees finite numbers (NaN breaks the ordering std::nth_element needs)
+      bool finite = true;
+      for (int k = 0; k < 9; k++) finite = finite && std::isfinite(c[k]);
+      for (int a = 0; a < 3; a++) finite = finite && std::isfinite(0.5f * (b.lo[a] + b.hi[a]));
+      if (!finite)
+         for (int a = 0; a < 3; a++) b.lo[a] = b.hi[a] = 0.0f;
       tb[i] = b;
       for (int a = 0; a < 3; a++) cen[3 * (size_t)i + a] = 0.5f * (b.lo[a] + b.hi[a]);
    }
@@ -269,7 +277,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
             int best_axis = -1, best_split = -1;
             for (int a = 0; a < 3; a++) {
                float lo = cb.lo[a], ext = cb.hi[a] - cb.lo[a];
-               if (!(ext > 0)) continue;
+               if (!(ext > 0) || !std::isfinite(ext)) continue;
                Box bb[NB];
                uint32_t bc[NB];
                for (int b = 0; b < NB; b++) {
@@ -461,7 +469,9 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
          if ((double)origin > mn) origin = std::nextafterf(origin, -INFINITY);
          double ext = mx - (double)origin;
          int e = -100;
-         if (ext > 0) {
+         if (!(ext < 1e38)) {
+            e = 120;  // non-finite or overflowing extent (only from non-finite world-space geometry): no search
+         } else if (ext > 0) {
             e = (int)std::ceil(std::log2(ext / 255.0));
             while (std::ldexp(255.0, e) < ext) e++;
             if (e < -100) e = -100;

@@ -477,6 +477,11 @@ int uh_add_mesh(uh_ctx* c, const UhVertex* vertices, uint32_t num_vertices, cons
    if (num_indices / 3 > (1u << kPrimBits)) return fail(c, UH_ERR_CAPACITY, "uh_add_mesh: more than 4 Mi triangles in one mesh");
    for (uint32_t i = 0; i < num_indices; i++)
       if (indices[i] >= num_vertices) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_add_mesh: index out of range");
+   for (uint32_t i = 0; i < num_vertices; i++)
+      if (!std::isfinite(vertices[i].pos[0]) || !std::isfinite(vertices[i].pos[1]) || !std::isfinite(vertices[i].pos[2]))
+         return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_add_mesh: vertex position is not finite");
+   for (int i = 0; i < 12; i++)
+      if (!std::isfinite(world3x4[i])) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_add_mesh: transform is not finite");
    HostMesh m;
    m.vertices.assign(vertices, vertices + num_vertices);
    m.indices.assign(indices, indices + num_indices);
@@ -510,6 +515,8 @@ int uh_get_num_lights(uh_ctx* c, uint32_t* out) {
 int uh_set_instance_transform(uh_ctx* c, uint32_t mesh_index, const float world3x4[12]) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (mesh_index >= c->meshes.size() || !world3x4) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_set_instance_transform: bad mesh index");
+   for (int i = 0; i < 12; i++)
+      if (!std::isfinite(world3x4[i])) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_set_instance_transform: transform is not finite");
    set_transform(c->meshes[mesh_index], world3x4);
    c->built = false;
    return UH_OK;

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(uint4* __restrict__ node
       const float org = (float)mn;
       const double ext = mx - (double)org;
       int e = -100;
-      if (ext > 0) {
+      if (!(ext < 1e38)) {
+         e = 120;  // non-finite or overflowing extent (only from non-finite world-space geometry): no search
+      } else if (ext > 0) {
          int x;
          double mant = frexp(ext / 255.0, &x);  // ext/255 = mant * 2^x, mant in [0.5, 1)
          e = (mant == 0.5) ? x - 1 : x;

@@ -22,7 +22,7 @@ static float rnd() {
    return (float)w / 4294967296.0f;
 }
 
-static int check(const std::vector<float>& corners, uint32_t max_leaf, int threads, const char* name) {
+static int check(const std::vector<float>& corners, uint32_t max_leaf, int threads, const char* name, bool geometry = true) {
    const uint32_t n = (uint32_t)(corners.size() / 9);
    std::vector<uint32_t> keys(n);
    for (uint32_t i = 0; i < n; i++) keys[i] = i;
@@ -68,7 +68,7 @@ static int check(const std::vector<float>& corners, uint32_t max_leaf, int threa
             float qhi = q.origin[a] + scale[a] * (float)((q.qhi[a] >> (8 * k)) & 0xff);
             // the kernel evaluates origin + scale*q in t-space; in world space allow one ulp of the sum
             float slack = 4e-7f * std::fmax(std::fabs(lo[a]), std::fabs(hi[a])) + 1e-30f;
-            if (!(qlo <= lo[a] + slack) || !(qhi >= hi[a] - slack)) fail("quantised box does not contain the full box", ni, (uint32_t)(k * 3 + a));
+            if (geometry && (!(qlo <= lo[a] + slack) || !(qhi >= hi[a] - slack))) fail("quantised box does not contain the full box", ni, (uint32_t)(k * 3 + a));
          }
          if (c & kLeafBit) {
             uint32_t first = c & kLeafFirstMask, cnt = (c >> kLeafCountShift) & 0xf;
@@ -81,7 +81,7 @@ static int check(const std::vector<float>& corners, uint32_t max_leaf, int threa
                const float* t = &corners[9 * (size_t)out.tri_order[p]];
                for (int v = 0; v < 3; v++)
                   for (int a = 0; a < 3; a++)
-                     if (!(t[3 * v + a] >= lo[a]) || !(t[3 * v + a] <= hi[a])) fail("triangle outside its leaf box", ni, p);
+                     if (geometry && (!(t[3 * v + a] >= lo[a]) || !(t[3 * v + a] <= hi[a]))) fail("triangle outside its leaf box", ni, p);
             }
          } else {
             if (c >= out.nodes.size()) {
@@ -96,7 +96,7 @@ static int check(const std::vector<float>& corners, uint32_t max_leaf, int threa
                   const float clo[3] = {ch.lox[j], ch.loy[j], ch.loz[j]}, chi[3] = {ch.hix[j], ch.hiy[j], ch.hiz[j]};
                   for (int a = 0; a < 3; a++) {
                      float pad = 2e-4f + 2e-5f * std::fmax(std::fabs(clo[a]), std::fabs(chi[a]));
-                     if (!(clo[a] >= lo[a] - pad) || !(chi[a] <= hi[a] + pad)) fail("grandchild box escapes its parent slot", ni, c);
+                     if (geometry && (!(clo[a] >= lo[a] - pad) || !(chi[a] <= hi[a] + pad))) fail("grandchild box escapes its parent slot", ni, c);
                   }
                }
             st.push_back({c});
@@ -152,6 +152,11 @@ int main() {
          planar.insert(planar.end(), t, t + 9);
       }
       errors += check(planar, 4, 4, "coplanar sheet");
+      // non-finite vertices must not break the structure (every packet in exactly one leaf, no crash): such
+      // triangles are never hit (NaN fails every comparison in the slab and triangle tests)
+      std::vector<float> poisoned = planar;
+      for (size_t i = 0; i < poisoned.size(); i += 997) poisoned[i] = (i & 1) ? NAN : ((i & 2) ? INFINITY : -INFINITY);
+      errors += check(poisoned, 4, 4, "NaN / inf vertices", false);
    }
    std::printf(errors ? "BVH CHECK FAILED (%d)\n" : "BVH CHECK OK\n", errors);
    return errors ? 1 : 0;

@@ -561,3 +561,26 @@ def test_device_build_equals_host_build(cornell, atrium, which):
         dev.rebuild_tlas()
         for a, b in zip(host.trace_closest(rays), dev.trace_closest(rays)):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_non_finite_geometry_is_rejected_at_the_boundary(cornell):
+    m = cornell.models[0][0].meshes[0]
+    r = rr.Renderer(16, 16)
+    for bad in (np.nan, np.inf):
+        v = m.vertices.copy()
+        v["pos"][1, 2] = bad
+        with pytest.raises(rr.UtopianError):
+            r.add_mesh(v, m.indices, m.material_struct(), None)
+    mesh = r.add_mesh(m.vertices, m.indices, m.material_struct(), None)
+    w = rr.identity3x4()
+    w[3] = np.inf
+    with pytest.raises(rr.UtopianError):
+        r.set_instance_transform(mesh, w)
+    # finite input whose world-space image overflows: the builders cope (such triangles are simply never hit)
+    big = rr.transform3x4((3e38, 3e38, 3e38), (0, 0, 0))
+    r.set_instance_transform(mesh, big)
+    for dev in (0, 1):
+        r.set_option("device_build", dev)
+        r.initialize_raytracing()
+        t, _, _ = r.trace_closest(random_rays(((-1, -1, -1), (1, 1, 1)), 1000, seed=3))
+        assert np.isfinite(t[:, 0]).all()

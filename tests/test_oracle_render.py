@@ -205,3 +205,25 @@ def test_oracle_bvh_equals_brute_force_on_torture_geometry():
     for x, y in zip(a, b):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     assert (a[1] == 0).sum() > 500 and not (a[1] == 1).any() and not (a[1] == 2).any() and not (a[1] == 3).any()
+
+
+def test_non_finite_geometry_is_rejected_at_the_boundary():
+    """a NaN / inf vertex or transform never reaches the builders (the driver's behaviour on such input is undefined)"""
+    import rust_renderer_amd as rr
+    scene = rr.scenes.cornell_scene(subdivisions=0, tex_size=4)
+    m = scene.models[0][0].meshes[0]
+    o = oa.OracleRenderer(16, 16)
+    for bad in (np.nan, np.inf, -np.inf):
+        v = m.vertices.copy()
+        v["pos"][1, 2] = bad
+        with pytest.raises(rr.UtopianError):
+            o.add_mesh(v, m.indices, m.material_struct(), None)
+        w = rr.identity3x4()
+        w[7] = bad
+        with pytest.raises(rr.UtopianError):
+            o.add_mesh(m.vertices, m.indices, m.material_struct(), w)
+    mesh = o.add_mesh(m.vertices, m.indices, m.material_struct(), None)
+    w = rr.identity3x4()
+    w[0] = np.nan
+    with pytest.raises(rr.UtopianError):
+        o.set_instance_transform(mesh, w)
