@@ -204,6 +204,8 @@ int uh_build_acceleration(uh_ctx* ctx);
 int uh_refit_acceleration(uh_ctx* ctx);
 
 /* ---- per frame ------------------------------------------------------------------------- */
+/* UH_ERR_INVALID_ARGUMENT for view->num_bounces > 64, view->samples_per_frame > 4096, view->num_lights beyond the
+ * lights added; UH_ERR_NOT_BUILT before uh_build_acceleration (or after moved instances without view->rebuild_tlas). */
 int uh_render_frame(uh_ctx* ctx, const UhViewUniformData* view, uint32_t pass_mask);
 /* `count` consecutive frames of the reference_pt pass with an unchanged camera: frame i is rendered
  * with total_samples = view->total_samples + i * samples_per_frame, exactly what `count` calls of

@@ -1004,6 +1004,7 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
    }
    if (!c->built) return fail(c, UH_ERR_NOT_BUILT, "uh_render_frame before uh_build_acceleration");
    if (view->num_bounces > kMaxBounces) return fail(c, UH_ERR_INVALID_ARGUMENT, "num_bounces > 64");
+   if (view->samples_per_frame > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "samples_per_frame > 4096 (the reference UI stops at 10)");
    if (view->num_lights > c->lights.size() && (view->lights_enabled == 1 || (pass_mask & UH_PASS_RESTIR)))
       return fail(c, UH_ERR_INVALID_ARGUMENT, "view.num_lights exceeds the lights added with uh_add_light");
    HIP_TRY(c, hipSetDevice(c->device));
