@@ -28,7 +28,7 @@ from .types import (
 )
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libutopian_hip.so")
+LIB_PATH = os.environ.get("UTOPIAN_HIP_LIB") or os.path.join(_HERE, "libutopian_hip.so")  # UTOPIAN_HIP_LIB: an alternative build of the same library (experiments)
 
 
 class UtopianError(RuntimeError):
