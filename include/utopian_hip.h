@@ -259,8 +259,22 @@ int uh_resolve_output(uh_ctx* ctx, uint32_t total_samples, uint32_t accumulation
 /* raw device pointers (zero-copy wrap by the caller, e.g. for RCCL): 0 accumulation RGBA32F,
  * 1 output BGRA8 */
 int uh_device_pointer(uh_ctx* ctx, int which, void** out);
-/* the HIP stream all work of this context is enqueued on (hipStream_t as void*) */
+/* the HIP stream all work of this context is enqueued on (hipStream_t as void*); also makes the context's device
+ * the calling thread's current device */
 int uh_stream(uh_ctx* ctx, void** out);
+
+/* ---- GPU extraction of the reference's marching-cubes density field (BASELINE configs[4]) --------
+ * Adds the iso-surface {density = 0} of utopian/shaders/marching_cubes/marching_cubes.comp:83-103 (torus over a box,
+ * plus the sphere of radius 8 |sin(0.3 time)|; shapes placed in a 32-unit domain) sampled on a resolution^3 grid over
+ * [lo, hi]^3 as one mesh with uh_add_mesh semantics. Extraction runs on the device (marching tetrahedra: the cube's 6
+ * tetrahedra are cut directly, see csrc/isosurface.hip for why not the reference's case table); vertex normals come
+ * from the density gradient, uv = position.xz / (hi - lo). *out_triangles receives the triangle count; when nothing
+ * crosses the iso value no mesh is added and *out_mesh_index is 0xffffffff. UH_ERR_CAPACITY above 4 Mi triangles. */
+int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo, float hi, float time, const UhGpuMaterial* material,
+                           const float world3x4[12], uint32_t* out_mesh_index, uint32_t* out_triangles);
+/* the context's host copy of a mesh (Model keeps CPU copies, primitive.rs:19-24): sizes, then the data */
+int uh_mesh_info(uh_ctx* ctx, uint32_t mesh_index, uint32_t* num_vertices, uint32_t* num_indices);
+int uh_read_mesh(uh_ctx* ctx, uint32_t mesh_index, UhVertex* vertices, uint32_t* indices);
 
 /* ---- several GPUs behind ONE application process (SURVEY.md section 8b "multi-GPU", 8e) ------------
  * The reference application is a single process with one render thread (prototype/src/main.rs:86-570);

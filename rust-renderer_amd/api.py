@@ -238,6 +238,32 @@ class Renderer:
             mesh_ids.append(self.add_mesh(mesh.vertices, mesh.indices, mat, w))
         return mesh_ids
 
+    def add_isosurface_mesh(self, resolution, lo, hi, time=0.0, material=None, world3x4=None):
+        """uh_add_isosurface_mesh: the reference's marching-cubes density field, extracted on the GPU.
+        Returns (mesh index or None, triangle count)."""
+        if material is None:
+            material = make_material(base_color=(0.8, 0.8, 0.8, 1.0), diffuse_map=self.default_diffuse_map())
+        w = identity3x4() if world3x4 is None else np.ascontiguousarray(world3x4, dtype=np.float32).reshape(12)
+        fn = self._lib.uh_add_isosurface_mesh
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.POINTER(GpuMaterial), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        fn.restype = C.c_int
+        mesh, tris = C.c_uint32(), C.c_uint32()
+        self._check(fn(self._ctx, int(resolution), float(lo), float(hi), float(time), C.byref(material), w.ctypes.data_as(C.POINTER(C.c_float)), C.byref(mesh), C.byref(tris)))
+        return (None if mesh.value == 0xFFFFFFFF else mesh.value), tris.value
+
+    def read_mesh(self, mesh_index):
+        """the context's host copy of a mesh: (vertices as VERTEX_DTYPE, indices)"""
+        lib = self._lib
+        lib.uh_mesh_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.uh_read_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.uh_mesh_info.restype = lib.uh_read_mesh.restype = C.c_int
+        nv, ni = C.c_uint32(), C.c_uint32()
+        self._check(lib.uh_mesh_info(self._ctx, mesh_index, C.byref(nv), C.byref(ni)))
+        v = np.zeros(nv.value, dtype=VERTEX_DTYPE)
+        idx = np.zeros(ni.value, dtype=np.uint32)
+        self._check(lib.uh_read_mesh(self._ctx, mesh_index, v.ctypes.data, idx.ctypes.data))
+        return v, idx
+
     def default_diffuse_map(self):
         """Renderer::initialize's default_diffuse_map (renderer.rs:202-220): a white texel."""
         if not hasattr(self, "_default_diffuse"):

@@ -1427,8 +1427,26 @@ int uh_device_pointer(uh_ctx* c, int which, void** out) {
    return UH_OK;
 }
 
+int uh_mesh_info(uh_ctx* c, uint32_t mesh_index, uint32_t* num_vertices, uint32_t* num_indices) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (mesh_index >= c->meshes.size()) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_mesh_info: bad mesh index");
+   if (num_vertices) *num_vertices = (uint32_t)c->meshes[mesh_index].vertices.size();
+   if (num_indices) *num_indices = (uint32_t)c->meshes[mesh_index].indices.size();
+   return UH_OK;
+}
+
+int uh_read_mesh(uh_ctx* c, uint32_t mesh_index, UhVertex* vertices, uint32_t* indices) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (mesh_index >= c->meshes.size()) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_read_mesh: bad mesh index");
+   const HostMesh& m = c->meshes[mesh_index];
+   if (vertices && !m.vertices.empty()) std::memcpy(vertices, m.vertices.data(), m.vertices.size() * sizeof(UhVertex));
+   if (indices && !m.indices.empty()) std::memcpy(indices, m.indices.data(), m.indices.size() * sizeof(uint32_t));
+   return UH_OK;
+}
+
 int uh_stream(uh_ctx* c, void** out) {
    if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));  // the caller is about to enqueue on it
    *out = (void*)c->stream;
    return UH_OK;
 }

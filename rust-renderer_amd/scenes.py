@@ -87,17 +87,29 @@ class Scene:
     lights: list  # [(x, y, z)]
     camera: Camera
     view_flags: dict = field(default_factory=dict)
+    # (resolution, lo, hi, host_fallback): an iso-surface mesh that a HIP renderer extracts on the GPU
+    # (uh_add_isosurface_mesh); other backends get host_fallback() -> Mesh in its place, as mesh 0
+    device_isosurface: tuple = None
+    device_triangles: int = 0
 
     @property
     def num_triangles(self):
-        return sum(m.num_triangles for model, _ in self.models for m in model.meshes)
+        return self.device_triangles + sum(m.num_triangles for model, _ in self.models for m in model.meshes)
 
     @property
     def num_meshes(self):
-        return sum(len(model.meshes) for model, _ in self.models)
+        return (1 if self.device_isosurface else 0) + sum(len(model.meshes) for model, _ in self.models)
 
     def upload(self, renderer):
         """Renderer::add_model / add_light for every model and light, then Raytracing::initialize."""
+        if self.device_isosurface:
+            res, lo, hi, host_fallback = self.device_isosurface
+            if renderer.backend == "hip":
+                _, self.device_triangles = renderer.add_isosurface_mesh(res, lo, hi)
+            else:
+                mesh = host_fallback()
+                self.device_triangles = mesh.num_triangles
+                renderer.add_model(Model([mesh], []), None)
         for model, transform in self.models:
             renderer.add_model(model, transform)
         for p in self.lights:
@@ -502,6 +514,7 @@ def scene_for_config(config, **kw):
     if config == 4:
         kw.pop("tex_size", None)
         kw.pop("detail", None)
+        kw.setdefault("device", True)
         return isosurface_scene(**kw)
     raise ValueError(f"config {config} is not defined in BASELINE.json")
 
@@ -571,10 +584,7 @@ def extract_isosurface(density, lo, hi, resolution, slab=16):
     return np.concatenate(tris) if tris else np.zeros((0, 3, 3))
 
 
-def isosurface_scene(resolution=512):
-    """BASELINE.json configs[4]: the 512^3 isosurface of the reference's density field (torus above a
-    box, marching_cubes.comp:83-103 scaled to a 32-unit domain), one Lambertian mesh on a ground
-    plane, sky + sun. ~1.3 M triangles at 512^3."""
+def _isosurface_host_mesh(resolution):
     T = extract_isosurface(reference_density, 0.0, 32.0, resolution)
     # drop degenerate slivers (zero area), keep the soup unindexed
     n = np.cross(T[:, 1] - T[:, 0], T[:, 2] - T[:, 0])
@@ -585,12 +595,23 @@ def isosurface_scene(resolution=512):
     nrm = -g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-20)  # density grows inwards
     uv = pos[:, [0, 2]] / 32.0
     verts = _pack_vertices(pos.astype(f32), nrm.astype(f32), uv.astype(f32))
-    idx = np.arange(len(pos), dtype=u32)
-    meshes = [Mesh(verts, idx, LAMBERTIAN, 0.0, (0.8, 0.8, 0.8, 1.0), None, identity3x4(), "isosurface"),
-              Mesh(*quad((-64, 4.99, -64), (0, 0, 160), (160, 0, 0), 32, 32, uv_scale=(8, 8)), base_color=(0.6, 0.6, 0.6, 1.0), name="ground")]
+    return Mesh(verts, np.arange(len(pos), dtype=u32), LAMBERTIAN, 0.0, (0.8, 0.8, 0.8, 1.0), None, identity3x4(), "isosurface")
+
+
+def isosurface_scene(resolution=512, device=False):
+    """BASELINE.json configs[4]: the 512^3 isosurface of the reference's density field (torus above a
+    box, marching_cubes.comp:83-103 scaled to a 32-unit domain), one Lambertian mesh on a ground
+    plane, sky + sun; ~1.65 M triangles at 512^3. device=True: a HIP renderer extracts the mesh on the
+    GPU at upload (uh_add_isosurface_mesh, milliseconds); otherwise (and for the oracle) the vectorised
+    host marching-tetrahedra pass below builds it (the better part of a minute at 512^3)."""
+    ground = Mesh(*quad((-64, 4.99, -64), (0, 0, 160), (160, 0, 0), 32, 32, uv_scale=(8, 8)), base_color=(0.6, 0.6, 0.6, 1.0), name="ground")
     cam = Camera((27.0, 19.0, 33.0), (16.0, 14.0, 16.0), 60.0, 16.0 / 9.0, 0.01, 1000.0)
     flags = dict(sky_enabled=1, sun_shadow_enabled=1, lights_enabled=0, use_ris_light_sampling=0)
-    return Scene("isosurface", [(Model(meshes, []), None)], [], cam, flags)
+    if device:
+        sc = Scene("isosurface", [(Model([ground], []), None)], [], cam, flags)
+        sc.device_isosurface = (resolution, 0.0, 32.0, lambda: _isosurface_host_mesh(resolution))
+        return sc
+    return Scene("isosurface", [(Model([_isosurface_host_mesh(resolution), ground], []), None)], [], cam, flags)
 
 
 BISTRO_SEED = 0x42495354
