@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only rank 0's tiles of an N-rank partition (what one rank sees at --gpus N)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=3")
+    ap.add_argument("--cook-torrance", action="store_true", help="extension (SURVEY 8f N2): the diffuse materials of configs 1-3 become Cook-Torrance (material type 4)")
     ap.add_argument("--cpu-sample", type=str, default="1920x1080x8", help="WxHx(max frames) rendered by the CPU oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline stops after the first frame that ends beyond this many seconds")
     return ap.parse_args()
@@ -79,6 +80,8 @@ def main():
     kw = dict(tex_size=args.tex_size)
     if args.detail != 1.0 or args.config != 3:
         kw["detail"] = args.detail
+    if args.cook_torrance and args.config in (1, 2, 3):
+        kw["cook_torrance"] = True
     scene = rr.scenes.scene_for_config(args.config, **kw)
     renderer = rr.Renderer(W, H, device=local_rank)
     for kv in args.opt:

@@ -61,7 +61,8 @@ typedef struct UhGpuMaterial {
    float metallic_factor;        /* @32 */
    float roughness_factor;       /* @36 */
    float padding[2];             /* @40 */
-   float raytrace_properties[4]; /* @48: x = 0 lambertian,1 metal,2 dielectric,3 diffuse light; y = fuzz | ior */
+   float raytrace_properties[4]; /* @48: x = 0 lambertian,1 metal,2 dielectric,3 diffuse light (reference.rchit:47-89), 4 = Cook-Torrance from
+                                  * metallic_factor / roughness_factor (extension, SURVEY 8f N2: no reference scene uses it); y = fuzz | ior */
 } UhGpuMaterial;
 
 /* utopian/src/renderer.rs:38-44 (12 B) */

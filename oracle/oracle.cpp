@@ -581,6 +581,33 @@ static inline V3 refract(V3 I, V3 N, float eta) {
    return I * eta - N * (eta * dn + std::sqrt(k));
 }
 
+// Material type 4 - an EXTENSION that no reference scene uses: the Cook-Torrance BRDF of
+// include/pbr_lighting.glsl:20-79 / include/brdf.glsl:3-36,82-85 evaluated for the Lambertian-style scatter
+// direction and returned as BRDF * cos / pdf (pdf = cos/pi): kD * baseColor + specular * pi.
+static V3 pbr_weight(V3 N, V3 V, V3 L, V3 base, float metallic, float roughness) {
+   const float PI = 3.14159265359f;
+   const V3 H = normalize(V + L);
+   const float a = roughness * roughness, a2 = a * a;                                   // brdf.glsl:5-6
+   const float NdotH = std::fmax(dot(N, H), 0.0f), NdotH2 = NdotH * NdotH;               // :7-8
+   float denom = NdotH2 * (a2 - 1.0f) + 1.0f;                                            // :11
+   denom = (PI * denom) * denom;                                                         // :12
+   const float NDF = a2 / denom;                                                         // :14
+   const float NdotV = std::fmax(dot(N, V), 0.0f), NdotL = std::fmax(dot(N, L), 0.0f);   // :30-31
+   const float r = roughness + 1.0f, k = (r * r) / 8.0f;                                 // :19-20
+   const float gV = NdotV / (NdotV * (1.0f - k) + k), gL = NdotL / (NdotL * (1.0f - k) + k);  // :22-25
+   const float G = gL * gV;                                                              // :35
+   const float c = std::fmin(std::fmax(1.0f - std::fmax(dot(H, V), 0.0f), 0.0f), 1.0f);  // :84
+   const float c5 = ((c * c) * (c * c)) * c;
+   const float om = 1.0f - metallic;
+   const V3 F0 = v3(0.04f * om + base.x * metallic, 0.04f * om + base.y * metallic, 0.04f * om + base.z * metallic);  // pbr_lighting.glsl:29-30
+   const V3 F = v3(F0.x + (1.0f - F0.x) * c5, F0.y + (1.0f - F0.y) * c5, F0.z + (1.0f - F0.z) * c5);
+   const V3 kD = v3((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);            // :65-67
+   const float den = (4.0f * NdotV) * NdotL + 0.0001f;                                   // :70
+   const float dg = NDF * G;
+   const V3 spec = v3((dg * F.x) / den, (dg * F.y) / den, (dg * F.z) / den);             // :69-71
+   return v3(kD.x * base.x + spec.x * PI, kD.y * base.y + spec.y * PI, kD.z * base.z + spec.z * PI);  // :75 times pi / NdotL
+}
+
 static void closest_hit_shader(Oracle& o, const Hit& h, V3 rayDir, Payload& pl) {
    const MeshRec& mesh = o.meshes[h.mesh];                                    // rchit:22
    const UhGpuMaterial& material = mesh.material;                             // rchit:23
@@ -629,6 +656,11 @@ static void closest_hit_shader(Oracle& o, const Hit& h, V3 rayDir, Payload& pl) 
          scatter = refract(nd, outward, ratio);
       isScattered = true;
       color = v3(1, 1, 1);
+   } else if (type == 4.0f) {
+      // EXTENSION (never produced by the reference's scenes): Cook-Torrance, see pbr_weight()
+      scatter = world_normal + randomPointInUnitSphere(pl.seed);
+      isScattered = dot(rayDir, world_normal) < 0.0f;
+      color = pbr_weight(world_normal, -1.0f * normalize(rayDir), normalize(scatter), color, material.metallic_factor, material.roughness_factor);
    } else {                                                                   // rchit:85-89 DiffuseLight
       isScattered = false;
       color = v3(1, 1, 1);

@@ -535,6 +535,9 @@ static int upload_scene_tables(uh_ctx* c) {
       ms[i].type = m.material.raytrace_properties[0];
       ms[i].property = m.material.raytrace_properties[1];
       ms[i].pad = 0;
+      ms[i].metallic = m.material.metallic_factor;
+      ms[i].roughness = m.material.roughness_factor;
+      ms[i].pad2[0] = ms[i].pad2[1] = 0.0f;
    }
    std::vector<float4> lights(2 * c->lights.size());
    for (size_t i = 0; i < c->lights.size(); i++) {

@@ -53,7 +53,7 @@ struct DeviceStats {
    unsigned long long closest_hits, misses;
 };
 
-// per-mesh shading record (64 B): inverse instance rotation/scale + the material fields the
+// per-mesh shading record (80 B): inverse instance rotation/scale + the material fields the
 // closest-hit shader reads (reference.rchit:22-23,32,40-41,47-89)
 struct alignas(16) MeshShade {
    float w2o[9];  // row-major inverse of the object-to-world upper 3x3
@@ -62,8 +62,10 @@ struct alignas(16) MeshShade {
    float type;      // raytrace_properties.x
    float property;  // raytrace_properties.y
    uint32_t pad;
+   float metallic, roughness;  // metallic_factor / roughness_factor: read by material type 4 only (Cook-Torrance extension)
+   float pad2[2];
 };
-static_assert(sizeof(MeshShade) == 64, "mesh shading record");
+static_assert(sizeof(MeshShade) == 80, "mesh shading record");
 
 struct TexInfo {
    const uchar4* texels;

@@ -1171,6 +1171,35 @@ __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState
 // ------------------------------------------------------------------------------------------
 // shade_hit — reference.rchit:20-92 + rgen:48-61 and the light-sample selection of rgen:81-110
 // ------------------------------------------------------------------------------------------
+// Material type 4 - an EXTENSION that no reference scene uses: the Cook-Torrance BRDF of
+// include/pbr_lighting.glsl:20-79 / include/brdf.glsl:3-36,82-85 (GGX D, Smith-Schlick G with k = (r+1)^2/8, Schlick F,
+// kD = (1-F)(1-metallic), +0.0001 in the denominator) evaluated for the Lambertian-style scatter direction
+// L = normalize(n + randomPointInUnitSphere) and returned as BRDF * cos / pdf with pdf = cos/pi, i.e.
+// kD * baseColor + specular * pi. Same operations in the same order as oracle.cpp::pbr_weight (bit-identical).
+__device__ __forceinline__ V3 pbr_weight(V3 N, V3 V, V3 L, V3 base, float metallic, float roughness) {
+   const float PI = 3.14159265359f;
+   const V3 H = normalize3(V + L);
+   const float a = roughness * roughness, a2 = a * a;
+   const float NdotH = fmaxf(dot3(N, H), 0.0f), NdotH2 = NdotH * NdotH;
+   float denom = NdotH2 * (a2 - 1.0f) + 1.0f;
+   denom = (PI * denom) * denom;
+   const float NDF = a2 / denom;
+   const float NdotV = fmaxf(dot3(N, V), 0.0f), NdotL = fmaxf(dot3(N, L), 0.0f);
+   const float r = roughness + 1.0f, k = (r * r) / 8.0f;
+   const float gV = NdotV / (NdotV * (1.0f - k) + k), gL = NdotL / (NdotL * (1.0f - k) + k);
+   const float G = gL * gV;
+   const float c = fminf(fmaxf(1.0f - fmaxf(dot3(H, V), 0.0f), 0.0f), 1.0f);
+   const float c5 = ((c * c) * (c * c)) * c;
+   const float om = 1.0f - metallic;
+   const V3 F0 = v3(0.04f * om + base.x * metallic, 0.04f * om + base.y * metallic, 0.04f * om + base.z * metallic);
+   const V3 F = v3(F0.x + (1.0f - F0.x) * c5, F0.y + (1.0f - F0.y) * c5, F0.z + (1.0f - F0.z) * c5);
+   const V3 kD = v3((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
+   const float den = (4.0f * NdotV) * NdotL + 0.0001f;
+   const float dg = NDF * G;
+   const V3 spec = v3((dg * F.x) / den, (dg * F.y) / den, (dg * F.z) / den);
+   return v3(kD.x * base.x + spec.x * PI, kD.y * base.y + spec.y * PI, kD.z * base.z + spec.z * PI);
+}
+
 __device__ __forceinline__ float schlick_reflectance(float cosine, float ref_idx) {  // rchit:12-18
    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
    r0 = r0 * r0;
@@ -1268,6 +1297,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
                scatter = refract3(nd, outward, ratio);
             scattered = true;
             color = v3(1, 1, 1);
+         } else if (ms.type == 4.0f) {
+            // EXTENSION (never produced by the reference's scenes): Cook-Torrance, see pbr_weight()
+            scatter = world_normal + random_point_in_unit_sphere(seed);
+            scattered = dot3(ray_dir, world_normal) < 0.0f;
+            color = pbr_weight(world_normal, -1.0f * normalize3(ray_dir), normalize3(scatter), color, ms.metallic, ms.roughness);
          } else {                                                                      // rchit:85-89
             scattered = false;
             color = v3(1, 1, 1);

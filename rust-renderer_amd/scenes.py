@@ -15,7 +15,7 @@ import numpy as np
 
 from .api import identity3x4, make_material, transform3x4
 from .camera import Camera
-from .types import DIELECTRIC, DIFFUSE_LIGHT, LAMBERTIAN, METAL, VERTEX_DTYPE
+from .types import DIELECTRIC, DIFFUSE_LIGHT, LAMBERTIAN, METAL, PBR, VERTEX_DTYPE
 
 f32 = np.float32
 u32 = np.uint32
@@ -65,9 +65,11 @@ class Mesh:
     texture: int = None  # index into Model.textures, None = default white map
     transform: np.ndarray = field(default_factory=identity3x4)
     name: str = ""
+    metallic: float = 1.0   # GpuMaterial.metallic_factor / roughness_factor (renderer.rs:20-36); read by material type PBR only
+    roughness: float = 1.0
 
     def material_struct(self):
-        return make_material(self.material_type, self.material_property, self.base_color)
+        return make_material(self.material_type, self.material_property, self.base_color, metallic=self.metallic, roughness=self.roughness)
 
     @property
     def num_triangles(self):
@@ -354,7 +356,7 @@ LIGHTS_SEED = 0x4C495445
 
 
 def sponza_class_scene(detail=1.0, tex_size=1024, with_spheres=False, num_lights=0, sphere_subdivisions=4, target_meshes=103, num_materials=25,
-                       num_textures=25, material_mix=False, seed=None, scene_name="sponza_class"):
+                       num_textures=25, material_mix=False, seed=None, scene_name="sponza_class", cook_torrance=False):
     """detail scales every tessellation factor linearly (triangles ~ detail^2). detail=1.0 gives
     the headline ~262 k-triangle scene; tests use detail ~0.1."""
     seed = SPONZA_SEED if seed is None else seed
@@ -477,7 +479,12 @@ def sponza_class_scene(detail=1.0, tex_size=1024, with_spheres=False, num_lights
                 mtype, prop = METAL, float(0.05 + 0.4 * pick[1])
             elif mname in ("vase", "curtain") and pick[0] > 0.8:
                 mtype, prop = DIELECTRIC, 1.5
-        meshes.append(Mesh(v, i, mtype, prop, (float(col[0]), float(col[1]), float(col[2]), 1.0), k % num_textures, identity3x4(), name=mname))
+        mesh = Mesh(v, i, mtype, prop, (float(col[0]), float(col[1]), float(col[2]), 1.0), k % num_textures, identity3x4(), name=mname)
+        if cook_torrance and mtype == LAMBERTIAN:
+            # extension: the diffuse surfaces become Cook-Torrance with per-mesh metallic / roughness
+            mr = hash_floats(seed, 2, stream=9500 + k).astype(np.float64)
+            mesh.material_type, mesh.metallic, mesh.roughness = PBR, float(mr[0] < 0.25) * float(0.5 + 0.5 * mr[1]), float(0.15 + 0.8 * mr[1])
+        meshes.append(mesh)
     models = [(Model(meshes, textures), None)]
 
     if with_spheres:  # scenes.rs:116-149
@@ -617,11 +624,11 @@ def isosurface_scene(resolution=512, device=False):
 BISTRO_SEED = 0x42495354
 
 
-def bistro_class_scene(detail=3.27, tex_size=1024, num_lights=64):
+def bistro_class_scene(detail=3.27, tex_size=1024, num_lights=64, cook_torrance=False):
     """config 4 of BASELINE.json ("Bistro Exterior full PBR, 3840x2160"): the same generator at
     ~3.3x tessellation (~2.8 M triangles), 130 meshes / materials with Metal and Dielectric mixed
     in, point lights on (uniform sampling). Bistro itself is not part of the reference checkout."""
     sc = sponza_class_scene(detail=detail, tex_size=tex_size, with_spheres=True, num_lights=num_lights, sphere_subdivisions=5, target_meshes=130,
-                            num_materials=130, num_textures=25, material_mix=True, seed=BISTRO_SEED, scene_name="bistro_class")
+                            num_materials=130, num_textures=25, material_mix=True, seed=BISTRO_SEED, scene_name="bistro_class", cook_torrance=cook_torrance)
     sc.view_flags.update(dict(lights_enabled=1, use_ris_light_sampling=0))
     return sc

@@ -19,6 +19,7 @@ assert RESERVOIR_DTYPE.itemsize == 16
 
 # MaterialType (utopian/src/gltf_loader.rs:11-17)
 LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = 0, 1, 2, 3
+PBR = 4  # extension: Cook-Torrance from metallic_factor / roughness_factor; no reference scene uses it
 
 
 class GpuMaterial(C.Structure):

@@ -485,10 +485,11 @@ def _soup_scene(seed):
         nrm = rng.normal(size=(nt * 3, 3)).astype(np.float32)
         nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
         uv = rng.uniform(-1.5, 2.5, size=(nt * 3, 2)).astype(np.float32)
-        mtype = int(rng.integers(0, 4))
+        mtype = int(rng.integers(0, 5))  # 4 = the Cook-Torrance extension
         prop = float(rng.uniform(0.0, 0.6)) if mtype == 1 else float(rng.uniform(1.1, 2.0))
         mesh = Mesh(_pack_vertices(pos, nrm, uv), np.arange(nt * 3, dtype=np.uint32), mtype, prop,
                     tuple(float(x) for x in rng.uniform(0.2, 1.0, size=3)) + (1.0,), int(rng.integers(0, 3)) if rng.random() < 0.7 else None)
+        mesh.metallic, mesh.roughness = float(rng.uniform(0, 1)), float(rng.uniform(0.05, 1))
         if rng.random() < 0.5:
             mesh.transform = rr.transform3x4(tuple(rng.uniform(0.3, 1.7, size=3) * rng.choice([-1, 1], size=3)), tuple(rng.uniform(-1, 1, size=3)), _rot(*rng.uniform(-3, 3, size=3)))
         meshes.append(mesh)
@@ -631,3 +632,16 @@ def test_isosurface_extraction_matches_host_generator_and_oracle():
     assert with_sphere > ntri
     none, zero = rr.Renderer(8, 8).add_isosurface_mesh(4, 100.0, 101.0)
     assert none is None and zero == 0
+
+
+def test_cook_torrance_extension_matches_oracle(atrium):
+    """material type 4: same arithmetic on both sides, bit for bit once the sky is off"""
+    scene = rr.scenes.sponza_class_scene(detail=0.1, tex_size=16, with_spheres=True, num_lights=8, sphere_subdivisions=2, cook_torrance=True)
+    assert any(m.material_type == rr.types.PBR for model, _ in scene.models for m in model.meshes)
+    W, H = 80, 48
+    gpu, cpu = make_pair(scene, W, H, threads=3)
+    for r in (gpu, cpu):
+        run_frames(r, scene, W, H, 3, rr.PASS_ALL, sky_enabled=0)
+    assert np.array_equal(gpu.read_accumulation().view(np.uint32), cpu.read_accumulation().view(np.uint32))
+    assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays)
+    assert gpu.read_accumulation()[..., :3].max() > 0.0
