@@ -171,7 +171,7 @@ using Vertex = UhVertex;
 using ViewUniformData = UhViewUniformData;
 using Reservoir = UhReservoir;
 constexpr uint32_t DEFAULT_TEXTURE_MAP = 0xffffffffu;  // gltf_loader.rs:9
-enum class MaterialType : uint32_t { Lambertian = 0, Metal = 1, Dielectric = 2, DiffuseLight = 3 };
+enum class MaterialType : uint32_t { Lambertian = 0, Metal = 1, Dielectric = 2, DiffuseLight = 3, CookTorrance = 4 /* extension, utopian_hip.h */ };
 
 struct Texture {
    uint32_t width = 0, height = 0;
@@ -297,6 +297,24 @@ class Renderer {
       UhStats s;
       check(uh_get_stats(ctx_, &s), "get_stats");
       return s;
+   }
+   // uh_set_option: "device_build", "frames_in_flight", ... (DESIGN.md "Options")
+   void set_option(const char* name, int value) { check(uh_set_option(ctx_, name, value), name); }
+   // marching_cubes.rs:17-83 / marching_cubes.comp: the density field's iso-surface, extracted on the GPU and added
+   // as a mesh of the scene; returns the triangle count (0: nothing crosses the iso value, no mesh added)
+   uint32_t add_isosurface_mesh(uint32_t resolution, float lo, float hi, float time, const Material& material, const Mat4& world = Mat4::identity()) {
+      UhGpuMaterial m;
+      std::memset(&m, 0, sizeof(m));
+      m.diffuse_map = default_diffuse_map_index_;
+      std::memcpy(m.base_color_factor, material.base_color_factor, sizeof(m.base_color_factor));
+      m.metallic_factor = material.metallic_factor;
+      m.roughness_factor = material.roughness_factor;
+      m.raytrace_properties[0] = (float)(uint32_t)material.material_type;
+      m.raytrace_properties[1] = material.material_property;
+      auto w = world.to_3x4();
+      uint32_t mesh = 0, tris = 0;
+      check(uh_add_isosurface_mesh(ctx_, resolution, lo, hi, time, &m, w.data(), &mesh, &tris), "add_isosurface_mesh");
+      return tris;
    }
    uh_ctx* handle() { return ctx_; }
    uint32_t width() const { return width_; }
