@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only rank 0's tiles of an N-rank partition (what one rank sees at --gpus N)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=3")
+    ap.add_argument("--spp", type=int, default=1, help="samples_per_frame (reference default 1, UI maximum 10); SURVEY 8d also asks for 64 spp as 8 frames x 8")
     ap.add_argument("--cook-torrance", action="store_true", help="extension (SURVEY 8f N2): the diffuse materials of configs 1-3 become Cook-Torrance (material type 4)")
     ap.add_argument("--cpu-sample", type=str, default="1920x1080x8", help="WxHx(max frames) rendered by the CPU oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline stops after the first frame that ends beyond this many seconds")
@@ -93,7 +94,7 @@ def main():
     elif args.emulate_world > 1:
         renderer.set_tile_partition(0, args.emulate_world, args.tile)
     pass_mask = rr.PASS_ALL if args.config == 2 else rr.PASS_REFERENCE_PT
-    view = scene.make_view(W, H)
+    view = scene.make_view(W, H, samples_per_frame=args.spp) if args.spp != 1 else scene.make_view(W, H)
     loop = rr.FrameLoop(renderer, view)
 
     def sync_all():
@@ -206,7 +207,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE.json configs[{args.config}]: {scene.name} synthetic scene ({scene.num_triangles} tris, {scene.num_meshes} meshes, textured materials), "
-                f"{W}x{H}, 1 spp/frame x {args.steps} frames, 5 bounces, sky + sun shadow rays"
+                f"{W}x{H}, {args.spp} spp/frame x {args.steps} frames, 5 bounces, sky + sun shadow rays"
                 + (f", {len(scene.lights)} lights " + ("ReSTIR DI" if view.use_ris_light_sampling else "uniform sampling") if view.lights_enabled else ", lights off"),
                 "rays_per_frame": total_rays / args.steps,
                 "partition": f"{args.tile}x{args.tile} tiles round-robin over {world} rank(s), 1 RCCL gather" if world > 1 else "single GPU",
