@@ -132,6 +132,10 @@ def main():
         k, v = kv.split("=")
         renderer.set_option(k, int(v))
 
+    # ---- untimed priming, independent of --warmup: the first multi-frame call makes the library create its
+    # frames-in-flight slots (streams, ~1 GB of path state each at 1080p; ~14 ms) - with --warmup 0 or 1 that
+    # would otherwise land inside the timed region
+    loop.frames(4, pass_mask)
     # ---- warmup
     loop.frames(args.warmup, pass_mask)
     if use_dist:
