@@ -2,7 +2,9 @@
 """bench.py — BASELINE.json metric: Mrays/s and ms/frame on the Sponza-class 1080p path trace.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  or plainly (python bench.py --gpus N): the script then starts its N ranks itself, as child processes under
+  torch.distributed.run on 127.0.0.1, before anything has touched a GPU, and exits with their status.
 
 A step = one frame = one pass of reference_pt_pass over the 1920x1080 framebuffer at 1 sample per
 pixel and 5 bounces (the reference's per-frame dispatch, renderers/mod.rs:357; 64 steps = the
@@ -24,6 +26,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+def _load_launch():
+    """rust-renderer_amd/launch.py by path: no torch, no HIP, not even the package - safe before any GPU is touched"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("uh_launch", os.path.join(ROOT, "rust-renderer_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+launch = _load_launch()
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
@@ -48,6 +63,7 @@ def parse():
     ap.add_argument("--cook-torrance", action="store_true", help="extension (SURVEY 8f N2): the diffuse materials of configs 1-3 become Cook-Torrance (material type 4)")
     ap.add_argument("--cpu-sample", type=str, default="1920x1080x8", help="WxHx(max frames) rendered by the CPU oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline stops after the first frame that ends beyond this many seconds")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the composition gather (nccl = RCCL; gloo only rehearses the launch on a GPU-less box)")
     return ap.parse_args()
 
 
@@ -56,9 +72,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and not launch.under_launcher():
+        # plain `python bench.py --gpus N`: become the launcher. Nothing has initialised a GPU yet (no torch, no
+        # library call); the N ranks are fresh child processes, this one only waits for them.
+        sys.exit(launch.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
         args.gpus = world
 
     import numpy as np
@@ -74,8 +92,12 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        print(f"[bench] rank {rank}/{world} joined the {args.backend} group", file=sys.stderr, flush=True)
 
     W, H = args.width, args.height
     kw = dict(tex_size=args.tex_size)

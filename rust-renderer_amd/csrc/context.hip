@@ -78,7 +78,7 @@ struct Slot {
    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
    DevBuf<float4> ray_o, ray_d, hit, thr, rad, pixcol;
    DevBuf<uint2> rng;
-   DevBuf<uint32_t> queues[5];
+   DevBuf<uint32_t> queues[3];
    DevBuf<Control> control;
    PathState ps{};
    bool ready = false;
@@ -121,7 +121,7 @@ struct Slot {
       ps.rad = rad.p;
       ps.pixcol = pixcol.p;
       ps.rng = rng.p;
-      for (int i = 0; i < 5; i++) ps.queue[i] = queues[i].p;
+      for (int i = 0; i < 3; i++) ps.queue[i] = queues[i].p;
       ps.shard_cap = shard_cap;
       ready = true;
       return hipSuccess;
@@ -172,7 +172,7 @@ struct uh_ctx {
    bool overlap_miss = true, overlap_shadow = true;
    uint32_t W = 0, H = 0;
    uint32_t num_cus = 256;
-   uint32_t closest_blocks_per_cu = 8, shadow_blocks_per_cu = 6;
+   uint32_t closest_blocks_per_cu = 6, shadow_blocks_per_cu = 5;  // what the refill kernels' LDS (stacks + ray pool) admits
    std::string err;
 
    // host scene
@@ -219,7 +219,7 @@ struct uh_ctx {
    bool count_visits = false, time_kernels = false, full_frame_restir = false, raw_visit_counts = false;
    uint32_t bvh_max_leaf = kMaxLeafTris;
    float bvh_sah_cost = 0.5f;  // SAH leaf termination: a node step costs about half a triangle test here (swept on MI355X)
-   int closest_variant = 0, shadow_variant = 18;  // measured fastest on MI355X (profiles/README.md)
+   int closest_variant = 3, shadow_variant = 3;  // refill kernels, threshold 8 idle lanes (0 = batch kernels)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
    float ms_by_kind[3] = {0, 0, 0};
@@ -1341,9 +1341,9 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->next_slot = 0;
    }
    else if (n == "trace_variant" || n == "closest_variant" || n == "shadow_variant") {
-      if (value < 0 || value > 29) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..29");
+      if (value < 0 || value > 4) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..4");
       if (n != "shadow_variant") c->closest_variant = value;
-      if (n != "closest_variant") c->shadow_variant = value > 21 ? 18 : value;
+      if (n != "closest_variant") c->shadow_variant = value;
    } else if (n == "trace_blocks_per_cu" || n == "closest_blocks_per_cu" || n == "shadow_blocks_per_cu") {
       if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 1..8");
       if (n != "shadow_blocks_per_cu") c->closest_blocks_per_cu = (uint32_t)value;

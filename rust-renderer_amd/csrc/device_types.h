@@ -12,8 +12,10 @@
 namespace uh {
 
 constexpr uint32_t kMaxBounces = 64;
-constexpr uint32_t kQueueKinds = 4;  // per bounce: RAY, HIT, MISS, LIGHT
-enum { Q_RAY = 0, Q_HIT = 1, Q_MISS = 2, Q_LIGHT = 3 };
+// per bounce: RAY (paths whose ray the bounce traces; the shading kernels tell hits from misses by the hit
+// record, so no hit / miss queues exist) and LIGHT (scattered paths that carry a light sample)
+constexpr uint32_t kQueueKinds = 2;
+enum { Q_RAY = 0, Q_LIGHT = 1 };
 constexpr uint32_t kLaunchSlots = kMaxBounces * 3 + 4;
 
 // Queues are sharded: path p lives in shard shard_of_run(p / 64) for its whole life, every queue
@@ -122,7 +124,7 @@ struct PathState {
    float4* rad;     // radiance.rgb, light index (bits)
    float4* pixcol;  // sum over the frame's samples
    uint2* rng;      // x = raygen rngState, y = rayPayload.randomSeed
-   uint32_t* queue[5];  // 0,1 = ray ping-pong; 2 = hit; 3 = miss; 4 = light; each kShards * shard_cap entries
+   uint32_t* queue[3];  // 0,1 = ray ping-pong; 2 = light; each kShards * shard_cap entries
    uint32_t shard_cap;  // entries per shard segment = pixels a shard can own (multiple of 64)
 };
 
@@ -140,11 +142,9 @@ struct LaunchCfg {
    uint32_t num_cus;
    uint32_t closest_blocks_per_cu, shadow_blocks_per_cu;
    bool count_visits;
-   // traversal kernel variants (options "closest_variant" / "shadow_variant"; all bit-identical in
-   // results): 0 = batch if-if; 1..5 = v2 while-while with lane refill at 64/32/16/8/1 idle lanes;
-   // 6..10 = v2 + parked leaf; 11..16 = v3 vote scheduling; 17..21 if-if + refill; 22..25 v5 (closest only:
-   // LDS-staged result lists); 26 (closest only) = variant 0 + entry-distance culling; 27..29 (closest only) = variant 0 with
-   // the top 32 / 64 / 128 nodes of the tree staged in LDS. Defaults measured fastest.
+   // traversal kernel variants (options "closest_variant" / "shadow_variant"; bit-identical in results):
+   // 0 = batch kernel (a wave walks 64 rays to the end of the slowest); 1..4 = persistent waves whose idle lanes
+   // take the next ray from an LDS pool once 1 / 4 / 8 / 16 lanes are idle (kernels.hip "Ray replacement").
    int closest_variant, shadow_variant;
    bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
 };

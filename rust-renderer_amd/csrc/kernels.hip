@@ -70,8 +70,6 @@ __device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, uint32
    }
 }
 
-constexpr uint32_t kChunk = 64;   // rays a wave takes from its shard's cursor per atomic (traversal v2)
-
 __device__ __forceinline__ float safe_rcp_dir(float x) {
    // the slab test only has to be conservative (boxes are padded by >= 1e-5 relative, the 1-ulp hardware
    // reciprocal is 1e-7): no IEEE division here; a zero component becomes +-1e-30 so no inf/NaN appears
@@ -122,11 +120,8 @@ __device__ __forceinline__ uint32_t trav_pop(Trav& t, const uint32_t* lds_col, c
 // inverted box (no child != empty test); only the nearest child is fully ordered (3 comparators);
 // pushes are branch-free (write always, advance the stack pointer by the hit bit).
 template <bool ANY>
-__device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill, const uint4* lds_nodes = nullptr,
-                                          uint32_t n_lds = 0) {
-   // n_lds > 0: the first n_lds nodes (BFS order = the top of the tree) are also staged in LDS; one flat
-   // load serves both address spaces per lane
-   const uint4* n = (n_lds && t.cur < n_lds) ? lds_nodes + 4 * t.cur : nodes + 4 * (size_t)t.cur;
+__device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill) {
+   const uint4* n = nodes + 4 * (size_t)t.cur;
    const uint4 w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
    const float ax = __uint_as_float(w0.w) * t.idir.x, ay = __uint_as_float(w1.x) * t.idir.y, az = __uint_as_float(w1.y) * t.idir.z;
    const float bx = (__uint_as_float(w0.x) - t.o.x) * t.idir.x, by = (__uint_as_float(w0.y) - t.o.y) * t.idir.y, bz = (__uint_as_float(w0.z) - t.o.z) * t.idir.z;
@@ -217,10 +212,10 @@ __device__ __forceinline__ bool leaf_step(const float4* __restrict__ tris, Trav&
    return false;
 }
 
-// batch (if-if) traversal of one ray: used by the stand-alone query kernels and trace variant 0
+// batch (if-if) traversal of one ray to its end: the batch kernels (variant 0) and the stand-alone any-hit query
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, float tlimit, Hit& best, uint32_t* lds_col,
-                                         uint32_t& n_nodes, uint32_t& n_tris, const uint4* lds_nodes = nullptr, uint32_t n_lds = 0) {
+                                         uint32_t& n_nodes, uint32_t& n_tris) {
    Trav t;
    trav_init(t, make_float4(o.x, o.y, o.z, tmin), make_float4(d.x, d.y, d.z, tmax), ANY ? tlimit : INFINITY);
    uint32_t spill[kSpillStack];
@@ -235,7 +230,7 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
    while (t.cur != kEmptyRef) {
       if (!(t.cur & kLeafBit)) {
          if (COUNT) n_nodes++;
-         node_step<ANY>(nodes, t, lds_col, spill, lds_nodes, n_lds);
+         node_step<ANY>(nodes, t, lds_col, spill);
       }
       // a lane that the node step just sent to a leaf tests that leaf's first triangle in the same iteration
       if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
@@ -254,113 +249,6 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
    }
    best = t.best;
    return ANY ? occluded : (best.idx != kEmptyRef);
-}
-
-// ------------------------------------------------------------------------------------------
-// Closest-hit traversal with ENTRY-DISTANCE culling: a stack entry is (child ref, tnear) and an
-// entry whose box starts beyond the best hit found since it was pushed is dropped at pop time
-// instead of costing a whole node step. 8-byte entries: the LDS part of the stack holds half as
-// many (same 16 KiB per block), the rest spills to private memory as before.
-// ------------------------------------------------------------------------------------------
-constexpr int kLdsStack2 = kLdsStack / 2;
-
-__device__ __forceinline__ void push2(Trav& t, uint2* col, uint2* spill, uint32_t ref, float tn) {
-   if (t.sp < kLdsStack2)
-      col[t.sp * 64] = make_uint2(ref, __float_as_uint(tn));
-   else if (t.sp < kLdsStack2 + kSpillStack)
-      spill[t.sp - kLdsStack2] = make_uint2(ref, __float_as_uint(tn));
-   else
-      return;
-   t.sp++;
-}
-__device__ __forceinline__ uint32_t pop2(Trav& t, const uint2* col, const uint2* spill) {
-   while (t.sp > 0) {
-      t.sp--;
-      const uint2 e = t.sp < kLdsStack2 ? col[t.sp * 64] : spill[t.sp - kLdsStack2];
-      // strict: a triangle at exactly best.t with a smaller key must still be found
-      if (!(__uint_as_float(e.y) > t.best.t)) return e.x;
-   }
-   return kEmptyRef;
-}
-
-__device__ __forceinline__ void node_step_cull(const uint4* __restrict__ nodes, Trav& t, uint2* col, uint2* spill) {
-   const uint4* n = nodes + 4 * (size_t)t.cur;
-   const uint4 w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
-   const float ax = __uint_as_float(w0.w) * t.idir.x, ay = __uint_as_float(w1.x) * t.idir.y, az = __uint_as_float(w1.y) * t.idir.z;
-   const float bx = (__uint_as_float(w0.x) - t.o.x) * t.idir.x, by = (__uint_as_float(w0.y) - t.o.y) * t.idir.y, bz = (__uint_as_float(w0.z) - t.o.z) * t.idir.z;
-   const bool nx = t.idir.x < 0.0f, ny = t.idir.y < 0.0f, nz = t.idir.z < 0.0f;
-   const uint32_t qnx = nx ? w2.y : w1.z, qfx = nx ? w1.z : w2.y;
-   const uint32_t qny = ny ? w2.z : w1.w, qfy = ny ? w1.w : w2.z;
-   const uint32_t qnz = nz ? w2.w : w2.x, qfz = nz ? w2.x : w2.w;
-   const float tcap = t.best.t;
-   float tn[4];
-   uint32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
-#pragma unroll
-   for (int k = 0; k < 4; k++) {
-      const float t0x = fmaf((float)((qnx >> (8 * k)) & 0xffu), ax, bx), t1x = fmaf((float)((qfx >> (8 * k)) & 0xffu), ax, bx);
-      const float t0y = fmaf((float)((qny >> (8 * k)) & 0xffu), ay, by), t1y = fmaf((float)((qfy >> (8 * k)) & 0xffu), ay, by);
-      const float t0z = fmaf((float)((qnz >> (8 * k)) & 0xffu), az, bz), t1z = fmaf((float)((qfz >> (8 * k)) & 0xffu), az, bz);
-      const float tnear = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, t.tmin));
-      const float tfar = fminf(fminf(t1x, t1y), fminf(t1z, tcap));
-      tn[k] = (tnear <= tfar) ? tnear : INFINITY;
-   }
-   auto cswap = [&](int i, int j) {
-      bool s = tn[j] < tn[i];
-      float ta = s ? tn[j] : tn[i], tb = s ? tn[i] : tn[j];
-      uint32_t ca = s ? cr[j] : cr[i], cb = s ? cr[i] : cr[j];
-      tn[i] = ta;
-      tn[j] = tb;
-      cr[i] = ca;
-      cr[j] = cb;
-   };
-   cswap(0, 1);
-   cswap(2, 3);
-   cswap(0, 2);
-   if (t.sp + 3 <= kLdsStack2) {
-      uint2* p = col + t.sp * 64;
-      int h3 = tn[3] < INFINITY ? 1 : 0, h2 = tn[2] < INFINITY ? 1 : 0, h1 = tn[1] < INFINITY ? 1 : 0;
-      p[0] = make_uint2(cr[3], __float_as_uint(tn[3]));
-      p += h3 * 64;
-      p[0] = make_uint2(cr[2], __float_as_uint(tn[2]));
-      p += h2 * 64;
-      p[0] = make_uint2(cr[1], __float_as_uint(tn[1]));
-      t.sp += h3 + h2 + h1;
-   } else {
-      if (tn[3] < INFINITY) push2(t, col, spill, cr[3], tn[3]);
-      if (tn[2] < INFINITY) push2(t, col, spill, cr[2], tn[2]);
-      if (tn[1] < INFINITY) push2(t, col, spill, cr[1], tn[1]);
-   }
-   t.cur = (tn[0] < INFINITY) ? cr[0] : pop2(t, col, spill);
-}
-
-template <bool COUNT>
-__device__ __forceinline__ bool traverse_cull(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, Hit& best, uint32_t* lds_col, uint32_t& n_nodes, uint32_t& n_tris) {
-   Trav t;
-   trav_init(t, make_float4(o.x, o.y, o.z, tmin), make_float4(d.x, d.y, d.z, tmax), INFINITY);
-   uint2 spill[kSpillStack];
-   // the wave's [kLdsStack][64] dwords seen as [kLdsStack2][64] entry pairs
-   uint2* col = reinterpret_cast<uint2*>(lds_col - lane_id()) + lane_id();
-   const uint4* __restrict__ nodes = sc.nodes;
-   const float4* __restrict__ tris = sc.tris;
-   uint32_t tk = 0;
-   while (t.cur != kEmptyRef) {
-      if (!(t.cur & kLeafBit)) {
-         if (COUNT) n_nodes++;
-         node_step_cull(nodes, t, col, spill);
-      }
-      if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
-         const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
-         if (COUNT) n_tris++;
-         tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
-         tk++;
-         if (tk >= cnt) {
-            tk = 0;
-            t.cur = pop2(t, col, spill);
-         }
-      }
-   }
-   best = t.best;
-   return best.idx != kEmptyRef;
 }
 
 // persistent-thread batch fetch: lane 0 pulls the next 64-item batch of its shard
@@ -383,58 +271,250 @@ __device__ __forceinline__ ShardCtx shard_ctx() {
 }
 
 // ------------------------------------------------------------------------------------------
-// trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes
+// Ray replacement ("refill") from a per-wave LDS ray pool.
+//
+// Thread-per-ray traversal leaves a lane idle from the moment its ray ends until the slowest ray of
+// the wave ends (bounce rays: mean 18 steps against a wave maximum of 43, profiles/README.md). Here a
+// wave is persistent and every lane whose ray has ended takes the next ray out of a 64-entry pool in
+// LDS - a couple of ds_read_b128, no global round trip on the wave's critical path. The pool is kept
+// fed by a three-stage pipeline, one stage per "refill event" (= the pool ran empty):
+//    stage 1  lane 0 reserves the next 64-ray chunk of the shard's queue (one returning atomic),
+//    stage 2  the 64 path ids of the chunk reserved one event earlier are loaded,
+//    stage 3  the rays of the ids loaded one event earlier go global -> LDS by LDS-DMA
+//             (global_load_lds_dwordx4: per-lane source address, 64 x 16 B contiguous in LDS).
+// Every stage consumes what was issued a whole pool (about 20 wave iterations) earlier, so its wait
+// finds the data there. The traversal kernels write nothing but their per-path result: no queue is
+// built here (the shading kernels classify hits and misses themselves), so the loop has no atomic
+// whose value it needs at once.
 // ------------------------------------------------------------------------------------------
-// MODE 0: plain; 1: entry-distance culling; >= 32: the top MODE nodes of the tree staged in LDS
-template <bool COUNT, int MODE>
-__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
-                                                          uint32_t cursor_slot, int ray_kind) {
+constexpr uint32_t kPool = 64;
+
+template <int NA>
+struct alignas(16) RayPool {
+   float4 v[NA][kPool];  // one LDS-DMA instruction fills one of these arrays
+   uint32_t id[kPool];
+};
+
+__device__ __forceinline__ void dma16(const float4* gsrc, float4* lds_dst) {
+   // lds_dst is wave-uniform; lane l's 16 bytes land at lds_dst + l
+   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Where a wave's rays come from: a (shard segment of a) queue of path ids, or the identity (ray i = record i)
+// when `queue` is null; chunks are handed out by an atomic cursor, or - `cursor` null - statically
+// (chunk k of wave w = (k * num_waves + w) * 64).
+struct RaySource {
+   const uint32_t* queue;
+   uint32_t count;
+   uint32_t* cursor;
+   uint32_t wave_index, num_waves;  // static chunk assignment only
+};
+
+template <int NA>
+struct Feeder {
+   // wave-uniform state (ballot / readfirstlane derived: lives in SGPRs)
+   uint32_t pos = 0, n = 0;     // pool entries [pos, n) are unread
+   uint32_t load_n = 0;         // entries the LDS-DMA in flight delivers
+   uint32_t q_n = 0;            // valid lanes of q_id
+   uint32_t static_k = 0;
+   uint32_t iterations = 0;
+   bool loading = false, have_base = false, drained = false;
+   // per-lane pipeline registers
+   uint32_t r_base = 0;         // lane 0: what the newest cursor atomic returned
+   uint32_t q_id = 0;           // path id of lane l's ray in the chunk that enters the pool next
+
+   __device__ __forceinline__ bool empty() const { return pos >= n && !loading && q_n == 0 && !have_base && drained; }
+
+   // the DMA issued one event ago has landed (its wait also covers every older load of the wave)
+   __device__ __forceinline__ void land() {
+      if (loading) {
+         wait_vm0();
+         pos = 0;
+         n = load_n;
+         loading = false;
+      }
+   }
+
+   // one refill event: called when the pool is empty and nothing is in flight
+   template <typename SrcFn>
+   __device__ __forceinline__ void advance(const RaySource& src, RayPool<NA>& pool, SrcFn&& source_of) {
+      const uint32_t lane = lane_id();
+      if (q_n) {  // stage 3
+         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pool's last entries have been read
+         if (lane < q_n) {
+#pragma unroll
+            for (int a = 0; a < NA; a++) dma16(source_of(a, q_id), pool.v[a]);
+            pool.id[lane] = q_id;
+         }
+         load_n = q_n;
+         loading = true;
+         q_n = 0;
+      }
+      if (have_base) {  // stage 2
+         const uint32_t b = __builtin_amdgcn_readfirstlane(r_base);
+         have_base = false;
+         if (b < src.count) {
+            q_n = src.count - b < kPool ? src.count - b : kPool;
+            if (lane < q_n) q_id = src.queue ? src.queue[b + lane] : b + lane;
+         } else {
+            drained = true;
+         }
+      }
+      if (!drained) {  // stage 1
+         if (src.cursor) {
+            if (lane == 0) r_base = atomicAdd(src.cursor, kPool);
+         } else {
+            r_base = (static_k * src.num_waves + src.wave_index) * kPool;
+            static_k++;
+         }
+         have_base = true;
+      }
+   }
+};
+
+// what a traversal wave does per iteration for its idle lanes; returns false when the wave is out of work.
+// kRefill: idle lanes that make a refill worth its instructions (every lane that ends costs a pool read + trav_init)
+template <int NA, int kRefill, typename SrcFn, typename TakeFn>
+__device__ __forceinline__ bool refill_lanes(Feeder<NA>& f, const RaySource& src, RayPool<NA>& pool, bool lane_idle, SrcFn&& source_of, TakeFn&& take) {
+   // exit condition every wave reaches whatever the data: a traversal step visits a node or a triangle once, so a
+   // wave that has run this many iterations is not walking a tree any more (corrupt references) - leave
+   if (++f.iterations > (1u << 24)) return false;
+   const unsigned long long idle = __ballot(lane_idle);
+   if (idle == 0ull) return true;
+   const uint32_t n_idle = (uint32_t)__popcll(idle);
+   f.land();
+   const uint32_t avail = f.n - f.pos;
+   if (avail != 0 && (n_idle >= (uint32_t)kRefill || n_idle == 64u)) {
+      const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      if (lane_idle && prefix < avail) take(f.pos + prefix);
+      f.pos += n_idle < avail ? n_idle : avail;
+   }
+   if (f.pos >= f.n && !f.loading) {
+      if (f.empty()) return n_idle != 64u || avail != 0;  // nothing left to hand out: done once every lane is idle
+      f.advance(src, pool, source_of);
+   }
+   return true;
+}
+
+// one if-if step of a lane's traversal (see traverse()); returns true when the ray has ended
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const float4* __restrict__ tris, Trav& t, uint32_t& tk, uint32_t* lds_col, uint32_t* spill,
+                                          bool& occluded, uint32_t& n_nodes, uint32_t& n_tris) {
+   if (!(t.cur & kLeafBit)) {
+      if (COUNT) n_nodes++;
+      node_step<ANY>(nodes, t, lds_col, spill);
+   }
+   if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
+      const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+      if (COUNT) n_tris++;
+      if (tri_test<ANY>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
+         occluded = true;
+         t.cur = kEmptyRef;
+      } else {
+         tk++;
+         if (tk >= cnt) {
+            tk = 0;
+            t.cur = trav_pop(t, lds_col, spill);
+         }
+      }
+   }
+   return t.cur == kEmptyRef;
+}
+
+// ------------------------------------------------------------------------------------------
+// trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes.
+// Reads the bounce's ray queue, writes hit[path] = (t, u, v, packet) or packet = kEmptyRef.
+// ------------------------------------------------------------------------------------------
+template <bool COUNT, int kRefill>
+__global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const uint32_t* __restrict__ queue_base, const float4* __restrict__ ray_o,
+                                                               const float4* __restrict__ ray_d, float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl,
+                                                               DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   __shared__ RayPool<2> s_pool[kWavesPerBlock];
    const uint32_t lane = lane_id();
    const uint32_t wave = threadIdx.x >> 6;
    uint32_t* lds_col = &s_stack[wave][0][lane];
+   RayPool<2>& pool = s_pool[wave];
+   RaySource src;
+   if (queue_base) {  // path tracer: this block's shard of the bounce's ray queue, chunks from the shard's cursor
+      const ShardCtx sx = shard_ctx();
+      src.queue = queue_base + sx.shard * shard_cap;
+      src.count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
+      src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
+      src.wave_index = src.num_waves = 0;
+      if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)src.count);
+   } else {  // stand-alone query over raw_count rays (uh_trace_closest, the G-buffer cast): ray i = record i
+      src.queue = nullptr;
+      src.count = raw_count;
+      src.cursor = nullptr;
+      src.wave_index = blockIdx.x * kWavesPerBlock + wave;
+      src.num_waves = gridDim.x * kWavesPerBlock;
+   }
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   auto source_of = [&](int a, uint32_t id) { return (a == 0 ? ray_o : ray_d) + id; };
+   Feeder<2> f;
+   Trav t;
+   t.cur = kEmptyRef;
+   t.sp = 0;
+   uint32_t id = 0, tk = 0, n_nodes = 0, n_tris = 0;
+   uint32_t spill[kSpillStack];
+   auto take = [&](uint32_t slot) {
+      id = pool.id[slot];
+      trav_init(t, pool.v[0][slot], pool.v[1][slot], INFINITY);
+      tk = 0;
+   };
+   while (refill_lanes<2, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
+      if (t.cur != kEmptyRef) {
+         bool occluded = false;
+         if (trav_step<false, COUNT>(nodes, tris, t, tk, lds_col, spill, occluded, n_nodes, n_tris))
+            hit_out[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
+      }
+   }
+   if (COUNT) {
+      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+   }
+}
+
+// The plain batch form (option closest_variant = 0): a wave takes 64 rays, every lane walks its ray to the end,
+// then the wave takes the next 64. Kept as the baseline the refill kernels are measured against, and for the
+// per-ray visit counts of the diagnostics (DIAG: u,v of the result carry the ray's node / triangle visits).
+template <bool COUNT, bool DIAG>
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_batch(SceneDev sc, const uint32_t* __restrict__ queue_base,
+                                                                                                      const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                                                                      float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl, DeviceStats* stats,
+                                                                                                      uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   const uint32_t lane = lane_id();
+   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
+   uint32_t n_nodes = 0, n_tris = 0;
+   if (!queue_base) {
+      for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < raw_count; i += gridDim.x * kBlock) {
+         float4 ro = ray_o[i], rd = ray_d[i];
+         Hit h;
+         if (DIAG) n_nodes = n_tris = 0;
+         traverse<false, DIAG>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
+         hit_out[i] = DIAG ? make_float4(h.t, (float)n_nodes, (float)n_tris, __uint_as_float(h.idx)) : make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
+      }
+      return;
+   }
    const ShardCtx sx = shard_ctx();
-   const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
-   uint32_t* q_hit = ps.queue[2] + seg;
-   uint32_t* q_miss = ps.queue[3] + seg;
-   uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
-   uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
+   const uint32_t* __restrict__ queue = queue_base + sx.shard * shard_cap;
    uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
-   uint32_t n_nodes = 0, n_tris = 0;
-   __shared__ uint4 s_top[MODE >= 32 ? 4 * MODE : 1];
-   const uint32_t n_top = MODE >= 32 ? (sc.num_nodes < (uint32_t)MODE ? sc.num_nodes : (uint32_t)MODE) : 0;
-   if (MODE >= 32) {
-      for (uint32_t k = threadIdx.x; k < 4 * n_top; k += kBlock) s_top[k] = sc.nodes[k];
-      __syncthreads();
-   }
    for (;;) {
       uint32_t base = next_batch(cursor);
       if (base >= count) break;
       uint32_t i = base + lane;
-      bool active = i < count;
-      uint32_t id = 0;
-      Hit h;
-      h.idx = kEmptyRef;
-      h.t = 0.0f;
-      h.u = h.v = 0.0f;
-      if (active) {
-         id = queue[i];
-         float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
-         if (MODE == 1)
-            traverse_cull<COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, h, lds_col, n_nodes, n_tris);
-         else if (MODE >= 32)
-            traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris, s_top, n_top);
-         else
-            traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
-         ps.hit[id] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
+      if (i < count) {
+         const uint32_t id = queue[i];
+         float4 ro = ray_o[id], rd = ray_d[id];
+         Hit h;
+         traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
+         hit_out[id] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
       }
-      bool is_hit = active && h.idx != kEmptyRef, is_miss = active && h.idx == kEmptyRef;
-      uint32_t slot = wave_append(n_hit, is_hit);
-      if (is_hit) q_hit[slot] = id;
-      slot = wave_append(n_miss, is_miss);
-      if (is_miss) q_miss[slot] = id;
    }
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
    if (COUNT) {
@@ -443,73 +523,111 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    }
 }
 
-// stand-alone closest-hit query over n rays (identity queue): uh_trace_closest and the G-buffer cast
-// DIAG (option "raw_visit_counts"): u,v of the result carry the ray's node / triangle visit counts instead
-template <bool DIAG>
-__global__ __launch_bounds__(kBlock, 8) void k_trace_closest_raw(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                              float4* __restrict__ hit_out, uint32_t count) {
-   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
-   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane_id()];
-   uint32_t n_nodes = 0, n_tris = 0;
-   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
-      float4 ro = ray_o[i], rd = ray_d[i];
-      Hit h;
-      if (DIAG) n_nodes = n_tris = 0;
-      traverse<false, DIAG>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
-      hit_out[i] = DIAG ? make_float4(h.t, (float)n_nodes, (float)n_tris, __uint_as_float(h.idx)) : make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
-   }
-}
-
 // ------------------------------------------------------------------------------------------
 // trace_shadow — reference.rgen:67 (sun) and :115 (light): visibility only. The reference runs
 // its closest-hit / miss shaders on these rays too, but the raygen reads nothing except
 // colorDistance.w (rgen:69,118-119), so the sky integral and material fetch are dead work here.
 // Occluded <=> some triangle has tmin < t < tmax (sun) and additionally t <= distance_to_light.
+// An unoccluded ray adds its path's throughput (x light weight) to the path's radiance (rgen:69-78 / :118-122).
 // ------------------------------------------------------------------------------------------
-template <bool COUNT, bool LIGHT>
-__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
-                                                         uint32_t cursor_slot) {
+struct ShadowRay {
+   float4 ro, rd, lit;  // origin / direction (tmin, tmax in w) and the radiance record the path gets if the ray is unoccluded
+   float tlimit;
+};
+template <bool LIGHT>
+__device__ __forceinline__ ShadowRay make_shadow_ray(const SceneDev& sc, const FrameParams& fp, float4 ro, float4 thr, float4 rad) {
+   ShadowRay s;
+   s.ro = make_float4(ro.x, ro.y, ro.z, 0.001f);
+   s.tlimit = INFINITY;
+   if (LIGHT) {
+      const int light_index = (int)__float_as_uint(rad.w);
+      V3 lpos = v3(0, 0, 0);
+      if (light_index >= 0 && (uint32_t)light_index < sc.num_lights) lpos = xyz(sc.lights[2 * light_index]);
+      const V3 o = v3(ro.x, ro.y, ro.z);
+      const V3 dir = normalize3(lpos - o);  // rgen:113
+      s.tlimit = length3(lpos - o);         // rgen:114
+      const float f = thr.w;
+      s.lit = make_float4(rad.x + thr.x * f, rad.y + thr.y * f, rad.z + thr.z * f, rad.w);
+      s.rd = make_float4(dir.x, dir.y, dir.z, 10000.0f);
+   } else {
+      s.lit = make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w);
+      s.rd = make_float4(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2], 10000.0f);  // rgen:64
+   }
+   return s;
+}
+
+template <bool COUNT, bool LIGHT, int kRefill>
+__global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+                                                              uint32_t cursor_slot) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   __shared__ RayPool<3> s_pool[kWavesPerBlock];
    const uint32_t lane = lane_id();
    const uint32_t wave = threadIdx.x >> 6;
    uint32_t* lds_col = &s_stack[wave][0][lane];
+   RayPool<3>& pool = s_pool[wave];
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
-   // sun rays leave from every scattered path = the next bounce's ray queue; light rays from Q_LIGHT
-   const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[4] : ps.queue[(bounce + 1) & 1]) + seg;
+   RaySource src;
+   // sun rays leave from every scattered path = the next bounce's ray queue; light rays from the light queue
+   src.queue = (LIGHT ? ps.queue[2] : ps.queue[(bounce + 1) & 1]) + seg;
+   src.count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
+   src.wave_index = src.num_waves = 0;
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)src.count);
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   const float4* ray_o = ps.ray_o;
+   const float4* thr = ps.thr;
+   const float4* rad = ps.rad;
+   auto source_of = [&](int a, uint32_t id) { return (a == 0 ? ray_o : a == 1 ? thr : rad) + id; };
+   Feeder<3> f;
+   Trav t;
+   t.cur = kEmptyRef;
+   t.sp = 0;
+   uint32_t id = 0, tk = 0, n_nodes = 0, n_tris = 0;
+   float4 lit = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+   uint32_t spill[kSpillStack];
+   auto take = [&](uint32_t slot) {
+      id = pool.id[slot];
+      const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, pool.v[0][slot], pool.v[1][slot], pool.v[2][slot]);
+      lit = s.lit;
+      trav_init(t, s.ro, s.rd, s.tlimit);
+      tk = 0;
+   };
+   while (refill_lanes<3, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
+      if (t.cur != kEmptyRef) {
+         bool occluded = false;
+         if (trav_step<true, COUNT>(nodes, tris, t, tk, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) ps.rad[id] = lit;
+      }
+   }
+   if (COUNT) {
+      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
+   }
+}
+
+// batch form (option shadow_variant = 0), the baseline of the refill kernel
+template <bool COUNT, bool LIGHT>
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_shadow_batch(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats,
+                                                                                                     uint32_t bounce, uint32_t cursor_slot) {
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   const uint32_t lane = lane_id();
+   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[2] : ps.queue[(bounce + 1) & 1]) + seg;
    const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   const float tmin = 0.001f, tmax = 10000.0f;
    uint32_t n_nodes = 0, n_tris = 0;
    for (;;) {
       uint32_t base = next_batch(cursor);
       if (base >= count) break;
       uint32_t i = base + lane;
       if (i < count) {
-         uint32_t id = queue[i];
-         float4 ro = ps.ray_o[id];
-         V3 o = v3(ro.x, ro.y, ro.z);
-         float4 thr = ps.thr[id], rad = ps.rad[id];
-         V3 dir;
-         float tlimit = INFINITY, f = 1.0f;
-         if (LIGHT) {
-            int light_index = (int)__float_as_uint(rad.w);
-            V3 lpos = v3(0, 0, 0);
-            if (light_index >= 0 && (uint32_t)light_index < sc.num_lights) lpos = xyz(sc.lights[2 * light_index]);
-            dir = normalize3(lpos - o);      // rgen:113
-            tlimit = length3(lpos - o);      // rgen:114
-            f = thr.w;
-         } else {
-            dir = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);  // rgen:64
-         }
+         const uint32_t id = queue[i];
+         const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, ps.ray_o[id], ps.thr[id], ps.rad[id]);
          Hit h;
-         bool occluded = traverse<true, COUNT>(sc, o, dir, tmin, tmax, tlimit, h, lds_col, n_nodes, n_tris);
-         if (!occluded) {  // rgen:69-78 / :118-122
-            if (LIGHT)
-               ps.rad[id] = make_float4(rad.x + thr.x * f, rad.y + thr.y * f, rad.z + thr.z * f, rad.w);
-            else
-               ps.rad[id] = make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w);
-         }
+         if (!traverse<true, COUNT>(sc, xyz(s.ro), xyz(s.rd), s.ro.w, s.rd.w, s.tlimit, h, lds_col, n_nodes, n_tris)) ps.rad[id] = s.lit;
       }
    }
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
@@ -519,6 +637,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    }
 }
 
+// stand-alone any-hit query (uh_trace_any): occluded[i] = 1 when some triangle lies in (tmin, tmax) of ray i
 __global__ __launch_bounds__(kBlock) void k_trace_any_raw(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                           uint32_t* __restrict__ occluded, uint32_t count) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
@@ -528,571 +647,6 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_raw(SceneDev sc, const flo
       float4 ro = ray_o[i], rd = ray_d[i];
       Hit h;
       occluded[i] = traverse<true, false>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, INFINITY, h, lds_col, n_nodes, n_tris) ? 1u : 0u;
-   }
-}
-
-// ------------------------------------------------------------------------------------------
-// Traversal v2 — persistent waves with per-lane ray replacement ("while-while" with dynamic fetch).
-// A wave keeps a pool of kChunk rays taken from its shard's cursor with ONE atomic; a lane whose ray
-// is finished goes idle, and as soon as kRefillIdle lanes are idle the wave (a) appends the finished
-// rays to the hit / miss queues with one ballot-aggregated atomic each and (b) hands every idle lane
-// the next ray of the pool. The inner structure is while-while: all lanes first descend interior
-// nodes until each holds a leaf (or is done), then the leaves are intersected together, so a wave
-// does not pay node + leaf cost in every iteration the way the if-if form of traverse() does.
-// ------------------------------------------------------------------------------------------
-// wave-uniform pool refill; returns false when the shard's queue is drained
-__device__ __forceinline__ bool pool_refill(uint32_t* cursor, uint32_t count, uint32_t& pool_pos, uint32_t& pool_end) {
-   uint32_t base = 0;
-   if (lane_id() == 0) base = atomicAdd(cursor, kChunk);
-   base = __builtin_amdgcn_readfirstlane(base);
-   if (base >= count) return false;
-   pool_pos = base;
-   pool_end = min(base + kChunk, count);
-   return true;
-}
-
-template <bool COUNT, int kRefillIdle, int kMode>
-__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_v2(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
-                                                             uint32_t cursor_slot, int ray_kind) {
-   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
-   const uint32_t lane = lane_id();
-   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
-   const ShardCtx sx = shard_ctx();
-   const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
-   uint32_t* q_hit = ps.queue[2] + seg;
-   uint32_t* q_miss = ps.queue[3] + seg;
-   uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
-   uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
-   const uint4* __restrict__ nodes = sc.nodes;
-   const float4* __restrict__ tris = sc.tris;
-   uint32_t spill[kSpillStack];
-   uint32_t pool_pos = 0, pool_end = 0;
-   bool drained = false;
-   bool active = false;
-   uint32_t pend = 0, id = 0;  // pend: 1 = finished with a hit, 2 = finished with a miss, not yet queued
-   uint32_t tk = 0;            // next triangle of the current leaf (kMode 2)
-   Trav t;
-   t.cur = kEmptyRef;
-   t.sp = 0;
-   uint32_t n_nodes = 0, n_tris = 0;
-   for (;;) {
-      const unsigned long long idle_mask = __ballot(!active);
-      const int n_idle = __popcll(idle_mask);
-      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
-         // (a) queue the finished rays
-         uint32_t slot = wave_append(n_hit, pend == 1);
-         if (pend == 1) q_hit[slot] = id;
-         slot = wave_append(n_miss, pend == 2);
-         if (pend == 2) q_miss[slot] = id;
-         pend = 0;
-         // (b) hand out new rays
-         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
-         if (!drained) {
-            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-            const uint32_t idx = pool_pos + prefix;
-            if (!active && idx < pool_end) {
-               id = queue[idx];
-               trav_init(t, ps.ray_o[id], ps.ray_d[id], INFINITY);
-               tk = 0;
-               active = true;
-            }
-            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
-         }
-         if (__ballot(active) == 0ull) {
-            if (drained) break;
-            continue;
-         }
-      }
-      if (active) {
-         if (kMode == 2) {
-            // if-if: one node step, then one triangle if the lane stands at a leaf (see traverse())
-            if (!(t.cur & kLeafBit)) {
-               if (COUNT) n_nodes++;
-               node_step<false>(nodes, t, lds_col, spill);
-            }
-            if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
-               const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
-               if (COUNT) n_tris++;
-               tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
-               tk++;
-               if (tk >= cnt) {
-                  tk = 0;
-                  t.cur = trav_pop(t, lds_col, spill);
-               }
-            }
-         } else if (kMode == 1) {
-            // speculative while-while: a lane that reaches a leaf parks it and keeps descending from
-            // its stack, so it does not idle while the rest of the wave is still in interior nodes.
-            // (Hits are order-independent, so walking on with a stale tbest only costs a few visits.)
-            uint32_t parked = kEmptyRef;
-            for (;;) {
-               if (t.cur != kEmptyRef && (t.cur & kLeafBit) && parked == kEmptyRef) {
-                  parked = t.cur;
-                  t.cur = trav_pop(t, lds_col, spill);
-               }
-               if (t.cur == kEmptyRef || (t.cur & kLeafBit)) break;
-               if (COUNT) n_nodes++;
-               node_step<false>(nodes, t, lds_col, spill);
-            }
-            if (parked != kEmptyRef) {
-               const uint32_t keep = t.cur;
-               t.cur = parked;
-               leaf_step<false>(tris, t, n_tris);
-               t.cur = keep;
-            }
-         } else {
-            while (t.cur != kEmptyRef && !(t.cur & kLeafBit)) {
-               if (COUNT) n_nodes++;
-               node_step<false>(nodes, t, lds_col, spill);
-            }
-            if (t.cur != kEmptyRef) {
-               leaf_step<false>(tris, t, n_tris);
-               t.cur = trav_pop(t, lds_col, spill);
-            }
-         }
-         if (t.cur == kEmptyRef) {
-            ps.hit[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
-            pend = t.best.idx != kEmptyRef ? 1u : 2u;
-            active = false;
-         }
-      }
-   }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
-   if (COUNT) {
-      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
-      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
-   }
-}
-
-template <bool COUNT, bool LIGHT, int kRefillIdle, int kMode>
-__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_shadow_v2(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats,
-                                                            uint32_t bounce, uint32_t cursor_slot) {
-   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
-   const uint32_t lane = lane_id();
-   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
-   const ShardCtx sx = shard_ctx();
-   const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[4] : ps.queue[(bounce + 1) & 1]) + seg;
-   const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   const uint4* __restrict__ nodes = sc.nodes;
-   const float4* __restrict__ tris = sc.tris;
-   uint32_t spill[kSpillStack];
-   uint32_t pool_pos = 0, pool_end = 0;
-   bool drained = false, active = false;
-   uint32_t id = 0, tk = 0;
-   float4 lit = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-   Trav t;
-   t.cur = kEmptyRef;
-   t.sp = 0;
-   uint32_t n_nodes = 0, n_tris = 0;
-   for (;;) {
-      const unsigned long long idle_mask = __ballot(!active);
-      const int n_idle = __popcll(idle_mask);
-      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
-         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
-         if (!drained) {
-            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-            const uint32_t idx = pool_pos + prefix;
-            if (!active && idx < pool_end) {
-               id = queue[idx];
-               float4 ro = ps.ray_o[id];
-               ro.w = 0.001f;
-               float4 rd;
-               float tlimit = INFINITY;
-               // the radiance this path gets if the ray turns out unoccluded (rgen:69-78 / :118-122) is formed
-               // NOW, beside the ray fetch: a load at the moment a lane finishes would stall the whole wave
-               // in almost every iteration (some lane finishes in nearly each one)
-               const float4 thr = ps.thr[id], rad = ps.rad[id];
-               if (LIGHT) {
-                  int light_index = (int)__float_as_uint(rad.w);
-                  V3 lpos = v3(0, 0, 0);
-                  if (light_index >= 0 && (uint32_t)light_index < sc.num_lights) lpos = xyz(sc.lights[2 * light_index]);
-                  V3 o = v3(ro.x, ro.y, ro.z);
-                  V3 dir = normalize3(lpos - o);  // rgen:113
-                  tlimit = length3(lpos - o);     // rgen:114
-                  const float f = thr.w;
-                  lit = make_float4(rad.x + thr.x * f, rad.y + thr.y * f, rad.z + thr.z * f, rad.w);
-                  rd = make_float4(dir.x, dir.y, dir.z, 10000.0f);
-               } else {
-                  lit = make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w);
-                  rd = make_float4(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2], 10000.0f);  // rgen:64
-               }
-               trav_init(t, ro, rd, tlimit);
-               tk = 0;
-               active = true;
-            }
-            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
-         }
-         if (__ballot(active) == 0ull) {
-            if (drained) break;
-            continue;
-         }
-      }
-      if (active) {
-         bool occluded = false;
-         if (kMode == 2) {
-            if (!(t.cur & kLeafBit)) {
-               if (COUNT) n_nodes++;
-               node_step<true>(nodes, t, lds_col, spill);
-            }
-            if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {  // also the leaf the node step just descended to
-               const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
-               if (COUNT) n_tris++;
-               occluded = tri_test<true>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
-               tk++;
-               if (occluded) {
-                  t.cur = kEmptyRef;
-               } else if (tk >= cnt) {
-                  tk = 0;
-                  t.cur = trav_pop(t, lds_col, spill);
-               }
-            }
-         } else if (kMode == 1) {
-            uint32_t parked = kEmptyRef;
-            for (;;) {
-               if (t.cur != kEmptyRef && (t.cur & kLeafBit) && parked == kEmptyRef) {
-                  parked = t.cur;
-                  t.cur = trav_pop(t, lds_col, spill);
-               }
-               if (t.cur == kEmptyRef || (t.cur & kLeafBit)) break;
-               if (COUNT) n_nodes++;
-               node_step<true>(nodes, t, lds_col, spill);
-            }
-            if (parked != kEmptyRef) {
-               const uint32_t keep = t.cur;
-               t.cur = parked;
-               occluded = leaf_step<true>(tris, t, n_tris);
-               t.cur = occluded ? kEmptyRef : keep;
-            }
-         } else {
-            while (t.cur != kEmptyRef && !(t.cur & kLeafBit)) {
-               if (COUNT) n_nodes++;
-               node_step<true>(nodes, t, lds_col, spill);
-            }
-            if (t.cur != kEmptyRef) {
-               occluded = leaf_step<true>(tris, t, n_tris);
-               t.cur = occluded ? kEmptyRef : trav_pop(t, lds_col, spill);
-            }
-         }
-         if (t.cur == kEmptyRef) {
-            if (!occluded) ps.rad[id] = lit;
-            active = false;
-         }
-      }
-   }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
-   if (COUNT) {
-      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
-      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
-   }
-}
-
-// ------------------------------------------------------------------------------------------
-// Traversal v5 (closest hit) — if-if one-node / one-triangle steps + per-lane refill, with the
-// finished ray ids staged in two per-wave LDS lists (hit / miss) that are flushed to the global
-// queues 64 ids at a time. The refill path therefore contains no global atomic (the v2 refill lost
-// to two returning atomics per refill); queue atomics stay at the batch kernel's rate of one per
-// 64 rays per queue.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void flush_list(uint32_t* list, uint32_t& n, uint32_t take, uint32_t* counter, uint32_t* queue) {
-   const uint32_t lane = lane_id();
-   uint32_t base = 0;
-   if (lane == 0) base = atomicAdd(counter, take);
-   base = __builtin_amdgcn_readfirstlane(base);
-   if (lane < take) queue[base + lane] = list[lane];
-   // move the tail (at most 63 entries) to the front; one wave, LDS ops in order: read, then write
-   const uint32_t rest = n - take;
-   uint32_t tmp = 0;
-   if (lane < rest) tmp = list[take + lane];
-   if (lane < rest) list[lane] = tmp;
-   n = rest;
-}
-
-template <bool COUNT, int kRefillIdle>
-__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_v5(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats,
-                                                                                                  uint32_t bounce, uint32_t cursor_slot, int ray_kind) {
-   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
-   __shared__ uint32_t s_out[kWavesPerBlock][2][128];
-   const uint32_t lane = lane_id();
-   const uint32_t wave = threadIdx.x >> 6;
-   uint32_t* lds_col = &s_stack[wave][0][lane];
-   uint32_t* hit_list = s_out[wave][0];
-   uint32_t* miss_list = s_out[wave][1];
-   const ShardCtx sx = shard_ctx();
-   const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
-   uint32_t* q_hit = ps.queue[2] + seg;
-   uint32_t* q_miss = ps.queue[3] + seg;
-   uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
-   uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
-   const uint4* __restrict__ nodes = sc.nodes;
-   const float4* __restrict__ tris = sc.tris;
-   uint32_t spill[kSpillStack];
-   uint32_t pool_pos = 0, pool_end = 0;
-   bool drained = false, active = false;
-   uint32_t id = 0, tk = 0;
-   uint32_t n_hq = 0, n_mq = 0;  // wave-uniform fill of the two LDS lists
-   Trav t;
-   t.cur = kEmptyRef;
-   t.sp = 0;
-   uint32_t n_nodes = 0, n_tris = 0;
-   for (;;) {
-      const unsigned long long idle_mask = __ballot(!active);
-      const int n_idle = __popcll(idle_mask);
-      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
-         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
-         if (!drained) {
-            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-            const uint32_t idx = pool_pos + prefix;
-            if (!active && idx < pool_end) {
-               id = queue[idx];
-               trav_init(t, ps.ray_o[id], ps.ray_d[id], INFINITY);
-               tk = 0;
-               active = true;
-            }
-            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
-         }
-         if (__ballot(active) == 0ull) {
-            if (drained) break;
-            continue;
-         }
-      }
-      if (active) {
-         if (!(t.cur & kLeafBit)) {
-            if (COUNT) n_nodes++;
-            node_step<false>(nodes, t, lds_col, spill);
-         }
-         if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
-            const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
-            if (COUNT) n_tris++;
-            tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
-            tk++;
-            if (tk >= cnt) {
-               tk = 0;
-               t.cur = trav_pop(t, lds_col, spill);
-            }
-         }
-      }
-      const bool fin = active && t.cur == kEmptyRef;
-      if (__ballot(fin) != 0ull) {
-         const bool is_hit = fin && t.best.idx != kEmptyRef, is_miss = fin && t.best.idx == kEmptyRef;
-         if (fin) {
-            ps.hit[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
-            active = false;
-         }
-         const unsigned long long hm = __ballot(is_hit), mm = __ballot(is_miss);
-         if (is_hit) hit_list[n_hq + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u))] = id;
-         if (is_miss) miss_list[n_mq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = id;
-         n_hq += (uint32_t)__popcll(hm);
-         n_mq += (uint32_t)__popcll(mm);
-         if (n_hq >= 64u) flush_list(hit_list, n_hq, 64u, n_hit, q_hit);
-         if (n_mq >= 64u) flush_list(miss_list, n_mq, 64u, n_miss, q_miss);
-      }
-   }
-   if (n_hq) flush_list(hit_list, n_hq, n_hq, n_hit, q_hit);
-   if (n_mq) flush_list(miss_list, n_mq, n_mq, n_miss, q_miss);
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
-   if (COUNT) {
-      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
-      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
-   }
-}
-
-// ------------------------------------------------------------------------------------------
-// Traversal v3 — "vote" scheduling on top of the v2 refill. The v2 counters (profiles/r01c_*) show
-// the SIMDs ~70 % busy issuing VALU while only ~30 % of the lanes in those instructions are live:
-// lanes sit out whenever the wave is in the other phase (interior node vs triangle). Here every
-// loop iteration runs exactly ONE phase for the whole wave, chosen by ballot: a triangle step (one
-// triangle per lane that stands at a leaf) when at least kLeafVote lanes want one or nobody wants
-// a node step, else a node step. Lanes of the minority wait one iteration instead of dragging a
-// sparsely populated phase through the SIMD.
-// ------------------------------------------------------------------------------------------
-template <bool COUNT, int kRefillIdle, int kLeafVote>
-__global__ __launch_bounds__(kBlock) void k_trace_closest_v3(SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
-                                                             uint32_t cursor_slot, int ray_kind) {
-   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
-   const uint32_t lane = lane_id();
-   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
-   const ShardCtx sx = shard_ctx();
-   const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
-   uint32_t* q_hit = ps.queue[2] + seg;
-   uint32_t* q_miss = ps.queue[3] + seg;
-   uint32_t* n_hit = &ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
-   uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
-   const uint4* __restrict__ nodes = sc.nodes;
-   const float4* __restrict__ tris = sc.tris;
-   uint32_t spill[kSpillStack];
-   uint32_t pool_pos = 0, pool_end = 0;
-   bool drained = false, active = false;
-   uint32_t pend = 0, id = 0, tk = 0;
-   Trav t;
-   t.cur = kEmptyRef;
-   t.sp = 0;
-   uint32_t n_nodes = 0, n_tris = 0;
-   for (;;) {
-      const unsigned long long idle_mask = __ballot(!active);
-      const int n_idle = __popcll(idle_mask);
-      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
-         uint32_t slot = wave_append(n_hit, pend == 1);
-         if (pend == 1) q_hit[slot] = id;
-         slot = wave_append(n_miss, pend == 2);
-         if (pend == 2) q_miss[slot] = id;
-         pend = 0;
-         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
-         if (!drained) {
-            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-            const uint32_t idx = pool_pos + prefix;
-            if (!active && idx < pool_end) {
-               id = queue[idx];
-               trav_init(t, ps.ray_o[id], ps.ray_d[id], INFINITY);
-               tk = 0;
-               active = true;
-            }
-            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
-         }
-         if (__ballot(active) == 0ull) {
-            if (drained) break;
-            continue;
-         }
-      }
-      const bool at_leaf = active && (t.cur & kLeafBit);
-      const int n_leaf = __popcll(__ballot(at_leaf));
-      const int n_node = 64 - n_idle - n_leaf;  // n_idle is exact here: nothing changed `active` since the ballot unless we refilled
-      const bool tri_phase = (n_leaf >= kLeafVote) || (__ballot(active && !at_leaf) == 0ull);
-      (void)n_node;
-      if (tri_phase) {
-         if (at_leaf) {
-            const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
-            if (COUNT) n_tris++;
-            tri_test<false>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
-            tk++;
-            if (tk >= cnt) {
-               tk = 0;
-               t.cur = trav_pop(t, lds_col, spill);
-            }
-         }
-      } else if (active && !at_leaf) {
-         if (COUNT) n_nodes++;
-         node_step<false>(nodes, t, lds_col, spill);
-      }
-      if (active && t.cur == kEmptyRef) {
-         ps.hit[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
-         pend = t.best.idx != kEmptyRef ? 1u : 2u;
-         active = false;
-      }
-   }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
-   if (COUNT) {
-      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
-      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
-   }
-}
-
-template <bool COUNT, bool LIGHT, int kRefillIdle, int kLeafVote>
-__global__ __launch_bounds__(kBlock) void k_trace_shadow_v3(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats,
-                                                            uint32_t bounce, uint32_t cursor_slot) {
-   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
-   const uint32_t lane = lane_id();
-   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
-   const ShardCtx sx = shard_ctx();
-   const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[4] : ps.queue[(bounce + 1) & 1]) + seg;
-   const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   const uint4* __restrict__ nodes = sc.nodes;
-   const float4* __restrict__ tris = sc.tris;
-   uint32_t spill[kSpillStack];
-   uint32_t pool_pos = 0, pool_end = 0;
-   bool drained = false, active = false;
-   uint32_t id = 0, tk = 0;
-   float f = 1.0f;
-   Trav t;
-   t.cur = kEmptyRef;
-   t.sp = 0;
-   uint32_t n_nodes = 0, n_tris = 0;
-   for (;;) {
-      const unsigned long long idle_mask = __ballot(!active);
-      const int n_idle = __popcll(idle_mask);
-      if ((n_idle >= kRefillIdle && !drained) || n_idle == 64) {
-         if (!drained && pool_pos >= pool_end) drained = !pool_refill(cursor, count, pool_pos, pool_end);
-         if (!drained) {
-            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-            const uint32_t idx = pool_pos + prefix;
-            if (!active && idx < pool_end) {
-               id = queue[idx];
-               float4 ro = ps.ray_o[id];
-               ro.w = 0.001f;
-               float4 rd;
-               float tlimit = INFINITY;
-               if (LIGHT) {
-                  float4 thr = ps.thr[id], rad = ps.rad[id];
-                  int light_index = (int)__float_as_uint(rad.w);
-                  V3 lpos = v3(0, 0, 0);
-                  if (light_index >= 0 && (uint32_t)light_index < sc.num_lights) lpos = xyz(sc.lights[2 * light_index]);
-                  V3 o = v3(ro.x, ro.y, ro.z);
-                  V3 dir = normalize3(lpos - o);  // rgen:113
-                  tlimit = length3(lpos - o);     // rgen:114
-                  f = thr.w;
-                  rd = make_float4(dir.x, dir.y, dir.z, 10000.0f);
-               } else {
-                  rd = make_float4(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2], 10000.0f);  // rgen:64
-               }
-               trav_init(t, ro, rd, tlimit);
-               tk = 0;
-               active = true;
-            }
-            pool_pos = min(pool_pos + (uint32_t)n_idle, pool_end);
-         }
-         if (__ballot(active) == 0ull) {
-            if (drained) break;
-            continue;
-         }
-      }
-      const bool at_leaf = active && (t.cur & kLeafBit);
-      const int n_leaf = __popcll(__ballot(at_leaf));
-      const bool tri_phase = (n_leaf >= kLeafVote) || (__ballot(active && !at_leaf) == 0ull);
-      bool occluded = false;
-      if (tri_phase) {
-         if (at_leaf) {
-            const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
-            if (COUNT) n_tris++;
-            occluded = tri_test<true>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best);
-            tk++;
-            if (occluded) {
-               t.cur = kEmptyRef;
-            } else if (tk >= cnt) {
-               tk = 0;
-               t.cur = trav_pop(t, lds_col, spill);
-            }
-         }
-      } else if (active && !at_leaf) {
-         if (COUNT) n_nodes++;
-         node_step<true>(nodes, t, lds_col, spill);
-      }
-      if (active && t.cur == kEmptyRef) {
-         if (!occluded) {  // rgen:69-78 / :118-122
-            float4 thr = ps.thr[id], rad = ps.rad[id];
-            if (LIGHT)
-               ps.rad[id] = make_float4(rad.x + thr.x * f, rad.y + thr.y * f, rad.z + thr.z * f, rad.w);
-            else
-               ps.rad[id] = make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w);
-         }
-         active = false;
-      }
-   }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
-   if (COUNT) {
-      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
-      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
    }
 }
 
@@ -1143,29 +697,73 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
 }
 
 // ------------------------------------------------------------------------------------------
-// shade_miss — reference.rmiss:10-31 + rgen:48-57 for paths whose ray left the scene
+// shade_miss — reference.rmiss:10-31 + rgen:48-57 for paths whose ray left the scene.
+// Walks the bounce's RAY queue and picks out the paths whose hit record says "miss" (the traversal
+// kernels build no hit / miss queues). The sky integral is ~3k VALU instructions per path, so the
+// misses are first compacted inside the wave: ids collect in a per-wave LDS list and the integral
+// runs on 64 of them at a time with every lane live.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
-   const ShardCtx sx = shard_ctx();
-   const uint32_t* __restrict__ queue = ps.queue[3] + sx.shard * ps.shard_cap;
-   const uint32_t count = ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   for (uint32_t i = sx.lb * kBlock + threadIdx.x; i < count; i += sx.nb * kBlock) {
-      uint32_t id = queue[i];
-      V3 sky_color = v3(0.0f, 0.0f, 0.0f);
-      if (fp.sky_enabled == 1) {
-         float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
-         V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
-         sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
-      }
-      float4 thr = make_float4(1.0f, 1.0f, 1.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (bounce != 0) {
-         thr = ps.thr[id];
-         rad = ps.rad[id];
-      }
-      V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
-      ps.rad[id] = make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w);   // rgen:55
+__device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const PathState& ps, uint32_t id, uint32_t bounce) {
+   V3 sky_color = v3(0.0f, 0.0f, 0.0f);
+   if (fp.sky_enabled == 1) {
+      float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
+      V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
+      sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
    }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->misses, (unsigned long long)count);
+   float4 thr = make_float4(1.0f, 1.0f, 1.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+   if (bounce != 0) {
+      thr = ps.thr[id];
+      rad = ps.rad[id];
+   }
+   V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
+   ps.rad[id] = make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w);   // rgen:55
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
+   __shared__ uint32_t s_list[kWavesPerBlock][128];
+   __shared__ uint32_t s_total;
+   if (threadIdx.x == 0) s_total = 0;
+   __syncthreads();
+   const uint32_t lane = lane_id();
+   uint32_t* list = s_list[threadIdx.x >> 6];
+   const ShardCtx sx = shard_ctx();
+   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + sx.shard * ps.shard_cap;
+   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
+   const uint32_t stride = sx.nb * kBlock;
+   const uint32_t rounds = (count + stride - 1) / stride;
+   uint32_t n_list = 0, n_total = 0;  // wave-uniform
+   for (uint32_t r = 0; r < rounds; r++) {
+      const uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
+      bool miss = false;
+      uint32_t id = 0;
+      if (i < count) {
+         id = queue[i];
+         miss = __float_as_uint(ps.hit[id].w) == kEmptyRef;
+      }
+      const unsigned long long mask = __ballot(miss);
+      if (mask == 0ull) continue;
+      const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      if (miss) list[n_list + prefix] = id;
+      n_list += (uint32_t)__popcll(mask);
+      __builtin_amdgcn_wave_barrier();
+      if (n_list >= 64u) {
+         shade_miss_path(fp, ps, list[lane], bounce);
+         n_total += 64u;
+         // move the tail (at most 63 ids) to the front: one wave, LDS operations execute in order
+         const uint32_t rest = n_list - 64u;
+         uint32_t tmp = 0;
+         if (lane < rest) tmp = list[64u + lane];
+         __builtin_amdgcn_wave_barrier();
+         if (lane < rest) list[lane] = tmp;
+         __builtin_amdgcn_wave_barrier();
+         n_list = rest;
+      }
+   }
+   if (lane < n_list) shade_miss_path(fp, ps, list[lane], bounce);
+   n_total += n_list;
+   if (lane == 0 && n_total) atomicAdd(&s_total, n_total);
+   __syncthreads();
+   if (threadIdx.x == 0 && s_total) atomicAdd(&stats->misses, (unsigned long long)s_total);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1228,26 +826,34 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
    __shared__ TexInfo s_tex[kLdsTextures];
    const uint32_t n_lds_mesh = sc.num_meshes < kLdsMeshes ? sc.num_meshes : kLdsMeshes;
    const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
+   __shared__ uint32_t s_hits;
+   if (threadIdx.x == 0) s_hits = 0;
    if (threadIdx.x < n_lds_mesh) s_mesh[threadIdx.x] = sc.meshes[threadIdx.x];
    if (threadIdx.x < n_lds_tex) s_tex[threadIdx.x] = sc.textures[threadIdx.x];
    __syncthreads();
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t count = ctl->q_count[qc_index(bounce, Q_HIT, sx.shard)];
-   const uint32_t* __restrict__ queue = ps.queue[2] + seg;
+   // the bounce's RAY queue: paths whose hit record says "miss" belong to k_shade_miss and are skipped here
+   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
+   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
    uint32_t* q_next = ps.queue[(bounce + 1) & 1] + seg;
    uint32_t* n_next = &ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
-   uint32_t* q_light = ps.queue[4] + seg;
+   uint32_t* q_light = ps.queue[2] + seg;
    uint32_t* n_light = &ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)];
    const uint32_t stride = sx.nb * kBlock;
    const uint32_t rounds = (count + stride - 1) / stride;
+   uint32_t n_hits = 0;
    for (uint32_t r = 0; r < rounds; r++) {
       uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
       bool scattered = false, want_light = false;
       uint32_t id = 0;
+      float4 hr = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmptyRef));
       if (i < count) {
          id = queue[i];
-         float4 hr = ps.hit[id];
+         hr = ps.hit[id];
+      }
+      if (__float_as_uint(hr.w) != kEmptyRef) {
+         n_hits++;
          float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
          const V3 ray_dir = v3(rd.x, rd.y, rd.z);
          const float t = hr.x, bu = hr.y, bv = hr.z;
@@ -1360,7 +966,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
       slot = wave_append(n_light, want_light);
       if (want_light) q_light[slot] = id;
    }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->closest_hits, (unsigned long long)count);
+   // closest_hits: per-block sum, one atomic per block
+   for (int o = 32; o > 0; o >>= 1) n_hits += __shfl_xor(n_hits, o);
+   if (lane_id() == 0 && n_hits) atomicAdd(&s_hits, n_hits);
+   __syncthreads();
+   if (threadIdx.x == 0 && s_hits) atomicAdd(&stats->closest_hits, (unsigned long long)s_hits);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1614,8 +1224,8 @@ static inline dim3 shade_grid(const LaunchCfg& c, uint32_t n) {
 
 uint32_t query_trace_occupancy() {
    int a = 0, b = 0;
-   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<false, 0>, kBlock, 0) != hipSuccess) a = 4;
-   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kBlock, 0) != hipSuccess) b = 4;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest_batch<false, false>, kBlock, 0) != hipSuccess) a = 4;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow_batch<false, false>, kBlock, 0) != hipSuccess) b = 4;
    int m = a < b ? a : b;
    if (m < 1) m = 1;
    if (m > 8) m = 8;
@@ -1626,97 +1236,44 @@ void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState&
    k_generate<<<stream_grid(c, fp.n_owned * fp.batch_frames), kBlock, 0, c.stream>>>(fp, ps, ctl, sample);
 }
 
+// closest-hit traversal over a sharded queue of path ids (queue != null) or over n raw rays (queue == null).
+// Variant 0 = batch kernel; 1..4 = refill kernel with a refill threshold of 1 / 4 / 8 / 16 idle lanes.
+static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, const uint32_t* queue, const float4* ray_o, const float4* ray_d, float4* hit,
+                           uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag) {
+#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, queue, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
+   const bool count = c.count_visits && queue;
+   if (diag) {
+      UH_CLOSEST((k_trace_closest_batch<false, true>));
+      return;
+   }
+   switch (c.closest_variant) {
+      case 0:
+         if (count) UH_CLOSEST((k_trace_closest_batch<true, false>));
+         else UH_CLOSEST((k_trace_closest_batch<false, false>));
+         break;
+      case 1:
+         if (count) UH_CLOSEST((k_trace_closest<true, 1>));
+         else UH_CLOSEST((k_trace_closest<false, 1>));
+         break;
+      case 2:
+         if (count) UH_CLOSEST((k_trace_closest<true, 4>));
+         else UH_CLOSEST((k_trace_closest<false, 4>));
+         break;
+      case 4:
+         if (count) UH_CLOSEST((k_trace_closest<true, 16>));
+         else UH_CLOSEST((k_trace_closest<false, 16>));
+         break;
+      default:
+         if (count) UH_CLOSEST((k_trace_closest<true, 8>));
+         else UH_CLOSEST((k_trace_closest<false, 8>));
+         break;
+   }
+#undef UH_CLOSEST
+}
+
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                           uint32_t cursor_slot, int ray_kind) {
-   if (c.closest_variant == 0) {
-      if (c.count_visits)
-         k_trace_closest<true, 0><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
-      else
-         k_trace_closest<false, 0><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
-      return;
-   }
-   if (c.closest_variant >= 27 && c.closest_variant <= 29) {  // top of the tree staged in LDS: 32 / 64 / 128 nodes
-#define UH_LAUNCH_TOP(N)                                                                                                          \
-   do {                                                                                                                           \
-      if (c.count_visits)                                                                                                         \
-         k_trace_closest<true, N><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);     \
-      else                                                                                                                        \
-         k_trace_closest<false, N><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);    \
-   } while (0)
-      if (c.closest_variant == 27) UH_LAUNCH_TOP(32);
-      else if (c.closest_variant == 28) UH_LAUNCH_TOP(64);
-      else UH_LAUNCH_TOP(128);
-#undef UH_LAUNCH_TOP
-      return;
-   }
-   if (c.closest_variant == 26) {  // entry-distance culling
-      if (c.count_visits)
-         k_trace_closest<true, 1><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
-      else
-         k_trace_closest<false, 1><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);
-      return;
-   }
-   if (c.closest_variant >= 22) {
-#define UH_LAUNCH_V5(IDLE)                                                                                                           \
-   do {                                                                                                                              \
-      if (c.count_visits)                                                                                                            \
-         k_trace_closest_v5<true, IDLE><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);  \
-      else                                                                                                                           \
-         k_trace_closest_v5<false, IDLE><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind); \
-   } while (0)
-      switch (c.closest_variant) {
-         case 22: UH_LAUNCH_V5(32); break;
-         case 23: UH_LAUNCH_V5(16); break;
-         case 24: UH_LAUNCH_V5(8); break;
-         default: UH_LAUNCH_V5(4); break;
-      }
-#undef UH_LAUNCH_V5
-      return;
-   }
-   if (c.closest_variant >= 11 && c.closest_variant <= 16) {
-#define UH_LAUNCH_V3(IDLE, VOTE)                                                                                                          \
-   do {                                                                                                                                   \
-      if (c.count_visits)                                                                                                                 \
-         k_trace_closest_v3<true, IDLE, VOTE><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);  \
-      else                                                                                                                                \
-         k_trace_closest_v3<false, IDLE, VOTE><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind); \
-   } while (0)
-      switch (c.closest_variant) {
-         case 11: UH_LAUNCH_V3(16, 16); break;
-         case 12: UH_LAUNCH_V3(16, 24); break;
-         case 13: UH_LAUNCH_V3(16, 32); break;
-         case 14: UH_LAUNCH_V3(8, 24); break;
-         case 15: UH_LAUNCH_V3(24, 24); break;
-         default: UH_LAUNCH_V3(16, 40); break;
-      }
-#undef UH_LAUNCH_V3
-      return;
-   }
-#define UH_LAUNCH_V2(IDLE, POST)                                                                                                          \
-   do {                                                                                                                                   \
-      if (c.count_visits)                                                                                                                 \
-         k_trace_closest_v2<true, IDLE, POST><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind);  \
-      else                                                                                                                                \
-         k_trace_closest_v2<false, IDLE, POST><<<closest_grid(c), kBlock, 0, c.stream>>>(sc, ps, ctl, stats, bounce, cursor_slot, ray_kind); \
-   } while (0)
-   switch (c.closest_variant) {
-      case 1: UH_LAUNCH_V2(64, 0); break;
-      case 2: UH_LAUNCH_V2(32, 0); break;
-      case 3: UH_LAUNCH_V2(16, 0); break;
-      case 4: UH_LAUNCH_V2(8, 0); break;
-      case 5: UH_LAUNCH_V2(1, 0); break;
-      case 6: UH_LAUNCH_V2(64, 1); break;
-      case 7: UH_LAUNCH_V2(32, 1); break;
-      case 8: UH_LAUNCH_V2(16, 1); break;
-      case 9: UH_LAUNCH_V2(8, 1); break;
-      case 10: UH_LAUNCH_V2(1, 1); break;
-      case 17: UH_LAUNCH_V2(48, 2); break;
-      case 18: UH_LAUNCH_V2(32, 2); break;
-      case 19: UH_LAUNCH_V2(16, 2); break;
-      case 20: UH_LAUNCH_V2(8, 2); break;
-      default: UH_LAUNCH_V2(1, 2); break;
-   }
-#undef UH_LAUNCH_V2
+   launch_closest(c, closest_grid(c), sc, ps.queue[bounce & 1], ps.ray_o, ps.ray_d, ps.hit, ps.shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, 0, false);
 }
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
@@ -1730,78 +1287,34 @@ void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev&
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
                          uint32_t bounce, uint32_t cursor_slot, bool light) {
-   if (c.shadow_variant >= 11 && c.shadow_variant <= 16) {  // (22..25 are closest-only kernels; shadow falls back to the 17..21 family)
-#define UH_LAUNCH_S3(IDLE, VOTE)                                                                                                              \
-   do {                                                                                                                                       \
-      if (light) {                                                                                                                            \
-         if (c.count_visits)                                                                                                                  \
-            k_trace_shadow_v3<true, true, IDLE, VOTE><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);    \
-         else                                                                                                                                 \
-            k_trace_shadow_v3<false, true, IDLE, VOTE><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);   \
-      } else {                                                                                                                                \
-         if (c.count_visits)                                                                                                                  \
-            k_trace_shadow_v3<true, false, IDLE, VOTE><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);   \
-         else                                                                                                                                 \
-            k_trace_shadow_v3<false, false, IDLE, VOTE><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);  \
-      }                                                                                                                                       \
+#define UH_SHADOW(KERNEL) KERNEL<<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot)
+#define UH_SHADOW_RF(K)                                             \
+   do {                                                             \
+      if (light) {                                                  \
+         if (c.count_visits) UH_SHADOW((k_trace_shadow<true, true, K>));    \
+         else UH_SHADOW((k_trace_shadow<false, true, K>));          \
+      } else {                                                      \
+         if (c.count_visits) UH_SHADOW((k_trace_shadow<true, false, K>));   \
+         else UH_SHADOW((k_trace_shadow<false, false, K>));         \
+      }                                                             \
    } while (0)
-      switch (c.shadow_variant) {
-         case 11: UH_LAUNCH_S3(16, 16); break;
-         case 12: UH_LAUNCH_S3(16, 24); break;
-         case 13: UH_LAUNCH_S3(16, 32); break;
-         case 14: UH_LAUNCH_S3(8, 24); break;
-         case 15: UH_LAUNCH_S3(24, 24); break;
-         default: UH_LAUNCH_S3(16, 40); break;
-      }
-#undef UH_LAUNCH_S3
-      return;
+   switch (c.shadow_variant) {
+      case 0:
+         if (light) {
+            if (c.count_visits) UH_SHADOW((k_trace_shadow_batch<true, true>));
+            else UH_SHADOW((k_trace_shadow_batch<false, true>));
+         } else {
+            if (c.count_visits) UH_SHADOW((k_trace_shadow_batch<true, false>));
+            else UH_SHADOW((k_trace_shadow_batch<false, false>));
+         }
+         break;
+      case 1: UH_SHADOW_RF(1); break;
+      case 2: UH_SHADOW_RF(4); break;
+      case 4: UH_SHADOW_RF(16); break;
+      default: UH_SHADOW_RF(8); break;
    }
-   if (c.shadow_variant != 0) {
-#define UH_LAUNCH_S2(IDLE, POST)                                                                                                              \
-   do {                                                                                                                                 \
-      if (light) {                                                                                                                      \
-         if (c.count_visits)                                                                                                            \
-            k_trace_shadow_v2<true, true, IDLE, POST><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);    \
-         else                                                                                                                           \
-            k_trace_shadow_v2<false, true, IDLE, POST><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);   \
-      } else {                                                                                                                          \
-         if (c.count_visits)                                                                                                            \
-            k_trace_shadow_v2<true, false, IDLE, POST><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);   \
-         else                                                                                                                           \
-            k_trace_shadow_v2<false, false, IDLE, POST><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);  \
-      }                                                                                                                                 \
-   } while (0)
-      switch (c.shadow_variant) {
-         case 1: UH_LAUNCH_S2(64, 0); break;
-         case 2: UH_LAUNCH_S2(32, 0); break;
-         case 3: UH_LAUNCH_S2(16, 0); break;
-         case 4: UH_LAUNCH_S2(8, 0); break;
-         case 5: UH_LAUNCH_S2(1, 0); break;
-         case 6: UH_LAUNCH_S2(64, 1); break;
-         case 7: UH_LAUNCH_S2(32, 1); break;
-         case 8: UH_LAUNCH_S2(16, 1); break;
-         case 9: UH_LAUNCH_S2(8, 1); break;
-         case 10: UH_LAUNCH_S2(1, 1); break;
-         case 17: UH_LAUNCH_S2(48, 2); break;
-         case 18: UH_LAUNCH_S2(32, 2); break;
-         case 19: UH_LAUNCH_S2(16, 2); break;
-         case 20: UH_LAUNCH_S2(8, 2); break;
-         default: UH_LAUNCH_S2(1, 2); break;
-      }
-#undef UH_LAUNCH_S2
-      return;
-   }
-   if (light) {
-      if (c.count_visits)
-         k_trace_shadow<true, true><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
-      else
-         k_trace_shadow<false, true><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
-   } else {
-      if (c.count_visits)
-         k_trace_shadow<true, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
-      else
-         k_trace_shadow<false, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot);
-   }
+#undef UH_SHADOW_RF
+#undef UH_SHADOW
 }
 
 void launch_finish_sample(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, const Images& im, uint32_t sample, bool last) {
@@ -1817,7 +1330,7 @@ void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& s
    (void)ctl;
    const uint32_t n = fp.W * fp.H;
    k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps);
-   k_trace_closest_raw<false><<<dim3(c.num_cus * c.closest_blocks_per_cu), kBlock, 0, c.stream>>>(sc, ps.ray_o, ps.ray_d, ps.hit, n);
+   launch_closest(c, dim3(c.num_cus * c.closest_blocks_per_cu), sc, nullptr, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n, false);
    k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats);
 }
 
@@ -1835,10 +1348,9 @@ void launch_spatial_reuse(const LaunchCfg& c, const FrameParams& fp, const Scene
 }
 
 void launch_trace_closest_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n) {
-   if (c.raw_visit_counts)
-      k_trace_closest_raw<true><<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, hit, n);
-   else
-      k_trace_closest_raw<false><<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, hit, n);
+   // a grid that fills the chip once; smaller queries get one block per 256 rays
+   const uint32_t full = c.num_cus * c.closest_blocks_per_cu, need = (n + kBlock - 1) / kBlock;
+   launch_closest(c, dim3(need < full ? (need ? need : 1) : full), sc, nullptr, ray_o, ray_d, hit, 0, nullptr, nullptr, 0, 0, 0, n, c.raw_visit_counts);
 }
 void launch_trace_any_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n) {
    k_trace_any_raw<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, occluded, n);

@@ -138,3 +138,61 @@ def test_config4_scene_class_at_4k_sampled_tiles_and_group():
     group = scene.upload(rr.MultiGpuRenderer(W4, H4, devices=[0, 0], tile_size=TILE))
     run_frames(group, scene, W4, H4, 2, rr.PASS_REFERENCE_PT, use_ris_light_sampling=0)
     assert np.array_equal(gpu.read_accumulation().view(np.uint32), group.read_accumulation().view(np.uint32))
+
+
+def test_config0_rtiow_256_matches_oracle():
+    """BASELINE configs[0]: RTIOW 3 spheres (Lambertian ground + centre, dielectric, metal; icospheres of 5
+    subdivisions, 81,920 triangles) + 1 point light, 256x256, 1 spp, 5 bounces, sky + sun + uniform light
+    sampling - the whole frame through the HIP path against the whole frame from the oracle"""
+    scene = rr.scenes.scene_for_config(0)
+    assert scene.num_triangles == 4 * 20 * 4 ** 5 and len(scene.lights) == 1
+    w = h = 256
+    gpu = scene.upload(rr.Renderer(w, h))
+    cpu = scene.upload(oa.OracleRenderer(w, h))
+    for r in (gpu, cpu):
+        run_frames(r, scene, w, h, 1, rr.PASS_REFERENCE_PT)
+    a, b = gpu.read_accumulation(), cpu.read_accumulation()
+    assert per_pixel_l2(a, b) <= L2_TOL
+    assert np.abs(a - b).max() <= 1e-4  # geometry, materials and light terms are bit-identical; the sky integral is not
+    s, t = gpu.get_stats(), cpu.get_stats()
+    assert list(s.rays) == list(t.rays) and s.rays[0] == w * h and s.rays[3] > 0  # light shadow rays were traced
+    assert s.closest_hits == t.closest_hits and s.misses == t.misses
+    # all three sphere materials are in the image: the 8-bit outputs agree to 1 LSB (sRGB pow)
+    assert np.abs(gpu.read_output_bgra8().astype(np.int16) - cpu.read_output_bgra8().astype(np.int16)).max() <= 1
+
+
+def test_config4_isosurface_512_at_1080p_sampled_tiles():
+    """BASELINE configs[4]: the 512^3 iso-surface of the reference's marching-cubes density field
+    (marching_cubes.comp:83-103) extracted on the GPU, path traced at 1920x1080. The oracle gets the very
+    triangles the device extracted (read_mesh) and renders a sample of tiles spread over the frame."""
+    scene = rr.scenes.scene_for_config(4)
+    gpu = rr.Renderer(W, H)
+    iso, ntri = gpu.add_isosurface_mesh(512, 0.0, 32.0)
+    assert iso == 0 and 1_000_000 < ntri < 4_000_000  # SURVEY 8d: "~1-3 M tris"
+    for model, transform in scene.models:  # the ground plane
+        gpu.add_model(model, transform)
+    gpu.initialize_raytracing()
+    v, idx = gpu.read_mesh(iso)
+    assert len(idx) == 3 * ntri
+    # every extracted vertex lies on the iso-surface to a fraction of a cell (sampled: 5 M vertices)
+    pick = np.arange(0, len(v), 97)
+    assert np.abs(rr.scenes.reference_density(v["pos"][pick, :3].astype(np.float64))).max() < 0.2 * 32.0 / 512
+    cpu = oa.OracleRenderer(W, H)
+    cpu.add_mesh(v, idx, rr.make_material(base_color=(0.8, 0.8, 0.8, 1.0), diffuse_map=cpu.default_diffuse_map()), None)
+    for model, transform in scene.models:
+        cpu.add_model(model, transform)
+    cpu.initialize_raytracing()
+    cpu.set_tile_partition(3, 61, TILE)  # 8-9 of the 510 tiles
+    for r in (gpu, cpu):
+        run_frames(r, scene, W, H, 2, rr.PASS_REFERENCE_PT)
+    mask = sampled(61, 3)
+    assert mask.sum() >= 30_000
+    a, b = gpu.read_accumulation()[mask], cpu.read_accumulation()[mask]
+    assert per_pixel_l2(a, b) <= L2_TOL
+    assert np.abs(a - b).max() <= 1e-4
+    s = gpu.get_stats()
+    assert s.rays[0] == 2 * W * H and s.closest_hits + s.misses == s.rays[0] + s.rays[1] and s.rays[3] == 0
+    acc = gpu.read_accumulation()
+    assert np.isfinite(acc).all() and (acc[..., :3] >= 0).all()
+    # the surface is in the picture: the frame's centre rows hit geometry, not only sky
+    assert s.closest_hits > W * H

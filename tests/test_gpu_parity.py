@@ -186,9 +186,9 @@ def test_instance_transform_rebuild(cornell):
     assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
 
 
-@pytest.mark.parametrize("variant", [1, 3, 5, 8, 11, 14, 17, 19, 21, 22, 23, 25, 26, 27, 29])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
 def test_traversal_variants_are_bit_identical(atrium, variant):
-    """every traversal kernel variant must produce the same image and the same ray counts"""
+    """the batch kernels (0) and every refill threshold (1, 2, 4; 3 is the default) must produce the same image and the same ray counts"""
     W, H = 160, 90
     ref = atrium.upload(rr.Renderer(W, H))
     alt = atrium.upload(rr.Renderer(W, H))

@@ -6,4 +6,4 @@ for b in 6 7; do run --opt closest_blocks_per_cu=$b; done
 for b in 4 5 7 8; do run --opt shadow_blocks_per_cu=$b; done
 for f in 2 4; do run --opt frames_in_flight=$f; done
 for b in 2 3 6 8; do run --opt batch_frames=$b; done
-for v in 0 3 18; do run --opt shadow_variant=$v; done
+for v in 0 1 2 4; do run --opt shadow_variant=$v; done
