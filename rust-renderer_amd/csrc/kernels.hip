@@ -38,9 +38,9 @@ __device__ __forceinline__ V3 cross_fma(V3 a, V3 b) {
    return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
 
+// Moeller-Trumbore on a baked packet (a = v0.xyz e1.x, b = e1.yz e2.xy, c = e2.z key): DESIGN.md "Arithmetic contract"
 template <bool ANY>
-__device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, uint32_t i, V3 o, V3 d, float tmin, float tlimit, Hit& best) {
-   float4 a = tris[3 * (size_t)i + 0], b = tris[3 * (size_t)i + 1], c = tris[3 * (size_t)i + 2];
+__device__ __forceinline__ bool tri_compute(float4 a, float4 b, float4 c, uint32_t i, V3 o, V3 d, float tmin, float tlimit, Hit& best) {
    V3 v0 = v3(a.x, a.y, a.z), e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, c.x);
    uint32_t key = __float_as_uint(c.y);
    V3 p = cross_fma(d, e2);
@@ -68,6 +68,11 @@ __device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, uint32
       }
       return false;
    }
+}
+template <bool ANY>
+__device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, uint32_t i, V3 o, V3 d, float tmin, float tlimit, Hit& best) {
+   float4 a = tris[3 * (size_t)i + 0], b = tris[3 * (size_t)i + 1], c = tris[3 * (size_t)i + 2];
+   return tri_compute<ANY>(a, b, c, i, o, d, tmin, tlimit, best);
 }
 
 __device__ __forceinline__ float safe_rcp_dir(float x) {
@@ -110,7 +115,16 @@ __device__ __forceinline__ void trav_push(Trav& t, uint32_t* lds_col, uint32_t* 
 __device__ __forceinline__ uint32_t trav_pop(Trav& t, const uint32_t* lds_col, const uint32_t* spill) {
    if (t.sp == 0) return kEmptyRef;
    t.sp--;
-   return t.sp < kLdsStack ? lds_col[t.sp * 64] : spill[t.sp - kLdsStack];
+   if (t.sp < kLdsStack) {
+      // inline asm: written as `sp < kLdsStack ? lds_col[..] : spill[..]` hipcc selects between the LDS and the scratch
+      // pointer and issues ONE flat_load - every pop then takes a slot of the vector memory addresser, the unit the
+      // traversal kernels load most (one slot per lane and load, profiles/r02_microbench_rates.txt)
+      uint32_t v;
+      const uint32_t at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)lds_col + 256u * (uint32_t)t.sp;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(at) : "memory");
+      return v;
+   }
+   return spill[t.sp - kLdsStack];
 }
 
 // one interior node (quantised, 64 B): slab-test the 4 children, continue with the nearest, push
@@ -120,9 +134,7 @@ __device__ __forceinline__ uint32_t trav_pop(Trav& t, const uint32_t* lds_col, c
 // inverted box (no child != empty test); only the nearest child is fully ordered (3 comparators);
 // pushes are branch-free (write always, advance the stack pointer by the hit bit).
 template <bool ANY>
-__device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill) {
-   const uint4* n = nodes + 4 * (size_t)t.cur;
-   const uint4 w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
+__device__ __forceinline__ void node_compute(const uint4 w0, const uint4 w1, const uint4 w2, const uint4 ch, Trav& t, uint32_t* lds_col, uint32_t* spill) {
    const float ax = __uint_as_float(w0.w) * t.idir.x, ay = __uint_as_float(w1.x) * t.idir.y, az = __uint_as_float(w1.y) * t.idir.z;
    const float bx = (__uint_as_float(w0.x) - t.o.x) * t.idir.x, by = (__uint_as_float(w0.y) - t.o.y) * t.idir.y, bz = (__uint_as_float(w0.z) - t.o.z) * t.idir.z;
    const bool nx = t.idir.x < 0.0f, ny = t.idir.y < 0.0f, nz = t.idir.z < 0.0f;
@@ -199,6 +211,14 @@ __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav&
    }
    t.cur = (tn[0] < INFINITY) ? cr[0] : trav_pop(t, lds_col, spill);
 }
+
+template <bool ANY>
+__device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill) {
+   const uint4* n = nodes + 4 * (size_t)t.cur;
+   const uint4 w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
+   node_compute<ANY>(w0, w1, w2, ch, t, lds_col, spill);
+}
+
 
 // one leaf: up to 4 triangle packets. Returns true when an any-hit walk found an occluder.
 template <bool ANY>
@@ -397,10 +417,45 @@ __device__ __forceinline__ bool refill_lanes(Feeder<NA>& f, const RaySource& src
    return true;
 }
 
-// one if-if step of a lane's traversal (see traverse()); returns true when the ray has ended
-template <bool ANY, bool COUNT>
+// one step of a lane's traversal; returns true when the ray has ended.
+// PHASED = false: node step, then - for a lane that stands at a leaf, also one the node step just sent there - one
+//   triangle: two dependent global round trips per wave iteration (some lane is at a leaf in nearly every one).
+// PHASED = true: ONE load phase per iteration - a lane at a node loads its node, a lane at a leaf its next triangle,
+//   all loads are in flight together, then both groups compute. A lane that reaches a leaf tests it an iteration
+//   later, but the wave waits for memory once per iteration instead of twice.
+template <bool ANY, bool COUNT, bool PHASED>
 __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const float4* __restrict__ tris, Trav& t, uint32_t& tk, uint32_t* lds_col, uint32_t* spill,
                                           bool& occluded, uint32_t& n_nodes, uint32_t& n_tris) {
+   if (PHASED) {
+      const bool at_node = !(t.cur & kLeafBit);
+      const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
+      uint4 w0, w1, w2, ch;
+      float4 ta, tb, tc;
+      if (at_node) {
+         const uint4* n = nodes + 4 * (size_t)t.cur;
+         w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
+      } else {
+         const float4* p = tris + 3 * (size_t)(first + tk);
+         ta = p[0], tb = p[1], tc = p[2];
+      }
+      if (at_node) {
+         if (COUNT) n_nodes++;
+         node_compute<ANY>(w0, w1, w2, ch, t, lds_col, spill);
+      } else {
+         if (COUNT) n_tris++;
+         if (tri_compute<ANY>(ta, tb, tc, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
+            occluded = true;
+            t.cur = kEmptyRef;
+         } else {
+            tk++;
+            if (tk >= cnt) {
+               tk = 0;
+               t.cur = trav_pop(t, lds_col, spill);
+            }
+         }
+      }
+      return t.cur == kEmptyRef;
+   }
    if (!(t.cur & kLeafBit)) {
       if (COUNT) n_nodes++;
       node_step<ANY>(nodes, t, lds_col, spill);
@@ -426,7 +481,7 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
 // trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes.
 // Reads the bounce's ray queue, writes hit[path] = (t, u, v, packet) or packet = kEmptyRef.
 // ------------------------------------------------------------------------------------------
-template <bool COUNT, int kRefill>
+template <bool COUNT, int kRefill, bool PHASED>
 __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const uint32_t* __restrict__ queue_base, const float4* __restrict__ ray_o,
                                                                const float4* __restrict__ ray_d, float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl,
                                                                DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
@@ -468,7 +523,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
    while (refill_lanes<2, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<false, COUNT>(nodes, tris, t, tk, lds_col, spill, occluded, n_nodes, n_tris))
+         if (trav_step<false, COUNT, PHASED>(nodes, tris, t, tk, lds_col, spill, occluded, n_nodes, n_tris))
             hit_out[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
       }
    }
@@ -556,7 +611,7 @@ __device__ __forceinline__ ShadowRay make_shadow_ray(const SceneDev& sc, const F
    return s;
 }
 
-template <bool COUNT, bool LIGHT, int kRefill>
+template <bool COUNT, bool LIGHT, int kRefill, bool PHASED>
 __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                                                               uint32_t cursor_slot) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
@@ -597,7 +652,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    while (refill_lanes<3, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<true, COUNT>(nodes, tris, t, tk, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) ps.rad[id] = lit;
+         if (trav_step<true, COUNT, PHASED>(nodes, tris, t, tk, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) ps.rad[id] = lit;
       }
    }
    if (COUNT) {
@@ -1237,7 +1292,8 @@ void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState&
 }
 
 // closest-hit traversal over a sharded queue of path ids (queue != null) or over n raw rays (queue == null).
-// Variant 0 = batch kernel; 1..4 = refill kernel with a refill threshold of 1 / 4 / 8 / 16 idle lanes.
+// Variant 0 = batch kernel; 1 = refill kernel (threshold 8 idle lanes) with chained node + triangle steps;
+// 2 / 3 / 4 = refill kernel with one load phase per iteration, threshold 4 / 8 (default) / 16 idle lanes.
 static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, const uint32_t* queue, const float4* ray_o, const float4* ray_d, float4* hit,
                            uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag) {
 #define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, queue, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
@@ -1251,23 +1307,17 @@ static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, co
          if (count) UH_CLOSEST((k_trace_closest_batch<true, false>));
          else UH_CLOSEST((k_trace_closest_batch<false, false>));
          break;
-      case 1:
-         if (count) UH_CLOSEST((k_trace_closest<true, 1>));
-         else UH_CLOSEST((k_trace_closest<false, 1>));
-         break;
-      case 2:
-         if (count) UH_CLOSEST((k_trace_closest<true, 4>));
-         else UH_CLOSEST((k_trace_closest<false, 4>));
-         break;
-      case 4:
-         if (count) UH_CLOSEST((k_trace_closest<true, 16>));
-         else UH_CLOSEST((k_trace_closest<false, 16>));
-         break;
-      default:
-         if (count) UH_CLOSEST((k_trace_closest<true, 8>));
-         else UH_CLOSEST((k_trace_closest<false, 8>));
-         break;
+#define UH_CLOSEST_RF(K, TOP)                                        \
+   do {                                                              \
+      if (count) UH_CLOSEST((k_trace_closest<true, K, TOP>));        \
+      else UH_CLOSEST((k_trace_closest<false, K, TOP>));             \
+   } while (0)
+      case 1: UH_CLOSEST_RF(8, false); break;
+      case 2: UH_CLOSEST_RF(4, true); break;
+      case 4: UH_CLOSEST_RF(16, true); break;
+      default: UH_CLOSEST_RF(8, true); break;
    }
+#undef UH_CLOSEST_RF
 #undef UH_CLOSEST
 }
 
@@ -1288,14 +1338,14 @@ void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev&
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
                          uint32_t bounce, uint32_t cursor_slot, bool light) {
 #define UH_SHADOW(KERNEL) KERNEL<<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot)
-#define UH_SHADOW_RF(K)                                             \
+#define UH_SHADOW_RF(K, TOP)                                             \
    do {                                                             \
       if (light) {                                                  \
-         if (c.count_visits) UH_SHADOW((k_trace_shadow<true, true, K>));    \
-         else UH_SHADOW((k_trace_shadow<false, true, K>));          \
+         if (c.count_visits) UH_SHADOW((k_trace_shadow<true, true, K, TOP>));    \
+         else UH_SHADOW((k_trace_shadow<false, true, K, TOP>));          \
       } else {                                                      \
-         if (c.count_visits) UH_SHADOW((k_trace_shadow<true, false, K>));   \
-         else UH_SHADOW((k_trace_shadow<false, false, K>));         \
+         if (c.count_visits) UH_SHADOW((k_trace_shadow<true, false, K, TOP>));   \
+         else UH_SHADOW((k_trace_shadow<false, false, K, TOP>));         \
       }                                                             \
    } while (0)
    switch (c.shadow_variant) {
@@ -1308,10 +1358,10 @@ void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneD
             else UH_SHADOW((k_trace_shadow_batch<false, false>));
          }
          break;
-      case 1: UH_SHADOW_RF(1); break;
-      case 2: UH_SHADOW_RF(4); break;
-      case 4: UH_SHADOW_RF(16); break;
-      default: UH_SHADOW_RF(8); break;
+      case 1: UH_SHADOW_RF(8, false); break;
+      case 2: UH_SHADOW_RF(4, true); break;
+      case 4: UH_SHADOW_RF(16, true); break;
+      default: UH_SHADOW_RF(8, true); break;
    }
 #undef UH_SHADOW_RF
 #undef UH_SHADOW
