@@ -142,8 +142,14 @@ def main():
     for k, v in (("frames_in_flight", 1), ("overlap_miss", 0), ("overlap_shadow", 0), ("batch_frames", 1)):
         renderer.set_option(k, v)
     renderer.reset_stats()
-    for _ in range(0 if args.no_alone else 4):
+    renderer.synchronize()
+    t_fbf = time.perf_counter()
+    for _ in range(0 if args.no_alone else 8):
         loop.frame(pass_mask)
+    renderer.synchronize()
+    # what an interactive caller of uh_render_frame sees: one frame at a time, nothing in flight, no batching
+    # (per-kernel event timing is on in these frames: a few percent of launch overhead included)
+    frame_by_frame_ms = None if args.no_alone else (time.perf_counter() - t_fbf) / 8 * 1e3
     alone = renderer.get_stats()
     alone_ms = alone.trace_closest_ms / max(alone.trace_closest_launches, 1)
     alone_rays = float(alone.rays[rr.RAY_PRIMARY] + alone.rays[rr.RAY_BOUNCE]) / max(alone.trace_closest_launches, 1)
@@ -201,23 +207,6 @@ def main():
         total_rays = my_rays
 
     if rank == 0:
-        # roofline of the dominant kernel on THIS rank: algorithmic bytes per SURVEY.md §8d
-        # (48 B ray record + hit record, 128 B per BVH4 node visited, 48 B per triangle tested)
-        algo_bytes = my_closest * (48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0)
-        launches = max(st.trace_closest_launches, 1)
-        avg_ms = st.trace_closest_ms / launches
-        achieved = (algo_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # the bytes this build's layout actually requests for the same visits: 4 B queue id + 32 B ray + 16 B hit
-        # record + 4 B hit/miss queue entry per ray, 64-byte quantised nodes, 48-byte triangle packets
-        layout_bytes = my_closest * (56.0 + nodes_per_ray * 64.0 + tris_per_ray * 48.0)
-        requested = (layout_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_trace_closest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
             "metric": "Mrays/s (path rays: primary + bounce + sun-shadow + light-shadow) at 1080p, 64 spp = 64 frames x 1 spp",
             "value": total_rays / elapsed / 1e6,
@@ -237,38 +226,90 @@ def main():
                 + (f", {len(scene.lights)} lights " + ("ReSTIR DI" if view.use_ris_light_sampling else "uniform sampling") if view.lights_enabled else ", lights off"),
                 "rays_per_frame": total_rays / args.steps,
                 "partition": f"{args.tile}x{args.tile} tiles round-robin over {world} rank(s), 1 RCCL gather" if world > 1 else "single GPU",
+                "frame_by_frame_ms": frame_by_frame_ms,
             },
-            "roofline": {
-                "kernel": "k_trace_closest",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "requested_by_layout": {"GB/s": requested, "frac": requested / HBM_PEAK_GBS,
-                                        "note": "same visits priced with this build's 64-byte nodes and actual record sizes instead of SURVEY 8d's 128-byte node"},
-                "avg_launch_ms": avg_ms,
-                "launches": st.trace_closest_launches,
-                "nodes_per_ray": nodes_per_ray,
-                "tris_per_ray": tris_per_ray,
-                "note": "timed-region launches overlap with up to 2 other frames in flight and the shadow traversals on a second stream; `alone` is the same kernel with the GPU to itself (untimed calibration frames)",
-                "alone": {
-                    "avg_launch_ms": alone_ms,
-                    "achieved": (alone_rays * (48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0)) / (alone_ms * 1e-3) / 1e9 if alone_ms > 0 else 0.0,
-                    "frac": ((alone_rays * (48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0)) / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms > 0 else 0.0,
-                },
-                "kernel_share_of_step": st.trace_closest_ms / (elapsed * 1e3),
-                "trace_shadow_ms": st.trace_shadow_ms,
-                "shade_ms": st.shade_ms,
-            },
+            "roofline": roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, signature(args, scene, W, H)),
         }
+        if os.environ.get("UH_BENCH_SIGNATURE"):  # tools/pmc_summary.py stamps counter profiles with it
+            json.dump(signature(args, scene, W, H), open(os.environ["UH_BENCH_SIGNATURE"], "w"))
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, scene)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def signature(args, scene, W, H):
+    """what a committed counter profile must match before its per-launch figures are quoted for this run"""
+    return {"config": args.config, "width": W, "height": H, "spp": args.spp, "triangles": int(scene.num_triangles), "opts": sorted(args.opt),
+            "emulate_world": args.emulate_world, "gpus": args.gpus}
+
+
+def load_profile(sig):
+    """profiles/bench_counters.json (tools/pmc_summary.py over the rocprofv3 --pmc passes of this very command line):
+    per-launch counter figures of the dominant kernel, used only when its signature equals this run's"""
+    path = os.path.join(ROOT, "profiles", "bench_counters.json")
+    try:
+        prof = json.load(open(path))
+    except Exception:
+        return None
+    return prof if prof.get("signature") == sig else None
+
+
+def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, sig):
+    """Roofline block of the dominant kernel, k_trace_closest.
+    `achieved` / `frac` are HBM-side bytes from the rocprofv3 counters (FETCH_SIZE / WRITE_SIZE passes of this command
+    line, committed under profiles/) over the launch duration measured live with HIP events: physical, <= 1 by
+    construction. SURVEY 8d's algorithmic bytes (every node visit priced at 128 B whether or not a cache serves it) are
+    kept as `algorithmic_gbps`, a work metric. What actually limits the kernel is reported under `limiter`."""
+    launches = max(st.trace_closest_launches, 1)
+    avg_ms = st.trace_closest_ms / launches
+    rays_per_launch = my_closest / launches
+    algo_bytes = rays_per_launch * (48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0)  # SURVEY.md 8d
+    prof = load_profile(sig)
+    k = (prof or {}).get("kernels", {}).get("k_trace_closest", {})
+    traffic = k.get("hbm_bytes_per_launch")
+    achieved = traffic / (avg_ms * 1e-3) / 1e9 if (traffic and avg_ms > 0) else None
+    # vector-memory issue: every per-lane load or store of <= 16 B takes one slot of the CU's texture addresser / data
+    # path, and that path retires one lane per clock (profiles/r02_microbench_rates.txt: 1.0-1.1 clk per lane-load for
+    # random 64-B and 128-B records alike, 4 lanes on one line or not). Lane operations of one closest-hit ray in this
+    # layout: 4 per node visit (64-B node), 3 per triangle tested (48-B packet), 4 for queue id + ray (2 LDS-DMA) + hit.
+    lane_ops = 4.0 * nodes_per_ray + 3.0 * tris_per_ray + 4.0
+    peak_lane_rate = 256 * 2.4e9  # CUs x max clock (MI355X_MICROARCH.md); the clock under load is lower
+    alone_rate = alone_rays * lane_ops / (alone_ms * 1e-3) if alone_ms > 0 else 0.0
+    r = {
+        "kernel": "k_trace_closest",
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
+        "traffic": traffic,
+        "traffic_source": (prof or {}).get("source") if traffic else "no committed counter profile matches this run's configuration: traffic is null rather than borrowed",
+        "avg_launch_ms": avg_ms,
+        "launches": st.trace_closest_launches,
+        "rays_per_launch": rays_per_launch,
+        "nodes_per_ray": nodes_per_ray,
+        "tris_per_ray": tris_per_ray,
+        "algorithmic_gbps": algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+        "algorithmic_note": "SURVEY 8d work metric (48 B/ray + 128 B/node visit + 48 B/triangle); served by L1/L2/Infinity Cache, so it may exceed the HBM peak - not a roofline fraction",
+        "limiter": {
+            "what": "vector-memory issue (TA/TD): one <=16-byte lane operation per clock per CU; neither HBM nor VALU nor MFMA bounds this path",
+            "lane_ops_per_ray": lane_ops,
+            "unit": "G lane-ops/s",
+            "peak": peak_lane_rate / 1e9,
+            "achieved_alone": alone_rate / 1e9,
+            "frac_alone": alone_rate / peak_lane_rate,
+            "avg_launch_ms_alone": alone_ms,
+            "note": "`alone` = the kernel with the GPU to itself (untimed calibration frames, one frame per launch); timed-region launches share the chip with other frames' kernels",
+        },
+        "valu": {kk: k.get(kk) for kk in ("wave_instr_per_launch", "issue_frac", "lane_utilisation", "ta_busy_frac", "td_busy_frac")} if k else None,
+        "kernel_share_of_step": st.trace_closest_ms / (elapsed * 1e3),
+        "trace_shadow_ms": st.trace_shadow_ms,
+        "shade_ms": st.shade_ms,
+    }
+    return r
 
 
 def usable_cores():
@@ -289,6 +330,7 @@ def cpu_baseline(args, scene):
     import oracle_api as oa
     import rust_renderer_amd as rr
 
+    native = oa.build_native()  # -O3 -march=native for THIS box's cores (the portable .so is -O3 -mavx2 -mfma)
     w, h, frames = (int(x) for x in args.cpu_sample.split("x"))
     cores = usable_cores()
     o = scene.upload(oa.OracleRenderer(w, h, threads=cores))
@@ -307,6 +349,8 @@ def cpu_baseline(args, scene):
         "cores": cores,
         "kind": "port",
         "sample": f"same scene and camera at {w}x{h}, {frames} frames x 1 spp, 5 bounces ({s.path_rays} rays in {dt:.1f} s)",
+        "build": "g++ -O3 -march=native -ffp-contract=off" if native else "g++ -O3 -mavx2 -mfma -ffp-contract=off (no compiler on this box for a native build)",
+        "acceleration_structure": "the oracle's own median-split BVH2 (the parity checker, not a tuned CPU tracer): a reported baseline, not a speed-up claim",
     }
 
 

@@ -242,7 +242,7 @@ int uh_reset_stats(uh_ctx* ctx);
  * "device_build" (0/1; 1 = uh_build_acceleration builds a Morton-order tree ON THE DEVICE in a few ms instead
  * of the host SAH tree in tens to hundreds: same hits bit for bit, about 30 % more traversal work per ray -
  * for geometry that changes every few frames), tuning knobs documented in DESIGN.md ("frames_in_flight",
- * "batch_frames", "closest_variant", "shadow_variant", "*_blocks_per_cu", "bvh_max_leaf", "bvh_sah_cost_x100") */
+ * "batch_frames", "closest_variant", "shadow_variant", "*_blocks_per_cu", "device_build", "full_frame_restir") */
 int uh_set_option(uh_ctx* ctx, const char* name, int value);
 
 /* ---- multi-GPU framebuffer tile partition (one process per GPU) ------------------------ */

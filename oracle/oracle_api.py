@@ -24,13 +24,26 @@ def build_oracle(force=False):
     return LIB_PATH
 
 
+def build_native():
+    """-O3 -march=native build for the machine this runs on (bench.py's cpu_baseline leg); falls back to the portable
+    library when no compiler is there. Must be called before the first lib()."""
+    global LIB_PATH
+    try:
+        subprocess.run(["make", "-C", _HERE, "-B", "native"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        LIB_PATH = os.path.join(_HERE, "_native", "liboracle.so")
+        return True
+    except Exception:
+        return False
+
+
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        build_oracle()
+        if not LIB_PATH.endswith(os.path.join("_native", "liboracle.so")):
+            build_oracle()
         _lib = C.CDLL(LIB_PATH)
         L = _lib
         L.orc_create.argtypes, L.orc_create.restype = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)], C.c_int

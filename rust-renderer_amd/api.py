@@ -221,13 +221,32 @@ class Renderer:
         )
         return out.value
 
+    def initialize(self, default_textures=None):
+        """Renderer::initialize (renderer.rs:202-220): the four default maps get bindless indices 0..3 - diffuse (white),
+        normal (flat), occlusion (white), metallic-roughness - before any model texture. `default_textures`: four
+        (H, W, 4) uint8 arrays (the files of utopian/data/textures/defaults/); without them 1x1 texels of the same
+        values are used (the files are constant images except for +-1 LSB dither in the normal map)."""
+        if hasattr(self, "_defaults"):
+            return self._defaults
+        if default_textures is None:
+            texel = lambda *rgba: np.array(rgba, dtype=np.uint8).reshape(1, 1, 4)
+            default_textures = [texel(255, 255, 255, 255), texel(127, 127, 255, 255), texel(255, 255, 255, 255), texel(0, 255, 0, 255)]
+        diffuse, normal, occlusion, mr = (self.add_texture(t) for t in default_textures)
+        self._defaults = dict(diffuse=diffuse, normal=normal, occlusion=occlusion, metallic_roughness=mr)
+        self._default_diffuse = diffuse
+        return self._defaults
+
     def add_model(self, model, transform=None):
-        """model: scenes.Model (textures + meshes). Texture indices are remapped to bindless
-        indices exactly like Renderer::add_model does (renderer.rs:226-262)."""
+        """model: scenes.Model (textures + meshes). Texture indices are remapped to bindless indices exactly like
+        Renderer::add_model does (renderer.rs:222-262): a map that is DEFAULT_TEXTURE_MAP (None here) takes the
+        renderer's default of its kind, every other one is a fresh bindless texture."""
         tex_map = {}
         mesh_ids = []
+        defaults = getattr(self, "_defaults", None)
         for mesh in model.meshes:
             mat = mesh.material_struct()
+            if defaults:  # the reference assigns all four maps; the path tracer reads diffuse_map only (rchit:40)
+                mat.normal_map, mat.metallic_roughness_map, mat.occlusion_map = defaults["normal"], defaults["metallic_roughness"], defaults["occlusion"]
             if mesh.texture is not None:
                 if mesh.texture not in tex_map:
                     tex_map[mesh.texture] = self.add_texture(model.textures[mesh.texture])

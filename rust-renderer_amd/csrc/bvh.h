@@ -1,46 +1,53 @@
-// bvh.h — memory layout of the acceleration structure shared by the host builder (bvh_build.cpp)
-// and the gfx950 traversal kernels (kernels.hip). Replaces the driver-private BLAS/TLAS of
+// bvh.h — memory layout of the acceleration structure shared by the host builder (bvh_build.cpp), the device builder
+// and refit (lbvh.hip, refit.hip) and the gfx950 traversal kernels (kernels.hip). Replaces the driver-private BLAS/TLAS of
 // VK_KHR_acceleration_structure (reference: utopian/src/raytracing.rs:113-398).
 //
-// One flattened BVH4 over world-space triangles (instance transforms baked at build time):
-//   node     128 B = one gfx950 L2 line: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4] meta[4]
-//   TriPacket 48 B: v0, e1 = v1-v0, e2 = v2-v0, key = mesh<<22 | primitive, 2 spare dwords
+// One flattened BVH4 over world-space triangles (instance transforms baked at build time). Every leaf is ONE triangle.
+//   node        48 B = three 16-byte loads per visit (Node4C below)
+//   TriPacket   48 B = three loads per triangle test: v0, e1 = v1-v0, e2 = v2-v0, key = mesh<<22 | primitive, 2 spare dwords
 //   ShadePacket 64 B (same order as TriPacket): object-space vertex normals, uvs, mesh index
+// Why 48-byte nodes with implicit child addresses: the traversal kernels are bound by the CU's vector-memory issue
+// rate - one <=16-byte lane load per clock, whatever the address or the cache level that serves it
+// (profiles/r02_microbench_rates.txt, profiles/r02g_counters.json: TA busy 79-87 %). A node visit therefore costs its
+// number of 16-byte loads, and four explicit 32-bit child references were a whole load of the former 64-byte node.
+// The children of a node are stored contiguously instead - its triangle children in the packet array from `tri_base`,
+// its node children in the node array from `child_base` - and a slot's reference is base + slot.
 #pragma once
 #include <cstdint>
 #include <vector>
 
 namespace uh {
 
-constexpr uint32_t kLeafBit = 0x80000000u;    // child ref: bit31 = leaf
+constexpr uint32_t kLeafBit = 0x80000000u;    // child ref / stack entry: bit31 = triangle, low bits = packet index
 constexpr uint32_t kEmptyRef = 0xffffffffu;   // unused child slot / empty stack
-constexpr uint32_t kLeafCountShift = 27;      // leaf ref: bits 27..30 = triangle count (1..15)
-constexpr uint32_t kLeafFirstMask = 0x07ffffffu;
-constexpr uint32_t kMaxLeafTris = 4;
+constexpr uint32_t kMaxTriangles = 0x7ffffffeu;
 constexpr uint32_t kPrimBits = 22;            // key = mesh << 22 | prim  (mesh < 1024, prim < 4 Mi)
 constexpr uint32_t kPrimMask = (1u << kPrimBits) - 1;
 
+// full-precision node (host builder output; tests and the quantiser read it): padded child boxes + explicit child refs
 struct alignas(16) Node4 {
    float lox[4], loy[4], loz[4];
    float hix[4], hiy[4], hiz[4];
-   uint32_t child[4];
-   uint32_t meta[4];  // meta[0] = number of used child slots
+   uint32_t child[4];  // kLeafBit | packet, node index, or kEmptyRef. Slot order: triangles, then nodes, then empty.
+   uint32_t meta[4];   // meta[0] = number of used child slots
 };
-static_assert(sizeof(Node4) == 128, "one node = one 128-byte line");
+static_assert(sizeof(Node4) == 128, "full-precision node");
 
-// Device node: the same 4 children with boxes quantised to 8 bits per plane relative to the node's
-// own box (origin + 2^e * q), rounded outwards, so the slab test stays conservative and the hit
-// result does not change. 64 B = four dwordx4 loads per visit instead of seven, half the bytes:
-// the traversal kernels are bound by the L1/L2/Infinity-Cache gather of node lines, not by VALU.
-struct alignas(16) Node4Q {
+// Device node. The children's boxes are quantised to 8 bits per plane relative to the node's own box
+// (plane = origin + 2^(e-127) * q), rounded outwards, so the slab test stays conservative and hits do not change.
+// Slots [0, n_tri) are triangles: packet tri_base + slot. Slots [n_tri, n_child) are nodes: node child_base + (slot - n_tri).
+// The remaining slots are empty: an inverted box (qlo = 255, qhi = 0) that no ray hits.
+struct alignas(16) Node4C {
    float origin[3];    // lower corner of the node's own (padded) box
-   float scale_x;      // per-axis quantisation step, a power of two
-   float scale_yz[2];
-   uint32_t qlo[3];    // per axis: child k's quantised lower plane in byte k
-   uint32_t qhi[3];    // per axis: upper plane. Empty slot: qlo = 255, qhi = 0 (inverted box, never hit)
-   uint32_t child[4];
+   uint32_t meta;      // bits 0-7 / 8-15 / 16-23: biased exponent of the x / y / z quantisation step (a power of two);
+                       // bits 24-26: n_tri; bits 28-30: n_child
+   uint32_t qlo[3];    // per axis: child slot k's quantised lower plane in byte k
+   uint32_t qhi[3];    // per axis: upper plane
+   uint32_t child_base;
+   uint32_t tri_base;
 };
-static_assert(sizeof(Node4Q) == 64, "quantised node = half a 128-byte line");
+static_assert(sizeof(Node4C) == 48, "device node = three 16-byte loads");
+constexpr uint32_t kMetaTriShift = 24, kMetaChildShift = 28;
 
 struct alignas(16) TriPacket {
    float v0[3];
@@ -69,13 +76,22 @@ struct BuildInput {
 
 struct BuildOutput {
    std::vector<Node4> nodes;         // BFS order, node 0 = root (full-precision, padded child boxes)
-   std::vector<Node4Q> qnodes;       // the same tree, quantised (what the kernels traverse)
-   std::vector<uint32_t> tri_order;  // packet i holds input triangle tri_order[i]
-   uint32_t max_depth = 0;
+   std::vector<Node4C> cnodes;       // the same tree, quantised (what the kernels traverse)
+   std::vector<uint32_t> tri_order;  // packet i holds input triangle tri_order[i]; the triangle children of a node are consecutive packets
+   uint32_t max_depth = 0;           // depth of the 4-wide tree (root = 0)
    std::vector<uint32_t> level_start;  // BFS level l = nodes [level_start[l], level_start[l+1]); children always lie in a later level
 };
 
-// Binned-SAH BVH2 build, collapsed to BVH4, emitted breadth-first. Host-side, multi-threaded.
-void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_t max_leaf_tris = kMaxLeafTris, float sah_traversal_cost = 1.0f);
+// Binned-SAH BVH2 down to single triangles, collapsed to BVH4, emitted breadth-first. Host-side, multi-threaded.
+// balanced: median splits only (depth ceil(log2 n)) - the fallback for geometry whose SAH tree is deeper than the
+// traversal stack holds (kMaxTreeLevels).
+void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool balanced = false);
+
+// A traversal pushes at most 3 entries per level; the kernels' stack holds 16 (LDS) + 96 (scratch) entries per ray.
+constexpr uint32_t kTraversalStackEntries = 16 + 96;
+constexpr uint32_t kMaxTreeLevels = kTraversalStackEntries / 3;
+
+// the quantiser shared by the host builder and (restated, same arithmetic) the refit kernel: child boxes of one node -> Node4C planes
+void quantise_node(const Node4& nd, Node4C& q);
 
 }  // namespace uh

@@ -1,7 +1,8 @@
 // bvh_build.cpp — host builder of the flattened BVH4 (see bvh.h). Replaces
 // Raytracing::create_bottom_level_acceleration_structure / create_top_level_acceleration_structure
 // (reference: utopian/src/raytracing.rs:113-217, :279-398), whose build runs inside the Vulkan
-// driver. Binned SAH (16 bins, 3 axes) -> BVH2 -> greedy collapse to 4-wide nodes by surface area.
+// driver. Binned SAH (16 bins, 3 axes) -> BVH2 down to single triangles -> greedy collapse to 4-wide nodes by surface
+// area, emitted breadth-first with every node's triangle children and node children in contiguous slots (bvh.h).
 #include "bvh.h"
 
 #include <algorithm>
@@ -52,8 +53,7 @@ struct Builder {
    std::vector<uint32_t>& idx;
    std::vector<Node2> nodes;
    uint32_t max_depth = 0;
-   uint32_t max_leaf = kMaxLeafTris;
-   float sah_traversal_cost = 1.0f;
+   bool balanced = false;  // median splits only: depth ceil(log2 n), for geometry whose SAH tree would be too deep for the traversal stack
 
    Builder(const std::vector<Box>& tb_, const std::vector<float>& cen_, std::vector<uint32_t>& idx_) : tb(tb_), cen(cen_), idx(idx_) {}
 
@@ -122,15 +122,10 @@ struct Builder {
             }
          }
       }
-      if (count <= max_leaf) {
-         // SAH termination: split only when a traversal step plus the area-weighted triangle tests of
-         // the two sides is cheaper than testing all `count` triangles here (unit = one triangle test;
-         // a node step costs about sah_traversal_cost of them on this kernel)
-         float area = box.half_area();
-         if (best_axis < 0 || !(area > 0) || sah_traversal_cost + best_cost / area >= (float)count) return make_leaf();
-      }
+      // no SAH termination: every leaf is one triangle (a 4-wide node holds up to four of them as children, each with
+      // its own box, and only the ones a ray's slab test passes cost a triangle fetch)
       uint32_t mid;
-      if (best_axis < 0 || depth > 48) {
+      if (best_axis < 0 || depth > 48 || balanced) {
          // degenerate centroids (or runaway depth): split the range in half along the widest axis
          int a = 0;
          for (int k = 1; k < 3; k++)
@@ -170,10 +165,69 @@ inline void padded(const Box& b, float* lo, float* hi) {
 
 }  // namespace
 
-void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_t max_leaf_tris, float sah_traversal_cost) {
-   if (max_leaf_tris < 1) max_leaf_tris = 1;
-   if (max_leaf_tris > 15) max_leaf_tris = 15;
+void quantise_node(const Node4& nd, Node4C& q) {
+   // origin = min over the children, step = 2^e with e minimal such that the node's extent fits 255 steps;
+   // lower planes round down, upper planes round up (in double). refit.hip restates this arithmetic.
+   const float* lo[3] = {nd.lox, nd.loy, nd.loz};
+   const float* hi[3] = {nd.hix, nd.hiy, nd.hiz};
+   uint32_t exps = 0;
+   for (int a = 0; a < 3; a++) {
+      double mn = INFINITY, mx = -INFINITY;
+      for (int k = 0; k < 4; k++)
+         if (nd.child[k] != kEmptyRef) {
+            mn = std::fmin(mn, (double)lo[a][k]);
+            mx = std::fmax(mx, (double)hi[a][k]);
+         }
+      if (!(mn <= mx)) mn = mx = 0.0;
+      float origin = (float)mn;
+      if ((double)origin > mn) origin = std::nextafterf(origin, -INFINITY);
+      double ext = mx - (double)origin;
+      int e = -100;
+      if (!(ext < 1e38)) {
+         e = 120;  // non-finite or overflowing extent (only from non-finite world-space geometry): no search
+      } else if (ext > 0) {
+         e = (int)std::ceil(std::log2(ext / 255.0));
+         while (std::ldexp(255.0, e) < ext) e++;
+         if (e < -100) e = -100;
+      }
+      double scale = std::ldexp(1.0, e);
+      uint32_t wlo = 0, whi = 0;
+      for (int k = 0; k < 4; k++) {
+         if (nd.child[k] == kEmptyRef) {
+            wlo |= 0xffu << (8 * k);  // inverted box: the slab test fails for every ray
+            continue;
+         }
+         double a0 = std::floor(((double)lo[a][k] - (double)origin) / scale);
+         double a1 = std::ceil(((double)hi[a][k] - (double)origin) / scale);
+         if (a0 < 0) a0 = 0;
+         if (a1 > 255) a1 = 255;  // cannot trigger: ext <= 255 * scale
+         if (a0 > 255) a0 = 255;
+         wlo |= (uint32_t)a0 << (8 * k);
+         whi |= (uint32_t)a1 << (8 * k);
+      }
+      q.origin[a] = origin;
+      q.qlo[a] = wlo;
+      q.qhi[a] = whi;
+      exps |= (uint32_t)(e + 127) << (8 * a);  // e in [-100, 120]: a normal float's biased exponent
+   }
+   uint32_t n_tri = 0, n_child = 0;
+   for (int k = 0; k < 4; k++)
+      if (nd.child[k] != kEmptyRef) {
+         n_child++;
+         if (nd.child[k] & kLeafBit) n_tri++;
+      }
+   q.meta = exps | (n_tri << kMetaTriShift) | (n_child << kMetaChildShift);
+   q.child_base = q.tri_base = 0;
+   for (int k = 0; k < 4; k++) {
+      if (nd.child[k] == kEmptyRef) continue;
+      if ((nd.child[k] & kLeafBit) && k == 0) q.tri_base = nd.child[k] & ~kLeafBit;
+      if (!(nd.child[k] & kLeafBit) && (uint32_t)k == n_tri) q.child_base = nd.child[k];
+   }
+}
+
+void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool balanced) {
    out.nodes.clear();
+   out.cnodes.clear();
    out.tri_order.clear();
    out.level_start.assign({0u, 1u});
    out.max_depth = 0;
@@ -209,21 +263,14 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
       std::memset(&root, 0, sizeof(root));
       for (int k = 0; k < 4; k++) root.child[k] = kEmptyRef;
       out.nodes.push_back(root);
-      Node4Q q;  // empty scene: a root whose four slots are empty (every ray misses)
-      std::memset(&q, 0, sizeof(q));
-      q.scale_x = q.scale_yz[0] = q.scale_yz[1] = 1.0f;
-      for (int a = 0; a < 3; a++) {
-         q.qlo[a] = 0xffffffffu;
-         q.qhi[a] = 0u;
-      }
-      for (int k = 0; k < 4; k++) q.child[k] = kEmptyRef;
-      out.qnodes.push_back(q);
+      Node4C q;  // empty scene: a root whose four slots are empty (every ray misses)
+      quantise_node(root, q);
+      out.cnodes.push_back(q);
       return;
    }
    {
       Builder top(tb, cen, out.tri_order);
-      top.max_leaf = max_leaf_tris;
-      top.sah_traversal_cost = sah_traversal_cost;
+      top.balanced = balanced;
       if (num_threads <= 1 || n < 65536) {
          top.build(0, n, 0);
          n2.swap(top.nodes);
@@ -342,8 +389,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
                size_t j = next.fetch_add(1);
                if (j >= jobs.size()) break;
                Builder b(tb, cen, out.tri_order);
-               b.max_leaf = max_leaf_tris;
-               b.sah_traversal_cost = sah_traversal_cost;
+               b.balanced = balanced;
                b.build(jobs[j].first, jobs[j].count, jobs[j].depth);
                sub[j].swap(b.nodes);
                sub_depth[j] = b.max_depth;
@@ -369,11 +415,12 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
       }
    }
 
-   // ---- collapse to BVH4, breadth-first emission
-   struct Slot {
-      int32_t n2;        // source BVH2 node
-   };
+   // ---- collapse to BVH4, breadth-first emission. Slot order inside a node: its triangle children first (their
+   // packets are consecutive: the packet order is DEFINED here, node by node), then its node children (consecutive
+   // node indices), then empty slots.
    std::vector<int32_t> queue;  // BVH2 node index of each emitted BVH4 node
+   std::vector<uint32_t> packet_order;  // packet p holds input triangle packet_order[p]
+   packet_order.reserve(n);
    queue.push_back(0);
    out.nodes.reserve(n2.size() / 2 + 1);
    out.nodes.push_back(Node4());
@@ -382,7 +429,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
       int32_t ch[4];
       int nc = 0;
       if (src.left < 0) {
-         ch[nc++] = queue[qi];  // a leaf at the root: wrap it
+         ch[nc++] = queue[qi];  // a single triangle at the root: wrap it
       } else {
          ch[nc++] = src.left;
          ch[nc++] = src.right;
@@ -404,13 +451,10 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
             ch[nc++] = n2[c].right;
          }
       }
+      std::stable_partition(ch, ch + nc, [&](int32_t c) { return n2[c].left < 0; });  // triangles first
       Node4 nd;
       std::memset(&nd, 0, sizeof(nd));
-      for (int k = 0; k < 4; k++) {
-         nd.child[k] = kEmptyRef;
-         nd.lox[k] = nd.loy[k] = nd.loz[k] = 0.0f;
-         nd.hix[k] = nd.hiy[k] = nd.hiz[k] = 0.0f;
-      }
+      for (int k = 0; k < 4; k++) nd.child[k] = kEmptyRef;
       for (int k = 0; k < nc; k++) {
          const Node2& c = n2[ch[k]];
          float lo[3], hi[3];
@@ -422,7 +466,8 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
          nd.hiy[k] = hi[1];
          nd.hiz[k] = hi[2];
          if (c.left < 0) {
-            nd.child[k] = kLeafBit | (c.count << kLeafCountShift) | (c.first & kLeafFirstMask);
+            nd.child[k] = kLeafBit | (uint32_t)packet_order.size();
+            packet_order.push_back(out.tri_order[c.first]);
          } else {
             nd.child[k] = (uint32_t)out.nodes.size();
             out.nodes.push_back(Node4());
@@ -432,6 +477,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
       nd.meta[0] = (uint32_t)nc;
       out.nodes[qi] = nd;
    }
+   out.tri_order.swap(packet_order);
 
    // ---- BFS levels (for the on-device refit, which walks them deepest first)
    {
@@ -445,63 +491,12 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, uint32_
       for (size_t i = 0; i < out.nodes.size(); i++)
          if (i == 0 || depth[i] != depth[i - 1]) out.level_start.push_back((uint32_t)i);
       out.level_start.push_back((uint32_t)out.nodes.size());
+      out.max_depth = depth.empty() ? 0 : depth.back();
    }
 
-   // ---- quantise: per node, origin = min over its children, scale = 2^e with e minimal such that
-   // the node's extent fits 255 steps; lower planes round down, upper planes round up (in double)
-   out.qnodes.resize(out.nodes.size());
-   for (size_t i = 0; i < out.nodes.size(); i++) {
-      const Node4& nd = out.nodes[i];
-      Node4Q q;
-      std::memset(&q, 0, sizeof(q));
-      const float* lo[3] = {nd.lox, nd.loy, nd.loz};
-      const float* hi[3] = {nd.hix, nd.hiy, nd.hiz};
-      float scales[3];
-      for (int a = 0; a < 3; a++) {
-         double mn = INFINITY, mx = -INFINITY;
-         for (int k = 0; k < 4; k++)
-            if (nd.child[k] != kEmptyRef) {
-               mn = std::fmin(mn, (double)lo[a][k]);
-               mx = std::fmax(mx, (double)hi[a][k]);
-            }
-         if (!(mn <= mx)) mn = mx = 0.0;
-         float origin = (float)mn;
-         if ((double)origin > mn) origin = std::nextafterf(origin, -INFINITY);
-         double ext = mx - (double)origin;
-         int e = -100;
-         if (!(ext < 1e38)) {
-            e = 120;  // non-finite or overflowing extent (only from non-finite world-space geometry): no search
-         } else if (ext > 0) {
-            e = (int)std::ceil(std::log2(ext / 255.0));
-            while (std::ldexp(255.0, e) < ext) e++;
-            if (e < -100) e = -100;
-         }
-         double scale = std::ldexp(1.0, e);
-         uint32_t wlo = 0, whi = 0;
-         for (int k = 0; k < 4; k++) {
-            if (nd.child[k] == kEmptyRef) {
-               wlo |= 0xffu << (8 * k);  // inverted box: the slab test fails for every ray
-               continue;
-            }
-            double a0 = std::floor(((double)lo[a][k] - (double)origin) / scale);
-            double a1 = std::ceil(((double)hi[a][k] - (double)origin) / scale);
-            if (a0 < 0) a0 = 0;
-            if (a1 > 255) a1 = 255;  // cannot trigger: ext <= 255 * scale
-            if (a0 > 255) a0 = 255;
-            wlo |= (uint32_t)a0 << (8 * k);
-            whi |= (uint32_t)a1 << (8 * k);
-         }
-         q.origin[a] = origin;
-         q.qlo[a] = wlo;
-         q.qhi[a] = whi;
-         scales[a] = (float)scale;
-      }
-      q.scale_x = scales[0];
-      q.scale_yz[0] = scales[1];
-      q.scale_yz[1] = scales[2];
-      for (int k = 0; k < 4; k++) q.child[k] = nd.child[k];
-      out.qnodes[i] = q;
-   }
+   // ---- quantise
+   out.cnodes.resize(out.nodes.size());
+   for (size_t i = 0; i < out.nodes.size(); i++) quantise_node(out.nodes[i], out.cnodes[i]);
 }
 
 }  // namespace uh

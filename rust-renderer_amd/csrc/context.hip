@@ -198,7 +198,6 @@ struct uh_ctx {
    // on-device build (lbvh.hip, option "device_build"): per-triangle sources in mesh order, kept on the device
    // until a mesh is added, so that a rebuild after moved instances or changed parameters uploads nothing
    bool device_build = false, src_valid = false;
-   uint32_t device_leaf_tris = 1;  // swept: 1 / 2 / 3 / 4 triangles per leaf = 3.65 / 3.86 / 4.06 / 4.24 ms per frame
    DevBuf<float> d_src_corners;
    DevBuf<uint32_t> d_src_keys;
    DevBuf<float4> d_src_shade;
@@ -217,8 +216,6 @@ struct uh_ctx {
 
    // options / stats
    bool count_visits = false, time_kernels = false, full_frame_restir = false, raw_visit_counts = false;
-   uint32_t bvh_max_leaf = kMaxLeafTris;
-   float bvh_sah_cost = 0.5f;  // SAH leaf termination: a node step costs about half a triangle test here (swept on MI355X)
    int closest_variant = 3, shadow_variant = 3;  // refill kernels, threshold 8 idle lanes (0 = batch kernels)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
@@ -574,7 +571,7 @@ int uh_build_acceleration(uh_ctx* c) {
    // bake instance transforms: world = ((m0*x + m1*y) + m2*z) + m3 per row (identity: verbatim)
    size_t total = 0;
    for (const HostMesh& m : c->meshes) total += m.indices.size() / 3;
-   if (total > kLeafFirstMask) return fail(c, UH_ERR_CAPACITY, "scene has more than 2^27 triangles");
+   if (total > kMaxTriangles) return fail(c, UH_ERR_CAPACITY, "scene has more than 2^31 - 2 triangles");
    std::vector<float> corners(9 * total);
    std::vector<uint32_t> keys(total);
    size_t t = 0;
@@ -606,7 +603,13 @@ int uh_build_acceleration(uh_ctx* c) {
    int threads = (int)std::thread::hardware_concurrency();
    if (threads < 1) threads = 1;
    if (threads > 32) threads = 32;
-   build_bvh4(in, bo, threads, c->bvh_max_leaf, c->bvh_sah_cost);
+   build_bvh4(in, bo, threads);
+   if (bo.level_start.size() - 1 > kMaxTreeLevels) {
+      // a tree deeper than the traversal stack holds (clustered / exponentially scaled geometry) would drop subtrees
+      // silently: rebuild it balanced (median splits, depth ceil(log2 n) / 1..2 per 4-wide level)
+      build_bvh4(in, bo, threads, true);
+      if (bo.level_start.size() - 1 > kMaxTreeLevels) return fail(c, UH_ERR_CAPACITY, "internal: balanced BVH deeper than the traversal stack");
+   }
 
    // packets in leaf order
    std::vector<TriPacket> tp(total);
@@ -642,13 +645,13 @@ int uh_build_acceleration(uh_ctx* c) {
       }
       s.mesh = mi;
    }
-   if (bo.qnodes.empty()) return fail(c, UH_ERR_INVALID_ARGUMENT, "internal: BVH builder produced no root node");
+   if (bo.cnodes.empty()) return fail(c, UH_ERR_INVALID_ARGUMENT, "internal: BVH builder produced no root node");
    if (int st = sync_all(c)) return st;
    if (int st = upload_scene_tables(c)) return st;
-   HIP_TRY(c, c->d_nodes.alloc(bo.qnodes.size() * 4));
+   HIP_TRY(c, c->d_nodes.alloc(bo.cnodes.size() * 3));
    HIP_TRY(c, c->d_tris.alloc(total * 3));
    HIP_TRY(c, c->d_shade.alloc(total * 4));
-   HIP_TRY(c, hipMemcpy(c->d_nodes.p, bo.qnodes.data(), bo.qnodes.size() * sizeof(Node4Q), hipMemcpyHostToDevice));
+   HIP_TRY(c, hipMemcpy(c->d_nodes.p, bo.cnodes.data(), bo.cnodes.size() * sizeof(Node4C), hipMemcpyHostToDevice));
    if (total) {
       HIP_TRY(c, hipMemcpy(c->d_tris.p, tp.data(), total * sizeof(TriPacket), hipMemcpyHostToDevice));
       HIP_TRY(c, hipMemcpy(c->d_shade.p, sp.data(), total * sizeof(ShadePacket), hipMemcpyHostToDevice));
@@ -731,7 +734,7 @@ static int build_on_device(uh_ctx* c) {
    auto t0 = std::chrono::steady_clock::now();
    size_t total = 0;
    for (const HostMesh& m : c->meshes) total += m.indices.size() / 3;
-   if (total > kLeafFirstMask) return fail(c, UH_ERR_CAPACITY, "scene has more than 2^27 triangles");
+   if (total > kMaxTriangles) return fail(c, UH_ERR_CAPACITY, "scene has more than 2^31 - 2 triangles");
    if (int st = sync_all(c)) return st;
    if (int st = upload_scene_tables(c)) return st;
    if (!c->src_valid) {
@@ -798,7 +801,7 @@ static int build_on_device(uh_ctx* c) {
    for (int a = 0; a < 3; a++)
       if (!(lo[a] <= hi[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a])) lo[a] = hi[a] = 0.0f;
    const size_t node_cap = total > 1 ? total : 1;
-   HIP_TRY(c, c->d_nodes.alloc(node_cap * 4));
+   HIP_TRY(c, c->d_nodes.alloc(node_cap * 3));
    HIP_TRY(c, c->d_tris.alloc(total * 3));
    HIP_TRY(c, c->d_shade.alloc(total * 4));
    HIP_TRY(c, c->d_obj_corners.alloc(9 * total));
@@ -816,7 +819,6 @@ static int build_on_device(uh_ctx* c) {
       la.bounds_hi[a] = hi[a];
    }
    la.num_tris = (uint32_t)total;
-   la.leaf_tris = c->device_leaf_tris;
    la.nodes = reinterpret_cast<uint4*>(c->d_nodes.p);
    la.node_capacity = (uint32_t)node_cap;
    la.tris = c->d_tris.p;
@@ -825,6 +827,14 @@ static int build_on_device(uh_ctx* c) {
    uint32_t num_nodes = 1;
    hipError_t e = lbvh_build(la, c->stream, c->level_start, &num_nodes);
    if (e != hipSuccess) return fail(c, UH_ERR_HIP, std::string("device BVH build: ") + hipGetErrorString(e));
+   if (c->level_start.size() - 1 > kMaxTreeLevels) {
+      // a Morton tree over clustered geometry can be a long chain; deeper than the traversal stack it would drop
+      // subtrees silently: this scene gets the host builder (which has a balanced fallback of its own)
+      c->device_build = false;
+      const int st = uh_build_acceleration(c);
+      c->device_build = true;
+      return st;
+   }
    if (total) {
       RefitArgs a;
       a.obj_corners = c->d_obj_corners.p;
@@ -1303,11 +1313,7 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->count_visits = value != 0;
    else if (n == "raw_visit_counts")
       c->raw_visit_counts = value != 0;
-   else if (n == "device_build_leaf") {
-      if (value < 1 || value > 15) return fail(c, UH_ERR_INVALID_ARGUMENT, "device_build_leaf must be 1..15");
-      if (c->device_leaf_tris != (uint32_t)value) c->built = c->topology_valid = false;
-      c->device_leaf_tris = (uint32_t)value;
-   } else if (n == "device_build") {
+   else if (n == "device_build") {
       if (c->device_build != (value != 0)) c->built = c->topology_valid = false;
       c->device_build = value != 0;
    }
@@ -1319,15 +1325,7 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->time_kernels = value != 0;
    } else if (n == "full_frame_restir")
       c->full_frame_restir = value != 0;
-   else if (n == "bvh_max_leaf") {
-      if (value < 1 || value > 15) return fail(c, UH_ERR_INVALID_ARGUMENT, "bvh_max_leaf must be 1..15");
-      if (c->bvh_max_leaf != (uint32_t)value) c->built = c->topology_valid = false;  // needs a rebuild, not a refit
-      c->bvh_max_leaf = (uint32_t)value;
-   } else if (n == "bvh_sah_cost_x100") {
-      if (value < 0 || value > 1000) return fail(c, UH_ERR_INVALID_ARGUMENT, "bvh_sah_cost_x100 must be 0..1000");
-      if (c->bvh_sah_cost != (float)value / 100.0f) c->built = c->topology_valid = false;
-      c->bvh_sah_cost = (float)value / 100.0f;
-   } else if (n == "overlap_miss")
+   else if (n == "overlap_miss")
       c->overlap_miss = value != 0;
    else if (n == "overlap_shadow")
       c->overlap_shadow = value != 0;

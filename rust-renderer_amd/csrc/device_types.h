@@ -80,7 +80,7 @@ struct TexInfo {
 };
 
 struct SceneDev {
-   const uint4* nodes;    // 4 uint4 per Node4Q (quantised BVH4 node, 64 B)
+   const uint4* nodes;    // 3 uint4 per Node4C (quantised BVH4 node with implicit child addresses, 48 B)
    const float4* tris;    // 3 float4 per TriPacket
    const float4* shade;   // 4 float4 per ShadePacket
    const MeshShade* meshes;
@@ -180,7 +180,7 @@ struct RefitArgs {
    const RefitMesh* meshes;
    float4* tris;               // TriPacket array, rewritten
    float* world_corners;       // scratch, 9 floats per packet
-   uint4* nodes;               // Node4Q array, boxes rewritten, child refs kept
+   uint4* nodes;               // Node4C array: origin, step exponents and planes rewritten; counts and bases kept
    float* node_box;            // scratch, 6 floats per node (unpadded)
    const uint32_t* level_start;  // HOST array: BFS level l = nodes [level_start[l], level_start[l+1])
    uint32_t num_levels;
@@ -196,8 +196,7 @@ struct LbvhArgs {
    const RefitMesh* meshes;
    float bounds_lo[3], bounds_hi[3];  // world-space box containing every centroid (Morton normalisation)
    uint32_t num_tris;
-   uint32_t leaf_tris;           // subtrees of at most this many triangles become leaves
-   uint4* nodes;                 // out: Node4Q array (child refs valid, boxes to be refitted)
+   uint4* nodes;                 // out: Node4C array (child counts and bases valid, boxes to be refitted)
    uint32_t node_capacity;       // nodes the array can hold
    float4* tris;                 // out: TriPacket array in leaf order (keys; refit writes the geometry)
    float4* shade;                // out: ShadePacket array in leaf order

@@ -19,7 +19,7 @@ namespace uh {
 constexpr int kBlock = 256;                 // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kLdsStack = 16;               // per-lane traversal stack entries kept in LDS (16 KiB per 256-thread block -> 8 blocks/CU)
-constexpr int kSpillStack = 48;             // overflow entries in private memory (rarely touched)
+constexpr int kSpillStack = 96;             // overflow entries in private memory (rarely touched); the host refuses trees deeper than the two together hold
 
 // ------------------------------------------------------------------------------------------
 // BVH4 traversal (thread per ray). Closest hit: min t over all triangles with tmin < t < tmax,
@@ -127,24 +127,32 @@ __device__ __forceinline__ uint32_t trav_pop(Trav& t, const uint32_t* lds_col, c
    return spill[t.sp - kLdsStack];
 }
 
-// one interior node (quantised, 64 B): slab-test the 4 children, continue with the nearest, push
+// one interior node (Node4C, 48 B = three loads): slab-test the 4 children, continue with the nearest, push
 // the other hits. plane = origin + scale * q  =>  t = q * (scale * idir) + (origin - o) * idir.
-// Instruction diet (the kernel is VALU-issue bound, profiles/r01c_*): the near / far plane words
-// are picked once per axis by the sign of idir instead of min/max per plane; an empty slot is an
-// inverted box (no child != empty test); only the nearest child is fully ordered (3 comparators);
-// pushes are branch-free (write always, advance the stack pointer by the hit bit).
+//   w0 = origin.xyz, meta (step exponents, n_tri, n_child) ; w1 = qlo.xyz, qhi.x ; w2 = qhi.y, qhi.z, child_base, tri_base
+// Child references are implicit (bvh.h): slot k is triangle packet tri_base + k below n_tri, node child_base + k - n_tri above.
+// Instruction diet: the near / far plane words are picked once per axis by the sign of idir instead of min/max per
+// plane; an empty slot is an inverted box (no child != empty test); only the nearest child is fully ordered
+// (3 comparators); pushes are branch-free (write always, advance the stack pointer by the hit bit).
 template <bool ANY>
-__device__ __forceinline__ void node_compute(const uint4 w0, const uint4 w1, const uint4 w2, const uint4 ch, Trav& t, uint32_t* lds_col, uint32_t* spill) {
-   const float ax = __uint_as_float(w0.w) * t.idir.x, ay = __uint_as_float(w1.x) * t.idir.y, az = __uint_as_float(w1.y) * t.idir.z;
+__device__ __forceinline__ void node_compute(const uint4 w0, const uint4 w1, const uint4 w2, Trav& t, uint32_t* lds_col, uint32_t* spill) {
+   const uint32_t meta = w0.w;
+   // a power-of-two step is its biased exponent moved to bits 23..30
+   const float sx = __uint_as_float((meta & 0xffu) << 23), sy = __uint_as_float((meta << 15) & 0x7f800000u), sz = __uint_as_float((meta << 7) & 0x7f800000u);
+   const float ax = sx * t.idir.x, ay = sy * t.idir.y, az = sz * t.idir.z;
    const float bx = (__uint_as_float(w0.x) - t.o.x) * t.idir.x, by = (__uint_as_float(w0.y) - t.o.y) * t.idir.y, bz = (__uint_as_float(w0.z) - t.o.z) * t.idir.z;
    const bool nx = t.idir.x < 0.0f, ny = t.idir.y < 0.0f, nz = t.idir.z < 0.0f;
-   // qlo = (w1.z, w1.w, w2.x), qhi = (w2.y, w2.z, w2.w)
-   const uint32_t qnx = nx ? w2.y : w1.z, qfx = nx ? w1.z : w2.y;
-   const uint32_t qny = ny ? w2.z : w1.w, qfy = ny ? w1.w : w2.z;
-   const uint32_t qnz = nz ? w2.w : w2.x, qfz = nz ? w2.x : w2.w;
+   // qlo = (w1.x, w1.y, w1.z), qhi = (w1.w, w2.x, w2.y)
+   const uint32_t qnx = nx ? w1.w : w1.x, qfx = nx ? w1.x : w1.w;
+   const uint32_t qny = ny ? w2.x : w1.y, qfy = ny ? w1.y : w2.x;
+   const uint32_t qnz = nz ? w2.y : w1.z, qfz = nz ? w1.z : w2.y;
    const float tcap = ANY ? fminf(t.best.t, t.tlimit) : t.best.t;  // closest: tlimit is +inf
    float tn[4];
-   uint32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
+   const uint32_t n_tri = (meta >> kMetaTriShift) & 7u;
+   const uint32_t tri0 = kLeafBit | w2.w, node0 = w2.z - n_tri;
+   uint32_t cr[4];
+#pragma unroll
+   for (int k = 0; k < 4; k++) cr[k] = ((uint32_t)k < n_tri ? tri0 : node0) + (uint32_t)k;
    bool hit[4];
 #pragma unroll
    for (int k = 0; k < 4; k++) {
@@ -214,23 +222,11 @@ __device__ __forceinline__ void node_compute(const uint4 w0, const uint4 w1, con
 
 template <bool ANY>
 __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill) {
-   const uint4* n = nodes + 4 * (size_t)t.cur;
-   const uint4 w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
-   node_compute<ANY>(w0, w1, w2, ch, t, lds_col, spill);
+   const uint4* n = nodes + 3 * (size_t)t.cur;
+   const uint4 w0 = n[0], w1 = n[1], w2 = n[2];
+   node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
 }
 
-
-// one leaf: up to 4 triangle packets. Returns true when an any-hit walk found an occluder.
-template <bool ANY>
-__device__ __forceinline__ bool leaf_step(const float4* __restrict__ tris, Trav& t, uint32_t& n_tris) {
-   const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
-   n_tris += cnt;
-   for (uint32_t k = 0; k < cnt; k++) {
-      bool h = tri_test<ANY>(tris, first + k, t.o, t.d, t.tmin, t.tlimit, t.best);
-      if (ANY && h) return true;
-   }
-   return false;
-}
 
 // batch (if-if) traversal of one ray to its end: the batch kernels (variant 0) and the stand-alone any-hit query
 template <bool ANY, bool COUNT>
@@ -242,29 +238,20 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
    bool occluded = false;
-   // if-if with ONE triangle per iteration: in a divergent wave both branches are issued every
-   // iteration, so (a) the leaf branch must be short (a whole-leaf loop made every iteration pay up
-   // to 4 triangle tests for the few lanes standing at a leaf) and (b) a lane that the node step has
-   // just sent to a leaf uses this iteration's leaf branch too instead of idling through it
-   uint32_t tk = 0;
+   // if-if: in a divergent wave both branches are issued every iteration, so a lane that the node step has just
+   // sent to a triangle uses this iteration's triangle branch too instead of idling through it
    while (t.cur != kEmptyRef) {
       if (!(t.cur & kLeafBit)) {
          if (COUNT) n_nodes++;
          node_step<ANY>(nodes, t, lds_col, spill);
       }
-      // a lane that the node step just sent to a leaf tests that leaf's first triangle in the same iteration
       if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
-         const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
          if (COUNT) n_tris++;
-         if (tri_test<ANY>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
+         if (tri_test<ANY>(tris, t.cur & ~kLeafBit, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
             occluded = true;
             break;
          }
-         tk++;
-         if (tk >= cnt) {
-            tk = 0;
-            t.cur = trav_pop(t, lds_col, spill);
-         }
+         t.cur = trav_pop(t, lds_col, spill);
       }
    }
    best = t.best;
@@ -424,34 +411,30 @@ __device__ __forceinline__ bool refill_lanes(Feeder<NA>& f, const RaySource& src
 //   all loads are in flight together, then both groups compute. A lane that reaches a leaf tests it an iteration
 //   later, but the wave waits for memory once per iteration instead of twice.
 template <bool ANY, bool COUNT, bool PHASED>
-__device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const float4* __restrict__ tris, Trav& t, uint32_t& tk, uint32_t* lds_col, uint32_t* spill,
-                                          bool& occluded, uint32_t& n_nodes, uint32_t& n_tris) {
+__device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const float4* __restrict__ tris, Trav& t, uint32_t* lds_col, uint32_t* spill, bool& occluded,
+                                          uint32_t& n_nodes, uint32_t& n_tris) {
    if (PHASED) {
       const bool at_node = !(t.cur & kLeafBit);
-      const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
-      uint4 w0, w1, w2, ch;
+      const uint32_t packet = t.cur & ~kLeafBit;
+      uint4 w0, w1, w2;
       float4 ta, tb, tc;
       if (at_node) {
-         const uint4* n = nodes + 4 * (size_t)t.cur;
-         w0 = n[0], w1 = n[1], w2 = n[2], ch = n[3];
+         const uint4* n = nodes + 3 * (size_t)t.cur;
+         w0 = n[0], w1 = n[1], w2 = n[2];
       } else {
-         const float4* p = tris + 3 * (size_t)(first + tk);
+         const float4* p = tris + 3 * (size_t)packet;
          ta = p[0], tb = p[1], tc = p[2];
       }
       if (at_node) {
          if (COUNT) n_nodes++;
-         node_compute<ANY>(w0, w1, w2, ch, t, lds_col, spill);
+         node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
       } else {
          if (COUNT) n_tris++;
-         if (tri_compute<ANY>(ta, tb, tc, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
+         if (tri_compute<ANY>(ta, tb, tc, packet, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
             occluded = true;
             t.cur = kEmptyRef;
          } else {
-            tk++;
-            if (tk >= cnt) {
-               tk = 0;
-               t.cur = trav_pop(t, lds_col, spill);
-            }
+            t.cur = trav_pop(t, lds_col, spill);
          }
       }
       return t.cur == kEmptyRef;
@@ -461,17 +444,12 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
       node_step<ANY>(nodes, t, lds_col, spill);
    }
    if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
-      const uint32_t first = t.cur & kLeafFirstMask, cnt = (t.cur >> kLeafCountShift) & 0xf;
       if (COUNT) n_tris++;
-      if (tri_test<ANY>(tris, first + tk, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
+      if (tri_test<ANY>(tris, t.cur & ~kLeafBit, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
          occluded = true;
          t.cur = kEmptyRef;
       } else {
-         tk++;
-         if (tk >= cnt) {
-            tk = 0;
-            t.cur = trav_pop(t, lds_col, spill);
-         }
+         t.cur = trav_pop(t, lds_col, spill);
       }
    }
    return t.cur == kEmptyRef;
@@ -513,17 +491,16 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
    Trav t;
    t.cur = kEmptyRef;
    t.sp = 0;
-   uint32_t id = 0, tk = 0, n_nodes = 0, n_tris = 0;
+   uint32_t id = 0, n_nodes = 0, n_tris = 0;
    uint32_t spill[kSpillStack];
    auto take = [&](uint32_t slot) {
       id = pool.id[slot];
       trav_init(t, pool.v[0][slot], pool.v[1][slot], INFINITY);
-      tk = 0;
    };
    while (refill_lanes<2, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<false, COUNT, PHASED>(nodes, tris, t, tk, lds_col, spill, occluded, n_nodes, n_tris))
+         if (trav_step<false, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris))
             hit_out[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
       }
    }
@@ -639,7 +616,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    Trav t;
    t.cur = kEmptyRef;
    t.sp = 0;
-   uint32_t id = 0, tk = 0, n_nodes = 0, n_tris = 0;
+   uint32_t id = 0, n_nodes = 0, n_tris = 0;
    float4 lit = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
    uint32_t spill[kSpillStack];
    auto take = [&](uint32_t slot) {
@@ -647,12 +624,11 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
       const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, pool.v[0][slot], pool.v[1][slot], pool.v[2][slot]);
       lit = s.lit;
       trav_init(t, s.ro, s.rd, s.tlimit);
-      tk = 0;
    };
    while (refill_lanes<3, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<true, COUNT, PHASED>(nodes, tris, t, tk, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) ps.rad[id] = lit;
+         if (trav_step<true, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) ps.rad[id] = lit;
       }
    }
    if (COUNT) {

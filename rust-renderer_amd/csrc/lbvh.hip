@@ -9,9 +9,9 @@
 //   2. radix sort of the 64-bit keys (hipcub / rocPRIM)
 //   3. binary radix tree over the sorted keys (Karras 2012: every internal node finds its range and split
 //      from the common-prefix lengths, all nodes in parallel)
-//   4. collapse to 4-wide nodes, breadth-first, one launch per level: a subtree of at most kLeafTris
-//      triangles becomes a leaf (a contiguous run of the sorted order), other children get node slots of
-//      the next level from one atomic counter
+//   4. collapse to 4-wide nodes, breadth-first, one launch per level: every leaf is one triangle; a node takes the
+//      node slots of its node children from the next level's counter and the packet slots of its triangle children
+//      from a packet counter, one atomic each, so both groups are contiguous (bvh.h: implicit child addresses)
 //   5. boxes + quantisation: the refit kernels (refit.hip) - a device build is "topology here, boxes by refit"
 // The tree is a Morton-order tree, not a SAH one: it builds in a few milliseconds instead of tens to hundreds and
 // costs about a quarter more traversal work per ray (DESIGN.md "On-device build"). Hits do not depend on the tree (bvh.h), so a
@@ -97,21 +97,28 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_tree(const unsigned long long* 
    node2[i] = make_uint4(left, right, (uint32_t)first, (uint32_t)(last - first + 1));
 }
 
+// an unfitted node: boxes and step exponents come from the refit kernels; counts and bases are final
+__device__ __forceinline__ void write_topology(uint4* nd, uint32_t n_tri, uint32_t n_child, uint32_t child_base, uint32_t tri_base) {
+   const uint32_t meta = (127u | (127u << 8) | (127u << 16)) | (n_tri << kMetaTriShift) | (n_child << kMetaChildShift);
+   nd[0] = make_uint4(0u, 0u, 0u, meta);
+   nd[1] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
+   nd[2] = make_uint4(0u, 0u, child_base, tri_base);
+}
+
 // one BFS level of the 4-wide tree: level node `idx` (global index level_first + idx) collapses the
 // binary subtree rooted at internal node src[idx]
 __global__ __launch_bounds__(kBlock) void k_lbvh_collapse(const uint4* __restrict__ node2, const uint32_t* __restrict__ src, uint32_t level_first, uint32_t level_count,
-                                                          uint32_t next_first, uint32_t* __restrict__ next_src, uint32_t* __restrict__ next_count, uint4* __restrict__ nodes,
-                                                          uint32_t kLeafTris) {
+                                                          uint32_t next_first, uint32_t* __restrict__ next_src, uint32_t* __restrict__ next_count, uint32_t* __restrict__ tri_count,
+                                                          uint32_t* __restrict__ order, uint4* __restrict__ nodes) {
    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
    if (idx >= level_count) return;
    auto count_of = [&](uint32_t ref) { return (ref & kLeafBit) ? 1u : node2[ref].w; };
-   auto first_of = [&](uint32_t ref) { return (ref & kLeafBit) ? (ref & ~kLeafBit) : node2[ref].z; };
    const uint4 root = node2[src[idx]];
    uint32_t ch[4] = {root.x, root.y, kEmptyRef, kEmptyRef};
    int nc = 2;
    while (nc < 4) {
       int pick = -1;
-      uint32_t best = kLeafTris;
+      uint32_t best = 1;
       for (int k = 0; k < nc; k++) {
          const uint32_t c = count_of(ch[k]);
          if (c > best) {
@@ -124,39 +131,35 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_collapse(const uint4* __restric
       ch[pick] = e.x;
       ch[nc++] = e.y;
    }
-   uint32_t out[4] = {kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef};
+   uint32_t n_tri = 0;
+   for (int k = 0; k < nc; k++)
+      if (ch[k] & kLeafBit) n_tri++;
+   const uint32_t n_node = (uint32_t)nc - n_tri;
+   const uint32_t tri_base = n_tri ? atomicAdd(tri_count, n_tri) : 0u;
+   const uint32_t slot = n_node ? atomicAdd(next_count, n_node) : 0u;
+   uint32_t t = 0, m = 0;
    for (int k = 0; k < nc; k++) {
-      const uint32_t c = count_of(ch[k]);
-      if (c <= kLeafTris) {
-         out[k] = kLeafBit | (c << kLeafCountShift) | (first_of(ch[k]) & kLeafFirstMask);
-      } else {
-         const uint32_t slot = atomicAdd(next_count, 1u);
-         next_src[slot] = ch[k];
-         out[k] = next_first + slot;
-      }
+      if (ch[k] & kLeafBit)
+         order[tri_base + t++] = ch[k] & ~kLeafBit;  // position in the sorted order of the packet's triangle
+      else
+         next_src[slot + m++] = ch[k];
    }
-   uint4* nd = nodes + 4 * (size_t)(level_first + idx);
-   nd[0] = make_uint4(0u, 0u, 0u, __float_as_uint(1.0f));
-   nd[1] = make_uint4(__float_as_uint(1.0f), __float_as_uint(1.0f), 0xffffffffu, 0xffffffffu);
-   nd[2] = make_uint4(0xffffffffu, 0u, 0u, 0u);
-   nd[3] = make_uint4(out[0], out[1], out[2], out[3]);
+   write_topology(nodes + 3 * (size_t)(level_first + idx), n_tri, (uint32_t)nc, next_first + slot, tri_base);
 }
 
-// a tree without internal binary nodes (n <= kLeafTris): one root whose first child is the only leaf
-__global__ void k_lbvh_tiny(uint4* __restrict__ nodes, uint32_t n) {
-   nodes[0] = make_uint4(0u, 0u, 0u, __float_as_uint(1.0f));
-   nodes[1] = make_uint4(__float_as_uint(1.0f), __float_as_uint(1.0f), 0xffffffffu, 0xffffffffu);
-   nodes[2] = make_uint4(0xffffffffu, 0u, 0u, 0u);
-   nodes[3] = make_uint4(n ? (kLeafBit | (n << kLeafCountShift)) : kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef);
+// a tree without internal binary nodes (n <= 1): one root whose only child, if any, is the triangle
+__global__ void k_lbvh_tiny(uint4* __restrict__ nodes, uint32_t* __restrict__ order, uint32_t n) {
+   write_topology(nodes, n, n, 0u, 0u);
+   if (n) order[0] = 0u;
 }
 
-// packets in sorted order: object-space corners (refit input), key, shading packet
-__global__ __launch_bounds__(kBlock) void k_lbvh_gather(const unsigned long long* __restrict__ keys, const float* __restrict__ src_corners, const uint32_t* __restrict__ src_keys,
-                                                        const float4* __restrict__ src_shade, float* __restrict__ obj_corners, float4* __restrict__ tris,
-                                                        float4* __restrict__ shade, uint32_t n) {
+// packet p takes the triangle at position order[p] of the sorted order: object-space corners (refit input), key, shading packet
+__global__ __launch_bounds__(kBlock) void k_lbvh_gather(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ order, const float* __restrict__ src_corners,
+                                                        const uint32_t* __restrict__ src_keys, const float4* __restrict__ src_shade, float* __restrict__ obj_corners,
+                                                        float4* __restrict__ tris, float4* __restrict__ shade, uint32_t n) {
    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
    if (i >= n) return;
-   const uint32_t s = (uint32_t)(keys[i] & 0xffffffffull);
+   const uint32_t s = (uint32_t)(keys[order[i]] & 0xffffffffull);
    for (int k = 0; k < 9; k++) obj_corners[9 * (size_t)i + k] = src_corners[9 * (size_t)s + k];
    for (int k = 0; k < 4; k++) shade[4 * (size_t)i + k] = src_shade[4 * (size_t)s + k];
    tris[3 * (size_t)i + 2] = make_float4(0.0f, __uint_as_float(src_keys[s]), 0.0f, 0.0f);  // the key; refit writes the rest
@@ -165,37 +168,19 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_gather(const unsigned long long
 }  // namespace
 
 // Builds topology + packets on `stream`. `level_start` (host) receives the BFS levels. Returns the node count.
-// Scratch (keys x2, sort temp, binary nodes, level lists, counters) is allocated and freed here.
+// Scratch (keys x2, sort temp, binary nodes, level lists, packet order, counters) is allocated and freed here.
 hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_t>& level_start, uint32_t* out_nodes) {
    const uint32_t n = a.num_tris;
-   const uint32_t kLeafTris = a.leaf_tris < 1 ? 1u : (a.leaf_tris > 15 ? 15u : a.leaf_tris);  // subtrees of at most this many triangles become leaves
    level_start.assign({0u, 1u});
    *out_nodes = 1;
-   if (n <= kLeafTris) {
-      k_lbvh_tiny<<<1, 1, 0, stream>>>(a.nodes, n);
-      if (n) {
-         // identity order
-         unsigned long long* keys = nullptr;
-         hipError_t e = hipMalloc(&keys, n * sizeof(unsigned long long));
-         if (e != hipSuccess) return e;
-         std::vector<unsigned long long> h(n);
-         for (uint32_t i = 0; i < n; i++) h[i] = i;
-         e = hipMemcpyAsync(keys, h.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice, stream);
-         if (e == hipSuccess) k_lbvh_gather<<<1, kBlock, 0, stream>>>(keys, a.src_corners, a.src_keys, a.src_shade, a.obj_corners, a.tris, a.shade, n);
-         hipError_t e2 = hipStreamSynchronize(stream);
-         (void)hipFree(keys);
-         return e != hipSuccess ? e : e2;
-      }
-      return hipStreamSynchronize(stream);
-   }
    unsigned long long *keys_in = nullptr, *keys_out = nullptr;
    uint4* node2 = nullptr;
-   uint32_t *list_a = nullptr, *list_b = nullptr, *counter = nullptr;
+   uint32_t *list_a = nullptr, *list_b = nullptr, *counter = nullptr, *order = nullptr;
    void* temp = nullptr;
    size_t temp_bytes = 0;
    hipError_t e = hipSuccess;
    auto cleanup = [&]() {
-      for (void* p : {(void*)keys_in, (void*)keys_out, (void*)node2, (void*)list_a, (void*)list_b, (void*)counter, temp})
+      for (void* p : {(void*)keys_in, (void*)keys_out, (void*)node2, (void*)list_a, (void*)list_b, (void*)counter, (void*)order, temp})
          if (p) (void)hipFree(p);
    };
 #define LB_TRY(expr)            \
@@ -203,12 +188,25 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
       cleanup();                \
       return e;                 \
    }
+   const size_t n1 = n ? n : 1;
+   LB_TRY(hipMalloc(&order, n1 * sizeof(uint32_t)));
+   LB_TRY(hipMalloc(&keys_out, n1 * sizeof(unsigned long long)));
+   if (n <= 1) {
+      k_lbvh_tiny<<<1, 1, 0, stream>>>(a.nodes, order, n);
+      if (n) {
+         const unsigned long long zero_key = 0ull;  // the one triangle, source index 0
+         LB_TRY(hipMemcpyAsync(keys_out, &zero_key, sizeof(zero_key), hipMemcpyHostToDevice, stream));
+         k_lbvh_gather<<<1, kBlock, 0, stream>>>(keys_out, order, a.src_corners, a.src_keys, a.src_shade, a.obj_corners, a.tris, a.shade, n);
+      }
+      e = hipStreamSynchronize(stream);
+      cleanup();
+      return e;
+   }
    LB_TRY(hipMalloc(&keys_in, n * sizeof(unsigned long long)));
-   LB_TRY(hipMalloc(&keys_out, n * sizeof(unsigned long long)));
    LB_TRY(hipMalloc(&node2, (size_t)n * sizeof(uint4)));
    LB_TRY(hipMalloc(&list_a, (size_t)n * sizeof(uint32_t)));
    LB_TRY(hipMalloc(&list_b, (size_t)n * sizeof(uint32_t)));
-   LB_TRY(hipMalloc(&counter, sizeof(uint32_t)));
+   LB_TRY(hipMalloc(&counter, 2 * sizeof(uint32_t)));  // [0] node slots of the next level, [1] packet slots (whole tree)
    const dim3 grid((n + kBlock - 1) / kBlock);
    const float3 lo = make_float3(a.bounds_lo[0], a.bounds_lo[1], a.bounds_lo[2]);
    auto inv = [](float l, float h) { return h > l ? 1.0f / (h - l) : 0.0f; };
@@ -218,12 +216,12 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
    LB_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
    LB_TRY(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys_in, keys_out, (int)n, 0, 62, stream));
    k_lbvh_tree<<<grid, kBlock, 0, stream>>>(keys_out, node2, n);
-   k_lbvh_gather<<<grid, kBlock, 0, stream>>>(keys_out, a.src_corners, a.src_keys, a.src_shade, a.obj_corners, a.tris, a.shade, n);
    // breadth-first collapse, one launch per level; the level sizes come back through one counter
    level_start.assign({0u});
    uint32_t level_first = 0, level_count = 1;
    const uint32_t zero = 0;
    LB_TRY(hipMemcpyAsync(list_a, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, stream));  // level 0 = binary root 0
+   LB_TRY(hipMemsetAsync(counter, 0, 2 * sizeof(uint32_t), stream));
    uint32_t *cur = list_a, *nxt = list_b;
    while (level_count) {
       const uint32_t next_first = level_first + level_count;
@@ -232,7 +230,7 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
          return hipErrorInvalidValue;
       }
       LB_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
-      k_lbvh_collapse<<<dim3((level_count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(node2, cur, level_first, level_count, next_first, nxt, counter, a.nodes, kLeafTris);
+      k_lbvh_collapse<<<dim3((level_count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(node2, cur, level_first, level_count, next_first, nxt, counter, counter + 1, order, a.nodes);
       uint32_t produced = 0;
       LB_TRY(hipMemcpyAsync(&produced, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       LB_TRY(hipStreamSynchronize(stream));
@@ -242,6 +240,8 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
       std::swap(cur, nxt);
    }
    *out_nodes = level_first;
+   k_lbvh_gather<<<grid, kBlock, 0, stream>>>(keys_out, order, a.src_corners, a.src_keys, a.src_shade, a.obj_corners, a.tris, a.shade, n);
+   LB_TRY(hipStreamSynchronize(stream));
    LB_TRY(hipGetLastError());
 #undef LB_TRY
    cleanup();

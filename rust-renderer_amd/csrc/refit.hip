@@ -50,35 +50,35 @@ __global__ __launch_bounds__(kBlock) void k_refit_triangles(const float* __restr
 }
 
 // one thread per node of one BFS level (deepest level first): tight box of every child, the node's
-// own tight box for its parent, and the re-quantised 64-byte node
+// own tight box for its parent, and the re-quantised 48-byte node (bvh.h Node4C; child slots are implicit:
+// triangles tri_base + k below n_tri, nodes child_base + k - n_tri up to n_child, empty slots above)
 __global__ __launch_bounds__(kBlock) void k_refit_level(uint4* __restrict__ nodes, float* __restrict__ node_box, const float* __restrict__ world_corners, uint32_t first,
                                                         uint32_t count) {
    uint32_t j = blockIdx.x * kBlock + threadIdx.x;
    if (j >= count) return;
    const uint32_t ni = first + j;
-   uint4* nd = nodes + 4 * (size_t)ni;
-   const uint4 ch = nd[3];
-   const uint32_t child[4] = {ch.x, ch.y, ch.z, ch.w};
+   uint4* nd = nodes + 3 * (size_t)ni;
+   const uint32_t meta = nd[0].w;
+   const uint4 w2 = nd[2];
+   const uint32_t n_tri = (meta >> kMetaTriShift) & 7u, n_child = (meta >> kMetaChildShift) & 7u;
+   const uint32_t child_base = w2.z, tri_base = w2.w;
    float lo[4][3], hi[4][3];
    float tlo[3] = {INFINITY, INFINITY, INFINITY}, thi[3] = {-INFINITY, -INFINITY, -INFINITY};
-   for (int k = 0; k < 4; k++) {
+   for (uint32_t k = 0; k < 4; k++) {
       float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-      if (child[k] == 0xffffffffu) {
+      if (k >= n_child) {
          for (int a = 0; a < 3; a++) lo[k][a] = hi[k][a] = 0.0f;
          continue;
       }
-      if (child[k] & 0x80000000u) {
-         const uint32_t f = child[k] & 0x07ffffffu, cnt = (child[k] >> 27) & 0xf;
-         for (uint32_t t = 0; t < cnt; t++) {
-            const float* wc = world_corners + 9 * (size_t)(f + t);
-            for (int v = 0; v < 3; v++)
-               for (int a = 0; a < 3; a++) {
-                  blo[a] = fminf(blo[a], wc[3 * v + a]);
-                  bhi[a] = fmaxf(bhi[a], wc[3 * v + a]);
-               }
-         }
+      if (k < n_tri) {
+         const float* wc = world_corners + 9 * (size_t)(tri_base + k);
+         for (int v = 0; v < 3; v++)
+            for (int a = 0; a < 3; a++) {
+               blo[a] = fminf(blo[a], wc[3 * v + a]);
+               bhi[a] = fmaxf(bhi[a], wc[3 * v + a]);
+            }
       } else {
-         const float* b = node_box + 6 * (size_t)child[k];
+         const float* b = node_box + 6 * (size_t)(child_base + k - n_tri);
          for (int a = 0; a < 3; a++) {
             blo[a] = b[a];
             bhi[a] = b[3 + a];
@@ -98,17 +98,16 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(uint4* __restrict__ node
       nb[a] = tlo[a];
       nb[3 + a] = thi[a];
    }
-   // quantise exactly as bvh_build.cpp does: origin = min lower plane, scale = smallest power of two
+   // quantise exactly as bvh_build.cpp quantise_node does: origin = min lower plane, step = smallest power of two
    // whose 255 steps cover the extent, lower planes round down and upper planes up (in double)
-   float origin[3], scale[3];
-   uint32_t qlo[3], qhi[3];
+   float origin[3];
+   uint32_t qlo[3], qhi[3], exps = 0;
    for (int a = 0; a < 3; a++) {
       double mn = INFINITY, mx = -INFINITY;
-      for (int k = 0; k < 4; k++)
-         if (child[k] != 0xffffffffu) {
-            mn = fmin(mn, (double)lo[k][a]);
-            mx = fmax(mx, (double)hi[k][a]);
-         }
+      for (uint32_t k = 0; k < n_child; k++) {
+         mn = fmin(mn, (double)lo[k][a]);
+         mx = fmax(mx, (double)hi[k][a]);
+      }
       if (!(mn <= mx)) mn = mx = 0.0;
       const float org = (float)mn;
       const double ext = mx - (double)org;
@@ -124,8 +123,8 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(uint4* __restrict__ node
       }
       const double s = ldexp(1.0, e);
       uint32_t wlo = 0, whi = 0;
-      for (int k = 0; k < 4; k++) {
-         if (child[k] == 0xffffffffu) {
+      for (uint32_t k = 0; k < 4; k++) {
+         if (k >= n_child) {
             wlo |= 0xffu << (8 * k);
             continue;
          }
@@ -138,13 +137,13 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(uint4* __restrict__ node
          whi |= (uint32_t)a1 << (8 * k);
       }
       origin[a] = org;
-      scale[a] = (float)s;
+      exps |= (uint32_t)(e + 127) << (8 * a);
       qlo[a] = wlo;
       qhi[a] = whi;
    }
-   nd[0] = make_uint4(__float_as_uint(origin[0]), __float_as_uint(origin[1]), __float_as_uint(origin[2]), __float_as_uint(scale[0]));
-   nd[1] = make_uint4(__float_as_uint(scale[1]), __float_as_uint(scale[2]), qlo[0], qlo[1]);
-   nd[2] = make_uint4(qlo[2], qhi[0], qhi[1], qhi[2]);
+   nd[0] = make_uint4(__float_as_uint(origin[0]), __float_as_uint(origin[1]), __float_as_uint(origin[2]), (meta & 0xff000000u) | exps);
+   nd[1] = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
+   nd[2] = make_uint4(qhi[1], qhi[2], child_base, tri_base);
 }
 
 }  // namespace

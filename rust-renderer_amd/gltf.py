@@ -8,8 +8,9 @@ reference's loader (utopian/src/gltf_loader.rs:47-218):
 * material: base colour factor / metallic / roughness; diffuse_map = the glTF *texture* index used to
   index the model's *image* list (the reference's own quirk, gltf_loader.rs:103-107 vs :183-207);
   material_type Lambertian, property 0 (callers override, e.g. scenes.rs:116-121);
-* images become RGBA8 (RGB8 is expanded, gltf_loader.rs:179-194).
-Buffers may be base64 data URIs or files next to the .gltf; images need Pillow.
+* images become RGBA8 (RGB8 is expanded, anything else is the reference's "Unsupported image format!",
+  gltf_loader.rs:179-198); PNG is decoded in-repo (image_decode.py), JPEG needs Pillow (optional).
+Buffers may be base64 data URIs or files next to the .gltf.
 `instance_transform_3x4` applies the scale-rotation-translation round trip of
 Raytracing::fill_instance_array (raytracing.rs:229-248), which drops shear.
 """
@@ -19,6 +20,7 @@ import os
 
 import numpy as np
 
+from .image_decode import load_image_rgba8
 from .scenes import Mesh, Model
 from .types import LAMBERTIAN, VERTEX_DTYPE
 
@@ -79,14 +81,11 @@ def load_gltf(path):
     buffers = [_load_uri(b["uri"], base_dir) for b in gltf.get("buffers", [])]
     model = Model([], [])
     for image in gltf.get("images", []):
-        from PIL import Image  # only needed for textured assets
-        import io
-
         data = _load_uri(image["uri"], base_dir) if "uri" in image else bytes(
             buffers[gltf["bufferViews"][image["bufferView"]]["buffer"]][
                 gltf["bufferViews"][image["bufferView"]].get("byteOffset", 0):][: gltf["bufferViews"][image["bufferView"]]["byteLength"]]
         )
-        model.textures.append(np.array(Image.open(io.BytesIO(data)).convert("RGBA"), dtype=np.uint8))
+        model.textures.append(load_image_rgba8(bytes(data)))
 
     def load_node(index, parent):
         node = gltf["nodes"][index]

@@ -16,6 +16,11 @@ def short(name):
     return name.split("(")[0].replace("void ", "").replace("uh::", "")
 
 
+def base_name(k):
+    """kernel name without its template arguments: the variants of one kernel share a profile entry"""
+    return k.split("<")[0].strip()
+
+
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
@@ -51,6 +56,33 @@ def main():
         out["kernels"][k] = {"counters": e, "derived": d}
     dst = os.path.join(ROOT, "profiles", f"{tag}_counters.json")
     json.dump(out, open(dst, "w"), indent=1)
+    if "--bench" in sys.argv:
+        # profiles/bench_counters.json: what bench.py quotes (roofline.traffic / roofline.valu) when the signature of its
+        # run equals the one of the profiled command line (gpurun_out/bench_signature.json, written by that run)
+        sig = json.load(open(os.path.join(ROOT, "gpurun_out", "bench_signature.json")))
+        bench = {"signature": sig, "source": f"profiles/{tag}_counters.json (rocprofv3 --pmc passes, tools/pmc_passes.sh)",
+                 "note": "per launch, median over the kernel's dispatches; hbm_bytes = 2*FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md HBM: FETCH_SIZE reports half the bytes "
+                         "of wide reads on gfx950 - calibrated for coalesced 16-B loads; for the 64-B node gathers of the traversal kernels the x2 may overstate by up to 2x, "
+                         "so hbm_bytes is an upper bound there); Infinity-Cache hits are counted in", "kernels": {}}
+        for k, v in out["kernels"].items():
+            m = {c: x["median"] for c, x in v["counters"].items()}
+            e = bench["kernels"].setdefault(base_name(k), {})
+            if e:
+                continue  # first variant seen wins (one variant per run)
+            if "FETCH_SIZE" in m or "WRITE_SIZE" in m:
+                e["fetch_kib_per_launch"], e["write_kib_per_launch"] = m.get("FETCH_SIZE"), m.get("WRITE_SIZE")
+                e["hbm_bytes_per_launch"] = 2048.0 * m.get("FETCH_SIZE", 0.0) + 1024.0 * m.get("WRITE_SIZE", 0.0)
+            if m.get("SQ_INSTS_VALU"):
+                e["wave_instr_per_launch"] = m["SQ_INSTS_VALU"]
+            d = v["derived"]
+            e["issue_frac"], e["lane_utilisation"] = d.get("valu_issue_frac"), d.get("lane_utilisation")
+            if m.get("GRBM_GUI_ACTIVE"):
+                clk = m["GRBM_GUI_ACTIVE"] / 8.0
+                e["ta_busy_frac"] = m.get("TA_TA_BUSY_sum", 0.0) / 256.0 / clk if m.get("TA_TA_BUSY_sum") else None
+                e["td_busy_frac"] = m.get("TD_TD_BUSY_sum", 0.0) / 256.0 / clk if m.get("TD_TD_BUSY_sum") else None
+                e["launch_clk"] = clk
+            e["variant"] = k
+        json.dump(bench, open(os.path.join(ROOT, "profiles", "bench_counters.json"), "w"), indent=1)
     for k, v in out["kernels"].items():
         print(k, json.dumps({a: round(b, 4) for a, b in v["derived"].items()}))
         print("   ", {c: round(x["median"]) for c, x in v["counters"].items()})
