@@ -225,7 +225,7 @@ class Renderer:
         """Renderer::initialize (renderer.rs:202-220): the four default maps get bindless indices 0..3 - diffuse (white),
         normal (flat), occlusion (white), metallic-roughness - before any model texture. `default_textures`: four
         (H, W, 4) uint8 arrays (the files of utopian/data/textures/defaults/); without them 1x1 texels of the same
-        values are used (the files are constant images except for +-1 LSB dither in the normal map)."""
+        values are used (the files are constant images except for +-2 LSB dither in the normal map)."""
         if hasattr(self, "_defaults"):
             return self._defaults
         if default_textures is None:

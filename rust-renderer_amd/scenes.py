@@ -608,9 +608,9 @@ def _isosurface_host_mesh(resolution):
 def isosurface_scene(resolution=512, device=False):
     """BASELINE.json configs[4]: the 512^3 isosurface of the reference's density field (torus above a
     box, marching_cubes.comp:83-103 scaled to a 32-unit domain), one Lambertian mesh on a ground
-    plane, sky + sun; ~1.65 M triangles at 512^3. device=True: a HIP renderer extracts the mesh on the
-    GPU at upload (uh_add_isosurface_mesh, milliseconds); otherwise (and for the oracle) the vectorised
-    host marching-tetrahedra pass below builds it (the better part of a minute at 512^3)."""
+    plane, sky + sun. device=True: a HIP renderer extracts the mesh on the GPU at upload (uh_add_isosurface_mesh:
+    table-driven marching cubes, ~0.8 M triangles at 512^3, milliseconds); otherwise (and for the oracle) the
+    vectorised host marching-tetrahedra pass below builds it (~1.65 M triangles, the better part of a minute)."""
     ground = Mesh(*quad((-64, 4.99, -64), (0, 0, 160), (160, 0, 0), 32, 32, uv_scale=(8, 8)), base_color=(0.6, 0.6, 0.6, 1.0), name="ground")
     cam = Camera((27.0, 19.0, 33.0), (16.0, 14.0, 16.0), 60.0, 16.0 / 9.0, 0.01, 1000.0)
     flags = dict(sky_enabled=1, sun_shadow_enabled=1, lights_enabled=0, use_ris_light_sampling=0)
