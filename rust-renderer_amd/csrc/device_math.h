@@ -259,6 +259,50 @@ __device__ __forceinline__ bool owns_pixel(const FrameParams& fp, uint32_t x, ui
    return tile % fp.tp_world == fp.tp_rank;
 }
 
+// ---- streaming (non-temporal) access to per-path state -----------------------------------------
+// Path state is touched once per kernel and is hundreds of MB per wavefront of frames; the BVH (nodes + triangle packets,
+// tens of MB) is what the traversal kernels re-read. `nt` loads / stores ask the caches not to keep the stream, so that it
+// does not push the tree out of the 4 MiB L2 of each XCD. PathState::stream_nt switches it (option "stream_nt").
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld_stream(const float4* p, bool nt) {
+   if (nt) {
+      const v4f_t v = __builtin_nontemporal_load((const v4f_t*)p);
+      return make_float4(v.x, v.y, v.z, v.w);
+   }
+   return *p;
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 x, bool nt) {
+   if (nt) {
+      const v4f_t v = {x.x, x.y, x.z, x.w};
+      __builtin_nontemporal_store(v, (v4f_t*)p);
+   } else {
+      *p = x;
+   }
+}
+__device__ __forceinline__ uint2 ld_stream(const uint2* p, bool nt) {
+   if (nt) {
+      const v2u_t v = __builtin_nontemporal_load((const v2u_t*)p);
+      return make_uint2(v.x, v.y);
+   }
+   return *p;
+}
+__device__ __forceinline__ void st_stream(uint2* p, uint2 x, bool nt) {
+   if (nt) {
+      const v2u_t v = {x.x, x.y};
+      __builtin_nontemporal_store(v, (v2u_t*)p);
+   } else {
+      *p = x;
+   }
+}
+__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_stream(uint32_t* p, uint32_t x, bool nt) {
+   if (nt)
+      __builtin_nontemporal_store(x, p);
+   else
+      *p = x;
+}
+
 // ---- wave64 helpers ---------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

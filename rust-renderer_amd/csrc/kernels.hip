@@ -302,9 +302,12 @@ struct alignas(16) RayPool {
    uint32_t id[kPool];
 };
 
-__device__ __forceinline__ void dma16(const float4* gsrc, float4* lds_dst) {
-   // lds_dst is wave-uniform; lane l's 16 bytes land at lds_dst + l
-   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+__device__ __forceinline__ void dma16(const float4* gsrc, float4* lds_dst, bool nt) {
+   // lds_dst is wave-uniform; lane l's 16 bytes land at lds_dst + l. aux = 2: the nt cache policy
+   if (nt)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
+   else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -316,6 +319,7 @@ struct RaySource {
    uint32_t count;
    uint32_t* cursor;
    uint32_t wave_index, num_waves;  // static chunk assignment only
+   bool nt;                         // stream the ray records past the caches (PathState::stream_nt)
 };
 
 template <int NA>
@@ -351,7 +355,7 @@ struct Feeder {
          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pool's last entries have been read
          if (lane < q_n) {
 #pragma unroll
-            for (int a = 0; a < NA; a++) dma16(source_of(a, q_id), pool.v[a]);
+            for (int a = 0; a < NA; a++) dma16(source_of(a, q_id), pool.v[a], src.nt);
             pool.id[lane] = q_id;
          }
          load_n = q_n;
@@ -363,7 +367,7 @@ struct Feeder {
          have_base = false;
          if (b < src.count) {
             q_n = src.count - b < kPool ? src.count - b : kPool;
-            if (lane < q_n) q_id = src.queue ? src.queue[b + lane] : b + lane;
+            if (lane < q_n) q_id = src.queue ? ld_stream(src.queue + b + lane, src.nt) : b + lane;
          } else {
             drained = true;
          }
@@ -462,7 +466,7 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
 template <bool COUNT, int kRefill, bool PHASED>
 __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const uint32_t* __restrict__ queue_base, const float4* __restrict__ ray_o,
                                                                const float4* __restrict__ ray_d, float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl,
-                                                               DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
+                                                               DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count, uint32_t stream_nt) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    __shared__ RayPool<2> s_pool[kWavesPerBlock];
    const uint32_t lane = lane_id();
@@ -476,8 +480,10 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
       src.count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
       src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
       src.wave_index = src.num_waves = 0;
+      src.nt = stream_nt != 0;
       if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)src.count);
-   } else {  // stand-alone query over raw_count rays (uh_trace_closest, the G-buffer cast): ray i = record i
+   } else {
+      src.nt = false;  // stand-alone query over raw_count rays (uh_trace_closest, the G-buffer cast): ray i = record i
       src.queue = nullptr;
       src.count = raw_count;
       src.cursor = nullptr;
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
       if (t.cur != kEmptyRef) {
          bool occluded = false;
          if (trav_step<false, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris))
-            hit_out[id] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx));
+            st_stream(hit_out + id, make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx)), src.nt);
       }
    }
    if (COUNT) {
@@ -517,7 +523,7 @@ template <bool COUNT, bool DIAG>
 __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_batch(SceneDev sc, const uint32_t* __restrict__ queue_base,
                                                                                                       const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                                                                       float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl, DeviceStats* stats,
-                                                                                                      uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
+                                                                                                      uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count, uint32_t /*stream_nt*/) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    const uint32_t lane = lane_id();
    uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
@@ -605,6 +611,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    src.count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    src.wave_index = src.num_waves = 0;
+   src.nt = ps.stream_nt != 0;
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)src.count);
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    while (refill_lanes<3, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<true, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) ps.rad[id] = lit;
+         if (trav_step<true, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) st_stream(ps.rad + id, lit, src.nt);
       }
    }
    if (COUNT) {
@@ -706,11 +713,11 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
          float jx = random_float(rng), jy = random_float(rng);                                  // rgen:31
          V3 o, d;
          primary_ray(fp, px, py, jx, jy, o, d);
-         ps.ray_o[id] = make_float4(o.x, o.y, o.z, 0.001f);
-         ps.ray_d[id] = make_float4(d.x, d.y, d.z, 10000.0f);
+         st_stream(ps.ray_o + id, make_float4(o.x, o.y, o.z, 0.001f), ps.stream_nt != 0);
+         st_stream(ps.ray_d + id, make_float4(d.x, d.y, d.z, 10000.0f), ps.stream_nt != 0);
          // throughput = 1 / radiance = 0 / pixelColor = 0 (rgen:26,39-40) are not materialised: the
          // bounce-0 shading kernels and the first finish_sample use the constants directly
-         ps.rng[id] = make_uint2(rng, seed);
+         st_stream(ps.rng + id, make_uint2(rng, seed), ps.stream_nt != 0);
       }
       // the 64 paths of a wave normally share one run (hence one shard); at tile edges that are not
       // 64-aligned they may not, so append shard by shard
@@ -735,19 +742,20 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
 // runs on 64 of them at a time with every lane live.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const PathState& ps, uint32_t id, uint32_t bounce) {
+   const bool nt = ps.stream_nt != 0;
    V3 sky_color = v3(0.0f, 0.0f, 0.0f);
    if (fp.sky_enabled == 1) {
-      float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
+      float4 ro = ld_stream(ps.ray_o + id, nt), rd = ld_stream(ps.ray_d + id, nt);
       V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
       sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
    }
    float4 thr = make_float4(1.0f, 1.0f, 1.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
    if (bounce != 0) {
-      thr = ps.thr[id];
-      rad = ps.rad[id];
+      thr = ld_stream(ps.thr + id, nt);
+      rad = ld_stream(ps.rad + id, nt);
    }
    V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
-   ps.rad[id] = make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w);   // rgen:55
+   st_stream(ps.rad + id, make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w), nt);   // rgen:55
 }
 
 __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
@@ -768,8 +776,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState
       bool miss = false;
       uint32_t id = 0;
       if (i < count) {
-         id = queue[i];
-         miss = __float_as_uint(ps.hit[id].w) == kEmptyRef;
+         id = ld_stream(queue + i, ps.stream_nt != 0);
+         miss = __float_as_uint(ld_stream(ps.hit + id, ps.stream_nt != 0).w) == kEmptyRef;
       }
       const unsigned long long mask = __ballot(miss);
       if (mask == 0ull) continue;
@@ -874,18 +882,19 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
    const uint32_t stride = sx.nb * kBlock;
    const uint32_t rounds = (count + stride - 1) / stride;
    uint32_t n_hits = 0;
+   const bool nt = ps.stream_nt != 0;
    for (uint32_t r = 0; r < rounds; r++) {
       uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
       bool scattered = false, want_light = false;
       uint32_t id = 0;
       float4 hr = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmptyRef));
       if (i < count) {
-         id = queue[i];
-         hr = ps.hit[id];
+         id = ld_stream(queue + i, nt);
+         hr = ld_stream(ps.hit + id, nt);
       }
       if (__float_as_uint(hr.w) != kEmptyRef) {
          n_hits++;
-         float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
+         float4 ro = ld_stream(ps.ray_o + id, nt), rd = ld_stream(ps.ray_d + id, nt);
          const V3 ray_dir = v3(rd.x, rd.y, rd.z);
          const float t = hr.x, bu = hr.y, bv = hr.z;
          const uint32_t pk = __float_as_uint(hr.w);
@@ -907,7 +916,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
          V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);       // rchit:40
          color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
 
-         uint2 rng = ps.rng[id];
+         uint2 rng = ld_stream(ps.rng + id, nt);
          uint32_t seed = rng.y;
          V3 scatter = v3(0, 0, 0);
          if (ms.type == 0.0f) {                                                        // rchit:47-50
@@ -946,20 +955,20 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
          rng.y = seed;                                                                 // rchit:91
 
          float4 thr4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-         if (bounce != 0) thr4 = ps.thr[id];
+         if (bounce != 0) thr4 = ld_stream(ps.thr + id, nt);
          V3 thr = v3(thr4.x, thr4.y, thr4.z) * color;                                  // rgen:48
          // the radiance record is only touched when this path ends here (rgen:53-57) or a light sample
          // has to be parked in its w component; a scattered path with lights off leaves it alone
          if (!scattered) {                                                             // rgen:53-57
             float4 rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (bounce != 0) rad4 = ps.rad[id];
-            ps.rad[id] = make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, rad4.w);
-            ps.rng[id] = rng;
+            if (bounce != 0) rad4 = ld_stream(ps.rad + id, nt);
+            st_stream(ps.rad + id, make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, rad4.w), nt);
+            st_stream(ps.rng + id, rng, nt);
          } else {
             V3 origin = v3(ro.x, ro.y, ro.z) + t * ray_dir;                            // rgen:59
             origin = offset_ray(origin, world_normal);                                 // rgen:60
-            ps.ray_o[id] = make_float4(origin.x, origin.y, origin.z, 0.001f);
-            ps.ray_d[id] = make_float4(scatter.x, scatter.y, scatter.z, 10000.0f);     // rgen:61
+            st_stream(ps.ray_o + id, make_float4(origin.x, origin.y, origin.z, 0.001f), nt);
+            st_stream(ps.ray_d + id, make_float4(scatter.x, scatter.y, scatter.z, 10000.0f), nt);     // rgen:61
             float f = 0.0f;
             int light_index = 0;
             if (fp.lights_enabled == 1) {                                              // rgen:81-110
@@ -981,21 +990,21 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
                   f = target_function(sc.lights, sc.num_lights, light_index, origin) * light_sample_weight;  // rgen:121
                }
             }
-            ps.thr[id] = make_float4(thr.x, thr.y, thr.z, f);
+            st_stream(ps.thr + id, make_float4(thr.x, thr.y, thr.z, f), nt);
             if (bounce == 0) {
                // first write of this path's radiance record (generate does not materialise the zero)
-               ps.rad[id] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)light_index));
+               st_stream(ps.rad + id, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)light_index)), nt);
             } else if (fp.lights_enabled == 1) {
-               float4 rad4 = ps.rad[id];
-               ps.rad[id] = make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index));
+               float4 rad4 = ld_stream(ps.rad + id, nt);
+               st_stream(ps.rad + id, make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index)), nt);
             }
-            ps.rng[id] = rng;
+            st_stream(ps.rng + id, rng, nt);
          }
       }
       uint32_t slot = wave_append(n_next, scattered);
-      if (scattered) q_next[slot] = id;
+      if (scattered) st_stream(q_next + slot, id, nt);
       slot = wave_append(n_light, want_light);
-      if (want_light) q_light[slot] = id;
+      if (want_light) st_stream(q_light + slot, id, nt);
    }
    // closest_hits: per-block sum, one atomic per block
    for (int o = 32; o > 0; o >>= 1) n_hits += __shfl_xor(n_hits, o);
@@ -1271,8 +1280,9 @@ void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState&
 // Variant 0 = batch kernel; 1 = refill kernel (threshold 8 idle lanes) with chained node + triangle steps;
 // 2 / 3 / 4 = refill kernel with one load phase per iteration, threshold 4 / 8 (default) / 16 idle lanes.
 static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, const uint32_t* queue, const float4* ray_o, const float4* ray_d, float4* hit,
-                           uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag) {
-#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, queue, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
+                           uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag,
+                           uint32_t stream_nt = 0) {
+#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, queue, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n, stream_nt)
    const bool count = c.count_visits && queue;
    if (diag) {
       UH_CLOSEST((k_trace_closest_batch<false, true>));
@@ -1299,7 +1309,7 @@ static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, co
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                           uint32_t cursor_slot, int ray_kind) {
-   launch_closest(c, closest_grid(c), sc, ps.queue[bounce & 1], ps.ray_o, ps.ray_d, ps.hit, ps.shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, 0, false);
+   launch_closest(c, closest_grid(c), sc, ps.queue[bounce & 1], ps.ray_o, ps.ray_d, ps.hit, ps.shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, 0, false, ps.stream_nt);
 }
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {

@@ -165,6 +165,36 @@ int main() {
       for (size_t i = 0; i < poisoned.size(); i += 997) poisoned[i] = (i & 1) ? NAN : ((i & 2) ? INFINITY : -INFINITY);
       errors += check(poisoned, 4, "NaN / inf vertices", false);
    }
+   {
+      // clusters on a geometric series (each a factor 0.5 closer to the origin than the one before): SAH peels them off one
+      // by one and the tree becomes a chain. The traversal stack holds kTraversalStackEntries entries = kMaxTreeLevels
+      // levels; the context rebuilds such a scene balanced (csrc/context.hip), which must fit for any triangle count.
+      std::vector<float> chain;
+      g_state = 99;
+      for (int k = 0; k < 120; k++) {
+         const float s = std::ldexp(1.0f, -k);
+         for (int i = 0; i < 3; i++) {
+            float c[3] = {s * (1.0f + 0.1f * rnd()), s * 0.1f * rnd(), s * 0.1f * rnd()};
+            for (int v = 0; v < 3; v++)
+               for (int a = 0; a < 3; a++) chain.push_back(c[a] + s * 0.01f * rnd());
+         }
+      }
+      errors += check(chain, 2, "geometric-series clusters (SAH)");
+      std::vector<uint32_t> keys(chain.size() / 9);
+      BuildInput in{chain.data(), keys.data(), (uint32_t)keys.size()};
+      BuildOutput sah, bal;
+      build_bvh4(in, sah, 1);
+      build_bvh4(in, bal, 1, true);
+      std::printf("geometric-series clusters: SAH tree %zu levels, balanced tree %zu levels (the stack holds %u)\n", sah.level_start.size() - 1, bal.level_start.size() - 1, kMaxTreeLevels);
+      if (bal.level_start.size() - 1 > kMaxTreeLevels) {
+         std::printf("FAIL: balanced tree deeper than the traversal stack\n");
+         errors++;
+      }
+      if (sah.level_start.size() - 1 <= 12) {
+         std::printf("FAIL: the chain scene no longer produces a deep SAH tree (test lost its point)\n");
+         errors++;
+      }
+   }
    std::printf(errors ? "BVH CHECK FAILED (%d)\n" : "BVH CHECK OK\n", errors);
    return errors ? 1 : 0;
 }

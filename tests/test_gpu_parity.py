@@ -545,6 +545,12 @@ def test_device_build_equals_host_build(cornell, atrium, which):
         for a, b in zip(host.trace_closest(rays), dev.trace_closest(rays)):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         assert np.array_equal(host.trace_any(rays), dev.trace_any(rays))
+    else:
+        # zero triangles (zero-size packet arrays, a root with no child): every query misses, on both builders
+        for r in (host, dev):
+            tuv, mesh, prim = r.trace_closest(rays[:500])
+            assert (tuv[:, 0] == -1.0).all() and (mesh == 0xFFFFFFFF).all() and (prim == 0xFFFFFFFF).all()
+            assert not r.trace_any(rays[:500]).any()
     for r in (host, dev):
         run_frames(r, scene, W, H, 2, rr.PASS_ALL if scene.lights else rr.PASS_REFERENCE_PT)
     assert np.array_equal(host.read_accumulation().view(np.uint32), dev.read_accumulation().view(np.uint32))
@@ -562,6 +568,49 @@ def test_device_build_equals_host_build(cornell, atrium, which):
         dev.rebuild_tlas()
         for a, b in zip(host.trace_closest(rays), dev.trace_closest(rays)):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _chain_scene(clusters=300):
+    """clusters on a geometric series towards the origin: a SAH (and a Morton) tree over them is a chain far deeper than the
+    traversal stack (16 LDS + 96 scratch entries = 37 levels); the builders must notice and fall back to a balanced tree"""
+    from rust_renderer_amd.camera import Camera
+    from rust_renderer_amd.scenes import Mesh, Model, Scene, _pack_vertices
+    u = rr.scenes.hash_floats(0xC4A1, clusters * 3 * 12).reshape(clusters, 3, 12)
+    pos = []
+    for k in range(clusters):
+        s = np.float32(0.78) ** k * 4.0
+        for i in range(3):
+            c = np.float32([s * (1.0 + 0.1 * u[k, i, 0]), s * 0.3 * (u[k, i, 1] - 0.5), s * 0.3 * (u[k, i, 2] - 0.5)])
+            pos += [c + s * 0.2 * (u[k, i, 3 + 3 * v: 6 + 3 * v] - 0.5) for v in range(3)]
+    pos = np.asarray(pos, dtype=np.float32)
+    m = Mesh(_pack_vertices(pos, np.tile(np.float32([0, 0, 1]), (len(pos), 1)), np.zeros((len(pos), 2), np.float32)), np.arange(len(pos), dtype=np.uint32))
+    return Scene("chain", [(Model([m], []), None)], [], Camera((0, 0, 6), (0, 0, 0), 60.0, 1.0, 0.01, 100.0))
+
+
+@pytest.mark.parametrize("device_build", [0, 1])
+def test_deep_clustered_geometry_keeps_every_hit(device_build):
+    """a tree deeper than the traversal stack used to drop subtrees silently (trav_push past capacity). Now
+    the host builder rebuilds balanced when the SAH tree has more than kMaxTreeLevels levels, and a device build of
+    such a scene falls back to the host builder: closest hits and any-hits equal the oracle's brute force."""
+    scene = _chain_scene()
+    gpu = rr.Renderer(32, 32)
+    gpu.set_option("device_build", device_build)
+    scene.upload(gpu)
+    cpu = scene.upload(oa.OracleRenderer(32, 32, brute_force=True))
+    n = 20000
+    u = rr.scenes.hash_floats(77, 6 * n).reshape(n, 6)
+    rays = np.empty((n, 8), dtype=np.float32)
+    rays[:, 0:3] = (u[:, :3] - 0.5) * np.float32([12, 4, 4])
+    rays[:, 3] = 0.001
+    # aim at points on the chain's axis, most of them close to the origin where the deep clusters are
+    target = np.zeros((n, 3), dtype=np.float32)
+    target[:, 0] = 4.4 * u[:, 3] ** 6
+    rays[:, 4:7] = target - rays[:, 0:3] + (u[:, 3:6] - 0.5) * 0.05
+    rays[:, 7] = 10000.0
+    for a, b in zip(gpu.trace_closest(rays), cpu.trace_closest(rays)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert (gpu.trace_closest(rays)[0][:, 0] > 0).mean() > 0.05
+    assert np.array_equal(gpu.trace_any(rays), cpu.trace_any(rays))
 
 
 def test_non_finite_geometry_is_rejected_at_the_boundary(cornell):

@@ -1,0 +1,9 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+run() { printf "%-50s" "$*"; timeout -k 10 200 python bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-alone "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%.1f Mrays/s %.3f ms | closest %.3f ms/launch shadow_ms %.1f shade_ms %.1f' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['trace_shadow_ms'], r['shade_ms']))"; }
+run
+run --opt stream_nt=1
+run
+run --opt stream_nt=1
+run --config 2 --steps 16
+run --config 2 --steps 16 --opt stream_nt=1
