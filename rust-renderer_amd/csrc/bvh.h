@@ -24,14 +24,14 @@ constexpr uint32_t kMaxTriangles = 0x7ffffffeu;
 constexpr uint32_t kPrimBits = 22;            // key = mesh << 22 | prim  (mesh < 1024, prim < 4 Mi)
 constexpr uint32_t kPrimMask = (1u << kPrimBits) - 1;
 
-// full-precision node (host builder output; tests and the quantiser read it): padded child boxes + explicit child refs
-struct alignas(16) Node4 {
-   float lox[4], loy[4], loz[4];
-   float hix[4], hiy[4], hiz[4];
-   uint32_t child[4];  // kLeafBit | packet, node index, or kEmptyRef. Slot order: triangles, then nodes, then empty.
-   uint32_t meta[4];   // meta[0] = number of used child slots
+constexpr int kMaxWidth = 8;
+// full-precision node (host builder output; tests and the quantiser read it): padded child boxes + explicit child refs.
+// Up to `width` (4 or 8) children are used. Slot order: triangles, then nodes, then empty.
+struct NodeW {
+   float lo[3][kMaxWidth], hi[3][kMaxWidth];
+   uint32_t child[kMaxWidth];  // kLeafBit | packet, node index, or kEmptyRef
+   uint32_t count;             // number of used child slots
 };
-static_assert(sizeof(Node4) == 128, "full-precision node");
 
 // Device node. The children's boxes are quantised to 8 bits per plane relative to the node's own box
 // (plane = origin + 2^(e-127) * q), rounded outwards, so the slab test stays conservative and hits do not change.
@@ -75,8 +75,9 @@ struct BuildInput {
 };
 
 struct BuildOutput {
-   std::vector<Node4> nodes;         // BFS order, node 0 = root (full-precision, padded child boxes)
-   std::vector<Node4C> cnodes;       // the same tree, quantised (what the kernels traverse)
+   uint32_t width = 4;               // children per node
+   std::vector<NodeW> nodes;         // BFS order, node 0 = root (full-precision, padded child boxes)
+   std::vector<Node4C> cnodes;       // width 4: the same tree, quantised (what the kernels traverse)
    std::vector<uint32_t> tri_order;  // packet i holds input triangle tri_order[i]; the triangle children of a node are consecutive packets
    uint32_t max_depth = 0;           // depth of the 4-wide tree (root = 0)
    std::vector<uint32_t> level_start;  // BFS level l = nodes [level_start[l], level_start[l+1]); children always lie in a later level
@@ -85,13 +86,13 @@ struct BuildOutput {
 // Binned-SAH BVH2 down to single triangles, collapsed to BVH4, emitted breadth-first. Host-side, multi-threaded.
 // balanced: median splits only (depth ceil(log2 n)) - the fallback for geometry whose SAH tree is deeper than the
 // traversal stack holds (kMaxTreeLevels).
-void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool balanced = false);
+void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool balanced = false, uint32_t width = 4);
 
 // A traversal pushes at most 3 entries per level; the kernels' stack holds 16 (LDS) + 96 (scratch) entries per ray.
 constexpr uint32_t kTraversalStackEntries = 16 + 96;
 constexpr uint32_t kMaxTreeLevels = kTraversalStackEntries / 3;
 
 // the quantiser shared by the host builder and (restated, same arithmetic) the refit kernel: child boxes of one node -> Node4C planes
-void quantise_node(const Node4& nd, Node4C& q);
+void quantise_node(const NodeW& nd, Node4C& q);
 
 }  // namespace uh

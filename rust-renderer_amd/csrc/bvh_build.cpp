@@ -165,11 +165,11 @@ inline void padded(const Box& b, float* lo, float* hi) {
 
 }  // namespace
 
-void quantise_node(const Node4& nd, Node4C& q) {
+void quantise_node(const NodeW& nd, Node4C& q) {
    // origin = min over the children, step = 2^e with e minimal such that the node's extent fits 255 steps;
    // lower planes round down, upper planes round up (in double). refit.hip restates this arithmetic.
-   const float* lo[3] = {nd.lox, nd.loy, nd.loz};
-   const float* hi[3] = {nd.hix, nd.hiy, nd.hiz};
+   const float* lo[3] = {nd.lo[0], nd.lo[1], nd.lo[2]};
+   const float* hi[3] = {nd.hi[0], nd.hi[1], nd.hi[2]};
    uint32_t exps = 0;
    for (int a = 0; a < 3; a++) {
       double mn = INFINITY, mx = -INFINITY;
@@ -225,7 +225,10 @@ void quantise_node(const Node4& nd, Node4C& q) {
    }
 }
 
-void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool balanced) {
+void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool balanced, uint32_t width) {
+   if (width < 2) width = 2;
+   if (width > (uint32_t)kMaxWidth) width = kMaxWidth;
+   out.width = width;
    out.nodes.clear();
    out.cnodes.clear();
    out.tri_order.clear();
@@ -259,13 +262,15 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    // are then built concurrently on disjoint ranges of the index array.
    std::vector<Node2> n2;
    if (n == 0) {
-      Node4 root;
+      NodeW root;
       std::memset(&root, 0, sizeof(root));
-      for (int k = 0; k < 4; k++) root.child[k] = kEmptyRef;
+      for (int k = 0; k < kMaxWidth; k++) root.child[k] = kEmptyRef;
       out.nodes.push_back(root);
-      Node4C q;  // empty scene: a root whose four slots are empty (every ray misses)
-      quantise_node(root, q);
-      out.cnodes.push_back(q);
+      if (width == 4) {
+         Node4C q;  // empty scene: a root whose four slots are empty (every ray misses)
+         quantise_node(root, q);
+         out.cnodes.push_back(q);
+      }
       return;
    }
    {
@@ -423,10 +428,11 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    packet_order.reserve(n);
    queue.push_back(0);
    out.nodes.reserve(n2.size() / 2 + 1);
-   out.nodes.push_back(Node4());
+   out.nodes.push_back(NodeW());
+   const int W = (int)width;
    for (size_t qi = 0; qi < queue.size(); qi++) {
       const Node2& src = n2[queue[qi]];
-      int32_t ch[4];
+      int32_t ch[kMaxWidth];
       int nc = 0;
       if (src.left < 0) {
          ch[nc++] = queue[qi];  // a single triangle at the root: wrap it
@@ -434,7 +440,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
          ch[nc++] = src.left;
          ch[nc++] = src.right;
          for (;;) {
-            if (nc == 4) break;
+            if (nc == W) break;
             int pick = -1;
             float pa = -1.0f;
             for (int k = 0; k < nc; k++)
@@ -452,29 +458,27 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
          }
       }
       std::stable_partition(ch, ch + nc, [&](int32_t c) { return n2[c].left < 0; });  // triangles first
-      Node4 nd;
+      NodeW nd;
       std::memset(&nd, 0, sizeof(nd));
-      for (int k = 0; k < 4; k++) nd.child[k] = kEmptyRef;
+      for (int k = 0; k < kMaxWidth; k++) nd.child[k] = kEmptyRef;
       for (int k = 0; k < nc; k++) {
          const Node2& c = n2[ch[k]];
          float lo[3], hi[3];
          padded(c.box, lo, hi);
-         nd.lox[k] = lo[0];
-         nd.loy[k] = lo[1];
-         nd.loz[k] = lo[2];
-         nd.hix[k] = hi[0];
-         nd.hiy[k] = hi[1];
-         nd.hiz[k] = hi[2];
+         for (int a = 0; a < 3; a++) {
+            nd.lo[a][k] = lo[a];
+            nd.hi[a][k] = hi[a];
+         }
          if (c.left < 0) {
             nd.child[k] = kLeafBit | (uint32_t)packet_order.size();
             packet_order.push_back(out.tri_order[c.first]);
          } else {
             nd.child[k] = (uint32_t)out.nodes.size();
-            out.nodes.push_back(Node4());
+            out.nodes.push_back(NodeW());
             queue.push_back(ch[k]);
          }
       }
-      nd.meta[0] = (uint32_t)nc;
+      nd.count = (uint32_t)nc;
       out.nodes[qi] = nd;
    }
    out.tri_order.swap(packet_order);
@@ -483,7 +487,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    {
       std::vector<uint32_t> depth(out.nodes.size(), 0);
       for (size_t i = 0; i < out.nodes.size(); i++)
-         for (int k = 0; k < 4; k++) {
+         for (int k = 0; k < kMaxWidth; k++) {
             uint32_t ch = out.nodes[i].child[k];
             if (ch != kEmptyRef && !(ch & kLeafBit)) depth[ch] = depth[i] + 1;
          }
@@ -495,8 +499,10 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    }
 
    // ---- quantise
-   out.cnodes.resize(out.nodes.size());
-   for (size_t i = 0; i < out.nodes.size(); i++) quantise_node(out.nodes[i], out.cnodes[i]);
+   if (width == 4) {
+      out.cnodes.resize(out.nodes.size());
+      for (size_t i = 0; i < out.nodes.size(); i++) quantise_node(out.nodes[i], out.cnodes[i]);
+   }
 }
 
 }  // namespace uh

@@ -200,6 +200,8 @@ struct uh_ctx {
    // on-device build (lbvh.hip, option "device_build"): per-triangle sources in mesh order, kept on the device
    // until a mesh is added, so that a rebuild after moved instances or changed parameters uploads nothing
    bool device_build = false, src_valid = false;
+   uint32_t device_build_kind = 1;  // 1 = PLOC, 2 = radix tree (lbvh.hip)
+   uint32_t ploc_radius = 8;  // swept 4..64: tree quality flat (21.7-23.0 nodes/ray), build time grows with it (profiles/README.md)
    DevBuf<float> d_src_corners;
    DevBuf<uint32_t> d_src_keys;
    DevBuf<float4> d_src_shade;
@@ -821,6 +823,8 @@ static int build_on_device(uh_ctx* c) {
       la.bounds_hi[a] = hi[a];
    }
    la.num_tris = (uint32_t)total;
+   la.kind = c->device_build_kind;
+   la.ploc_radius = c->ploc_radius;
    la.nodes = reinterpret_cast<uint4*>(c->d_nodes.p);
    la.node_capacity = (uint32_t)node_cap;
    la.tris = c->d_tris.p;
@@ -1317,8 +1321,11 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
    else if (n == "raw_visit_counts")
       c->raw_visit_counts = value != 0;
    else if (n == "device_build") {
-      if (c->device_build != (value != 0)) c->built = c->topology_valid = false;
+      // 0 = host SAH builder; 1 = device build, PLOC; 2 = device build, radix tree
+      if (value < 0 || value > 2) return fail(c, UH_ERR_INVALID_ARGUMENT, "device_build must be 0, 1 (PLOC) or 2 (radix tree)");
+      if (c->device_build != (value != 0) || (value && c->device_build_kind != (uint32_t)value)) c->built = c->topology_valid = false;
       c->device_build = value != 0;
+      if (value) c->device_build_kind = (uint32_t)value;
    }
    else if (n == "time_kernels") {
       if (c->time_kernels && !value) {
@@ -1328,7 +1335,11 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->time_kernels = value != 0;
    } else if (n == "full_frame_restir")
       c->full_frame_restir = value != 0;
-   else if (n == "stream_nt")
+   else if (n == "ploc_radius") {
+      if (value < 1 || value > 64) return fail(c, UH_ERR_INVALID_ARGUMENT, "ploc_radius must be 1..64");
+      if (c->ploc_radius != (uint32_t)value && c->device_build) c->built = c->topology_valid = false;
+      c->ploc_radius = (uint32_t)value;
+   } else if (n == "stream_nt")
       c->stream_nt = value != 0;
    else if (n == "overlap_miss")
       c->overlap_miss = value != 0;

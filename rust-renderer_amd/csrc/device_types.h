@@ -197,6 +197,8 @@ struct LbvhArgs {
    const RefitMesh* meshes;
    float bounds_lo[3], bounds_hi[3];  // world-space box containing every centroid (Morton normalisation)
    uint32_t num_tris;
+   uint32_t kind;                // binary tree under the 4-wide collapse: 1 = PLOC (default), 2 = radix tree (Karras)
+   uint32_t ploc_radius;         // PLOC: places searched to either side for the nearest neighbour (1..64)
    uint4* nodes;                 // out: Node4C array (child counts and bases valid, boxes to be refitted)
    uint32_t node_capacity;       // nodes the array can hold
    float4* tris;                 // out: TriPacket array in leaf order (keys; refit writes the geometry)

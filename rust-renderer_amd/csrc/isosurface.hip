@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 
+#include "device_scan.h"
 #include "mc_tables.h"
 #include "utopian_hip.h"
 
@@ -168,44 +169,6 @@ __global__ __launch_bounds__(kBlock) void k_iso_count(IsoParams q, uint32_t* __r
    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 
-// ---- exclusive scan of the per-block counts on the device: chunks of 2048 (8 per thread), chunk totals by one block, add back
-constexpr uint32_t kScanPer = 8, kScanChunk = kBlock * kScanPer;
-__global__ __launch_bounds__(kBlock) void k_scan_chunks(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ chunk_totals) {
-   __shared__ uint32_t scan[kBlock];
-   const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanPer;
-   uint32_t v[kScanPer], sum = 0;
-   for (uint32_t k = 0; k < kScanPer; k++) {
-      v[k] = base + k < n ? data[base + k] : 0u;
-      sum += v[k];
-   }
-   uint32_t prefix = block_exclusive_scan(sum, scan);
-   for (uint32_t k = 0; k < kScanPer; k++) {
-      if (base + k < n) data[base + k] = prefix;
-      prefix += v[k];
-   }
-   if (threadIdx.x == kBlock - 1) chunk_totals[blockIdx.x] = prefix;
-}
-__global__ __launch_bounds__(kBlock) void k_scan_totals(uint32_t* __restrict__ chunk_totals, uint32_t n_chunks, unsigned long long* __restrict__ grand_total) {
-   // one block; n_chunks <= kScanChunk (a 1024^3 grid has 2048 chunks)
-   __shared__ uint32_t scan[kBlock];
-   const uint32_t base = threadIdx.x * kScanPer;
-   uint32_t v[kScanPer], sum = 0;
-   for (uint32_t k = 0; k < kScanPer; k++) {
-      v[k] = base + k < n_chunks ? chunk_totals[base + k] : 0u;
-      sum += v[k];
-   }
-   uint32_t prefix = block_exclusive_scan(sum, scan);
-   for (uint32_t k = 0; k < kScanPer; k++) {
-      if (base + k < n_chunks) chunk_totals[base + k] = prefix;
-      prefix += v[k];
-   }
-   if (threadIdx.x == kBlock - 1) *grand_total = prefix;
-}
-__global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ chunk_offsets) {
-   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-   if (i < n) data[i] += chunk_offsets[i / kScanChunk];
-}
-
 __global__ __launch_bounds__(kBlock) void k_iso_emit(IsoParams q, const uint32_t* __restrict__ block_offsets, UhVertex* __restrict__ verts) {
    __shared__ uint32_t scan[kBlock];
    const uint64_t cell = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -250,16 +213,13 @@ extern "C" int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo
          return UH_ERR_HIP;
       tables_loaded[dev] = true;
    }
-   const uint32_t n_chunks = (blocks + kScanChunk - 1) / kScanChunk;
-   if (n_chunks > kScanChunk) return UH_ERR_CAPACITY;
+   const uint32_t n_chunks = scan_chunk_count(blocks);
    if (hipMalloc(&d_counts, (size_t)blocks * sizeof(uint32_t)) != hipSuccess || hipMalloc(&d_chunks, (size_t)n_chunks * sizeof(uint32_t)) != hipSuccess ||
        hipMalloc(&d_total, sizeof(unsigned long long)) != hipSuccess)
       return fail(UH_ERR_OUT_OF_MEMORY);
    k_iso_count<<<blocks, kBlock, 0, stream>>>(q, d_counts);
    // exclusive scan of the per-block counts, on the device
-   k_scan_chunks<<<n_chunks, kBlock, 0, stream>>>(d_counts, blocks, d_chunks);
-   k_scan_totals<<<1, kBlock, 0, stream>>>(d_chunks, n_chunks, d_total);
-   k_scan_add<<<blocks / kBlock + 1, kBlock, 0, stream>>>(d_counts, blocks, d_chunks);
+   device_exclusive_scan_u32(d_counts, blocks, d_chunks, d_total, stream);
    unsigned long long total = 0;
    if (hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, stream) != hipSuccess) return fail(UH_ERR_HIP);
    if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail(UH_ERR_HIP);

@@ -7,20 +7,25 @@
 //   1. bake: object-space corners -> world centroid -> 30-bit Morton code in the scene bounds; the sort key is
 //      (morton << 32 | triangle) so keys are unique and the payload rides in the low word
 //   2. radix sort of the 64-bit keys (hipcub / rocPRIM)
-//   3. binary radix tree over the sorted keys (Karras 2012: every internal node finds its range and split
-//      from the common-prefix lengths, all nodes in parallel)
+//   3. binary tree over the sorted triangles, one of (LbvhArgs::kind):
+//      PLOC (default; Meister & Bittner 2018, "Parallel Locally-Ordered Clustering"): clusters (initially the triangles, in
+//      Morton order) look R places (option "ploc_radius") left and right for the neighbour whose union box has the smallest area; mutual
+//      nearest neighbours merge into a node; the survivors are compacted in order (device scan) and the round repeats
+//      until one cluster is left - about 20 rounds. Agglomerative by surface area: close to SAH quality.
+//      Radix tree (Karras 2012: every internal node finds its range and split from the common-prefix lengths, all nodes
+//      in parallel): one launch, a Morton-order tree, about a quarter more traversal work per ray.
 //   4. collapse to 4-wide nodes, breadth-first, one launch per level: every leaf is one triangle; a node takes the
 //      node slots of its node children from the next level's counter and the packet slots of its triangle children
 //      from a packet counter, one atomic each, so both groups are contiguous (bvh.h: implicit child addresses)
 //   5. boxes + quantisation: the refit kernels (refit.hip) - a device build is "topology here, boxes by refit"
-// The tree is a Morton-order tree, not a SAH one: it builds in a few milliseconds instead of tens to hundreds and
-// costs about a quarter more traversal work per ray (DESIGN.md "On-device build"). Hits do not depend on the tree (bvh.h), so a
-// device-built scene renders bit for bit what a host-built one does (tests/test_gpu_parity.py).
+// Both build in milliseconds instead of the host builder's tens to hundreds (DESIGN.md "On-device build"). Hits do not
+// depend on the tree (bvh.h), so a device-built scene renders bit for bit what a host-built one does (tests/test_gpu_parity.py).
 #include <hip/hip_runtime.h>
 
 #include <hipcub/hipcub.hpp>
 
 #include "bvh.h"
+#include "device_scan.h"
 #include "device_types.h"
 
 namespace uh {
@@ -97,6 +102,111 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_tree(const unsigned long long* 
    node2[i] = make_uint4(left, right, (uint32_t)first, (uint32_t)(last - first + 1));
 }
 
+// ---- PLOC ------------------------------------------------------------------------------------------------------------
+constexpr int kPlocMaxRadius = 64;
+
+struct Box6 {
+   float lo[3], hi[3];
+};
+__device__ __forceinline__ float half_area_union(const Box6& a, const Box6& b) {
+   const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]), dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]), dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+   return dx * dy + dy * dz + dz * dx;
+}
+
+// world-space box of the triangle at sorted position i (same bake as k_lbvh_keys / refit.hip); cluster i = leaf i
+__global__ __launch_bounds__(kBlock) void k_ploc_leaves(const unsigned long long* __restrict__ keys, const float* __restrict__ src_corners, const uint32_t* __restrict__ src_keys,
+                                                        const RefitMesh* __restrict__ meshes, Box6* __restrict__ box, uint32_t* __restrict__ cid, uint32_t n) {
+   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+   if (i >= n) return;
+   const uint32_t s = (uint32_t)(keys[i] & 0xffffffffull);
+   const RefitMesh m = meshes[src_keys[s] >> kPrimBits];
+   const float* oc = src_corners + 9 * (size_t)s;
+   Box6 b;
+   for (int a = 0; a < 3; a++) {
+      b.lo[a] = INFINITY;
+      b.hi[a] = -INFINITY;
+   }
+   for (int k = 0; k < 3; k++) {
+      const float x = oc[3 * k], y = oc[3 * k + 1], z = oc[3 * k + 2];
+      float w[3] = {x, y, z};
+      if (!m.identity) {
+         w[0] = ((m.o2w[0] * x + m.o2w[1] * y) + m.o2w[2] * z) + m.o2w[3];
+         w[1] = ((m.o2w[4] * x + m.o2w[5] * y) + m.o2w[6] * z) + m.o2w[7];
+         w[2] = ((m.o2w[8] * x + m.o2w[9] * y) + m.o2w[10] * z) + m.o2w[11];
+      }
+      for (int a = 0; a < 3; a++) {
+         // a non-finite corner (never hit) must not poison the area comparisons: it contributes nothing to the box
+         if (!(fabsf(w[a]) < 1e30f)) w[a] = 0.0f;
+         b.lo[a] = fminf(b.lo[a], w[a]);
+         b.hi[a] = fmaxf(b.hi[a], w[a]);
+      }
+   }
+   box[i] = b;
+   cid[i] = kLeafBit | i;
+}
+
+// nearest neighbour of every cluster within kPlocRadius places (ties: the smaller index)
+__global__ __launch_bounds__(kBlock) void k_ploc_nearest(const Box6* __restrict__ box, uint32_t* __restrict__ nn, uint32_t m, int kPlocRadius) {
+   __shared__ Box6 tile[kBlock + 2 * kPlocMaxRadius];
+   const int base = (int)(blockIdx.x * kBlock) - kPlocRadius;
+   for (int k = threadIdx.x; k < (int)kBlock + 2 * kPlocRadius; k += kBlock) {
+      const int g = base + k;
+      if (g >= 0 && g < (int)m) tile[k] = box[g];
+   }
+   __syncthreads();
+   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+   if (i >= m) return;
+   const Box6 me = tile[threadIdx.x + kPlocRadius];
+   float best = INFINITY;
+   uint32_t bj = i;  // a lone cluster (m == 1) points at itself
+   for (int d = -kPlocRadius; d <= kPlocRadius; d++) {
+      const int j = (int)i + d;
+      if (d == 0 || j < 0 || j >= (int)m) continue;
+      const float a = half_area_union(me, tile[threadIdx.x + kPlocRadius + d]);
+      if (a < best) {
+         best = a;
+         bj = (uint32_t)j;
+      }
+   }
+   nn[i] = bj;
+}
+
+// mutual nearest neighbours merge: the lower index keeps the place (new node), the higher one leaves
+__global__ __launch_bounds__(kBlock) void k_ploc_merge(const uint32_t* __restrict__ nn, Box6* __restrict__ box, uint32_t* __restrict__ cid, uint32_t* __restrict__ keep,
+                                                       uint4* __restrict__ node2, uint32_t* __restrict__ node_count, uint32_t m) {
+   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+   if (i >= m) return;
+   const uint32_t j = nn[i];
+   uint32_t k = 1;
+   if (j != i && nn[j] == i) {
+      if (i < j) {
+         const Box6 a = box[i], b = box[j];
+         Box6 u;
+         for (int x = 0; x < 3; x++) {
+            u.lo[x] = fminf(a.lo[x], b.lo[x]);
+            u.hi[x] = fmaxf(a.hi[x], b.hi[x]);
+         }
+         const uint32_t id = atomicAdd(node_count, 1u);
+         const uint32_t l = cid[i], r = cid[j];
+         const uint32_t cnt = ((l & kLeafBit) ? 1u : node2[l].w) + ((r & kLeafBit) ? 1u : node2[r].w);
+         node2[id] = make_uint4(l, r, __float_as_uint(half_area_union(a, b)), cnt);
+         box[i] = u;  // read by nobody else in this launch: j's thread only tests nn[] and leaves
+         cid[i] = id;
+      } else {
+         k = 0;
+      }
+   }
+   keep[i] = k;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ploc_compact(const uint32_t* __restrict__ keep, const uint32_t* __restrict__ offset, const Box6* __restrict__ box_in,
+                                                         const uint32_t* __restrict__ cid_in, Box6* __restrict__ box_out, uint32_t* __restrict__ cid_out, uint32_t m) {
+   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+   if (i >= m || !keep[i]) return;
+   box_out[offset[i]] = box_in[i];
+   cid_out[offset[i]] = cid_in[i];
+}
+
 // an unfitted node: boxes and step exponents come from the refit kernels; counts and bases are final
 __device__ __forceinline__ void write_topology(uint4* nd, uint32_t n_tri, uint32_t n_child, uint32_t child_base, uint32_t tri_base) {
    const uint32_t meta = (127u | (127u << 8) | (127u << 16)) | (n_tri << kMetaTriShift) | (n_child << kMetaChildShift);
@@ -109,18 +219,20 @@ __device__ __forceinline__ void write_topology(uint4* nd, uint32_t n_tri, uint32
 // binary subtree rooted at internal node src[idx]
 __global__ __launch_bounds__(kBlock) void k_lbvh_collapse(const uint4* __restrict__ node2, const uint32_t* __restrict__ src, uint32_t level_first, uint32_t level_count,
                                                           uint32_t next_first, uint32_t* __restrict__ next_src, uint32_t* __restrict__ next_count, uint32_t* __restrict__ tri_count,
-                                                          uint32_t* __restrict__ order, uint4* __restrict__ nodes) {
+                                                          uint32_t* __restrict__ order, uint4* __restrict__ nodes, bool by_area) {
    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
    if (idx >= level_count) return;
-   auto count_of = [&](uint32_t ref) { return (ref & kLeafBit) ? 1u : node2[ref].w; };
+   // open the node child with the largest box (PLOC: node2.z = half area as float bits) or the most triangles (radix tree: .z = 0)
+   auto weight_of = [&](uint32_t ref) { return (ref & kLeafBit) ? 0.0f : (by_area ? __uint_as_float(node2[ref].z) : (float)node2[ref].w); };
    const uint4 root = node2[src[idx]];
    uint32_t ch[4] = {root.x, root.y, kEmptyRef, kEmptyRef};
    int nc = 2;
    while (nc < 4) {
       int pick = -1;
-      uint32_t best = 1;
+      float best = -1.0f;
       for (int k = 0; k < nc; k++) {
-         const uint32_t c = count_of(ch[k]);
+         if (ch[k] & kLeafBit) continue;
+         const float c = weight_of(ch[k]);
          if (c > best) {
             best = c;
             pick = k;
@@ -176,11 +288,15 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
    unsigned long long *keys_in = nullptr, *keys_out = nullptr;
    uint4* node2 = nullptr;
    uint32_t *list_a = nullptr, *list_b = nullptr, *counter = nullptr, *order = nullptr;
+   Box6 *box_a = nullptr, *box_b = nullptr;
+   uint32_t *cid_a = nullptr, *cid_b = nullptr, *nn = nullptr, *keep = nullptr, *offsets = nullptr, *scan_chunks = nullptr;
+   unsigned long long* scan_total = nullptr;
    void* temp = nullptr;
    size_t temp_bytes = 0;
    hipError_t e = hipSuccess;
    auto cleanup = [&]() {
-      for (void* p : {(void*)keys_in, (void*)keys_out, (void*)node2, (void*)list_a, (void*)list_b, (void*)counter, (void*)order, temp})
+      for (void* p : {(void*)keys_in, (void*)keys_out, (void*)node2, (void*)list_a, (void*)list_b, (void*)counter, (void*)order, temp, (void*)box_a, (void*)box_b, (void*)cid_a,
+                      (void*)cid_b, (void*)nn, (void*)keep, (void*)offsets, (void*)scan_chunks, (void*)scan_total})
          if (p) (void)hipFree(p);
    };
 #define LB_TRY(expr)            \
@@ -215,12 +331,56 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
    LB_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_in, keys_out, (int)n, 0, 62, stream));
    LB_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
    LB_TRY(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys_in, keys_out, (int)n, 0, 62, stream));
-   k_lbvh_tree<<<grid, kBlock, 0, stream>>>(keys_out, node2, n);
+   uint32_t binary_root = 0;
+   const bool by_area = a.kind != 2;
+   if (by_area) {
+      // PLOC rounds: nearest neighbour, merge, compact (cluster arrays ping-pong), until one cluster is left
+      LB_TRY(hipMalloc(&box_a, (size_t)n * sizeof(Box6)));
+      LB_TRY(hipMalloc(&box_b, (size_t)n * sizeof(Box6)));
+      LB_TRY(hipMalloc(&cid_a, (size_t)n * sizeof(uint32_t)));
+      LB_TRY(hipMalloc(&cid_b, (size_t)n * sizeof(uint32_t)));
+      LB_TRY(hipMalloc(&nn, (size_t)n * sizeof(uint32_t)));
+      LB_TRY(hipMalloc(&keep, (size_t)n * sizeof(uint32_t)));
+      LB_TRY(hipMalloc(&offsets, (size_t)n * sizeof(uint32_t)));
+      LB_TRY(hipMalloc(&scan_chunks, (size_t)scan_chunk_count(n) * sizeof(uint32_t)));
+      LB_TRY(hipMalloc(&scan_total, sizeof(unsigned long long)));
+      LB_TRY(hipMemsetAsync(counter, 0, 2 * sizeof(uint32_t), stream));
+      k_ploc_leaves<<<grid, kBlock, 0, stream>>>(keys_out, a.src_corners, a.src_keys, a.meshes, box_a, cid_a, n);
+      uint32_t m = n;
+      const int radius = a.ploc_radius < 1 ? 1 : (a.ploc_radius > (uint32_t)kPlocMaxRadius ? kPlocMaxRadius : (int)a.ploc_radius);
+      Box6 *bi = box_a, *bo = box_b;
+      uint32_t *ci = cid_a, *co = cid_b;
+      for (int round = 0; m > 1; round++) {
+         if (round > 4096) {
+            cleanup();
+            return hipErrorUnknown;  // every round merges at least one pair (the globally closest pair is mutual): unreachable
+         }
+         const dim3 g((m + kBlock - 1) / kBlock);
+         k_ploc_nearest<<<g, kBlock, 0, stream>>>(bi, nn, m, radius);
+         k_ploc_merge<<<g, kBlock, 0, stream>>>(nn, bi, ci, keep, node2, counter, m);
+         LB_TRY(hipMemcpyAsync(offsets, keep, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+         device_exclusive_scan_u32(offsets, m, scan_chunks, scan_total, stream);
+         k_ploc_compact<<<g, kBlock, 0, stream>>>(keep, offsets, bi, ci, bo, co, m);
+         unsigned long long kept = 0;
+         LB_TRY(hipMemcpyAsync(&kept, scan_total, sizeof(kept), hipMemcpyDeviceToHost, stream));
+         LB_TRY(hipStreamSynchronize(stream));
+         if (kept == 0 || kept >= m) {
+            cleanup();
+            return hipErrorUnknown;
+         }
+         m = (uint32_t)kept;
+         std::swap(bi, bo);
+         std::swap(ci, co);
+      }
+      LB_TRY(hipMemcpyAsync(&binary_root, ci, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      LB_TRY(hipStreamSynchronize(stream));
+   } else {
+      k_lbvh_tree<<<grid, kBlock, 0, stream>>>(keys_out, node2, n);
+   }
    // breadth-first collapse, one launch per level; the level sizes come back through one counter
    level_start.assign({0u});
    uint32_t level_first = 0, level_count = 1;
-   const uint32_t zero = 0;
-   LB_TRY(hipMemcpyAsync(list_a, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, stream));  // level 0 = binary root 0
+   LB_TRY(hipMemcpyAsync(list_a, &binary_root, sizeof(uint32_t), hipMemcpyHostToDevice, stream));  // level 0 = the binary root
    LB_TRY(hipMemsetAsync(counter, 0, 2 * sizeof(uint32_t), stream));
    uint32_t *cur = list_a, *nxt = list_b;
    while (level_count) {
@@ -230,7 +390,7 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
          return hipErrorInvalidValue;
       }
       LB_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
-      k_lbvh_collapse<<<dim3((level_count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(node2, cur, level_first, level_count, next_first, nxt, counter, counter + 1, order, a.nodes);
+      k_lbvh_collapse<<<dim3((level_count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(node2, cur, level_first, level_count, next_first, nxt, counter, counter + 1, order, a.nodes, by_area);
       uint32_t produced = 0;
       LB_TRY(hipMemcpyAsync(&produced, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       LB_TRY(hipStreamSynchronize(stream));

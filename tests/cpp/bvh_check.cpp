@@ -54,7 +54,7 @@ static int check(const std::vector<float>& corners, int threads, const char* nam
    while (!st.empty()) {
       uint32_t ni = st.back().node;
       st.pop_back();
-      const Node4& nd = out.nodes[ni];
+      const NodeW& nd = out.nodes[ni];
       const Node4C& q = out.cnodes[ni];
       float scale[3];
       for (int a = 0; a < 3; a++) scale[a] = std::ldexp(1.0f, (int)((q.meta >> (8 * a)) & 0xff) - 127);
@@ -69,7 +69,7 @@ static int check(const std::vector<float>& corners, int threads, const char* nam
                if (((q.qlo[a] >> (8 * k)) & 0xff) != 0xff || ((q.qhi[a] >> (8 * k)) & 0xff) != 0) fail("empty slot is not an inverted box", ni, (uint32_t)k);
             continue;
          }
-         const float lo[3] = {nd.lox[k], nd.loy[k], nd.loz[k]}, hi[3] = {nd.hix[k], nd.hiy[k], nd.hiz[k]};
+         const float lo[3] = {nd.lo[0][k], nd.lo[1][k], nd.lo[2][k]}, hi[3] = {nd.hi[0][k], nd.hi[1][k], nd.hi[2][k]};
          for (int a = 0; a < 3; a++) {
             float qlo = q.origin[a] + scale[a] * (float)((q.qlo[a] >> (8 * k)) & 0xff);
             float qhi = q.origin[a] + scale[a] * (float)((q.qhi[a] >> (8 * k)) & 0xff);
@@ -97,10 +97,10 @@ static int check(const std::vector<float>& corners, int threads, const char* nam
             }
             node_refs[c]++;
             // child's own children must lie inside this slot's box (boxes are padded outwards at every level)
-            const Node4& ch = out.nodes[c];
+            const NodeW& ch = out.nodes[c];
             for (int j = 0; j < 4; j++)
                if (ch.child[j] != kEmptyRef) {
-                  const float clo[3] = {ch.lox[j], ch.loy[j], ch.loz[j]}, chi[3] = {ch.hix[j], ch.hiy[j], ch.hiz[j]};
+                  const float clo[3] = {ch.lo[0][j], ch.lo[1][j], ch.lo[2][j]}, chi[3] = {ch.hi[0][j], ch.hi[1][j], ch.hi[2][j]};
                   for (int a = 0; a < 3; a++) {
                      float pad = 2e-4f + 2e-5f * std::fmax(std::fabs(clo[a]), std::fabs(chi[a]));
                      if (geometry && (!(clo[a] >= lo[a] - pad) || !(chi[a] <= hi[a] + pad))) fail("grandchild box escapes its parent slot", ni, c);

@@ -528,8 +528,10 @@ def _single_triangle_scene():
     return Scene("one", [(Model([m], []), None)], [(0.0, 0.0, 3.0)], Camera((0, 0, 4), (0, 0, 0), 60.0, 1.0, 0.01, 100.0))
 
 
+@pytest.mark.parametrize("kind", [1, 2])
 @pytest.mark.parametrize("which", ["cornell", "atrium", "torture", "soup", "one", "empty"])
-def test_device_build_equals_host_build(cornell, atrium, which):
+def test_device_build_equals_host_build(cornell, atrium, which, kind):
+    """option device_build: 1 = PLOC, 2 = radix tree (csrc/lbvh.hip)"""
     from rust_renderer_amd.camera import Camera
     from rust_renderer_amd.scenes import Model, Scene
     scene = {"cornell": cornell, "atrium": atrium, "torture": torture_scene(), "soup": _soup_scene(11), "one": _single_triangle_scene(),
@@ -537,7 +539,7 @@ def test_device_build_equals_host_build(cornell, atrium, which):
     W, H = 72, 48
     host = scene.upload(rr.Renderer(W, H))
     dev = rr.Renderer(W, H)
-    dev.set_option("device_build", 1)
+    dev.set_option("device_build", kind)
     scene.upload(dev)
     assert dev.get_stats().bvh_triangles == host.get_stats().bvh_triangles == scene.num_triangles
     rays = random_rays(((-3, -1, -3), (3, 3, 3)) if which != "atrium" else ((-14, 0, -7), (14, 10, 7)), 30000, seed=21)
@@ -587,7 +589,7 @@ def _chain_scene(clusters=300):
     return Scene("chain", [(Model([m], []), None)], [], Camera((0, 0, 6), (0, 0, 0), 60.0, 1.0, 0.01, 100.0))
 
 
-@pytest.mark.parametrize("device_build", [0, 1])
+@pytest.mark.parametrize("device_build", [0, 1, 2])
 def test_deep_clustered_geometry_keeps_every_hit(device_build):
     """a tree deeper than the traversal stack used to drop subtrees silently (trav_push past capacity). Now
     the host builder rebuilds balanced when the SAH tree has more than kMaxTreeLevels levels, and a device build of
