@@ -866,6 +866,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
    const uint32_t n_lds_mesh = sc.num_meshes < kLdsMeshes ? sc.num_meshes : kLdsMeshes;
    const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
    __shared__ uint32_t s_hits;
+   __shared__ uint32_t s_list[kWavesPerBlock][128];
    if (threadIdx.x == 0) s_hits = 0;
    if (threadIdx.x < n_lds_mesh) s_mesh[threadIdx.x] = sc.meshes[threadIdx.x];
    if (threadIdx.x < n_lds_tex) s_tex[threadIdx.x] = sc.textures[threadIdx.x];
@@ -883,17 +884,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
    const uint32_t rounds = (count + stride - 1) / stride;
    uint32_t n_hits = 0;
    const bool nt = ps.stream_nt != 0;
-   for (uint32_t r = 0; r < rounds; r++) {
-      uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
+   // one path per lane: `valid` lanes shade their hit; every lane of the wave takes part in the queue appends
+   auto shade = [&](uint32_t id, bool valid) {
       bool scattered = false, want_light = false;
-      uint32_t id = 0;
-      float4 hr = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmptyRef));
-      if (i < count) {
-         id = ld_stream(queue + i, nt);
-         hr = ld_stream(ps.hit + id, nt);
-      }
-      if (__float_as_uint(hr.w) != kEmptyRef) {
-         n_hits++;
+      if (valid) {
+         const float4 hr = ld_stream(ps.hit + id, nt);
          float4 ro = ld_stream(ps.ray_o + id, nt), rd = ld_stream(ps.ray_d + id, nt);
          const V3 ray_dir = v3(rd.x, rd.y, rd.z);
          const float t = hr.x, bu = hr.y, bv = hr.z;
@@ -1005,9 +1000,44 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
       if (scattered) st_stream(q_next + slot, id, nt);
       slot = wave_append(n_light, want_light);
       if (want_light) st_stream(q_light + slot, id, nt);
+   };
+   // The bounce's RAY queue holds hits and misses (the traversal kernels build no hit / miss queues). Shading a wave of
+   // queue entries as they come leaves the lanes of the misses idle through the whole material evaluation, so the hits
+   // are first compacted inside the wave: their ids collect in a per-wave LDS list and are shaded 64 at a time.
+   uint32_t* list = s_list[threadIdx.x >> 6];
+   const uint32_t lane = lane_id();
+   uint32_t n_list = 0;  // wave-uniform
+   for (uint32_t r = 0; r < rounds; r++) {
+      const uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
+      bool is_hit = false;
+      uint32_t id = 0;
+      if (i < count) {
+         id = ld_stream(queue + i, nt);
+         is_hit = ld_stream(reinterpret_cast<const uint32_t*>(ps.hit + id) + 3, nt) != kEmptyRef;
+      }
+      const unsigned long long mask = __ballot(is_hit);
+      if (mask == 0ull) continue;
+      const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      if (is_hit) list[n_list + prefix] = id;
+      n_list += (uint32_t)__popcll(mask);
+      __builtin_amdgcn_wave_barrier();
+      if (n_list >= 64u) {
+         shade(list[lane], true);
+         n_hits += 64u;
+         const uint32_t rest = n_list - 64u;  // move the tail (at most 63 ids) to the front: one wave, LDS operations execute in order
+         uint32_t tmp = 0;
+         if (lane < rest) tmp = list[64u + lane];
+         __builtin_amdgcn_wave_barrier();
+         if (lane < rest) list[lane] = tmp;
+         __builtin_amdgcn_wave_barrier();
+         n_list = rest;
+      }
    }
-   // closest_hits: per-block sum, one atomic per block
-   for (int o = 32; o > 0; o >>= 1) n_hits += __shfl_xor(n_hits, o);
+   if (n_list) {
+      shade(lane < n_list ? list[lane] : 0u, lane < n_list);
+      n_hits += n_list;
+   }
+   // closest_hits: per-block sum, one atomic per block (n_hits is wave-uniform)
    if (lane_id() == 0 && n_hits) atomicAdd(&s_hits, n_hits);
    __syncthreads();
    if (threadIdx.x == 0 && s_hits) atomicAdd(&stats->closest_hits, (unsigned long long)s_hits);
@@ -1313,7 +1343,10 @@ void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathStat
 }
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
-   k_shade_miss<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, ps, ctl, stats, bounce);
+   // per-wave compaction leaves one partial batch of misses per wave: a grid of 4 blocks per CU (not one block per 256
+   // pixels) gives every wave enough rays that this tail is a small share of its sky integrals
+   const dim3 full = shade_grid(c, fp.W * fp.H * fp.batch_frames), lean = sharded_grid(c.num_cus * 4);
+   k_shade_miss<<<full.x < lean.x ? full : lean, kBlock, 0, c.stream>>>(fp, ps, ctl, stats, bounce);
 }
 
 void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
