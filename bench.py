@@ -274,8 +274,11 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     # vector-memory issue: every per-lane load or store of <= 16 B takes one slot of the CU's texture addresser / data
     # path, and that path retires one lane per clock (profiles/r02_microbench_rates.txt: 1.0-1.1 clk per lane-load for
     # random 64-B and 128-B records alike, 4 lanes on one line or not). Lane operations of one closest-hit ray in this
-    # layout: 4 per node visit (64-B node), 3 per triangle tested (48-B packet), 4 for queue id + ray (2 LDS-DMA) + hit.
-    lane_ops = 4.0 * nodes_per_ray + 3.0 * tris_per_ray + 4.0
+    # layout: 3 per node visit (48-B node), 3 per triangle tested (48-B packet), 4 for queue id + ray (2 LDS-DMA) + hit.
+    # The counters agree on WHERE the kernel sits (profiles/bench_counters.json: texture-data unit ~0.9 busy, texture
+    # addresser ~0.8, VALU issue ~0.5, HBM ~0.1) more than on the exact cost of one lane operation: read frac_alone as a
+    # model figure next to the measured busy fractions under `valu`.
+    lane_ops = 3.0 * nodes_per_ray + 3.0 * tris_per_ray + 4.0
     peak_lane_rate = 256 * 2.4e9  # CUs x max clock (MI355X_MICROARCH.md); the clock under load is lower
     alone_rate = alone_rays * lane_ops / (alone_ms * 1e-3) if alone_ms > 0 else 0.0
     r = {
@@ -295,7 +298,7 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
         "algorithmic_gbps": algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
         "algorithmic_note": "SURVEY 8d work metric (48 B/ray + 128 B/node visit + 48 B/triangle); served by L1/L2/Infinity Cache, so it may exceed the HBM peak - not a roofline fraction",
         "limiter": {
-            "what": "vector-memory issue (TA/TD): one <=16-byte lane operation per clock per CU; neither HBM nor VALU nor MFMA bounds this path",
+            "what": "the CU's vector-memory pipeline (texture addresser / texture data units, measured 0.8-0.9 busy): about one <=16-byte lane operation per clock per CU; neither HBM nor VALU nor MFMA bounds this path",
             "lane_ops_per_ray": lane_ops,
             "unit": "G lane-ops/s",
             "peak": peak_lane_rate / 1e9,

@@ -1124,9 +1124,9 @@ int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mas
    if (!view || count == 0) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: null view or zero frames");
    UhViewUniformData v = *view;
    uint32_t done = 0;
-   // auto: 4 frames per wavefront (swept on MI355X for 1, 2, 4 and 8 ranks' shares of the frame,
-   // tools/world_sweep.sh, profiles/README.md)
-   uint32_t batch = c->batch_frames ? c->batch_frames : 4;
+   // auto: about four frames' worth of paths per wavefront - 4 frames on a whole frame, 4 x world frames on a rank's 1 / world
+   // share of it (swept on MI355X for 1, 4 and 8 ranks' shares: tools/sweep_world8.sh, profiles/README.md)
+   uint32_t batch = c->batch_frames ? c->batch_frames : 4 * (c->tp_world ? c->tp_world : 1);
    if (batch > kMaxBatchFrames) batch = kMaxBatchFrames;
    // create every frames-in-flight slot now: the first call (an application's first frames, a benchmark's
    // warm-up) pays for the allocations and stream creation, not whichever later wavefront first reaches a slot

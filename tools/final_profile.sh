@@ -1,0 +1,22 @@
+#!/bin/bash
+# the round's committed evidence: default bench line, kernel trace + counter passes of the same command line, the other BASELINE configs
+root=${GRAFT_REPO_ROOT:-/root/repo}
+cd $root
+tag=${1:-r02}
+timeout -k 10 300 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+tools/profile_bench.sh $tag
+timeout -k 10 300 python bench.py --config 2 --steps 32 --no-cpu-baseline > gpurun_out/${tag}_bench_config2.json 2>/dev/null
+timeout -k 10 300 python bench.py --config 3 --width 3840 --height 2160 --steps 16 --no-cpu-baseline > gpurun_out/${tag}_bench_config3_4k.json 2>/dev/null
+timeout -k 10 300 python bench.py --config 4 --steps 64 --no-cpu-baseline > gpurun_out/${tag}_bench_config4_isosurface.json 2>/dev/null
+timeout -k 10 300 python bench.py --config 0 --width 256 --height 256 --steps 64 --cpu-sample 256x256x64 > gpurun_out/${tag}_bench_config0_rtiow.json 2>/dev/null
+for w in 2 4 8; do timeout -k 10 200 python bench.py --emulate-world $w --no-cpu-baseline > gpurun_out/${tag}_bench_emulated_world$w.json 2>/dev/null; done
+timeout -k 10 200 python bench.py --force-dist --no-cpu-baseline --steps 16 > gpurun_out/${tag}_bench_force_dist.json 2> gpurun_out/${tag}_bench_force_dist.err
+for f in gpurun_out/${tag}_bench*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-52s %9.1f %s  %8.3f ms/step  frame-by-frame %s" % (sys.argv[1].split("/")[-1], d["value"], d["unit"], d["ms_per_step"], d["config"].get("frame_by_frame_ms")))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+done
