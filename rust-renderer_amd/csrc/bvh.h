@@ -48,6 +48,16 @@ struct alignas(16) Node4C {
 };
 static_assert(sizeof(Node4C) == 48, "device node = three 16-byte loads");
 constexpr uint32_t kMetaTriShift = 24, kMetaChildShift = 28;
+// Stride of the device arrays in 16-byte units. A 48-byte record at a 48-byte stride straddles two 64-byte cache
+// sectors half of the time; at a 64-byte stride (the last 16 bytes unused) every record is one sector - more bytes of
+// working set against fewer sector fetches per record (measured: profiles/README.md "record stride").
+#ifndef UH_NODE_STRIDE16
+#define UH_NODE_STRIDE16 3
+#endif
+#ifndef UH_TRI_STRIDE16
+#define UH_TRI_STRIDE16 3
+#endif
+constexpr uint32_t kNodeStride16 = UH_NODE_STRIDE16, kTriStride16 = UH_TRI_STRIDE16;
 
 struct alignas(16) TriPacket {
    float v0[3];

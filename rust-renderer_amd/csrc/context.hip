@@ -652,12 +652,13 @@ int uh_build_acceleration(uh_ctx* c) {
    if (bo.cnodes.empty()) return fail(c, UH_ERR_INVALID_ARGUMENT, "internal: BVH builder produced no root node");
    if (int st = sync_all(c)) return st;
    if (int st = upload_scene_tables(c)) return st;
-   HIP_TRY(c, c->d_nodes.alloc(bo.cnodes.size() * 3));
-   HIP_TRY(c, c->d_tris.alloc(total * 3));
+   HIP_TRY(c, c->d_nodes.alloc(bo.cnodes.size() * kNodeStride16));
+   HIP_TRY(c, c->d_tris.alloc(total * kTriStride16));
    HIP_TRY(c, c->d_shade.alloc(total * 4));
-   HIP_TRY(c, hipMemcpy(c->d_nodes.p, bo.cnodes.data(), bo.cnodes.size() * sizeof(Node4C), hipMemcpyHostToDevice));
+   // 48-byte records into arrays of stride kNodeStride16 / kTriStride16 x 16 bytes
+   HIP_TRY(c, hipMemcpy2D(c->d_nodes.p, 16 * kNodeStride16, bo.cnodes.data(), sizeof(Node4C), sizeof(Node4C), bo.cnodes.size(), hipMemcpyHostToDevice));
    if (total) {
-      HIP_TRY(c, hipMemcpy(c->d_tris.p, tp.data(), total * sizeof(TriPacket), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy2D(c->d_tris.p, 16 * kTriStride16, tp.data(), sizeof(TriPacket), sizeof(TriPacket), total, hipMemcpyHostToDevice));
       HIP_TRY(c, hipMemcpy(c->d_shade.p, sp.data(), total * sizeof(ShadePacket), hipMemcpyHostToDevice));
    }
    c->scene.nodes = reinterpret_cast<const uint4*>(c->d_nodes.p);
@@ -805,8 +806,8 @@ static int build_on_device(uh_ctx* c) {
    for (int a = 0; a < 3; a++)
       if (!(lo[a] <= hi[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a])) lo[a] = hi[a] = 0.0f;
    const size_t node_cap = total > 1 ? total : 1;
-   HIP_TRY(c, c->d_nodes.alloc(node_cap * 3));
-   HIP_TRY(c, c->d_tris.alloc(total * 3));
+   HIP_TRY(c, c->d_nodes.alloc(node_cap * kNodeStride16));
+   HIP_TRY(c, c->d_tris.alloc(total * kTriStride16));
    HIP_TRY(c, c->d_shade.alloc(total * 4));
    HIP_TRY(c, c->d_obj_corners.alloc(9 * total));
    HIP_TRY(c, c->d_world_corners.alloc(9 * total));
@@ -1215,7 +1216,7 @@ int uh_trace_closest(uh_ctx* c, const float* rays, uint32_t n, float* out_tuv, u
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    // packet index -> key needs the packet table: read keys back once
    std::vector<TriPacket> tp(c->scene.num_tris);
-   if (!tp.empty()) HIP_TRY(c, hipMemcpy(tp.data(), c->d_tris.p, tp.size() * sizeof(TriPacket), hipMemcpyDeviceToHost));
+   if (!tp.empty()) HIP_TRY(c, hipMemcpy2D(tp.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), tp.size(), hipMemcpyDeviceToHost));
    for (uint32_t i = 0; i < n; i++) {
       uint32_t idx;
       std::memcpy(&idx, &h[i].w, 4);

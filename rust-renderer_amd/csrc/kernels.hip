@@ -71,7 +71,7 @@ __device__ __forceinline__ bool tri_compute(float4 a, float4 b, float4 c, uint32
 }
 template <bool ANY>
 __device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, uint32_t i, V3 o, V3 d, float tmin, float tlimit, Hit& best) {
-   float4 a = tris[3 * (size_t)i + 0], b = tris[3 * (size_t)i + 1], c = tris[3 * (size_t)i + 2];
+   float4 a = tris[kTriStride16 * (size_t)i + 0], b = tris[kTriStride16 * (size_t)i + 1], c = tris[kTriStride16 * (size_t)i + 2];
    return tri_compute<ANY>(a, b, c, i, o, d, tmin, tlimit, best);
 }
 
@@ -222,7 +222,7 @@ __device__ __forceinline__ void node_compute(const uint4 w0, const uint4 w1, con
 
 template <bool ANY>
 __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill) {
-   const uint4* n = nodes + 3 * (size_t)t.cur;
+   const uint4* n = nodes + kNodeStride16 * (size_t)t.cur;
    const uint4 w0 = n[0], w1 = n[1], w2 = n[2];
    node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
 }
@@ -423,10 +423,10 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
       uint4 w0, w1, w2;
       float4 ta, tb, tc;
       if (at_node) {
-         const uint4* n = nodes + 3 * (size_t)t.cur;
+         const uint4* n = nodes + kNodeStride16 * (size_t)t.cur;
          w0 = n[0], w1 = n[1], w2 = n[2];
       } else {
-         const float4* p = tris + 3 * (size_t)packet;
+         const float4* p = tris + kTriStride16 * (size_t)packet;
          ta = p[0], tb = p[1], tc = p[2];
       }
       if (at_node) {

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_collapse(const uint4* __restric
       else
          next_src[slot + m++] = ch[k];
    }
-   write_topology(nodes + 3 * (size_t)(level_first + idx), n_tri, (uint32_t)nc, next_first + slot, tri_base);
+   write_topology(nodes + kNodeStride16 * (size_t)(level_first + idx), n_tri, (uint32_t)nc, next_first + slot, tri_base);
 }
 
 // a tree without internal binary nodes (n <= 1): one root whose only child, if any, is the triangle
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_gather(const unsigned long long
    const uint32_t s = (uint32_t)(keys[order[i]] & 0xffffffffull);
    for (int k = 0; k < 9; k++) obj_corners[9 * (size_t)i + k] = src_corners[9 * (size_t)s + k];
    for (int k = 0; k < 4; k++) shade[4 * (size_t)i + k] = src_shade[4 * (size_t)s + k];
-   tris[3 * (size_t)i + 2] = make_float4(0.0f, __uint_as_float(src_keys[s]), 0.0f, 0.0f);  // the key; refit writes the rest
+   tris[kTriStride16 * (size_t)i + 2] = make_float4(0.0f, __uint_as_float(src_keys[s]), 0.0f, 0.0f);  // the key; refit writes the rest
 }
 
 }  // namespace

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void k_refit_triangles(const float* __restr
                                                             float* __restrict__ world_corners, uint32_t count) {
    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
    if (i >= count) return;
-   float4* pk = tris + 3 * (size_t)i;
+   float4* pk = tris + kTriStride16 * (size_t)i;
    const uint32_t key = __float_as_uint(pk[2].y);
    const RefitMesh m = meshes[key >> 22];
    const float* oc = obj_corners + 9 * (size_t)i;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(uint4* __restrict__ node
    uint32_t j = blockIdx.x * kBlock + threadIdx.x;
    if (j >= count) return;
    const uint32_t ni = first + j;
-   uint4* nd = nodes + 3 * (size_t)ni;
+   uint4* nd = nodes + kNodeStride16 * (size_t)ni;
    const uint32_t meta = nd[0].w;
    const uint4 w2 = nd[2];
    const uint32_t n_tri = (meta >> kMetaTriShift) & 7u, n_child = (meta >> kMetaChildShift) & 7u;
