@@ -420,20 +420,21 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
    if (PHASED) {
       const bool at_node = !(t.cur & kLeafBit);
       const uint32_t packet = t.cur & ~kLeafBit;
-      uint4 w0, w1, w2;
-      float4 ta, tb, tc;
-      if (at_node) {
-         const uint4* n = nodes + kNodeStride16 * (size_t)t.cur;
-         w0 = n[0], w1 = n[1], w2 = n[2];
-      } else {
-         const float4* p = tris + kTriStride16 * (size_t)packet;
-         ta = p[0], tb = p[1], tc = p[2];
-      }
+      // nodes and triangle packets are both three-quad records: ONE address and ONE set of loads for the whole wave.
+      // (Written as two branches, each with its own loads, the compiler gave the second branch's address the first
+      // branch's destination registers and made it wait for them: the two groups' loads ran one after the other.)
+      const uint4* rec = at_node ? nodes + kNodeStride16 * (size_t)packet : (const uint4*)tris + kTriStride16 * (size_t)packet;
+      uint4 w0 = rec[0], w1 = rec[1], w2 = rec[2];
+      // the packet's last two dwords are padding: without this the compiler loads them in the node branch only (a fourth load)
+      asm volatile("" : "+v"(w2.z), "+v"(w2.w));
       if (at_node) {
          if (COUNT) n_nodes++;
          node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
       } else {
          if (COUNT) n_tris++;
+         const float4 ta = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
+         const float4 tb = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
+         const float4 tc = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
          if (tri_compute<ANY>(ta, tb, tc, packet, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
             occluded = true;
             t.cur = kEmptyRef;
