@@ -123,7 +123,6 @@ struct Slot {
       ps.rng = rng.p;
       for (int i = 0; i < 3; i++) ps.queue[i] = queues[i].p;
       ps.shard_cap = shard_cap;
-      ps.stream_nt = 0;
       ready = true;
       return hipSuccess;
    }
@@ -171,7 +170,6 @@ struct uh_ctx {
    PathState& ps = slots[0].ps;
    DevBuf<Control>& control = slots[0].control;
    bool overlap_miss = true, overlap_shadow = true;
-   bool stream_nt = true;   // non-temporal access to per-path state (option "stream_nt"; +1-1.5 % frame rate, profiles/README.md)
    uint32_t W = 0, H = 0;
    uint32_t num_cus = 256;
    uint32_t closest_blocks_per_cu = 6, shadow_blocks_per_cu = 5;  // what the refill kernels' LDS (stacks + ray pool) admits
@@ -944,7 +942,6 @@ static int ensure_slot(uh_ctx* c, uint32_t i, uint32_t batch = 1) {
 static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
    LaunchCfg lc = cfg(c);
    lc.stream = s.stream;
-   s.ps.stream_nt = c->stream_nt ? 1u : 0u;
    Control* ctl = s.control.p;
    DeviceStats* st = c->dstats.p;
    // reference.rgen:28: samples of one frame run back to back (the raygen RNG state carries over)
@@ -1340,9 +1337,7 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 1 || value > 64) return fail(c, UH_ERR_INVALID_ARGUMENT, "ploc_radius must be 1..64");
       if (c->ploc_radius != (uint32_t)value && c->device_build) c->built = c->topology_valid = false;
       c->ploc_radius = (uint32_t)value;
-   } else if (n == "stream_nt")
-      c->stream_nt = value != 0;
-   else if (n == "overlap_miss")
+   } else if (n == "overlap_miss")
       c->overlap_miss = value != 0;
    else if (n == "overlap_shadow")
       c->overlap_shadow = value != 0;

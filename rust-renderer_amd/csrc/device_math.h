@@ -186,6 +186,39 @@ __device__ __noinline__ V3 integrate_scattering(V3 start, V3 dir, float ray_leng
 }
 }  // namespace sky
 
+// ---- explicit LDS reads of whole records ------------------------------------------------------
+// `cond ? lds_table[i] : global_table[i]` - however it is written - ends as flat loads of a selected pointer, and a flat
+// load takes the vector-memory path (the busiest unit of the shading kernel) even when it resolves to LDS. These read the
+// LDS copy with ds_read instructions whatever the surrounding code looks like.
+typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ MeshShade lds_fetch(const MeshShade* lds) {
+   const uint32_t at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const MeshShade*)lds;
+   u4_t q[5];
+   asm volatile(
+      "ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48\n\t"
+      "ds_read_b128 %4, %5 offset:64\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4])
+      : "v"(at)
+      : "memory");
+   MeshShade m;
+   static_assert(sizeof(m) == sizeof(q), "five quads");
+   __builtin_memcpy(&m, q, sizeof(m));
+   return m;
+}
+__device__ __forceinline__ TexInfo lds_fetch(const TexInfo* lds) {
+   const uint32_t at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const TexInfo*)lds;
+   struct {
+      u4_t a;
+      u2_t b;
+   } q;
+   asm volatile("ds_read_b128 %0, %2\n\tds_read_b64 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(q.a), "=&v"(q.b) : "v"(at) : "memory");
+   TexInfo t;
+   static_assert(sizeof(TexInfo) == 24, "texture descriptor: a quad and a pair");
+   __builtin_memcpy(&t, &q, sizeof(t));
+   return t;
+}
+
 // ---- texture sampling (utopian/src/texture.rs:85-98: RGBA8 UNORM, LINEAR, MIRRORED_REPEAT) ---
 __device__ __forceinline__ int mirror_index(int i, int n) {
    int period = 2 * n;
@@ -197,19 +230,45 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
 __device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __restrict__ lut, uint32_t index, float u, float v, const TexInfo* lds_tex = nullptr,
                                              uint32_t n_lds_tex = 0) {
    if (index >= sc.num_textures) return v3(1, 1, 1);
-   TexInfo t = (index < n_lds_tex) ? lds_tex[index] : sc.textures[index];
+   TexInfo t;
+   if (lds_tex) {
+      // unconditional LDS read + one-armed replacement: see the mesh record in k_shade_hit (no flat loads)
+      t = lds_fetch(lds_tex + (index < n_lds_tex ? index : 0u));
+      if (index >= n_lds_tex) t = sc.textures[index];
+   } else {
+      t = sc.textures[index];
+   }
    float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
    if (!(fabsf(x) < 1e9f) || !(fabsf(y) < 1e9f)) return v3(0, 0, 0);
    float fx = floorf(x), fy = floorf(y);
    float ax = x - fx, ay = y - fy;
    int x0 = mirror_index((int)fx, (int)t.w), x1 = mirror_index((int)fx + 1, (int)t.w);
    int y0 = mirror_index((int)fy, (int)t.h), y1 = mirror_index((int)fy + 1, (int)t.h);
-   auto tx = [&](int xx, int yy) {
-      const size_t at = t.tiles_x ? ((size_t)((yy >> 3) * t.tiles_x + (xx >> 3)) << 6) + ((yy & 7) << 3) + (xx & 7) : (size_t)yy * t.w + xx;
-      uchar4 p = t.texels[at];
-      return v3(lut[p.x], lut[p.y], lut[p.z]);
+   // the four texel addresses first (branch-free: a branch per texel put a wait behind every fetch and the four
+   // fetches ran one after the other), then the four fetches together, then the table look-ups
+   const bool tiled = t.tiles_x != 0;
+   auto address = [&](int xx, int yy) {
+      const uint32_t in_tiles = ((uint32_t)((yy >> 3) * (int)t.tiles_x + (xx >> 3)) << 6) + (uint32_t)(((yy & 7) << 3) + (xx & 7));
+      const uint32_t in_rows = (uint32_t)yy * t.w + (uint32_t)xx;
+      return tiled ? in_tiles : in_rows;
    };
-   V3 t00 = tx(x0, y0), t10 = tx(x1, y0), t01 = tx(x0, y1), t11 = tx(x1, y1);
+   const uchar4* q00 = t.texels + address(x0, y0);
+   const uchar4* q10 = t.texels + address(x1, y0);
+   const uchar4* q01 = t.texels + address(x0, y1);
+   const uchar4* q11 = t.texels + address(x1, y1);
+   // one block: as four C++ loads the compiler still made the third wait for the first (register reuse), and as loads
+   // through the descriptor's generic pointer they were flat loads
+   uint32_t w00, w10, w01, w11;
+   asm volatile(
+      "global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(w00), "=&v"(w10), "=&v"(w01), "=&v"(w11)
+      : "v"(q00), "v"(q10), "v"(q01), "v"(q11)
+      : "memory");
+   auto texel = [](uint32_t w) { return make_uchar4((unsigned char)(w & 0xffu), (unsigned char)((w >> 8) & 0xffu), (unsigned char)((w >> 16) & 0xffu), (unsigned char)(w >> 24)); };
+   const uchar4 p00 = texel(w00), p10 = texel(w10), p01 = texel(w01), p11 = texel(w11);
+   const V3 t00 = v3(lut[p00.x], lut[p00.y], lut[p00.z]), t10 = v3(lut[p10.x], lut[p10.y], lut[p10.z]);
+   const V3 t01 = v3(lut[p01.x], lut[p01.y], lut[p01.z]), t11 = v3(lut[p11.x], lut[p11.y], lut[p11.z]);
    V3 a = t00 * (1.0f - ax) + t10 * ax;
    V3 b = t01 * (1.0f - ax) + t11 * ax;
    return a * (1.0f - ay) + b * ay;
@@ -262,42 +321,48 @@ __device__ __forceinline__ bool owns_pixel(const FrameParams& fp, uint32_t x, ui
 // ---- streaming (non-temporal) access to per-path state -----------------------------------------
 // Path state is touched once per kernel and is hundreds of MB per wavefront of frames; the BVH (nodes + triangle packets,
 // tens of MB) is what the traversal kernels re-read. `nt` loads / stores ask the caches not to keep the stream, so that it
-// does not push the tree out of the 4 MiB L2 of each XCD. PathState::stream_nt switches it (option "stream_nt").
+// does not push the tree out of the 4 MiB L2 of each XCD (+1-1.5 % frame rate, profiles/README.md). A BUILD-time switch:
+// as a run-time flag every access was a branch with its own wait behind it, and the independent loads of a kernel's
+// prologue ran one after the other (k_shade_hit: eight dependent round trips instead of four).
+#ifndef UH_STREAM_NT
+#define UH_STREAM_NT 1
+#endif
+constexpr bool kStreamNt = UH_STREAM_NT != 0;
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float4 ld_stream(const float4* p, bool nt) {
-   if (nt) {
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+   if (kStreamNt) {
       const v4f_t v = __builtin_nontemporal_load((const v4f_t*)p);
       return make_float4(v.x, v.y, v.z, v.w);
    }
    return *p;
 }
-__device__ __forceinline__ void st_stream(float4* p, float4 x, bool nt) {
-   if (nt) {
+__device__ __forceinline__ void st_stream(float4* p, float4 x) {
+   if (kStreamNt) {
       const v4f_t v = {x.x, x.y, x.z, x.w};
       __builtin_nontemporal_store(v, (v4f_t*)p);
    } else {
       *p = x;
    }
 }
-__device__ __forceinline__ uint2 ld_stream(const uint2* p, bool nt) {
-   if (nt) {
+__device__ __forceinline__ uint2 ld_stream(const uint2* p) {
+   if (kStreamNt) {
       const v2u_t v = __builtin_nontemporal_load((const v2u_t*)p);
       return make_uint2(v.x, v.y);
    }
    return *p;
 }
-__device__ __forceinline__ void st_stream(uint2* p, uint2 x, bool nt) {
-   if (nt) {
+__device__ __forceinline__ void st_stream(uint2* p, uint2 x) {
+   if (kStreamNt) {
       const v2u_t v = {x.x, x.y};
       __builtin_nontemporal_store(v, (v2u_t*)p);
    } else {
       *p = x;
    }
 }
-__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ void st_stream(uint32_t* p, uint32_t x, bool nt) {
-   if (nt)
+__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) { return kStreamNt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_stream(uint32_t* p, uint32_t x) {
+   if (kStreamNt)
       __builtin_nontemporal_store(x, p);
    else
       *p = x;

@@ -126,7 +126,6 @@ struct PathState {
    uint2* rng;      // x = raygen rngState, y = rayPayload.randomSeed
    uint32_t* queue[3];  // 0,1 = ray ping-pong; 2 = light; each kShards * shard_cap entries
    uint32_t shard_cap;  // entries per shard segment = pixels a shard can own (multiple of 64)
-   uint32_t stream_nt;  // non-temporal loads / stores for the per-path records (device_math.h ld_stream / st_stream)
 };
 
 struct Images {

@@ -18,8 +18,11 @@ namespace uh {
 
 constexpr int kBlock = 256;                 // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kLdsStack = 16;               // per-lane traversal stack entries kept in LDS (16 KiB per 256-thread block -> 8 blocks/CU)
-constexpr int kSpillStack = 96;             // overflow entries in private memory (rarely touched); the host refuses trees deeper than the two together hold
+#ifndef UH_LDS_STACK
+#define UH_LDS_STACK 16
+#endif
+constexpr int kLdsStack = UH_LDS_STACK;      // per-lane traversal stack entries kept in LDS (16 KiB per 256-thread block)
+constexpr int kSpillStack = (int)kTraversalStackEntries - kLdsStack;             // overflow entries in private memory (rarely touched); the host refuses trees deeper than the two together hold
 
 // ------------------------------------------------------------------------------------------
 // BVH4 traversal (thread per ray). Closest hit: min t over all triangles with tmin < t < tmax,
@@ -302,9 +305,9 @@ struct alignas(16) RayPool {
    uint32_t id[kPool];
 };
 
-__device__ __forceinline__ void dma16(const float4* gsrc, float4* lds_dst, bool nt) {
+__device__ __forceinline__ void dma16(const float4* gsrc, float4* lds_dst) {
    // lds_dst is wave-uniform; lane l's 16 bytes land at lds_dst + l. aux = 2: the nt cache policy
-   if (nt)
+   if (kStreamNt)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
    else
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -319,7 +322,6 @@ struct RaySource {
    uint32_t count;
    uint32_t* cursor;
    uint32_t wave_index, num_waves;  // static chunk assignment only
-   bool nt;                         // stream the ray records past the caches (PathState::stream_nt)
 };
 
 template <int NA>
@@ -355,7 +357,7 @@ struct Feeder {
          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pool's last entries have been read
          if (lane < q_n) {
 #pragma unroll
-            for (int a = 0; a < NA; a++) dma16(source_of(a, q_id), pool.v[a], src.nt);
+            for (int a = 0; a < NA; a++) dma16(source_of(a, q_id), pool.v[a]);
             pool.id[lane] = q_id;
          }
          load_n = q_n;
@@ -367,7 +369,7 @@ struct Feeder {
          have_base = false;
          if (b < src.count) {
             q_n = src.count - b < kPool ? src.count - b : kPool;
-            if (lane < q_n) q_id = src.queue ? ld_stream(src.queue + b + lane, src.nt) : b + lane;
+            if (lane < q_n) q_id = src.queue ? ld_stream(src.queue + b + lane) : b + lane;
          } else {
             drained = true;
          }
@@ -467,7 +469,7 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
 template <bool COUNT, int kRefill, bool PHASED>
 __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const uint32_t* __restrict__ queue_base, const float4* __restrict__ ray_o,
                                                                const float4* __restrict__ ray_d, float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl,
-                                                               DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count, uint32_t stream_nt) {
+                                                               DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    __shared__ RayPool<2> s_pool[kWavesPerBlock];
    const uint32_t lane = lane_id();
@@ -481,10 +483,9 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
       src.count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
       src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
       src.wave_index = src.num_waves = 0;
-      src.nt = stream_nt != 0;
       if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)src.count);
    } else {
-      src.nt = false;  // stand-alone query over raw_count rays (uh_trace_closest, the G-buffer cast): ray i = record i
+      // stand-alone query over raw_count rays (uh_trace_closest, the G-buffer cast): ray i = record i
       src.queue = nullptr;
       src.count = raw_count;
       src.cursor = nullptr;
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
       if (t.cur != kEmptyRef) {
          bool occluded = false;
          if (trav_step<false, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris))
-            st_stream(hit_out + id, make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx)), src.nt);
+            st_stream(hit_out + id, make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx)));
       }
    }
    if (COUNT) {
@@ -524,7 +525,7 @@ template <bool COUNT, bool DIAG>
 __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_batch(SceneDev sc, const uint32_t* __restrict__ queue_base,
                                                                                                       const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                                                                       float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl, DeviceStats* stats,
-                                                                                                      uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count, uint32_t /*stream_nt*/) {
+                                                                                                      uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    const uint32_t lane = lane_id();
    uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
@@ -612,7 +613,6 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    src.count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    src.wave_index = src.num_waves = 0;
-   src.nt = ps.stream_nt != 0;
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)src.count);
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    while (refill_lanes<3, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<true, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) st_stream(ps.rad + id, lit, src.nt);
+         if (trav_step<true, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) st_stream(ps.rad + id, lit);
       }
    }
    if (COUNT) {
@@ -714,11 +714,11 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
          float jx = random_float(rng), jy = random_float(rng);                                  // rgen:31
          V3 o, d;
          primary_ray(fp, px, py, jx, jy, o, d);
-         st_stream(ps.ray_o + id, make_float4(o.x, o.y, o.z, 0.001f), ps.stream_nt != 0);
-         st_stream(ps.ray_d + id, make_float4(d.x, d.y, d.z, 10000.0f), ps.stream_nt != 0);
+         st_stream(ps.ray_o + id, make_float4(o.x, o.y, o.z, 0.001f));
+         st_stream(ps.ray_d + id, make_float4(d.x, d.y, d.z, 10000.0f));
          // throughput = 1 / radiance = 0 / pixelColor = 0 (rgen:26,39-40) are not materialised: the
          // bounce-0 shading kernels and the first finish_sample use the constants directly
-         st_stream(ps.rng + id, make_uint2(rng, seed), ps.stream_nt != 0);
+         st_stream(ps.rng + id, make_uint2(rng, seed));
       }
       // the 64 paths of a wave normally share one run (hence one shard); at tile edges that are not
       // 64-aligned they may not, so append shard by shard
@@ -743,20 +743,19 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
 // runs on 64 of them at a time with every lane live.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const PathState& ps, uint32_t id, uint32_t bounce) {
-   const bool nt = ps.stream_nt != 0;
    V3 sky_color = v3(0.0f, 0.0f, 0.0f);
    if (fp.sky_enabled == 1) {
-      float4 ro = ld_stream(ps.ray_o + id, nt), rd = ld_stream(ps.ray_d + id, nt);
+      float4 ro = ld_stream(ps.ray_o + id), rd = ld_stream(ps.ray_d + id);
       V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
       sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
    }
    float4 thr = make_float4(1.0f, 1.0f, 1.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
    if (bounce != 0) {
-      thr = ld_stream(ps.thr + id, nt);
-      rad = ld_stream(ps.rad + id, nt);
+      thr = ld_stream(ps.thr + id);
+      rad = ld_stream(ps.rad + id);
    }
    V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
-   st_stream(ps.rad + id, make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w), nt);   // rgen:55
+   st_stream(ps.rad + id, make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w));   // rgen:55
 }
 
 __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
@@ -777,8 +776,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState
       bool miss = false;
       uint32_t id = 0;
       if (i < count) {
-         id = ld_stream(queue + i, ps.stream_nt != 0);
-         miss = __float_as_uint(ld_stream(ps.hit + id, ps.stream_nt != 0).w) == kEmptyRef;
+         id = ld_stream(queue + i);
+         miss = __float_as_uint(ld_stream(ps.hit + id).w) == kEmptyRef;
       }
       const unsigned long long mask = __ballot(miss);
       if (mask == 0ull) continue;
@@ -867,7 +866,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
    const uint32_t n_lds_mesh = sc.num_meshes < kLdsMeshes ? sc.num_meshes : kLdsMeshes;
    const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
    __shared__ uint32_t s_hits;
-   __shared__ uint32_t s_list[kWavesPerBlock][128];
+   __shared__ uint32_t s_list[kWavesPerBlock][2][128];  // per wave: path ids, and the packet index the classification read with them
    if (threadIdx.x == 0) s_hits = 0;
    if (threadIdx.x < n_lds_mesh) s_mesh[threadIdx.x] = sc.meshes[threadIdx.x];
    if (threadIdx.x < n_lds_tex) s_tex[threadIdx.x] = sc.textures[threadIdx.x];
@@ -884,24 +883,32 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
    const uint32_t stride = sx.nb * kBlock;
    const uint32_t rounds = (count + stride - 1) / stride;
    uint32_t n_hits = 0;
-   const bool nt = ps.stream_nt != 0;
    // one path per lane: `valid` lanes shade their hit; every lane of the wave takes part in the queue appends
-   auto shade = [&](uint32_t id, bool valid) {
+   auto shade = [&](uint32_t id, uint32_t pk, bool valid) {
       bool scattered = false, want_light = false;
       if (valid) {
-         const float4 hr = ld_stream(ps.hit + id, nt);
-         float4 ro = ld_stream(ps.ray_o + id, nt), rd = ld_stream(ps.ray_d + id, nt);
+         // every record of the path is requested up front, together with the shading packet (whose index the
+         // classification below already read): one round trip for all of them, then one for the texels
+         const float4 hr = ld_stream(ps.hit + id);
+         float4 ro = ld_stream(ps.ray_o + id), rd = ld_stream(ps.ray_d + id);
+         uint2 rng = ld_stream(ps.rng + id);
+         float4 thr4 = ld_stream(ps.thr + id);  // unconditional (a branch would end the group of loads with a wait); unwritten before bounce 1
+         if (bounce == 0) thr4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
          const V3 ray_dir = v3(rd.x, rd.y, rd.z);
          const float t = hr.x, bu = hr.y, bv = hr.z;
-         const uint32_t pk = __float_as_uint(hr.w);
-         const float4* sp = sc.shade + 4 * (size_t)pk;
+         const float4* sp = sc.shade + 4 * (size_t)pk;  // pk = hr.w, known since the classification: no wait for hr before these
          float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
          const V3 n0 = v3(s0.x, s0.y, s0.z), n1 = v3(s0.w, s1.x, s1.y), n2 = v3(s1.z, s1.w, s2.x);
          const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
          const uint32_t mesh_index = __float_as_uint(s3.w);
-         const MeshShade ms = (mesh_index < n_lds_mesh) ? s_mesh[mesh_index] : sc.meshes[mesh_index];  // rchit:22-23
+         // rchit:22-23. The LDS copy is read unconditionally (clamped index, explicit ds_read: device_math.h lds_fetch)
+         // and replaced from global memory for the meshes beyond the LDS table
+         MeshShade ms = lds_fetch(s_mesh + (mesh_index < kLdsMeshes ? mesh_index : kLdsMeshes - 1));
+         if (mesh_index >= n_lds_mesh) ms = sc.meshes[mesh_index];
          const float bx = 1.0f - bu - bv, by = bu, bz = bv;                            // rchit:30
          V3 normal = (n0 * bx + n1 * by) + n2 * bz;                                    // rchit:31
+         // keeps the compiler from sinking the early loads to their first use
+         asm volatile("" : "+v"(rng.x), "+v"(rng.y), "+v"(thr4.x), "+v"(thr4.y), "+v"(thr4.z));
          V3 wn = v3((normal.x * ms.w2o[0] + normal.y * ms.w2o[3]) + normal.z * ms.w2o[6],
                     (normal.x * ms.w2o[1] + normal.y * ms.w2o[4]) + normal.z * ms.w2o[7],
                     (normal.x * ms.w2o[2] + normal.y * ms.w2o[5]) + normal.z * ms.w2o[8]);  // rchit:32
@@ -912,7 +919,6 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
          V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);       // rchit:40
          color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
 
-         uint2 rng = ld_stream(ps.rng + id, nt);
          uint32_t seed = rng.y;
          V3 scatter = v3(0, 0, 0);
          if (ms.type == 0.0f) {                                                        // rchit:47-50
@@ -950,21 +956,19 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
          }
          rng.y = seed;                                                                 // rchit:91
 
-         float4 thr4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-         if (bounce != 0) thr4 = ld_stream(ps.thr + id, nt);
          V3 thr = v3(thr4.x, thr4.y, thr4.z) * color;                                  // rgen:48
          // the radiance record is only touched when this path ends here (rgen:53-57) or a light sample
          // has to be parked in its w component; a scattered path with lights off leaves it alone
          if (!scattered) {                                                             // rgen:53-57
             float4 rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (bounce != 0) rad4 = ld_stream(ps.rad + id, nt);
-            st_stream(ps.rad + id, make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, rad4.w), nt);
-            st_stream(ps.rng + id, rng, nt);
+            if (bounce != 0) rad4 = ld_stream(ps.rad + id);
+            st_stream(ps.rad + id, make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, rad4.w));
+            st_stream(ps.rng + id, rng);
          } else {
             V3 origin = v3(ro.x, ro.y, ro.z) + t * ray_dir;                            // rgen:59
             origin = offset_ray(origin, world_normal);                                 // rgen:60
-            st_stream(ps.ray_o + id, make_float4(origin.x, origin.y, origin.z, 0.001f), nt);
-            st_stream(ps.ray_d + id, make_float4(scatter.x, scatter.y, scatter.z, 10000.0f), nt);     // rgen:61
+            st_stream(ps.ray_o + id, make_float4(origin.x, origin.y, origin.z, 0.001f));
+            st_stream(ps.ray_d + id, make_float4(scatter.x, scatter.y, scatter.z, 10000.0f));     // rgen:61
             float f = 0.0f;
             int light_index = 0;
             if (fp.lights_enabled == 1) {                                              // rgen:81-110
@@ -986,56 +990,66 @@ __global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev s
                   f = target_function(sc.lights, sc.num_lights, light_index, origin) * light_sample_weight;  // rgen:121
                }
             }
-            st_stream(ps.thr + id, make_float4(thr.x, thr.y, thr.z, f), nt);
+            st_stream(ps.thr + id, make_float4(thr.x, thr.y, thr.z, f));
             if (bounce == 0) {
                // first write of this path's radiance record (generate does not materialise the zero)
-               st_stream(ps.rad + id, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)light_index)), nt);
+               st_stream(ps.rad + id, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)light_index)));
             } else if (fp.lights_enabled == 1) {
-               float4 rad4 = ld_stream(ps.rad + id, nt);
-               st_stream(ps.rad + id, make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index)), nt);
+               float4 rad4 = ld_stream(ps.rad + id);
+               st_stream(ps.rad + id, make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index)));
             }
-            st_stream(ps.rng + id, rng, nt);
+            st_stream(ps.rng + id, rng);
          }
       }
       uint32_t slot = wave_append(n_next, scattered);
-      if (scattered) st_stream(q_next + slot, id, nt);
+      if (scattered) st_stream(q_next + slot, id);
       slot = wave_append(n_light, want_light);
-      if (want_light) st_stream(q_light + slot, id, nt);
+      if (want_light) st_stream(q_light + slot, id);
    };
    // The bounce's RAY queue holds hits and misses (the traversal kernels build no hit / miss queues). Shading a wave of
    // queue entries as they come leaves the lanes of the misses idle through the whole material evaluation, so the hits
    // are first compacted inside the wave: their ids collect in a per-wave LDS list and are shaded 64 at a time.
-   uint32_t* list = s_list[threadIdx.x >> 6];
+   uint32_t* list = s_list[threadIdx.x >> 6][0];
+   uint32_t* list_pk = s_list[threadIdx.x >> 6][1];
    const uint32_t lane = lane_id();
    uint32_t n_list = 0;  // wave-uniform
    for (uint32_t r = 0; r < rounds; r++) {
       const uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
-      bool is_hit = false;
-      uint32_t id = 0;
+      uint32_t id = 0, pk = kEmptyRef;
       if (i < count) {
-         id = ld_stream(queue + i, nt);
-         is_hit = ld_stream(reinterpret_cast<const uint32_t*>(ps.hit + id) + 3, nt) != kEmptyRef;
+         id = ld_stream(queue + i);
+         pk = reinterpret_cast<const uint32_t*>(ps.hit + id)[3];  // a plain load: shade() reads the record again
       }
+      const bool is_hit = pk != kEmptyRef;
       const unsigned long long mask = __ballot(is_hit);
       if (mask == 0ull) continue;
       const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      if (is_hit) list[n_list + prefix] = id;
+      if (is_hit) {
+         list[n_list + prefix] = id;
+         list_pk[n_list + prefix] = pk;
+      }
       n_list += (uint32_t)__popcll(mask);
       __builtin_amdgcn_wave_barrier();
       if (n_list >= 64u) {
-         shade(list[lane], true);
+         shade(list[lane], list_pk[lane], true);
          n_hits += 64u;
-         const uint32_t rest = n_list - 64u;  // move the tail (at most 63 ids) to the front: one wave, LDS operations execute in order
-         uint32_t tmp = 0;
-         if (lane < rest) tmp = list[64u + lane];
+         const uint32_t rest = n_list - 64u;  // move the tail (at most 63 entries) to the front: one wave, LDS operations execute in order
+         uint32_t tmp = 0, tmp_pk = 0;
+         if (lane < rest) {
+            tmp = list[64u + lane];
+            tmp_pk = list_pk[64u + lane];
+         }
          __builtin_amdgcn_wave_barrier();
-         if (lane < rest) list[lane] = tmp;
+         if (lane < rest) {
+            list[lane] = tmp;
+            list_pk[lane] = tmp_pk;
+         }
          __builtin_amdgcn_wave_barrier();
          n_list = rest;
       }
    }
    if (n_list) {
-      shade(lane < n_list ? list[lane] : 0u, lane < n_list);
+      shade(lane < n_list ? list[lane] : 0u, lane < n_list ? list_pk[lane] : 0u, lane < n_list);
       n_hits += n_list;
    }
    // closest_hits: per-block sum, one atomic per block (n_hits is wave-uniform)
@@ -1311,9 +1325,8 @@ void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState&
 // Variant 0 = batch kernel; 1 = refill kernel (threshold 8 idle lanes) with chained node + triangle steps;
 // 2 / 3 / 4 = refill kernel with one load phase per iteration, threshold 4 / 8 (default) / 16 idle lanes.
 static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, const uint32_t* queue, const float4* ray_o, const float4* ray_d, float4* hit,
-                           uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag,
-                           uint32_t stream_nt = 0) {
-#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, queue, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n, stream_nt)
+                           uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag) {
+#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, queue, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
    const bool count = c.count_visits && queue;
    if (diag) {
       UH_CLOSEST((k_trace_closest_batch<false, true>));
@@ -1340,7 +1353,7 @@ static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, co
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                           uint32_t cursor_slot, int ray_kind) {
-   launch_closest(c, closest_grid(c), sc, ps.queue[bounce & 1], ps.ray_o, ps.ray_d, ps.hit, ps.shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, 0, false, ps.stream_nt);
+   launch_closest(c, closest_grid(c), sc, ps.queue[bounce & 1], ps.ray_o, ps.ray_d, ps.hit, ps.shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, 0, false);
 }
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
