@@ -18,6 +18,9 @@ namespace uh {
 
 constexpr int kBlock = 256;                 // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
+#ifndef UH_SHADE_HIT_BLOCKS
+#define UH_SHADE_HIT_BLOCKS 4  // blocks per CU the register budget of k_shade_hit is sized for
+#endif
 #ifndef UH_LDS_STACK
 #define UH_LDS_STACK 16
 #endif
@@ -852,7 +855,7 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
    return I * eta - N * (eta * dn + sqrtf(k));
 }
 
-__global__ __launch_bounds__(kBlock) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, const UhReservoir* __restrict__ spatial_reservoirs,
+__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, const UhReservoir* __restrict__ spatial_reservoirs,
                                                       Control* ctl, DeviceStats* stats, uint32_t bounce) {
    // c / 255.0f table in LDS: the 12 per-fetch table gathers were texture-addresser traffic (the
    // kernel ran 86 % TA-busy at 2 % VALU, profiles/r01c_*); LDS serves them at no TA cost
