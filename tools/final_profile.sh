@@ -5,9 +5,10 @@ cd $root
 tag=${1:-r02}
 timeout -k 10 300 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tools/profile_bench.sh $tag
-timeout -k 10 300 python bench.py --config 2 --steps 32 --no-cpu-baseline > gpurun_out/${tag}_bench_config2.json 2>/dev/null
-timeout -k 10 300 python bench.py --config 3 --width 3840 --height 2160 --steps 16 --no-cpu-baseline > gpurun_out/${tag}_bench_config3_4k.json 2>/dev/null
-timeout -k 10 300 python bench.py --config 4 --steps 64 --no-cpu-baseline > gpurun_out/${tag}_bench_config4_isosurface.json 2>/dev/null
+# the other configs carry their own bounded CPU-oracle sample
+timeout -k 10 300 python bench.py --config 2 --steps 32 --cpu-sample 1920x1080x4 > gpurun_out/${tag}_bench_config2.json 2>/dev/null
+timeout -k 10 400 python bench.py --config 3 --width 3840 --height 2160 --steps 16 --cpu-sample 3840x2160x1 > gpurun_out/${tag}_bench_config3_4k.json 2>/dev/null
+timeout -k 10 300 python bench.py --config 4 --steps 64 --cpu-sample 1920x1080x8 > gpurun_out/${tag}_bench_config4_isosurface.json 2>/dev/null
 timeout -k 10 300 python bench.py --config 0 --width 256 --height 256 --steps 64 --cpu-sample 256x256x64 > gpurun_out/${tag}_bench_config0_rtiow.json 2>/dev/null
 for w in 2 4 8; do timeout -k 10 200 python bench.py --emulate-world $w --no-cpu-baseline > gpurun_out/${tag}_bench_emulated_world$w.json 2>/dev/null; done
 timeout -k 10 200 python bench.py --force-dist --no-cpu-baseline --steps 16 > gpurun_out/${tag}_bench_force_dist.json 2> gpurun_out/${tag}_bench_force_dist.err
