@@ -98,6 +98,15 @@ struct BuildOutput {
 // traversal stack holds (kMaxTreeLevels).
 void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool balanced = false, uint32_t width = 4);
 
+// Binned-SAH binary tree over `count` boxes (6 floats each: lo xyz, hi xyz) - the top of a device-built tree, over the
+// clusters its bottom-up rounds stopped at (lbvh.hip). Node 0 is the root (count >= 2); a child reference is a node
+// index, or kLeafBit | box index. Serial: meant for thousands of boxes.
+struct TopNode {
+   uint32_t left, right;
+   float half_area;
+};
+void build_sah_top(const float* boxes6, uint32_t count, std::vector<TopNode>& out);
+
 // A traversal pushes at most 3 entries per level; the kernels' stack holds 16 (LDS) + 96 (scratch) entries per ray.
 constexpr uint32_t kTraversalStackEntries = 16 + 96;
 constexpr uint32_t kMaxTreeLevels = kTraversalStackEntries / 3;

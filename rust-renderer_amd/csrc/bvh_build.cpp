@@ -225,6 +225,33 @@ void quantise_node(const NodeW& nd, Node4C& q) {
    }
 }
 
+void build_sah_top(const float* boxes6, uint32_t count, std::vector<TopNode>& out) {
+   out.clear();
+   if (count < 2) return;
+   std::vector<Box> tb(count);
+   std::vector<float> cen(3 * (size_t)count);
+   std::vector<uint32_t> idx(count);
+   for (uint32_t i = 0; i < count; i++) {
+      for (int a = 0; a < 3; a++) {
+         tb[i].lo[a] = boxes6[6 * (size_t)i + a];
+         tb[i].hi[a] = boxes6[6 * (size_t)i + 3 + a];
+         cen[3 * (size_t)i + a] = 0.5f * (tb[i].lo[a] + tb[i].hi[a]);
+      }
+      idx[i] = i;
+   }
+   Builder b(tb, cen, idx);
+   b.build(0, count, 0);
+   // Builder numbers a node before its children (node 0 = root) and gives leaves nodes of their own: renumber the interior ones
+   std::vector<uint32_t> interior(b.nodes.size(), 0);
+   uint32_t n_int = 0;
+   for (size_t i = 0; i < b.nodes.size(); i++)
+      if (b.nodes[i].left >= 0) interior[i] = n_int++;
+   out.resize(n_int);
+   auto ref = [&](int32_t c) { return b.nodes[c].left >= 0 ? interior[c] : (kLeafBit | idx[b.nodes[c].first]); };
+   for (size_t i = 0; i < b.nodes.size(); i++)
+      if (b.nodes[i].left >= 0) out[interior[i]] = TopNode{ref(b.nodes[i].left), ref(b.nodes[i].right), b.nodes[i].box.half_area()};
+}
+
 void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool balanced, uint32_t width) {
    if (width < 2) width = 2;
    if (width > (uint32_t)kMaxWidth) width = kMaxWidth;

@@ -199,6 +199,9 @@ struct uh_ctx {
    // until a mesh is added, so that a rebuild after moved instances or changed parameters uploads nothing
    bool device_build = false, src_valid = false;
    uint32_t device_build_kind = 1;  // 1 = PLOC, 2 = radix tree (lbvh.hip)
+   // PLOC rounds stop at this many clusters; a host SAH tree over them is the top (option "ploc_sah_top", 0 = PLOC to the root).
+   // Config-1 scene: 0 / 1,024 / 8,192 / 131,072 clusters = 21.7 / 20.3 / 20.1 / 19.0 nodes per ray, rebuild 7.7 / 6.0 / 9.4 / 66 ms (host tree: 18.8)
+   uint32_t ploc_sah_top = 1024;
    uint32_t ploc_radius = 8;  // swept 4..64: tree quality flat (21.7-23.0 nodes/ray), build time grows with it (profiles/README.md)
    DevBuf<float> d_src_corners;
    DevBuf<uint32_t> d_src_keys;
@@ -824,6 +827,7 @@ static int build_on_device(uh_ctx* c) {
    la.num_tris = (uint32_t)total;
    la.kind = c->device_build_kind;
    la.ploc_radius = c->ploc_radius;
+   la.sah_top = c->ploc_sah_top;
    la.nodes = reinterpret_cast<uint4*>(c->d_nodes.p);
    la.node_capacity = (uint32_t)node_cap;
    la.tris = c->d_tris.p;
@@ -1333,7 +1337,11 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->time_kernels = value != 0;
    } else if (n == "full_frame_restir")
       c->full_frame_restir = value != 0;
-   else if (n == "ploc_radius") {
+   else if (n == "ploc_sah_top") {
+      if (value < 0 || value > (1 << 20)) return fail(c, UH_ERR_INVALID_ARGUMENT, "ploc_sah_top must be 0..1048576");
+      if (c->ploc_sah_top != (uint32_t)value && c->device_build) c->built = c->topology_valid = false;
+      c->ploc_sah_top = (uint32_t)value;
+   } else if (n == "ploc_radius") {
       if (value < 1 || value > 64) return fail(c, UH_ERR_INVALID_ARGUMENT, "ploc_radius must be 1..64");
       if (c->ploc_radius != (uint32_t)value && c->device_build) c->built = c->topology_valid = false;
       c->ploc_radius = (uint32_t)value;

@@ -198,6 +198,7 @@ struct LbvhArgs {
    uint32_t num_tris;
    uint32_t kind;                // binary tree under the 4-wide collapse: 1 = PLOC (default), 2 = radix tree (Karras)
    uint32_t ploc_radius;         // PLOC: places searched to either side for the nearest neighbour (1..64)
+   uint32_t sah_top;             // PLOC: the rounds stop at this many clusters and a binned-SAH tree over them (host, bvh_build.cpp) is the top; <= 1: PLOC to the root
    uint4* nodes;                 // out: Node4C array (child counts and bases valid, boxes to be refitted)
    uint32_t node_capacity;       // nodes the array can hold
    float4* tris;                 // out: TriPacket array in leaf order (keys; refit writes the geometry)

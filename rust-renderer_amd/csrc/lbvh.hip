@@ -11,7 +11,8 @@
 //      PLOC (default; Meister & Bittner 2018, "Parallel Locally-Ordered Clustering"): clusters (initially the triangles, in
 //      Morton order) look R places (option "ploc_radius") left and right for the neighbour whose union box has the smallest area; mutual
 //      nearest neighbours merge into a node; the survivors are compacted in order (device scan) and the round repeats
-//      until one cluster is left - about 20 rounds. Agglomerative by surface area: close to SAH quality.
+//      until LbvhArgs::sah_top clusters are left (about 12 rounds for 8 K of 262 K); a binned-SAH tree over those clusters,
+//      built on the host in a millisecond or two, is the top of the tree (bvh_build.cpp build_sah_top).
 //      Radix tree (Karras 2012: every internal node finds its range and split from the common-prefix lengths, all nodes
 //      in parallel): one launch, a Morton-order tree, about a quarter more traversal work per ray.
 //   4. collapse to 4-wide nodes, breadth-first, one launch per level: every leaf is one triangle; a node takes the
@@ -23,6 +24,8 @@
 #include <hip/hip_runtime.h>
 
 #include <hipcub/hipcub.hpp>
+
+#include <cstring>
 
 #include "bvh.h"
 #include "device_scan.h"
@@ -350,7 +353,8 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
       const int radius = a.ploc_radius < 1 ? 1 : (a.ploc_radius > (uint32_t)kPlocMaxRadius ? kPlocMaxRadius : (int)a.ploc_radius);
       Box6 *bi = box_a, *bo = box_b;
       uint32_t *ci = cid_a, *co = cid_b;
-      for (int round = 0; m > 1; round++) {
+      const uint32_t stop_at = a.sah_top > 1 ? a.sah_top : 1;
+      for (int round = 0; m > stop_at; round++) {
          if (round > 4096) {
             cleanup();
             return hipErrorUnknown;  // every round merges at least one pair (the globally closest pair is mutual): unreachable
@@ -372,8 +376,37 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
          std::swap(bi, bo);
          std::swap(ci, co);
       }
-      LB_TRY(hipMemcpyAsync(&binary_root, ci, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      LB_TRY(hipStreamSynchronize(stream));
+      if (m > 1) {
+         // SAH top: the surviving clusters' boxes come to the host, a binned-SAH binary tree over them (thousands of boxes:
+         // a millisecond or two) goes back as binary nodes behind the ones the rounds made. Agglomeration is good at the
+         // bottom of the tree and greedy at the top, where a cluster only sees its 2R neighbours in Morton order.
+         std::vector<Box6> hb(m);
+         std::vector<uint32_t> hc(m);
+         uint32_t made = 0;
+         LB_TRY(hipMemcpyAsync(hb.data(), bi, (size_t)m * sizeof(Box6), hipMemcpyDeviceToHost, stream));
+         LB_TRY(hipMemcpyAsync(hc.data(), ci, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+         LB_TRY(hipMemcpyAsync(&made, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+         LB_TRY(hipStreamSynchronize(stream));
+         std::vector<TopNode> top;
+         build_sah_top(&hb[0].lo[0], m, top);
+         if (top.size() != (size_t)m - 1 || (size_t)made + top.size() > (size_t)n) {
+            cleanup();
+            return hipErrorUnknown;
+         }
+         std::vector<uint4> up(top.size());
+         auto ref = [&](uint32_t r) { return (r & kLeafBit) ? hc[r & ~kLeafBit] : made + r; };
+         for (size_t k = 0; k < top.size(); k++) {
+            uint32_t area_bits;
+            std::memcpy(&area_bits, &top[k].half_area, sizeof(area_bits));
+            up[k] = make_uint4(ref(top[k].left), ref(top[k].right), area_bits, 0u);
+         }
+         LB_TRY(hipMemcpyAsync(node2 + made, up.data(), up.size() * sizeof(uint4), hipMemcpyHostToDevice, stream));
+         LB_TRY(hipStreamSynchronize(stream));  // `up` leaves scope
+         binary_root = made;                    // TopNode 0 is the root
+      } else {
+         LB_TRY(hipMemcpyAsync(&binary_root, ci, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+         LB_TRY(hipStreamSynchronize(stream));
+      }
    } else {
       k_lbvh_tree<<<grid, kBlock, 0, stream>>>(keys_out, node2, n);
    }

@@ -195,6 +195,44 @@ int main() {
          errors++;
       }
    }
+   {
+      // build_sah_top (the host half of the device builder): a binary tree over boxes - count - 1 nodes, node 0 the root, every
+      // box in exactly one leaf, every other node referenced exactly once, a node's area that of its leaves' union
+      for (uint32_t count : {2u, 3u, 17u, 1000u, 5000u}) {
+         std::vector<float> boxes;
+         g_state = 4242 + count;
+         for (uint32_t i = 0; i < count; i++) {
+            float c[3] = {rnd() * 30 - 15, rnd() * 10, rnd() * 12 - 6}, e[3] = {rnd(), rnd() * 0.5f, rnd()};
+            for (int a = 0; a < 3; a++) boxes.push_back(c[a] - e[a]);
+            for (int a = 0; a < 3; a++) boxes.push_back(c[a] + e[a]);
+         }
+         if (count == 17) boxes.assign(boxes.size(), 0.25f);  // identical degenerate boxes: the split must still terminate
+         std::vector<TopNode> top;
+         build_sah_top(boxes.data(), count, top);
+         int bad = top.size() != count - 1;
+         std::vector<int> leaf_use(count, 0), node_use(top.size(), 0);
+         for (size_t k = 0; k < top.size() && !bad; k++)
+            for (uint32_t r : {top[k].left, top[k].right}) {
+               if (r & kLeafBit) {
+                  if ((r & ~kLeafBit) >= count) bad = 1; else leaf_use[r & ~kLeafBit]++;
+               } else {
+                  if (r >= top.size() || r == 0) bad = 1; else node_use[r]++;
+               }
+            }
+         for (uint32_t i = 0; i < count; i++) bad |= leaf_use[i] != 1;
+         for (size_t k = 1; k < top.size(); k++) bad |= node_use[k] != 1;
+         if (!bad) {
+            // area of the root = area of the union of all boxes
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t i = 0; i < count; i++)
+               for (int a = 0; a < 3; a++) lo[a] = std::fmin(lo[a], boxes[6 * i + a]), hi[a] = std::fmax(hi[a], boxes[6 * i + 3 + a]);
+            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            bad |= top[0].half_area != dx * dy + dy * dz + dz * dx;
+         }
+         std::printf("SAH top over %u boxes: %zu nodes, %s\n", count, top.size(), bad ? "FAILED" : "ok");
+         errors += bad;
+      }
+   }
    std::printf(errors ? "BVH CHECK FAILED (%d)\n" : "BVH CHECK OK\n", errors);
    return errors ? 1 : 0;
 }

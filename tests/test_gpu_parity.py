@@ -528,10 +528,15 @@ def _single_triangle_scene():
     return Scene("one", [(Model([m], []), None)], [(0.0, 0.0, 3.0)], Camera((0, 0, 4), (0, 0, 0), 60.0, 1.0, 0.01, 100.0))
 
 
-@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("kind", [1, 2, (1, 0), (1, 24)])
 @pytest.mark.parametrize("which", ["cornell", "atrium", "torture", "soup", "one", "empty"])
 def test_device_build_equals_host_build(cornell, atrium, which, kind):
-    """option device_build: 1 = PLOC, 2 = radix tree (csrc/lbvh.hip)"""
+    """option device_build: 1 = PLOC with a host SAH tree over the last ploc_sah_top clusters (default 1024: on these small
+    scenes the rounds never start and the whole binary tree is the SAH top; (1, 0) = PLOC to the root; (1, 24) = both halves),
+    2 = radix tree (csrc/lbvh.hip)"""
+    sah_top = None
+    if isinstance(kind, tuple):
+        kind, sah_top = kind
     from rust_renderer_amd.camera import Camera
     from rust_renderer_amd.scenes import Model, Scene
     scene = {"cornell": cornell, "atrium": atrium, "torture": torture_scene(), "soup": _soup_scene(11), "one": _single_triangle_scene(),
@@ -540,6 +545,8 @@ def test_device_build_equals_host_build(cornell, atrium, which, kind):
     host = scene.upload(rr.Renderer(W, H))
     dev = rr.Renderer(W, H)
     dev.set_option("device_build", kind)
+    if sah_top is not None:
+        dev.set_option("ploc_sah_top", sah_top)
     scene.upload(dev)
     assert dev.get_stats().bvh_triangles == host.get_stats().bvh_triangles == scene.num_triangles
     rays = random_rays(((-3, -1, -3), (3, 3, 3)) if which != "atrium" else ((-14, 0, -7), (14, 10, 7)), 30000, seed=21)
