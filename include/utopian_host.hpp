@@ -410,18 +410,21 @@ class Application {
       Mat4 pv = proj * view;                                    // main.rs:545-546, AFTER the frame
       std::memcpy(view_data.prev_frame_projection_view, pv.m, 64);
    }
-   // `count` frames of a static camera. The path-tracing pass alone is handed to the library in one
-   // call (uh_render_frames batches frames into shared wavefronts and keeps several in flight);
-   // anything involving the ReSTIR chain runs frame by frame through the graph.
+   // `count` frames of a static camera, handed to the library in one call (uh_render_frames batches frames into shared
+   // wavefronts and keeps several in flight). With the reservoir passes the first frame goes through the graph alone: it is
+   // the one that may still see another prev_frame_projection_view (main.rs:545-546 sets it AFTER a frame).
    void frames(uint32_t count, bool path_tracing_only) {
-      const bool uses_reservoirs = view_data.lights_enabled == 1 && view_data.use_ris_light_sampling == 1;
-      if (!path_tracing_only || uses_reservoirs || count < 2) {
+      if (!path_tracing_only && count > 0) {
+         frame();
+         count--;
+      }
+      if (count < 2) {
          for (uint32_t i = 0; i < count; i++) frame();
          return;
       }
       view_data.num_lights = renderer_.get_num_lights();
       view_data.total_samples += view_data.samples_per_frame;
-      renderer_.check(uh_render_frames(renderer_.handle(), &view_data, UH_PASS_REFERENCE_PT, count), "render_frames");
+      renderer_.check(uh_render_frames(renderer_.handle(), &view_data, path_tracing_only ? UH_PASS_REFERENCE_PT : UH_PASS_ALL, count), "render_frames");
       view_data.total_samples += (count - 1) * view_data.samples_per_frame;
    }
    Graph graph;

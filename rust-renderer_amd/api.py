@@ -525,16 +525,18 @@ class FrameLoop:
         v.prev_frame_projection_view[:] = cam.to_glam((proj @ view).astype(np.float32)).tolist()
 
     def frames(self, count, pass_mask=PASS_ALL):
-        """`count` frames of the loop. The path-tracing pass of a static camera is handed to
-        uh_render_frames in one call (the library batches frames into shared wavefronts); anything
-        involving the ReSTIR chain runs frame by frame."""
-        from .types import PASS_REFERENCE_PT
+        """`count` frames of the loop with the camera at rest. Everything that includes the path-tracing pass is handed to
+        uh_render_frames in one call (the library batches frames into shared wavefronts: 4 x world for the path tracer alone,
+        4 when the reservoir passes run too). The first frame of a run that includes the temporal pass goes alone:
+        it is the one that may still see another prev_frame_projection_view."""
+        from .types import PASS_REFERENCE_PT, PASS_TEMPORAL_REUSE
 
         v = self.view
-        batchable = (
-            self.renderer.backend.startswith("hip") and count > 1 and pass_mask == PASS_REFERENCE_PT
-            and not (v.lights_enabled == 1 and v.use_ris_light_sampling == 1)
-        )
+        batchable = self.renderer.backend.startswith("hip") and count > 1 and (pass_mask & PASS_REFERENCE_PT)
+        if batchable and (pass_mask & PASS_TEMPORAL_REUSE):
+            self.frame(pass_mask)
+            count -= 1
+            batchable = count > 1
         if not batchable:
             for _ in range(count):
                 self.frame(pass_mask)

@@ -147,6 +147,11 @@ struct Slot {
    }
 };
 
+// frames of the reservoir passes one uh_render_frames wavefront carries at most, and the ring of spatial buffers that
+// lets the next batch's chains run beside the current wavefront (two batches + the history slot)
+constexpr uint32_t kRestirBatch = 4;
+constexpr int kSpatialRing = 2 * (int)kRestirBatch + 1;
+
 struct uh_ctx {
    int device = 0;
    Slot slots[kMaxSlots];
@@ -156,14 +161,16 @@ struct uh_ctx {
    uint32_t shard_cap = 0;
    hipEvent_t last_acc = nullptr;     // ev_acc of the most recent frame (accumulation order)
    // G-buffer cast + reservoir passes run in call order on their own stream, beside path-tracing frames in flight.
-   // The path tracer of frame f reads spatial buffer `spatial_cur` while frame f+1's passes already run: its
-   // temporal pass reads the same buffer and its spatial pass writes the other one (after the last path-tracing
-   // frame that read THAT one has finished: spatial_reader[]).
+   // spatial_reuse_reservoirs is a RING of kSpatialRing buffers: the path tracer of frame f reads slot `spatial_cur` while
+   // frame f+1's passes already run - its temporal pass reads the same slot and its spatial pass writes the next one, after
+   // the last path-tracing wavefront that read THAT one has finished (spatial_reader[]). A batch of B static-camera frames
+   // runs its B reservoir chains back to back (slots cur+1 .. cur+B) and then ONE path-tracing wavefront in which the
+   // paths of frame f sample from slot cur+1+f (FrameParams::spatial_of): the ring holds two batches and the history.
    hipStream_t restir_stream = nullptr;
    hipEvent_t ev_restir = nullptr, rs_start = nullptr, rs_stop = nullptr;
    bool restir_recorded = false;
    int spatial_cur = 0;
-   hipEvent_t spatial_reader[2] = {nullptr, nullptr};
+   hipEvent_t spatial_reader[kSpatialRing] = {};
    hipEvent_t t_start = nullptr, t_stop = nullptr;  // bracket of the last uh_render_frame call (last_frame_ms)
    Slot* last_slot = nullptr;
    hipStream_t& stream = slots[0].stream;  // slot 0 also serves every non-frame operation
@@ -214,7 +221,7 @@ struct uh_ctx {
    // frame-persistent per-pixel images (graph resources of renderers/mod.rs:199-244)
    DevBuf<float4> accumulation, gbuffer;
    DevBuf<uchar4> output;
-   DevBuf<UhReservoir> reservoirs[3], spatial_alt;
+   DevBuf<UhReservoir> reservoirs[3], spatial_ring;  // ring slot 0 = reservoirs[2], slots 1.. = spatial_ring (allocated by the first reservoir pass)
    DevBuf<float4> gb_ray_o, gb_ray_d, gb_hit;  // scratch of the G-buffer cast (allocated by the first G-buffer pass)
    DevBuf<DeviceStats> dstats;
    Images im{};
@@ -398,7 +405,7 @@ void uh_destroy(uh_ctx* c) {
          if (ev) (void)hipEventDestroy(ev);
       (void)hipStreamDestroy(c->restir_stream);
    }
-   c->spatial_alt.release();
+   c->spatial_ring.release();
    c->gb_ray_o.release();
    c->gb_ray_d.release();
    c->gb_hit.release();
@@ -1042,11 +1049,14 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
    // the path tracer reads spatial_reuse_reservoirs when it samples lights from them (rgen:98)
    const bool reads_reservoirs = (pass_mask & UH_PASS_REFERENCE_PT) && fp.lights_enabled == 1 && fp.use_ris == 1;
 
-   if (batch > 1 && (restir_frame || reads_reservoirs || !(pass_mask & UH_PASS_REFERENCE_PT)))
-      return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: only the path-tracing pass without reservoir light sampling can be batched");
+   if (batch > 1 && !(pass_mask & UH_PASS_REFERENCE_PT)) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: a batch needs the path-tracing pass");
+   if (batch > kRestirBatch && restir_frame) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: more reservoir-pass frames in one batch than the spatial ring holds");
    const size_t npix = (size_t)c->W * c->H;
-   auto spatial_buf = [&](int which) { return which ? c->spatial_alt.p : c->reservoirs[2].p; };
+   auto spatial_buf = [&](int slot) { return slot ? c->spatial_ring.p + (size_t)(slot - 1) * npix : c->reservoirs[2].p; };
    c->t_start = c->t_stop = nullptr;
+   // the slot each frame of the batch samples lights from (rgen:98): without reservoir passes in this call, the current one
+   int read_slot[kMaxBatchFrames];
+   for (uint32_t f = 0; f < batch; f++) read_slot[f] = c->spatial_cur;
 
    if (restir_frame) {
       if (!c->restir_stream) {
@@ -1054,47 +1064,53 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
          HIP_TRY(c, hipEventCreateWithFlags(&c->ev_restir, hipEventDisableTiming));
          HIP_TRY(c, hipEventCreate(&c->rs_start));
          HIP_TRY(c, hipEventCreate(&c->rs_stop));
-         HIP_TRY(c, c->spatial_alt.alloc(npix));
-         // both spatial buffers start from the same (zeroed or uh_write_reservoirs) history
-         HIP_TRY(c, hipStreamSynchronize(c->stream));
-         HIP_TRY(c, hipMemcpy(c->spatial_alt.p, c->reservoirs[2].p, npix * sizeof(UhReservoir), hipMemcpyDeviceToDevice));
+         HIP_TRY(c, c->spatial_ring.alloc((size_t)(kSpatialRing - 1) * npix));  // every slot is written before it is read
+         HIP_TRY(c, hipStreamSynchronize(c->stream));  // slot 0 (zeroed at creation or uh_write_reservoirs) is the history
       }
       LaunchCfg rc = cfg(c);
       rc.stream = c->restir_stream;
       HIP_TRY(c, hipEventRecord(c->rs_start, c->restir_stream));
       c->t_start = c->rs_start;
-      Images im = c->im;  // reservoirs[2] = the current spatial buffer
-      im.prev_spatial = spatial_buf(c->spatial_cur);
-      if (pass_mask & UH_PASS_GBUFFER) {
-         if (!c->gb_hit.p) {
-            HIP_TRY(c, c->gb_ray_o.alloc(npix));
-            HIP_TRY(c, c->gb_ray_d.alloc(npix));
-            HIP_TRY(c, c->gb_hit.alloc(npix));
+      for (uint32_t f = 0; f < batch; f++) {
+         FrameParams ff = fp;  // frame f of the batch: its own RNG frame number (the reservoir kernels read nothing else per frame)
+         ff.frame_number = fp.frame_numbers[f];
+         ff.total_samples = fp.total_samples_of[f];
+         Images im = c->im;
+         im.prev_spatial = spatial_buf(c->spatial_cur);
+         im.reservoirs[2] = spatial_buf(c->spatial_cur);
+         if (pass_mask & UH_PASS_GBUFFER) {
+            if (!c->gb_hit.p) {
+               HIP_TRY(c, c->gb_ray_o.alloc(npix));
+               HIP_TRY(c, c->gb_ray_d.alloc(npix));
+               HIP_TRY(c, c->gb_hit.alloc(npix));
+            }
+            PathState gps;
+            std::memset(&gps, 0, sizeof(gps));
+            gps.ray_o = c->gb_ray_o.p;
+            gps.ray_d = c->gb_ray_d.p;
+            gps.hit = c->gb_hit.p;
+            launch_gbuffer(rc, ff, c->scene, gps, im, nullptr, c->dstats.p);
          }
-         PathState gps;
-         std::memset(&gps, 0, sizeof(gps));
-         gps.ray_o = c->gb_ray_o.p;
-         gps.ray_d = c->gb_ray_d.p;
-         gps.hit = c->gb_hit.p;
-         launch_gbuffer(rc, fp, c->scene, gps, im, nullptr, c->dstats.p);
-      }
-      if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(rc, fp, im);
-      if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(rc, fp, c->scene, im);
-      if (pass_mask & UH_PASS_TEMPORAL_REUSE) launch_temporal_reuse(rc, fp, c->scene, im);
-      if (pass_mask & UH_PASS_SPATIAL_REUSE) {
-         // writes the OTHER spatial buffer: the path-tracing frame that still reads the current one keeps going
-         const int nxt = c->spatial_cur ^ 1;
-         if (c->spatial_reader[nxt]) HIP_TRY(c, hipStreamWaitEvent(c->restir_stream, c->spatial_reader[nxt], 0));
-         im.reservoirs[2] = spatial_buf(nxt);
-         launch_spatial_reuse(rc, fp, c->scene, im);
-         c->spatial_cur = nxt;
-         c->im.reservoirs[2] = spatial_buf(nxt);
+         if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(rc, ff, im);
+         if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(rc, ff, c->scene, im);
+         if (pass_mask & UH_PASS_TEMPORAL_REUSE) launch_temporal_reuse(rc, ff, c->scene, im);
+         if (pass_mask & UH_PASS_SPATIAL_REUSE) {
+            // writes the NEXT slot of the ring: the path-tracing wavefronts that still read the current one keep going
+            const int nxt = (c->spatial_cur + 1) % kSpatialRing;
+            if (c->spatial_reader[nxt]) HIP_TRY(c, hipStreamWaitEvent(c->restir_stream, c->spatial_reader[nxt], 0));
+            im.reservoirs[2] = spatial_buf(nxt);
+            launch_spatial_reuse(rc, ff, c->scene, im);
+            c->spatial_cur = nxt;
+            c->im.reservoirs[2] = spatial_buf(nxt);
+         }
+         read_slot[f] = c->spatial_cur;
       }
       HIP_TRY(c, hipEventRecord(c->ev_restir, c->restir_stream));
       c->restir_recorded = true;
       HIP_TRY(c, hipEventRecord(c->rs_stop, c->restir_stream));
       c->t_stop = c->rs_stop;
    }
+   for (uint32_t f = 0; f < kMaxBatchFrames; f++) fp.spatial_of[f] = spatial_buf(read_slot[f < batch ? f : 0]);
 
    if (pass_mask & UH_PASS_REFERENCE_PT) {
       const uint32_t si = c->next_slot;
@@ -1108,7 +1124,8 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
       if (!c->t_start) c->t_start = s.frame_start;
       st = enqueue_path_trace(c, s, fp);
       if (st != UH_OK) return st;
-      if (reads_reservoirs) c->spatial_reader[c->spatial_cur] = s.ev_acc;
+      if (reads_reservoirs)
+         for (uint32_t f = 0; f < batch; f++) c->spatial_reader[read_slot[f]] = s.ev_acc;
       HIP_TRY(c, hipEventRecord(s.frame_stop, s.stream));
       c->t_stop = s.frame_stop;
       c->last_slot = &s;
@@ -1130,9 +1147,11 @@ int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mas
    // share of it (swept on MI355X for 1, 4 and 8 ranks' shares: tools/sweep_world8.sh, profiles/README.md)
    uint32_t batch = c->batch_frames ? c->batch_frames : 4 * (c->tp_world ? c->tp_world : 1);
    if (batch > kMaxBatchFrames) batch = kMaxBatchFrames;
+   if ((pass_mask & UH_PASS_RESTIR) && batch > kRestirBatch) batch = kRestirBatch;
+   if (!(pass_mask & UH_PASS_REFERENCE_PT)) batch = 1;  // reservoir passes alone: frame by frame
    // create every frames-in-flight slot now: the first call (an application's first frames, a benchmark's
    // warm-up) pays for the allocations and stream creation, not whichever later wavefront first reaches a slot
-   if (!(pass_mask & UH_PASS_RESTIR) && (pass_mask & UH_PASS_REFERENCE_PT))
+   if (pass_mask & UH_PASS_REFERENCE_PT)
       for (uint32_t i = 0; i < (c->frames_in_flight ? c->frames_in_flight : 1); i++)
          if (int st = ensure_slot(c, i, batch)) return st;
    while (done < count) {

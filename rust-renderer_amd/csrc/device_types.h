@@ -100,6 +100,8 @@ struct FrameParams {
    uint32_t batch_frames;
    uint32_t frame_numbers[kMaxBatchFrames];
    uint32_t total_samples_of[kMaxBatchFrames];
+   // spatial_reuse_reservoirs of each frame of the batch (rgen:98; a ring in the context: context.hip render_batch)
+   const UhReservoir* spatial_of[kMaxBatchFrames];
    float inv_view[16], inv_proj[16], prev_pv[16];
    float sun_dir[3];  // normalize(view.sun_dir), computed on the host with the contract's normalize
    uint32_t W, H, frame_number;

@@ -855,8 +855,7 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
    return I * eta - N * (eta * dn + sqrtf(k));
 }
 
-__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, const UhReservoir* __restrict__ spatial_reservoirs,
-                                                      Control* ctl, DeviceStats* stats, uint32_t bounce) {
+__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
    // c / 255.0f table in LDS: the 12 per-fetch table gathers were texture-addresser traffic (the
    // kernel ran 86 % TA-busy at 2 % VALU, profiles/r01c_*); LDS serves them at no TA cost
    __shared__ float s_lut[256];
@@ -980,7 +979,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
                uint32_t px = pix % fp.W;
                bool use_reservoir = (px > fp.W / 2 || fp.full_frame_restir) && fp.use_ris == 1;  // rgen:87
                if (use_reservoir) {
-                  UhReservoir rs = spatial_reservoirs[pix];                            // rgen:98
+                  UhReservoir rs = fp.spatial_of[id / (fp.W * fp.H)][pix];             // rgen:98 (the path's own frame of the batch)
                   light_sample_weight = rs.W_X;
                   total_weights = rs.W_sum;
                   light_index = rs.Y;
@@ -1368,7 +1367,7 @@ void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathStat
 
 void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
                       DeviceStats* stats, uint32_t bounce) {
-   k_shade_hit<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, im.reservoirs[2], ctl, stats, bounce);
+   k_shade_hit<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce);
 }
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,

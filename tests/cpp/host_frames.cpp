@@ -87,7 +87,10 @@ int main(int argc, char** argv) {
          app.graph.clear();
          app.graph.add_pass("reference_pt_pass", [pass_mask](Renderer& r, const ViewUniformData& v) { r.check(uh_render_frame(r.handle(), &v, pass_mask), "render_func"); });
       }
-      for (uint32_t i = 0; i < frames; i++) app.frame();
+      // the first half frame by frame through the graph, the rest as one static-camera run (uh_render_frames batches it)
+      const uint32_t by_graph = frames / 2;
+      for (uint32_t i = 0; i < by_graph; i++) app.frame();
+      app.frames(frames - by_graph, pass_mask == UH_PASS_REFERENCE_PT);
       std::vector<float> acc = renderer.read_accumulation();
       std::ofstream out(argv[2], std::ios::binary);
       out.write(reinterpret_cast<const char*>(acc.data()), (std::streamsize)(acc.size() * 4));

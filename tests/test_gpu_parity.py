@@ -236,17 +236,64 @@ def test_batched_frames_with_tile_partition(cornell):
     assert np.array_equal(ref.read_accumulation().view(np.uint32), alt.read_accumulation().view(np.uint32))
 
 
-def test_restir_frames_cannot_be_batched(atrium):
-    r = atrium.upload(rr.Renderer(64, 36))
-    r.set_option("batch_frames", 4)
-    v = atrium.make_view(64, 36)
-    v.total_samples = 1
-    with pytest.raises(rr.UtopianError, match="batched"):
-        r.render_frames(v, rr.PASS_ALL, 4)
-    # the host loop falls back to frame-by-frame for the ReSTIR chain
-    loop = rr.FrameLoop(r, atrium.make_view(64, 36))
-    loop.frames(3, rr.PASS_ALL)
-    assert loop.view.total_samples == 3 and (r.read_reservoirs(2)["M"] > 1).any()
+@pytest.mark.parametrize("batch,in_flight,frames,split", [(4, 2, 9, 0), (3, 3, 11, 1), (0, 4, 14, 0), (2, 1, 5, 1)])
+def test_batched_restir_frames_equal_frame_by_frame(atrium, batch, in_flight, frames, split):
+    """reservoir passes + path tracer of a static camera through uh_render_frames: B reservoir chains back to back (a ring of
+    spatial buffers), then one wavefront whose paths sample from their own frame's spatial reservoirs - bit for bit the
+    frame-by-frame protocol: radiance, all three reservoir buffers, ray counts; also when continued either way"""
+    W, H = 96, 54
+    kw = dict(use_ris_light_sampling=1)
+    ref = atrium.upload(rr.Renderer(W, H))
+    ref.set_option("frames_in_flight", 1)
+    ref.set_option("full_frame_restir", split)
+    loop = run_frames(ref, atrium, W, H, frames, rr.PASS_ALL, **kw)
+    alt = atrium.upload(rr.Renderer(W, H))
+    alt.set_option("batch_frames", batch)
+    alt.set_option("frames_in_flight", in_flight)
+    alt.set_option("full_frame_restir", split)
+    loop2 = rr.FrameLoop(alt, atrium.make_view(W, H, **kw))
+    loop2.frames(frames, rr.PASS_ALL)
+    assert loop2.view.total_samples == loop.view.total_samples == frames
+    assert (ref.read_reservoirs(2)["M"] > 1).any()
+    def same():
+        assert np.array_equal(ref.read_accumulation().view(np.uint32), alt.read_accumulation().view(np.uint32))
+        for which in range(3):
+            assert np.array_equal(ref.read_reservoirs(which), alt.read_reservoirs(which)), which
+        assert list(ref.get_stats().rays) == list(alt.get_stats().rays)
+    same()
+    loop.frame(rr.PASS_ALL)
+    loop2.frame(rr.PASS_ALL)
+    same()
+    for _ in range(3):
+        loop.frame(rr.PASS_ALL)
+    loop2.frames(3, rr.PASS_ALL)
+    same()
+
+
+def test_reservoir_passes_alone_run_frame_by_frame(atrium):
+    """uh_render_frames without the path-tracing pass: nothing to batch, the chains run one after the other"""
+    W, H = 64, 36
+    mask = rr.PASS_ALL & ~rr.PASS_REFERENCE_PT
+    ref = atrium.upload(rr.Renderer(W, H))
+    loop = run_frames(ref, atrium, W, H, 4, mask)
+    alt = atrium.upload(rr.Renderer(W, H))
+    alt.set_option("batch_frames", 4)
+    loop2 = rr.FrameLoop(alt, atrium.make_view(W, H))
+    for k in range(2):  # two calls of two frames: the camera is at rest, so prev_frame_projection_view only changes after the first
+        v = loop2.view
+        v.num_lights = alt.get_num_lights()
+        v.total_samples += 1
+        if k == 0:
+            alt.render_frames(v, mask, 1)
+            loop2.end_frame()
+            v.total_samples += 1
+            alt.render_frames(v, mask, 1)
+        else:
+            alt.render_frames(v, mask, 2)
+            v.total_samples += 1
+    assert loop2.view.total_samples == loop.view.total_samples == 4
+    for which in range(3):
+        assert np.array_equal(ref.read_reservoirs(which), alt.read_reservoirs(which)), which
 
 
 @pytest.mark.parametrize("W,H,world,tile,batch", [(97, 61, 1, 64, 3), (97, 61, 3, 20, 4), (65, 3, 2, 7, 2), (1, 1, 1, 64, 2), (130, 70, 8, 64, 8)])
