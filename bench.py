@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone", action="store_true", help="skip the untimed standalone-kernel calibration frames (profiling runs: every launch in the trace is then in the timed regime)")
-    ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only rank 0's tiles of an N-rank partition (what one rank sees at --gpus N)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only one rank's tiles of an N-rank partition (what one rank sees at --gpus N)")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="the rank --emulate-world stands in for")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=3")
     ap.add_argument("--spp", type=int, default=1, help="samples_per_frame (reference default 1, UI maximum 10); SURVEY 8d also asks for 64 spp as 8 frames x 8")
@@ -114,7 +115,7 @@ def main():
     if use_dist:
         renderer.set_tile_partition(rank, world, args.tile)
     elif args.emulate_world > 1:
-        renderer.set_tile_partition(0, args.emulate_world, args.tile)
+        renderer.set_tile_partition(args.emulate_rank % args.emulate_world, args.emulate_world, args.tile)
     pass_mask = rr.PASS_ALL if args.config == 2 else rr.PASS_REFERENCE_PT
     view = scene.make_view(W, H, samples_per_frame=args.spp) if args.spp != 1 else scene.make_view(W, H)
     loop = rr.FrameLoop(renderer, view)
