@@ -228,7 +228,7 @@ struct uh_ctx {
 
    // options / stats
    bool count_visits = false, time_kernels = false, full_frame_restir = false, raw_visit_counts = false;
-   int closest_variant = 3, shadow_variant = 3;  // refill kernels, threshold 8 idle lanes (0 = batch kernels)
+   int closest_variant = 1, shadow_variant = 1;  // refill kernels (0 = batch kernels)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
    float ms_by_kind[3] = {0, 0, 0};
@@ -1378,7 +1378,7 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->next_slot = 0;
    }
    else if (n == "trace_variant" || n == "closest_variant" || n == "shadow_variant") {
-      if (value < 0 || value > 4) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0..4");
+      if (value < 0 || value > 1) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0 (batch kernels) or 1 (refill kernels)");
       if (n != "shadow_variant") c->closest_variant = value;
       if (n != "closest_variant") c->shadow_variant = value;
    } else if (n == "trace_blocks_per_cu" || n == "closest_blocks_per_cu" || n == "shadow_blocks_per_cu") {

@@ -144,10 +144,9 @@ struct LaunchCfg {
    uint32_t num_cus;
    uint32_t closest_blocks_per_cu, shadow_blocks_per_cu;
    bool count_visits;
-   // traversal kernel variants (options "closest_variant" / "shadow_variant"; bit-identical in results):
-   // 0 = batch kernel (a wave walks 64 rays to the end of the slowest); 1..4 = persistent waves whose idle lanes
-   // take the next ray from an LDS pool (kernels.hip "Ray replacement"): 1 = chained node + triangle step, refill at
-   // 8 idle lanes; 2 / 3 / 4 = one load phase per iteration, refill at 4 / 8 / 16 idle lanes. 3 is the default.
+   // traversal kernels (options "closest_variant" / "shadow_variant"; bit-identical in results): 0 = batch kernel (a wave
+   // walks 64 rays to the end of the slowest - the baseline), anything else = persistent waves whose idle lanes take the
+   // next ray from an LDS pool (kernels.hip "Ray replacement"), the default
    int closest_variant, shadow_variant;
    bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
 };

@@ -390,8 +390,10 @@ struct Feeder {
 };
 
 // what a traversal wave does per iteration for its idle lanes; returns false when the wave is out of work.
-// kRefill: idle lanes that make a refill worth its instructions (every lane that ends costs a pool read + trav_init)
-template <int NA, int kRefill, typename SrcFn, typename TakeFn>
+// kRefill: idle lanes that make a refill worth its instructions (every lane that ends costs a pool read + trav_init);
+// 4 / 8 / 16 measured 3.10 / 3.10 / 3.15 ms per frame (profiles/README.md)
+constexpr int kRefill = 8;
+template <int NA, typename SrcFn, typename TakeFn>
 __device__ __forceinline__ bool refill_lanes(Feeder<NA>& f, const RaySource& src, RayPool<NA>& pool, bool lane_idle, SrcFn&& source_of, TakeFn&& take) {
    // exit condition every wave reaches whatever the data: a traversal step visits a node or a triangle once, so a
    // wave that has run this many iterations is not walking a tree any more (corrupt references) - leave
@@ -413,49 +415,31 @@ __device__ __forceinline__ bool refill_lanes(Feeder<NA>& f, const RaySource& src
    return true;
 }
 
-// one step of a lane's traversal; returns true when the ray has ended.
-// PHASED = false: node step, then - for a lane that stands at a leaf, also one the node step just sent there - one
-//   triangle: two dependent global round trips per wave iteration (some lane is at a leaf in nearly every one).
-// PHASED = true: ONE load phase per iteration - a lane at a node loads its node, a lane at a leaf its next triangle,
-//   all loads are in flight together, then both groups compute. A lane that reaches a leaf tests it an iteration
-//   later, but the wave waits for memory once per iteration instead of twice.
-template <bool ANY, bool COUNT, bool PHASED>
+// one step of a lane's traversal; returns true when the ray has ended. ONE load phase per iteration: a lane at a node loads
+// its node, a lane at a leaf its triangle, then both groups compute. A lane that reaches a leaf tests it an iteration later,
+// but the wave waits for memory once per iteration (a chained node -> triangle step, two dependent round trips per
+// iteration, measured 3.21 against 3.10 ms per frame: profiles/README.md).
+template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const float4* __restrict__ tris, Trav& t, uint32_t* lds_col, uint32_t* spill, bool& occluded,
                                           uint32_t& n_nodes, uint32_t& n_tris) {
-   if (PHASED) {
-      const bool at_node = !(t.cur & kLeafBit);
-      const uint32_t packet = t.cur & ~kLeafBit;
-      // nodes and triangle packets are both three-quad records: ONE address and ONE set of loads for the whole wave.
-      // (Written as two branches, each with its own loads, the compiler gave the second branch's address the first
-      // branch's destination registers and made it wait for them: the two groups' loads ran one after the other.)
-      const uint4* rec = at_node ? nodes + kNodeStride16 * (size_t)packet : (const uint4*)tris + kTriStride16 * (size_t)packet;
-      uint4 w0 = rec[0], w1 = rec[1], w2 = rec[2];
-      // the packet's last two dwords are padding: without this the compiler loads them in the node branch only (a fourth load)
-      asm volatile("" : "+v"(w2.z), "+v"(w2.w));
-      if (at_node) {
-         if (COUNT) n_nodes++;
-         node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
-      } else {
-         if (COUNT) n_tris++;
-         const float4 ta = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
-         const float4 tb = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
-         const float4 tc = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
-         if (tri_compute<ANY>(ta, tb, tc, packet, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
-            occluded = true;
-            t.cur = kEmptyRef;
-         } else {
-            t.cur = trav_pop(t, lds_col, spill);
-         }
-      }
-      return t.cur == kEmptyRef;
-   }
-   if (!(t.cur & kLeafBit)) {
+   const bool at_node = !(t.cur & kLeafBit);
+   const uint32_t packet = t.cur & ~kLeafBit;
+   // nodes and triangle packets are both three-quad records: ONE address and ONE set of loads for the whole wave.
+   // (Written as two branches, each with its own loads, the compiler gave the second branch's address the first
+   // branch's destination registers and made it wait for them: the two groups' loads ran one after the other.)
+   const uint4* rec = at_node ? nodes + kNodeStride16 * (size_t)packet : (const uint4*)tris + kTriStride16 * (size_t)packet;
+   uint4 w0 = rec[0], w1 = rec[1], w2 = rec[2];
+   // the packet's last two dwords are padding: without this the compiler loads them in the node branch only (a fourth load)
+   asm volatile("" : "+v"(w2.z), "+v"(w2.w));
+   if (at_node) {
       if (COUNT) n_nodes++;
-      node_step<ANY>(nodes, t, lds_col, spill);
-   }
-   if (t.cur != kEmptyRef && (t.cur & kLeafBit)) {
+      node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
+   } else {
       if (COUNT) n_tris++;
-      if (tri_test<ANY>(tris, t.cur & ~kLeafBit, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
+      const float4 ta = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
+      const float4 tb = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
+      const float4 tc = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
+      if (tri_compute<ANY>(ta, tb, tc, packet, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
          occluded = true;
          t.cur = kEmptyRef;
       } else {
@@ -469,7 +453,7 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
 // trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes.
 // Reads the bounce's ray queue, writes hit[path] = (t, u, v, packet) or packet = kEmptyRef.
 // ------------------------------------------------------------------------------------------
-template <bool COUNT, int kRefill, bool PHASED>
+template <bool COUNT>
 __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const uint32_t* __restrict__ queue_base, const float4* __restrict__ ray_o,
                                                                const float4* __restrict__ ray_d, float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl,
                                                                DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
@@ -508,10 +492,10 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
       id = pool.id[slot];
       trav_init(t, pool.v[0][slot], pool.v[1][slot], INFINITY);
    };
-   while (refill_lanes<2, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
+   while (refill_lanes<2>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<false, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris))
+         if (trav_step<false, COUNT>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris))
             st_stream(hit_out + id, make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx)));
       }
    }
@@ -599,7 +583,7 @@ __device__ __forceinline__ ShadowRay make_shadow_ray(const SceneDev& sc, const F
    return s;
 }
 
-template <bool COUNT, bool LIGHT, int kRefill, bool PHASED>
+template <bool COUNT, bool LIGHT>
 __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                                                               uint32_t cursor_slot) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
@@ -636,10 +620,10 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
       lit = s.lit;
       trav_init(t, s.ro, s.rd, s.tlimit);
    };
-   while (refill_lanes<3, kRefill>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
+   while (refill_lanes<3>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<true, COUNT, PHASED>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) st_stream(ps.rad + id, lit);
+         if (trav_step<true, COUNT>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) st_stream(ps.rad + id, lit);
       }
    }
    if (COUNT) {
@@ -1324,8 +1308,7 @@ void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState&
 }
 
 // closest-hit traversal over a sharded queue of path ids (queue != null) or over n raw rays (queue == null).
-// Variant 0 = batch kernel; 1 = refill kernel (threshold 8 idle lanes) with chained node + triangle steps;
-// 2 / 3 / 4 = refill kernel with one load phase per iteration, threshold 4 / 8 (default) / 16 idle lanes.
+// Variant 0 = batch kernel (the baseline), anything else = refill kernel (the default).
 static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, const uint32_t* queue, const float4* ray_o, const float4* ray_d, float4* hit,
                            uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag) {
 #define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, queue, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
@@ -1334,22 +1317,13 @@ static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, co
       UH_CLOSEST((k_trace_closest_batch<false, true>));
       return;
    }
-   switch (c.closest_variant) {
-      case 0:
-         if (count) UH_CLOSEST((k_trace_closest_batch<true, false>));
-         else UH_CLOSEST((k_trace_closest_batch<false, false>));
-         break;
-#define UH_CLOSEST_RF(K, TOP)                                        \
-   do {                                                              \
-      if (count) UH_CLOSEST((k_trace_closest<true, K, TOP>));        \
-      else UH_CLOSEST((k_trace_closest<false, K, TOP>));             \
-   } while (0)
-      case 1: UH_CLOSEST_RF(8, false); break;
-      case 2: UH_CLOSEST_RF(4, true); break;
-      case 4: UH_CLOSEST_RF(16, true); break;
-      default: UH_CLOSEST_RF(8, true); break;
+   if (c.closest_variant == 0) {
+      if (count) UH_CLOSEST((k_trace_closest_batch<true, false>));
+      else UH_CLOSEST((k_trace_closest_batch<false, false>));
+   } else {
+      if (count) UH_CLOSEST((k_trace_closest<true>));
+      else UH_CLOSEST((k_trace_closest<false>));
    }
-#undef UH_CLOSEST_RF
 #undef UH_CLOSEST
 }
 
@@ -1373,32 +1347,21 @@ void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev&
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
                          uint32_t bounce, uint32_t cursor_slot, bool light) {
 #define UH_SHADOW(KERNEL) KERNEL<<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot)
-#define UH_SHADOW_RF(K, TOP)                                             \
-   do {                                                             \
-      if (light) {                                                  \
-         if (c.count_visits) UH_SHADOW((k_trace_shadow<true, true, K, TOP>));    \
-         else UH_SHADOW((k_trace_shadow<false, true, K, TOP>));          \
-      } else {                                                      \
-         if (c.count_visits) UH_SHADOW((k_trace_shadow<true, false, K, TOP>));   \
-         else UH_SHADOW((k_trace_shadow<false, false, K, TOP>));         \
-      }                                                             \
-   } while (0)
-   switch (c.shadow_variant) {
-      case 0:
-         if (light) {
-            if (c.count_visits) UH_SHADOW((k_trace_shadow_batch<true, true>));
-            else UH_SHADOW((k_trace_shadow_batch<false, true>));
-         } else {
-            if (c.count_visits) UH_SHADOW((k_trace_shadow_batch<true, false>));
-            else UH_SHADOW((k_trace_shadow_batch<false, false>));
-         }
-         break;
-      case 1: UH_SHADOW_RF(8, false); break;
-      case 2: UH_SHADOW_RF(4, true); break;
-      case 4: UH_SHADOW_RF(16, true); break;
-      default: UH_SHADOW_RF(8, true); break;
+   if (c.shadow_variant == 0) {
+      if (light) {
+         if (c.count_visits) UH_SHADOW((k_trace_shadow_batch<true, true>));
+         else UH_SHADOW((k_trace_shadow_batch<false, true>));
+      } else {
+         if (c.count_visits) UH_SHADOW((k_trace_shadow_batch<true, false>));
+         else UH_SHADOW((k_trace_shadow_batch<false, false>));
+      }
+   } else if (light) {
+      if (c.count_visits) UH_SHADOW((k_trace_shadow<true, true>));
+      else UH_SHADOW((k_trace_shadow<false, true>));
+   } else {
+      if (c.count_visits) UH_SHADOW((k_trace_shadow<true, false>));
+      else UH_SHADOW((k_trace_shadow<false, false>));
    }
-#undef UH_SHADOW_RF
 #undef UH_SHADOW
 }
 

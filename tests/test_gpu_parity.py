@@ -186,9 +186,9 @@ def test_instance_transform_rebuild(cornell):
     assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0])
 def test_traversal_variants_are_bit_identical(atrium, variant):
-    """the batch kernels (0) and every refill threshold (1, 2, 4; 3 is the default) must produce the same image and the same ray counts"""
+    """the batch kernels (option trace_variant = 0: the baseline kept for A/B) and the default refill kernels must produce the same image and the same ray counts"""
     W, H = 160, 90
     ref = atrium.upload(rr.Renderer(W, H))
     alt = atrium.upload(rr.Renderer(W, H))
