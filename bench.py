@@ -161,6 +161,19 @@ def main():
         k, v = kv.split("=")
         renderer.set_option(k, int(v))
 
+    # ---- untimed: what an interactive caller sees with the library's defaults - uh_render_frame, then a synchronisation
+    # (a present) after every frame: side-stream overlap inside the frame, but no second frame in flight and no batching
+    interactive_frame_ms = None
+    if not args.no_alone:
+        for _ in range(4):  # every frames-in-flight slot exists before the clock starts
+            loop.frame(pass_mask)
+        renderer.synchronize()
+        t_int = time.perf_counter()
+        for _ in range(8):
+            loop.frame(pass_mask)
+            renderer.synchronize()
+        interactive_frame_ms = (time.perf_counter() - t_int) / 8 * 1e3
+
     # ---- untimed priming, independent of --warmup: the first multi-frame call makes the library create its
     # frames-in-flight slots (streams, ~1 GB of path state each at 1080p; ~14 ms) - with --warmup 0 or 1 that
     # would otherwise land inside the timed region
@@ -227,7 +240,8 @@ def main():
                 + (f", {len(scene.lights)} lights " + ("ReSTIR DI" if view.use_ris_light_sampling else "uniform sampling") if view.lights_enabled else ", lights off"),
                 "rays_per_frame": total_rays / args.steps,
                 "partition": f"{args.tile}x{args.tile} tiles round-robin over {world} rank(s), 1 RCCL gather" if world > 1 else "single GPU",
-                "frame_by_frame_ms": frame_by_frame_ms,
+                "frame_by_frame_ms": frame_by_frame_ms,      # fully serial: one stream, one frame, per-kernel event timing on
+                "interactive_frame_ms": interactive_frame_ms,  # default options, a synchronisation after every frame
             },
             "roofline": roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, signature(args, scene, W, H)),
         }
