@@ -140,8 +140,9 @@ __device__ __forceinline__ uint32_t trav_pop(Trav& t, const uint32_t* lds_col, c
 // Instruction diet: the near / far plane words are picked once per axis by the sign of idir instead of min/max per
 // plane; an empty slot is an inverted box (no child != empty test); only the nearest child is fully ordered
 // (3 comparators); pushes are branch-free (write always, advance the stack pointer by the hit bit).
+// Returns false when no child was hit: the caller pops (trav_step pops once for its node lanes and its leaf lanes together).
 template <bool ANY>
-__device__ __forceinline__ void node_compute(const uint4 w0, const uint4 w1, const uint4 w2, Trav& t, uint32_t* lds_col, uint32_t* spill) {
+__device__ __forceinline__ bool node_compute(const uint4 w0, const uint4 w1, const uint4 w2, Trav& t, uint32_t* lds_col, uint32_t* spill) {
    const uint32_t meta = w0.w;
    // a power-of-two step is its biased exponent moved to bits 23..30
    const float sx = __uint_as_float((meta & 0xffu) << 23), sy = __uint_as_float((meta << 15) & 0x7f800000u), sz = __uint_as_float((meta << 7) & 0x7f800000u);
@@ -190,8 +191,8 @@ __device__ __forceinline__ void node_compute(const uint4 w0, const uint4 w1, con
          if (p2) trav_push(t, lds_col, spill, cr[2]);
          if (p1) trav_push(t, lds_col, spill, cr[1]);
       }
-      t.cur = any ? next : trav_pop(t, lds_col, spill);
-      return;
+      t.cur = next;
+      return any;
    }
    {
       // closest hit: bring the nearest hit to slot 0 (3 comparators); slots 1..3 stay unordered
@@ -223,14 +224,15 @@ __device__ __forceinline__ void node_compute(const uint4 w0, const uint4 w1, con
       if (tn[2] < INFINITY) trav_push(t, lds_col, spill, cr[2]);
       if (tn[1] < INFINITY) trav_push(t, lds_col, spill, cr[1]);
    }
-   t.cur = (tn[0] < INFINITY) ? cr[0] : trav_pop(t, lds_col, spill);
+   t.cur = cr[0];
+   return tn[0] < INFINITY;
 }
 
 template <bool ANY>
 __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill) {
    const uint4* n = nodes + kNodeStride16 * (size_t)t.cur;
    const uint4 w0 = n[0], w1 = n[1], w2 = n[2];
-   node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
+   if (!node_compute<ANY>(w0, w1, w2, t, lds_col, spill)) t.cur = trav_pop(t, lds_col, spill);
 }
 
 
@@ -431,21 +433,23 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
    uint4 w0 = rec[0], w1 = rec[1], w2 = rec[2];
    // the packet's last two dwords are padding: without this the compiler loads them in the node branch only (a fourth load)
    asm volatile("" : "+v"(w2.z), "+v"(w2.w));
+   bool pop;  // one pop for both groups: an LDS read and its wait once per iteration, not once per branch
    if (at_node) {
       if (COUNT) n_nodes++;
-      node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
+      pop = !node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
    } else {
       if (COUNT) n_tris++;
       const float4 ta = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
       const float4 tb = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
       const float4 tc = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
+      pop = true;
       if (tri_compute<ANY>(ta, tb, tc, packet, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
          occluded = true;
          t.cur = kEmptyRef;
-      } else {
-         t.cur = trav_pop(t, lds_col, spill);
+         pop = false;
       }
    }
+   if (pop) t.cur = trav_pop(t, lds_col, spill);
    return t.cur == kEmptyRef;
 }
 
