@@ -114,7 +114,7 @@ def load_gltf(path):
             pbr = mat.get("pbrMetallicRoughness", {})
             tex = pbr.get("baseColorTexture", {}).get("index")
             mesh = Mesh(v, idx, LAMBERTIAN, 0.0, tuple(float(x) for x in pbr.get("baseColorFactor", [1, 1, 1, 1])), tex, transform[:3, :].reshape(12).copy(),
-                        name=mat.get("name", node.get("name", "")))
+                        name=mat.get("name", node.get("name", "")), metallic=float(pbr.get("metallicFactor", 1.0)), roughness=float(pbr.get("roughnessFactor", 1.0)))
             model.meshes.append(mesh)
 
     scenes = gltf.get("scenes", [])
