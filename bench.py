@@ -323,6 +323,12 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
             "note": "`alone` = the kernel with the GPU to itself (untimed calibration frames, one frame per launch); timed-region launches share the chip with other frames' kernels",
         },
         "valu": {kk: k.get(kk) for kk in ("wave_instr_per_launch", "issue_frac", "lane_utilisation", "ta_busy_frac", "td_busy_frac")} if k else None,
+        # every kernel of the frame against the HBM roofline, alone on the GPU (counter passes serialise the kernels): HBM-side
+        # bytes per launch over the launch's GRBM-active clocks at 2.4 GHz. k_shade_hit is the HBM-bound one (~0.76);
+        # the traversal kernels are VALU / vector-memory bound and sit far below it.
+        "hbm_frac_by_kernel": ({name: round(v["hbm_bytes_per_launch"] / (v["launch_clk"] / 2.4e9) / 8e12, 3)
+                                for name, v in prof["kernels"].items() if name.startswith("k_") and v.get("launch_clk") and v.get("hbm_bytes_per_launch")}
+                               if prof else None),
         "kernel_share_of_step": st.trace_closest_ms / (elapsed * 1e3),
         "trace_shadow_ms": st.trace_shadow_ms,
         "shade_ms": st.shade_ms,
