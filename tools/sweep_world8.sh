@@ -10,5 +10,3 @@ run --emulate-world $w --opt batch_frames=8 --opt trace_variant=0 $B
 run --emulate-world $w --opt frames_in_flight=8
 run --emulate-world $w --opt batch_frames=16 --opt frames_in_flight=2
 done
-( cd _r01 && printf "%-96s" "round-1 tree --emulate-world 8" && timeout -k 10 200 python bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-alone --emulate-world 8 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f Mrays/s %.3f ms' % (d['value'], d['ms_per_step']))" )
-( cd _r01 && printf "%-96s" "round-1 tree --emulate-world 4" && timeout -k 10 200 python bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-alone --emulate-world 4 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f Mrays/s %.3f ms' % (d['value'], d['ms_per_step']))" )
