@@ -149,7 +149,7 @@ struct Slot {
 
 // frames of the reservoir passes one uh_render_frames wavefront carries at most, and the ring of spatial buffers that
 // lets the next batch's chains run beside the current wavefront (two batches + the history slot)
-constexpr uint32_t kRestirBatch = 4;
+constexpr uint32_t kRestirBatch = 8;
 constexpr int kSpatialRing = 2 * (int)kRestirBatch + 1;
 
 struct uh_ctx {
@@ -1145,7 +1145,18 @@ int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mas
    uint32_t done = 0;
    // auto: about four frames' worth of paths per wavefront - 4 frames on a whole frame, 4 x world frames on a rank's 1 / world
    // share of it (swept on MI355X for 1, 4 and 8 ranks' shares: tools/sweep_world8.sh, profiles/README.md)
-   uint32_t batch = c->batch_frames ? c->batch_frames : 4 * (c->tp_world ? c->tp_world : 1);
+   uint32_t batch = c->batch_frames;
+   if (!batch) {
+      // auto: about 32 M paths per wavefront (1080p: 16 frames, 4K: 4, a rank's eighth of 1080p: 16, 256 x 256: 32) - what
+      // the launches need to fill the chip and amortise their tails; 1080p 4 / 8 / 12 / 16 frames = 6,271 / 6,341 / 6,388 /
+      // 6,398 Mrays/s, the short paths of the iso-surface scene 4,974 / 5,393 / - / 6,223 (tools/sweep_batch.sh,
+      // profiles/README.md) - within 33 M path-state records per slot (3.9 GB; path ids run over the whole frame even
+      // when a rank owns a part of it)
+      const uint64_t pixels = (uint64_t)c->W * c->H, owned = c->n_owned ? c->n_owned : pixels;
+      uint64_t b = (32u << 20) / (owned ? owned : 1), cap = (33u << 20) / (pixels ? pixels : 1);
+      if (b > cap) b = cap;
+      batch = (uint32_t)(b < 1 ? 1 : b);
+   }
    if (batch > kMaxBatchFrames) batch = kMaxBatchFrames;
    if ((pass_mask & UH_PASS_RESTIR) && batch > kRestirBatch) batch = kRestirBatch;
    if (!(pass_mask & UH_PASS_REFERENCE_PT)) batch = 1;  // reservoir passes alone: frame by frame
@@ -1369,7 +1380,7 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
    else if (n == "overlap_shadow")
       c->overlap_shadow = value != 0;
    else if (n == "batch_frames") {
-      if (value < 0 || value > (int)kMaxBatchFrames) return fail(c, UH_ERR_INVALID_ARGUMENT, "batch_frames must be 0 (auto) .. 16");
+      if (value < 0 || value > (int)kMaxBatchFrames) return fail(c, UH_ERR_INVALID_ARGUMENT, "batch_frames must be 0 (auto) .. 32");
       c->batch_frames = (uint32_t)value;
    } else if (n == "frames_in_flight") {
       if (value < 1 || value > (int)kMaxSlots) return fail(c, UH_ERR_INVALID_ARGUMENT, "frames_in_flight must be 1..8");

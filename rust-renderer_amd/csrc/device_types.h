@@ -90,7 +90,7 @@ struct SceneDev {
    uint32_t num_nodes, num_tris, num_meshes, num_textures, num_lights;
 };
 
-constexpr uint32_t kMaxBatchFrames = 16;
+constexpr uint32_t kMaxBatchFrames = 32;
 
 struct FrameParams {
    // A launch chain may carry `batch_frames` consecutive frames of the path-tracing pass as one
