@@ -80,6 +80,23 @@ def test_path_trace_matches_oracle(cornell, frames, spp):
     assert (og[..., 3] == 0).all()
 
 
+@pytest.mark.parametrize("sun", [(0.3, 0.8, 0.2), (-0.3, 0.8, 0.2), (0.3, -0.8, 0.2), (0.3, 0.8, -0.2), (-0.3, -0.8, 0.2), (-0.3, 0.8, -0.2), (0.3, -0.8, -0.2),
+                                 (-0.3, -0.8, -0.2), (0.0, 1.0, 0.0), (-0.0, 1.0, -0.0), (0.0, -1.0, 1e-35)])
+def test_sun_direction_octants_match_oracle(atrium, sun):
+    """the node step picks its near / far plane words by the sign of 1 / direction: every octant of the sun's shadow rays, and
+    zero / negative-zero / tiny components, against the oracle with the sky off"""
+    W, H = 96, 54
+    gpu, cpu = make_pair(atrium, W, H)
+    for r in (gpu, cpu):
+        loop = rr.FrameLoop(r, atrium.make_view(W, H, sky_enabled=0, lights_enabled=0, sun_shadow_enabled=1))
+        loop.view.sun_dir[:] = list(sun)
+        for _ in range(2):
+            loop.frame(rr.PASS_REFERENCE_PT)
+    assert np.array_equal(gpu.read_accumulation().view(np.uint32), cpu.read_accumulation().view(np.uint32))
+    assert list(gpu.get_stats().rays)[:4] == list(cpu.get_stats().rays)[:4]
+    assert gpu.read_accumulation()[..., :3].max() > 0 or sun[1] < 0, "a sun above the horizon lights something"
+
+
 def test_path_trace_atrium_all_materials(atrium):
     W, H = 160, 90
     gpu, cpu = make_pair(atrium, W, H)
