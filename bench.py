@@ -177,7 +177,7 @@ def main():
     # ---- untimed priming, independent of --warmup: the first multi-frame call makes the library create its
     # frames-in-flight slots (streams, ~1 GB of path state each at 1080p; ~14 ms) - with --warmup 0 or 1 that
     # would otherwise land inside the timed region
-    loop.frames(4, pass_mask)
+    loop.frames(16, pass_mask)  # one full wavefront at 1080p: every launch of a run has the size of the timed ones
     # ---- warmup
     loop.frames(args.warmup, pass_mask)
     if use_dist:
@@ -285,6 +285,9 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     prof = load_profile(sig)
     k = (prof or {}).get("kernels", {}).get("k_trace_closest", {})
     traffic = k.get("hbm_bytes_per_launch")
+    if traffic and k.get("closest_rays_per_launch"):
+        # the profiled run's launches may carry another number of frames than this run's: traffic goes with the rays
+        traffic *= rays_per_launch / k["closest_rays_per_launch"]
     achieved = traffic / (avg_ms * 1e-3) / 1e9 if (traffic and avg_ms > 0) else None
     # vector-memory issue: every per-lane load or store of <= 16 B takes one slot of the CU's texture addresser / data
     # path, and that path retires one lane per clock (profiles/r02_microbench_rates.txt: 1.0-1.1 clk per lane-load for

@@ -64,6 +64,15 @@ def main():
                  "note": "per launch, median over the kernel's dispatches; hbm_bytes = 2*FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md HBM: FETCH_SIZE reports half the bytes "
                          "of wide reads on gfx950 - calibrated for coalesced 16-B loads; for the 64-B node gathers of the traversal kernels the x2 may overstate by up to 2x, "
                          "so hbm_bytes is an upper bound there); Infinity-Cache hits are counted in", "kernels": {}}
+        # rays per k_trace_closest launch of the profiled run (the bench line its first pass printed): bench.py scales the
+        # per-launch traffic by its own rays per launch
+        profiled_rays = None
+        try:
+            for line in open(os.path.join(src, "pass1.log")):
+                if line.startswith("{") and '"roofline"' in line:
+                    profiled_rays = json.loads(line)["roofline"]["rays_per_launch"]
+        except OSError:
+            pass
         for k, v in out["kernels"].items():
             m = {c: x["median"] for c, x in v["counters"].items()}
             e = bench["kernels"].setdefault(base_name(k), {})
@@ -82,6 +91,8 @@ def main():
                 e["td_busy_frac"] = m.get("TD_TD_BUSY_sum", 0.0) / 256.0 / clk if m.get("TD_TD_BUSY_sum") else None
                 e["launch_clk"] = clk
             e["variant"] = k
+            if base_name(k) == "k_trace_closest" and profiled_rays:
+                e["closest_rays_per_launch"] = profiled_rays
         json.dump(bench, open(os.path.join(ROOT, "profiles", "bench_counters.json"), "w"), indent=1)
     for k, v in out["kernels"].items():
         print(k, json.dumps({a: round(b, 4) for a, b in v["derived"].items()}))
