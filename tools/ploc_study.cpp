@@ -166,6 +166,47 @@ int main(int argc, char** argv) {
       std::vector<int> idx(m); std::iota(idx.begin(), idx.end(), 0);
       root = sah_build(nodes, cb, cid, idx, 0, (int)m);
    }
+   // optional: tree rotations (Kensler 2008) over the finished binary tree, `rot` passes bottom-up
+   const int rot = argc > 4 ? std::atoi(argv[4]) : 0;
+   if (rot > 0) {
+      auto box_of = [&](int r) -> Box { return r < 0 ? tb[~r] : nodes[r].box; };
+      // post-order of internal nodes
+      std::vector<int> order;
+      {
+         std::vector<int> st{root};
+         while (!st.empty()) { int v = st.back(); st.pop_back(); if (v < 0) continue; order.push_back(v); st.push_back(nodes[v].l); st.push_back(nodes[v].r); }
+      }
+      for (int pass = 0; pass < rot; pass++) {
+         size_t applied = 0;
+         for (size_t oi = order.size(); oi-- > 0;) {
+            N2& n = nodes[order[oi]];
+            // refit first (children may have changed)
+            n.box = box_of(n.l); n.box.grow(box_of(n.r));
+            float best = 0; int which = -1;
+            // swap n.l with a child of n.r: n.r's box becomes union(n.l, other child)
+            for (int side = 0; side < 2; side++) {
+               int a = side ? n.r : n.l, b = side ? n.l : n.r;  // a stays a subtree that moves down into b
+               if (b < 0) continue;
+               for (int c = 0; c < 2; c++) {
+                  int keep = c ? nodes[b].l : nodes[b].r;  // stays under b
+                  Box nb = box_of(a); nb.grow(box_of(keep));
+                  float gain = nodes[b].box.area() - nb.area();
+                  if (gain > best) { best = gain; which = side * 2 + c; }
+               }
+            }
+            if (which >= 0) {
+               int side = which / 2, c = which % 2;
+               int& a = side ? n.r : n.l; int b = side ? n.l : n.r;
+               int& moved_up = c ? nodes[b].r : nodes[b].l;  // the child of b that swaps with a
+               std::swap(a, moved_up);
+               nodes[b].box = box_of(nodes[b].l); nodes[b].box.grow(box_of(nodes[b].r));
+               n.box = box_of(n.l); n.box.grow(box_of(n.r));
+               applied++;
+            }
+         }
+         std::printf("rotation pass %d: %zu rotations\n", pass, applied);
+      }
+   }
    double sah = 0; for (auto& n : nodes) sah += n.box.area();
    std::printf("radius %d, SAH top over %zu clusters after %d rounds: %zu binary nodes, summed area %.4g\n", radius, m, rounds, nodes.size(), sah);
    // collapse to 4-wide + walk
