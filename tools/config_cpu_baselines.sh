@@ -1,3 +1,5 @@
+#!/bin/bash
+# bench lines of configs 2-4 with their own bounded CPU-oracle sample
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 tag=r02
 timeout -k 10 300 python bench.py --config 2 --steps 32 --cpu-sample 1920x1080x4 > gpurun_out/${tag}_bench_config2.json 2>gpurun_out/c2.err

@@ -1,3 +1,4 @@
+"""Per-ray traversal statistics of the closest-hit kernel (diagnostic batch kernel: node / triangle visits per ray), config-1 scene."""
 import sys
 sys.path.insert(0, '/root/repo')
 import rust_renderer_amd as rr
