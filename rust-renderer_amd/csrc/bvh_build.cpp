@@ -485,6 +485,13 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
          }
       }
       std::stable_partition(ch, ch + nc, [&](int32_t c) { return n2[c].left < 0; });  // triangles first
+      {
+         // node children by descending surface area: a visibility walk takes the children in slot order, and the bigger
+         // subtree is the likelier one to hold an occluder (closest-hit rays order the children by distance anyway)
+         int nt = 0;
+         while (nt < nc && n2[ch[nt]].left < 0) nt++;
+         std::stable_sort(ch + nt, ch + nc, [&](int32_t a, int32_t b) { return n2[a].box.half_area() > n2[b].box.half_area(); });
+      }
       NodeW nd;
       std::memset(&nd, 0, sizeof(nd));
       for (int k = 0; k < kMaxWidth; k++) nd.child[k] = kEmptyRef;
