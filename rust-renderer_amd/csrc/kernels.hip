@@ -172,24 +172,26 @@ __device__ __forceinline__ bool node_compute(const uint4 w0, const uint4 w1, con
       tn[k] = hit[k] ? tnear : INFINITY;
    }
    if (ANY) {
-      // visibility walk: the order of the children does not matter to an unoccluded ray (it visits them all) and
-      // hardly to an occluded one (measured, profiles/README.md): no ordering network, the first hit child in
-      // slot order is next, the other hits are pushed
+      // visibility walk: no ordering network. The order of the children does not matter to an unoccluded ray (it visits
+      // them all); an occluded one ends sooner if the likelier occluder comes first. The builders store a node's node
+      // children in ascending surface area behind its triangle children (bvh_build.cpp, lbvh.hip), and the walk takes the
+      // hit children from the HIGHEST slot down: biggest subtree first, triangles last (tools/any_order_ab.sh: 13.1 ->
+      // 10.6 node visits per sun shadow ray). The other hits are pushed, lowest slot first, so that they pop in the same order.
       const bool any = hit[0] || hit[1] || hit[2] || hit[3];
-      const uint32_t next = hit[0] ? cr[0] : hit[1] ? cr[1] : hit[2] ? cr[2] : cr[3];
-      const bool p1 = hit[1] && hit[0], p2 = hit[2] && (hit[0] || hit[1]), p3 = hit[3] && (hit[0] || hit[1] || hit[2]);
+      const uint32_t next = hit[3] ? cr[3] : hit[2] ? cr[2] : hit[1] ? cr[1] : cr[0];
+      const bool p2 = hit[2] && hit[3], p1 = hit[1] && (hit[3] || hit[2]), p0 = hit[0] && (hit[3] || hit[2] || hit[1]);
       if (t.sp + 3 <= kLdsStack) {
          uint32_t* p = lds_col + t.sp * 64;
-         p[0] = cr[3];
-         p += (p3 ? 1 : 0) * 64;
-         p[0] = cr[2];
-         p += (p2 ? 1 : 0) * 64;
+         p[0] = cr[0];
+         p += (p0 ? 1 : 0) * 64;
          p[0] = cr[1];
-         t.sp += (p3 ? 1 : 0) + (p2 ? 1 : 0) + (p1 ? 1 : 0);
+         p += (p1 ? 1 : 0) * 64;
+         p[0] = cr[2];
+         t.sp += (p0 ? 1 : 0) + (p1 ? 1 : 0) + (p2 ? 1 : 0);
       } else {
-         if (p3) trav_push(t, lds_col, spill, cr[3]);
-         if (p2) trav_push(t, lds_col, spill, cr[2]);
+         if (p0) trav_push(t, lds_col, spill, cr[0]);
          if (p1) trav_push(t, lds_col, spill, cr[1]);
+         if (p2) trav_push(t, lds_col, spill, cr[2]);
       }
       t.cur = next;
       return any;

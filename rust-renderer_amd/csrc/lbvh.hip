@@ -246,19 +246,25 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_collapse(const uint4* __restric
       ch[pick] = e.x;
       ch[nc++] = e.y;
    }
-   uint32_t n_tri = 0;
-   for (int k = 0; k < nc; k++)
-      if (ch[k] & kLeafBit) n_tri++;
-   const uint32_t n_node = (uint32_t)nc - n_tri;
+   // node children in ascending weight (area, or triangle count for the radix tree): a visibility walk takes them from the
+   // highest slot down, biggest subtree first (kernels.hip node_compute, bvh_build.cpp)
+   uint32_t nd[4];
+   uint32_t n_node = 0, n_tri = 0;
+   for (int k = 0; k < nc; k++) {
+      if (ch[k] & kLeafBit) {
+         n_tri++;
+         continue;
+      }
+      uint32_t j = n_node++;
+      for (; j > 0 && weight_of(nd[j - 1]) > weight_of(ch[k]); j--) nd[j] = nd[j - 1];
+      nd[j] = ch[k];
+   }
    const uint32_t tri_base = n_tri ? atomicAdd(tri_count, n_tri) : 0u;
    const uint32_t slot = n_node ? atomicAdd(next_count, n_node) : 0u;
-   uint32_t t = 0, m = 0;
-   for (int k = 0; k < nc; k++) {
-      if (ch[k] & kLeafBit)
-         order[tri_base + t++] = ch[k] & ~kLeafBit;  // position in the sorted order of the packet's triangle
-      else
-         next_src[slot + m++] = ch[k];
-   }
+   uint32_t t = 0;
+   for (int k = 0; k < nc; k++)
+      if (ch[k] & kLeafBit) order[tri_base + t++] = ch[k] & ~kLeafBit;  // position in the sorted order of the packet's triangle
+   for (uint32_t m = 0; m < n_node; m++) next_src[slot + m] = nd[m];
    write_topology(nodes + kNodeStride16 * (size_t)(level_first + idx), n_tri, (uint32_t)nc, next_first + slot, tri_base);
 }
 
