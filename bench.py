@@ -136,24 +136,32 @@ def main():
     tris_per_ray = cs.tris_tested / max(closest_rays, 1)
     renderer.set_option("count_visits", 0)
 
-    # ---- untimed: the dominant kernel alone on the GPU (no frame overlap, no second stream), so its
-    # launch duration can be read without co-scheduled kernels sharing the chip
+    # ---- untimed: the dominant kernel alone on the GPU (no frame overlap, no second stream), in launches of the SAME size as
+    # the timed ones (one wavefront of the library's default batch): its serialised launch duration, without co-scheduled kernels
+    frames_rendered = 1
     renderer.set_option("time_kernels", 1)
-    saved = {}
-    for k, v in (("frames_in_flight", 1), ("overlap_miss", 0), ("overlap_shadow", 0), ("batch_frames", 1)):
+    serial = (("frames_in_flight", 1), ("overlap_miss", 0), ("overlap_shadow", 0))
+    for k, v in serial:
         renderer.set_option(k, v)
-    renderer.reset_stats()
-    renderer.synchronize()
-    t_fbf = time.perf_counter()
-    for _ in range(0 if args.no_alone else 8):
-        loop.frame(pass_mask)
-    renderer.synchronize()
-    # what an interactive caller of uh_render_frame sees: one frame at a time, nothing in flight, no batching
-    # (per-kernel event timing is on in these frames: a few percent of launch overhead included)
-    frame_by_frame_ms = None if args.no_alone else (time.perf_counter() - t_fbf) / 8 * 1e3
-    alone = renderer.get_stats()
-    alone_ms = alone.trace_closest_ms / max(alone.trace_closest_launches, 1)
-    alone_rays = float(alone.rays[rr.RAY_PRIMARY] + alone.rays[rr.RAY_BOUNCE]) / max(alone.trace_closest_launches, 1)
+    alone_ms = alone_rays = 0.0
+    frame_by_frame_ms = None
+    if not args.no_alone:
+        loop.frames(16, pass_mask)  # creates the slot; the same wavefront size as below
+        renderer.reset_stats()
+        loop.frames(16, pass_mask)
+        alone = renderer.get_stats()
+        alone_ms = alone.trace_closest_ms / max(alone.trace_closest_launches, 1)
+        alone_rays = float(alone.rays[rr.RAY_PRIMARY] + alone.rays[rr.RAY_BOUNCE]) / max(alone.trace_closest_launches, 1)
+        # what a caller of uh_render_frame sees with nothing overlapped: one frame per call, one stream, no batching
+        # (per-kernel event timing is on in these frames: a few percent of launch overhead included)
+        renderer.set_option("batch_frames", 1)
+        renderer.synchronize()
+        t_fbf = time.perf_counter()
+        for _ in range(8):
+            loop.frame(pass_mask)
+        renderer.synchronize()
+        frame_by_frame_ms = (time.perf_counter() - t_fbf) / 8 * 1e3
+        frames_rendered += 40
     renderer.set_option("time_kernels", 0)
     for k, v in (("frames_in_flight", 4), ("overlap_miss", 1), ("overlap_shadow", 1), ("batch_frames", 0)):
         renderer.set_option(k, v)
@@ -173,6 +181,7 @@ def main():
             loop.frame(pass_mask)
             renderer.synchronize()
         interactive_frame_ms = (time.perf_counter() - t_int) / 8 * 1e3
+        frames_rendered += 12
 
     # ---- untimed priming, independent of --warmup: the first multi-frame call makes the library create its
     # frames-in-flight slots (streams, ~1 GB of path state each at 1080p; ~14 ms) - with --warmup 0 or 1 that
@@ -180,6 +189,7 @@ def main():
     loop.frames(16, pass_mask)  # one full wavefront at 1080p: every launch of a run has the size of the timed ones
     # ---- warmup
     loop.frames(args.warmup, pass_mask)
+    frames_rendered += 16 + args.warmup + args.steps
     if use_dist:
         # warm the composition path too (RCCL connects its send/recv channels on first use, the
         # caching allocator takes its first staging buffers): one untimed gather + resolve
@@ -246,10 +256,19 @@ def main():
             "roofline": roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, signature(args, scene, W, H)),
         }
         if os.environ.get("UH_BENCH_SIGNATURE"):  # tools/pmc_summary.py stamps counter profiles with it
-            json.dump(signature(args, scene, W, H), open(os.environ["UH_BENCH_SIGNATURE"], "w"))
+            json.dump(dict(signature(args, scene, W, H), frames_total=frames_rendered), open(os.environ["UH_BENCH_SIGNATURE"], "w"))
+        parity_failed = False
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args, scene)
+            out["cpu_baseline"], ref = cpu_baseline(args, scene)
+            if ref is not None:
+                # the image this run TIMED, checked: the same scene object, resolution, view and frame numbers, through the same
+                # batched uh_render_frames path as the timed region, against the frames the CPU oracle has just rendered
+                out["parity"] = parity(args, rr, renderer, scene, pass_mask, W, H, ref)
+                parity_failed = not (out["parity"]["max_pixel_l2"] <= 1e-3 and out["parity"]["ray_counts_equal"])
         print(json.dumps(out), flush=True)
+        if parity_failed:
+            print("[bench] PARITY FAILED: the timed workload's image differs from the oracle's beyond 1e-3 per pixel, or the ray counts differ", file=sys.stderr, flush=True)
+            sys.exit(3)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -273,70 +292,122 @@ def load_profile(sig):
 
 
 def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, sig):
-    """Roofline block of the dominant kernel, k_trace_closest.
-    `achieved` / `frac` are HBM-side bytes from the rocprofv3 counters (FETCH_SIZE / WRITE_SIZE passes of this command
-    line, committed under profiles/) over the launch duration measured live with HIP events: physical, <= 1 by
-    construction. SURVEY 8d's algorithmic bytes (every node visit priced at 128 B whether or not a cache serves it) are
-    kept as `algorithmic_gbps`, a work metric. What actually limits the kernel is reported under `limiter`."""
+    """Roofline block of the dominant kernel, k_trace_closest - every figure physical and <= 1 by construction.
+    traffic   HBM-side bytes per launch from the rocprofv3 counter passes of this command line (profiles/bench_counters.json:
+              2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; an upper bound for 48-byte gathers),
+              scaled by rays per launch - quoted only when the profile's signature equals this run's
+    achieved  traffic / the kernel's SERIALISED launch duration, measured live with HIP events on the library's stream with
+              the kernel alone on the GPU in launches of the timed size (frac = achieved / 8 TB/s)
+    overlapped  the same bytes over the timed region's average launch duration, during which other frames' kernels share the chip
+    frame_hbm_frac  HBM-side bytes of ALL kernels per frame (counter passes, summed over every dispatch) / ms_per_step / 8 TB/s
+    algorithmic  SURVEY 8d's work metric at its contract price (128 B per node visit) and at the real record size (48 B): bytes the
+              caches serve, not a roofline fraction
+    bound     what the counters show limits the kernel (not HBM: see `limiter`)"""
     launches = max(st.trace_closest_launches, 1)
     avg_ms = st.trace_closest_ms / launches
     rays_per_launch = my_closest / launches
-    algo_bytes = rays_per_launch * (48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0)  # SURVEY.md 8d
+    per_ray_128 = 48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0  # SURVEY.md 8d
+    per_ray_48 = 48.0 + nodes_per_ray * 48.0 + tris_per_ray * 48.0    # nodes are 48-byte records (csrc/bvh.h)
     prof = load_profile(sig)
     k = (prof or {}).get("kernels", {}).get("k_trace_closest", {})
     traffic = k.get("hbm_bytes_per_launch")
     if traffic and k.get("closest_rays_per_launch"):
         # the profiled run's launches may carry another number of frames than this run's: traffic goes with the rays
         traffic *= rays_per_launch / k["closest_rays_per_launch"]
-    achieved = traffic / (avg_ms * 1e-3) / 1e9 if (traffic and avg_ms > 0) else None
-    # vector-memory issue: every per-lane load or store of <= 16 B takes one slot of the CU's texture addresser / data
-    # path, and that path retires one lane per clock (profiles/r02_microbench_rates.txt: 1.0-1.1 clk per lane-load for
-    # random 64-B and 128-B records alike, 4 lanes on one line or not). Lane operations of one closest-hit ray in this
-    # layout: 3 per node visit (48-B node), 3 per triangle tested (48-B packet), 4 for queue id + ray (2 LDS-DMA) + hit.
-    # The counters agree on WHERE the kernel sits (profiles/bench_counters.json: texture-data unit ~0.9 busy, texture
-    # addresser ~0.8, VALU issue ~0.5, HBM ~0.1) more than on the exact cost of one lane operation: read frac_alone as a
-    # model figure next to the measured busy fractions under `valu`.
+    # serialised duration of a launch of the timed size: the calibration launches are the same wavefronts, alone
+    serial_ms = alone_ms * (rays_per_launch / alone_rays) if (alone_ms > 0 and alone_rays > 0) else None
+    achieved = traffic / (serial_ms * 1e-3) / 1e9 if (traffic and serial_ms) else None
+    overlapped = traffic / (avg_ms * 1e-3) / 1e9 if (traffic and avg_ms > 0) else None
+    frame_bytes = (prof or {}).get("frame_hbm_bytes")
+    if frame_bytes and k.get("closest_rays_per_launch"):
+        frame_bytes *= rays_per_launch / k["closest_rays_per_launch"]  # same rays-per-frame normalisation
+    ms_per_step = elapsed / args.steps * 1e3
+    # vector-memory issue: every per-lane load or store of <= 16 B takes one slot of the CU's texture addresser / data path, and
+    # that path retires about one lane per clock (profiles/r02_microbench_rates.txt). Lane operations of one closest-hit ray: 3
+    # per node visit (48-B node), 3 per triangle tested (48-B packet), 4 for queue id + ray (2 LDS-DMA) + hit.
     lane_ops = 3.0 * nodes_per_ray + 3.0 * tris_per_ray + 4.0
     peak_lane_rate = 256 * 2.4e9  # CUs x max clock (MI355X_MICROARCH.md); the clock under load is lower
     alone_rate = alone_rays * lane_ops / (alone_ms * 1e-3) if alone_ms > 0 else 0.0
+    ref = serial_ms or avg_ms
     r = {
         "kernel": "k_trace_closest",
-        "bound": "hbm",
+        "bound": "vmem-issue/valu",
+        "bound_note": "counter passes: texture addresser / data units 0.9 busy, VALU issue 0.5 at 2 clk per instruction (~0.8 at the node step's real mix), HBM-side bytes well under the peak: the CU's vector-memory pipeline and VALU issue bound this kernel, HBM does not",
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
         "traffic": traffic,
-        "traffic_source": (prof or {}).get("source") if traffic else "no committed counter profile matches this run's configuration: traffic is null rather than borrowed",
-        "avg_launch_ms": avg_ms,
+        "traffic_source": ((prof or {}).get("source", "") + " - signature-matched to this command line, scaled by rays per launch; not collected in this run") if traffic
+        else "no committed counter profile matches this run's configuration: traffic is null rather than borrowed",
+        "serial_launch_ms": serial_ms,
+        "overlapped": {"avg_launch_ms": avg_ms, "achieved": overlapped, "frac": (overlapped / HBM_PEAK_GBS) if overlapped else None,
+                       "note": "timed region: launches of up to four wavefronts overlap on two streams each, so a launch's duration includes time the chip gave to other kernels"},
+        "frame_hbm_frac": (frame_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)) if frame_bytes else None,
+        "frame_hbm_bytes": frame_bytes,
         "launches": st.trace_closest_launches,
         "rays_per_launch": rays_per_launch,
         "nodes_per_ray": nodes_per_ray,
         "tris_per_ray": tris_per_ray,
-        "algorithmic_gbps": algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-        "algorithmic_note": "SURVEY 8d work metric (48 B/ray + 128 B/node visit + 48 B/triangle); served by L1/L2/Infinity Cache, so it may exceed the HBM peak - not a roofline fraction",
+        "algorithmic": {
+            "bytes_per_ray_at_128B_nodes": per_ray_128,
+            "gbps_at_128B_nodes": rays_per_launch * per_ray_128 / (ref * 1e-3) / 1e9 if ref else None,
+            "bytes_per_ray_at_48B_nodes": per_ray_48,
+            "gbps_at_48B_nodes": rays_per_launch * per_ray_48 / (ref * 1e-3) / 1e9 if ref else None,
+            "over": "serial_launch_ms" if serial_ms else "overlapped avg_launch_ms",
+            "note": "SURVEY 8d work metric: bytes REQUESTED per ray; L1 / L2 / Infinity Cache serve most of them, so this may exceed the HBM peak - not a roofline fraction",
+        },
         "limiter": {
-            "what": "the CU's vector-memory pipeline (texture addresser / texture data units, measured 0.8-0.9 busy): about one <=16-byte lane operation per clock per CU; neither HBM nor VALU nor MFMA bounds this path",
+            "what": "the CU's vector-memory pipeline: about one <=16-byte lane operation per clock per CU",
             "lane_ops_per_ray": lane_ops,
             "unit": "G lane-ops/s",
             "peak": peak_lane_rate / 1e9,
             "achieved_alone": alone_rate / 1e9,
             "frac_alone": alone_rate / peak_lane_rate,
-            "avg_launch_ms_alone": alone_ms,
-            "note": "`alone` = the kernel with the GPU to itself (untimed calibration frames, one frame per launch); timed-region launches share the chip with other frames' kernels",
         },
         "valu": {kk: k.get(kk) for kk in ("wave_instr_per_launch", "issue_frac", "lane_utilisation", "ta_busy_frac", "td_busy_frac")} if k else None,
-        # every kernel of the frame against the HBM roofline, alone on the GPU (counter passes serialise the kernels): HBM-side
-        # bytes per launch over the launch's GRBM-active clocks at 2.4 GHz. k_shade_hit is the HBM-bound one (~0.76);
-        # the traversal kernels are VALU / vector-memory bound and sit far below it.
-        "hbm_frac_by_kernel": ({name: round(v["hbm_bytes_per_launch"] / (v["launch_clk"] / 2.4e9) / 8e12, 3)
-                                for name, v in prof["kernels"].items() if name.startswith("k_") and v.get("launch_clk") and v.get("hbm_bytes_per_launch")}
+        # every kernel against the HBM roofline, alone on the GPU (counter passes serialise the kernels): HBM-side bytes per
+        # launch over the launch's duration from the counter CSV's own timestamps
+        "hbm_frac_by_kernel": ({name: round(v["hbm_bytes_per_launch"] / (v["launch_ns"] * 1e-9) / 8e12, 3)
+                                for name, v in prof["kernels"].items() if name.startswith("k_") and v.get("launch_ns") and v.get("hbm_bytes_per_launch")}
                                if prof else None),
-        "kernel_share_of_step": st.trace_closest_ms / (elapsed * 1e3),
+        "trace_closest_ms": st.trace_closest_ms,
         "trace_shadow_ms": st.trace_shadow_ms,
         "shade_ms": st.shade_ms,
     }
     return r
+
+
+def parity(args, rr, renderer, scene, pass_mask, W, H, ref):
+    """render the frames the CPU oracle rendered, from the same initial state, and compare linear radiance per pixel"""
+    import numpy as np
+
+    frames, ref_acc, ref_rays = ref
+    renderer.synchronize()
+    renderer.reset_accumulation()
+    if pass_mask & rr.PASS_RESTIR:
+        zero = np.zeros((H, W), dtype=rr.types.RESERVOIR_DTYPE)
+        for which in (0, 1, 2):
+            renderer.write_reservoirs(which, zero)  # the oracle starts from zeroed reservoir history
+    renderer.reset_stats()
+    view = scene.make_view(W, H, samples_per_frame=args.spp) if args.spp != 1 else scene.make_view(W, H)
+    loop = rr.FrameLoop(renderer, view)
+    loop.frames(frames, pass_mask)
+    acc = renderer.read_accumulation()[..., :3].astype(np.float64) / float(frames * args.spp)
+    want = ref_acc[..., :3].astype(np.float64) / float(frames * args.spp)
+    d2 = np.sum((acc - want) ** 2, axis=-1)
+    s = renderer.get_stats()
+    return {
+        "frames": frames,
+        "pixels": int(W * H),
+        "max_pixel_l2": float(np.sqrt(d2.max())),
+        "image_rms": float(np.sqrt(d2.mean())),
+        "pixels_bit_identical": int(np.sum(d2 == 0.0)),
+        "ray_counts_equal": bool(s.path_rays == ref_rays),
+        "rays": int(s.path_rays),
+        "tolerance": 1e-3,
+        "against": "oracle/oracle.cpp frames of the cpu_baseline leg (same scene object, tex size, resolution, flags, frame numbers)",
+    }
 
 
 def usable_cores():
@@ -361,7 +432,7 @@ def cpu_baseline(args, scene):
     w, h, frames = (int(x) for x in args.cpu_sample.split("x"))
     cores = usable_cores()
     o = scene.upload(oa.OracleRenderer(w, h, threads=cores))
-    loop = rr.FrameLoop(o, scene.make_view(w, h))
+    loop = rr.FrameLoop(o, scene.make_view(w, h, samples_per_frame=args.spp) if args.spp != 1 else scene.make_view(w, h))
     t0 = time.perf_counter()
     done = 0
     while done < frames and (done == 0 or time.perf_counter() - t0 < args.cpu_seconds):
@@ -370,6 +441,7 @@ def cpu_baseline(args, scene):
     frames = done
     dt = time.perf_counter() - t0
     s = o.get_stats()
+    ref = (frames, o.read_accumulation(), int(s.path_rays)) if (w, h) == (args.width, args.height) else None
     return {
         "value": s.path_rays / dt / 1e6,
         "unit": "Mrays/s",
@@ -378,7 +450,7 @@ def cpu_baseline(args, scene):
         "sample": f"same scene and camera at {w}x{h}, {frames} frames x 1 spp, 5 bounces ({s.path_rays} rays in {dt:.1f} s)",
         "build": "g++ -O3 -march=native -ffp-contract=off" if native else "g++ -O3 -mavx2 -mfma -ffp-contract=off (no compiler on this box for a native build)",
         "acceleration_structure": "the oracle's own median-split BVH2 (the parity checker, not a tuned CPU tracer): a reported baseline, not a speed-up claim",
-    }
+    }, ref
 
 
 if __name__ == "__main__":

@@ -130,6 +130,35 @@ typedef struct UhReservoir {
    int32_t M;
 } UhReservoir;
 
+/* ---- compile-time layout guard: a C11 / C++11 consumer (or a bindgen run over this header)
+ * learns of a packing mismatch when it compiles, not at run time. Sizes and offsets are the reference's. */
+#include <stddef.h>
+#if defined(__cplusplus)
+#define UH_LAYOUT_ASSERT(cond, msg) static_assert(cond, msg)
+#elif defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L
+#define UH_LAYOUT_ASSERT(cond, msg) _Static_assert(cond, msg)
+#else
+#define UH_LAYOUT_ASSERT(cond, msg) typedef char uh_layout_assert_[(cond) ? 1 : -1]
+#endif
+UH_LAYOUT_ASSERT(sizeof(UhVertex) == 80 && offsetof(UhVertex, normal) == 16 && offsetof(UhVertex, uv) == 32 && offsetof(UhVertex, color) == 48 &&
+                    offsetof(UhVertex, tangent) == 64, "UhVertex: std430 Vertex of bindless.glsl:4-11 (80 B)");
+UH_LAYOUT_ASSERT(sizeof(UhGpuMaterial) == 64 && offsetof(UhGpuMaterial, base_color_factor) == 16 && offsetof(UhGpuMaterial, metallic_factor) == 32 &&
+                    offsetof(UhGpuMaterial, roughness_factor) == 36 && offsetof(UhGpuMaterial, raytrace_properties) == 48, "UhGpuMaterial: renderer.rs:20-36 (64 B)");
+UH_LAYOUT_ASSERT(sizeof(UhGpuMesh) == 12, "UhGpuMesh: renderer.rs:38-44 (12 B)");
+UH_LAYOUT_ASSERT(sizeof(UhGpuLight) == 96 && offsetof(UhGpuLight, position) == 16 && offsetof(UhGpuLight, range) == 28 && offsetof(UhGpuLight, direction) == 32 &&
+                    offsetof(UhGpuLight, attenuation) == 48 && offsetof(UhGpuLight, light_type) == 60 && offsetof(UhGpuLight, intensity) == 64 &&
+                    offsetof(UhGpuLight, id) == 76, "UhGpuLight: renderer.rs:46-59 (96 B)");
+UH_LAYOUT_ASSERT(sizeof(UhViewUniformData) == 448 && offsetof(UhViewUniformData, inverse_view) == 128 && offsetof(UhViewUniformData, prev_frame_projection_view) == 256 &&
+                    offsetof(UhViewUniformData, eye_pos) == 320 && offsetof(UhViewUniformData, samples_per_frame) == 332 && offsetof(UhViewUniformData, sun_dir) == 336 &&
+                    offsetof(UhViewUniformData, total_samples) == 348 && offsetof(UhViewUniformData, num_bounces) == 352 && offsetof(UhViewUniformData, time) == 364 &&
+                    offsetof(UhViewUniformData, sky_enabled) == 392 && offsetof(UhViewUniformData, sun_shadow_enabled) == 396 &&
+                    offsetof(UhViewUniformData, lights_enabled) == 400 && offsetof(UhViewUniformData, max_num_lights_used) == 404 &&
+                    offsetof(UhViewUniformData, temporal_reuse_enabled) == 412 && offsetof(UhViewUniformData, spatial_reuse_enabled) == 416 &&
+                    offsetof(UhViewUniformData, accumulation_limit) == 424 && offsetof(UhViewUniformData, use_ris_light_sampling) == 428 &&
+                    offsetof(UhViewUniformData, raytracing_supported) == 432, "UhViewUniformData: std140 UBO_view of view.glsl:1-35 (448 B)");
+UH_LAYOUT_ASSERT(sizeof(UhReservoir) == 16 && offsetof(UhReservoir, W_sum) == 4 && offsetof(UhReservoir, W_X) == 8 && offsetof(UhReservoir, M) == 12,
+                 "UhReservoir: restir_sampling.glsl:51-57 (16 B)");
+
 /* ---- pass mask for uh_render_frame (pass order of renderers/mod.rs:246-358) -------------- */
 enum {
    UH_PASS_GBUFFER = 1u << 0,        /* gbuffer_pass (position only; produced by primary-ray cast) */

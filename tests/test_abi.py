@@ -86,3 +86,18 @@ def test_struct_layout_matches_header(tmp_path):
     assert [int(x) for x in lines[1].split()] == [32, 48, 64, 48, 64]
     assert [int(x) for x in lines[2].split()] == [320, 336, 352, 392, 412, 432]
     assert T.VERTEX_DTYPE.fields["uv"][1] == 32 and T.VERTEX_DTYPE.fields["tangent"][1] == 64
+
+
+def test_header_carries_compile_time_layout_guards(tmp_path):
+    """include/utopian_hip.h asserts every size / offset of SURVEY 8a A0 itself: it compiles as C11, as C89 (negative-array
+    form) and as C++11, and a consumer whose packing differs (here: a 1-byte float, forced by a macro) does not compile"""
+    src = tmp_path / "guard.c"
+    src.write_text('#include "utopian_hip.h"\nint main(void){return 0;}\n')
+    inc = ["-I", os.path.join(ROOT, "include")]
+    for cmd in (["gcc", "-std=c11"], ["gcc", "-std=c89"], ["g++", "-std=c++11", "-x", "c++"]):
+        subprocess.run(cmd + inc + ["-c", str(src), "-o", str(tmp_path / "guard.o")], check=True)
+    text = open(HEADER).read()
+    for name in ("UhVertex", "UhGpuMaterial", "UhGpuMesh", "UhGpuLight", "UhViewUniformData", "UhReservoir"):
+        assert re.search(r"UH_LAYOUT_ASSERT\(sizeof\(%s\) == \d+" % name, text), name
+    bad = subprocess.run(["gcc", "-std=c11", "-Dfloat=char"] + inc + ["-c", str(src), "-o", str(tmp_path / "bad.o")], capture_output=True, text=True)
+    assert bad.returncode != 0 and "UhVertex" in bad.stderr

@@ -39,6 +39,28 @@ def test_sampled_tiles_match_oracle_config2(sponza):
     assert np.abs(a - b).max() <= 1e-4  # only the sky integral (device exp/pow vs libm) differs
 
 
+@pytest.mark.parametrize("config, pass_mask, world, rank", [(1, rr.PASS_REFERENCE_PT, 53, 11), (2, rr.PASS_ALL, 47, 5)])
+def test_timed_workload_tex1024_matches_oracle(config, pass_mask, world, rank):
+    """the scene bench.py TIMES - configs[1] / configs[2] with the 1024^2 albedo maps (8x8-tiled texel layout on the device),
+    1920x1080 - through the batched uh_render_frames path the timed region uses, against the oracle on sampled tiles.
+    (bench.py repeats the comparison on the whole frame beside its timing: the `parity` block of its JSON line.)"""
+    scene = rr.scenes.scene_for_config(config, tex_size=1024)
+    gpu = scene.upload(rr.Renderer(W, H))
+    cpu = scene.upload(oa.OracleRenderer(W, H))
+    cpu.set_tile_partition(rank, world, TILE)
+    frames = 3
+    rr.FrameLoop(gpu, scene.make_view(W, H)).frames(frames, pass_mask)
+    run_frames(cpu, scene, W, H, frames, pass_mask)
+    mask = sampled(world, rank)
+    a, b = gpu.read_accumulation()[mask], cpu.read_accumulation()[mask]
+    assert per_pixel_l2(a / frames, b / frames) <= L2_TOL
+    assert np.abs(a - b).max() <= 1e-4 * frames  # only the sky integral (device exp/pow vs libm) differs
+    if config == 2:  # reservoir chain of the last frame: full frame, bit for bit
+        for which in range(3):
+            g, c = gpu.read_reservoirs(which), cpu.read_reservoirs(which)
+            assert np.array_equal(g.view(np.uint32), c.view(np.uint32)), which
+
+
 def test_restir_frame_matches_oracle_config3(sponza_lights):
     gpu = sponza_lights.upload(rr.Renderer(W, H))
     cpu = sponza_lights.upload(oa.OracleRenderer(W, H))

@@ -25,12 +25,18 @@ def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    durations = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> pass file -> dispatch durations (ns)
     for f in glob.glob(os.path.join(src, "**", "*_counter_collection.csv"), recursive=True):
         per_dispatch = collections.defaultdict(float)
+        span = {}
         for r in csv.DictReader(open(f)):
             per_dispatch[(r["Dispatch_Id"], short(r["Kernel_Name"]), r["Counter_Name"])] += float(r["Counter_Value"])
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                span[(r["Dispatch_Id"], short(r["Kernel_Name"]))] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         for (_, k, c), v in per_dispatch.items():
             vals[k][c].append(v)
+        for (_, k), ns in span.items():
+            durations[k][f].append(ns)
     out = {"note": "rocprofv3 --pmc, one process per pass (tools/pmc_passes.sh); per kernel and counter: median / mean over its dispatches. "
                    "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); valu_issue_frac = SQ_INSTS_VALU * 2 clk / (1024 SIMDs * GRBM_GUI_ACTIVE/8); "
                    "vmem_latency_clk = 4 * SQ_INST_LEVEL_VMEM / SQ_INSTS_VMEM_RD (level counters tick in quad-cycles)", "kernels": {}}
@@ -53,6 +59,11 @@ def main():
             d["l1_to_l2_read_latency_clk"] = m["TCP_TCC_READ_REQ_LATENCY_sum"] / m["TCP_TCC_READ_REQ_sum"]
         if m.get("TCP_TOTAL_CACHE_ACCESSES_sum") and m.get("TCP_TCC_READ_REQ_sum"):
             d["l1_miss_per_access"] = m["TCP_TCC_READ_REQ_sum"] / m["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        # dispatch duration under the counter passes (kernels serialised by the profiler): the counter CSVs carry start / end
+        # timestamps per dispatch, so no clock has to be assumed. Median over the dispatches of the pass with the most of them.
+        ns = max(durations[k].values(), key=len) if durations.get(k) else []
+        if ns:
+            d["launch_ns_median"], d["launch_ns_mean"], d["launch_ns_total"], d["launches"] = statistics.median(ns), sum(ns) / len(ns), sum(ns), len(ns)
         out["kernels"][k] = {"counters": e, "derived": d}
     dst = os.path.join(ROOT, "profiles", f"{tag}_counters.json")
     json.dump(out, open(dst, "w"), indent=1)
@@ -73,11 +84,25 @@ def main():
                     profiled_rays = json.loads(line)["roofline"]["rays_per_launch"]
         except OSError:
             pass
+        # HBM-side bytes of the WHOLE profiled run, every kernel and every dispatch (sum, not median x count), per frame the run
+        # rendered: bench.py's roofline.frame_hbm_frac = this / ms_per_step / 8 TB/s
+        total_bytes = 0.0
+        for k, v in out["kernels"].items():
+            c = v["counters"]
+            total_bytes += 2048.0 * c.get("FETCH_SIZE", {}).get("mean", 0.0) * c.get("FETCH_SIZE", {}).get("n", 0)
+            total_bytes += 1024.0 * c.get("WRITE_SIZE", {}).get("mean", 0.0) * c.get("WRITE_SIZE", {}).get("n", 0)
+        bench["run_hbm_bytes_total"] = total_bytes
+        if sig.get("frames_total"):
+            bench["frame_hbm_bytes"] = total_bytes / sig["frames_total"]
+            bench["frames_profiled"] = sig["frames_total"]
+        bench["signature"] = {a: b for a, b in sig.items() if a != "frames_total"}
         for k, v in out["kernels"].items():
             m = {c: x["median"] for c, x in v["counters"].items()}
             e = bench["kernels"].setdefault(base_name(k), {})
             if e:
                 continue  # first variant seen wins (one variant per run)
+            if v["derived"].get("launch_ns_median"):
+                e["launch_ns"] = v["derived"]["launch_ns_median"]  # serialised (counter passes run one kernel at a time)
             if "FETCH_SIZE" in m or "WRITE_SIZE" in m:
                 e["fetch_kib_per_launch"], e["write_kib_per_launch"] = m.get("FETCH_SIZE"), m.get("WRITE_SIZE")
                 e["hbm_bytes_per_launch"] = 2048.0 * m.get("FETCH_SIZE", 0.0) + 1024.0 * m.get("WRITE_SIZE", 0.0)
