@@ -144,7 +144,7 @@ def main():
     for k, v in serial:
         renderer.set_option(k, v)
     alone_ms = alone_rays = 0.0
-    frame_by_frame_ms = None
+    frame_by_frame_ms = serial_ms_per_frame = None
     if not args.no_alone:
         loop.frames(16, pass_mask)  # creates the slot; the same wavefront size as below
         renderer.reset_stats()
@@ -152,6 +152,7 @@ def main():
         alone = renderer.get_stats()
         alone_ms = alone.trace_closest_ms / max(alone.trace_closest_launches, 1)
         alone_rays = float(alone.rays[rr.RAY_PRIMARY] + alone.rays[rr.RAY_BOUNCE]) / max(alone.trace_closest_launches, 1)
+        serial_ms_per_frame = {"trace_closest": alone.trace_closest_ms / 16, "trace_shadow": alone.trace_shadow_ms / 16, "shade_hit_and_miss": alone.shade_ms / 16}
         # what a caller of uh_render_frame sees with nothing overlapped: one frame per call, one stream, no batching
         # (per-kernel event timing is on in these frames: a few percent of launch overhead included)
         renderer.set_option("batch_frames", 1)
@@ -252,6 +253,7 @@ def main():
                 "partition": f"{args.tile}x{args.tile} tiles round-robin over {world} rank(s), 1 RCCL gather" if world > 1 else "single GPU",
                 "frame_by_frame_ms": frame_by_frame_ms,      # fully serial: one stream, one frame, per-kernel event timing on
                 "interactive_frame_ms": interactive_frame_ms,  # default options, a synchronisation after every frame
+                "serial_kernel_ms_per_frame": serial_ms_per_frame,  # HIP-event time by kernel kind, one 16-frame wavefront alone on the GPU, nothing overlapped
             },
             "roofline": roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, signature(args, scene, W, H)),
         }

@@ -204,6 +204,10 @@ typedef struct UhStats {
    float trace_shadow_ms;
    float shade_ms;
    uint32_t trace_closest_launches;
+   uint32_t sun_grid_cells;     /* the sun-direction visibility grid in use (0 = none: the sun shadow rays walk the tree) */
+   uint32_t sun_grid_entries;   /* (triangle, cell) pairs it holds */
+   float sun_grid_build_ms;     /* host time of its last build (once per sun direction and geometry) */
+   float sun_grid_mean_list;    /* entries per occupied cell */
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;

@@ -237,6 +237,24 @@ struct uh_ctx {
    std::vector<EventPair> pending, free_events;
    uint32_t bvh_nodes = 0, bvh_tris = 0;
 
+   // sun shadow rays through a per-direction grid instead of the tree (sun_grid.h; option "sun_grid"). The grid belongs to one
+   // (geometry, sun direction) pair: it is built on the first frame that traces sun rays and again when the direction has
+   // changed and then stayed put for two consecutive frames - a sun that moves every frame keeps the tree walk.
+   bool sun_grid_enabled = true;
+   bool sun_valid = false;          // d_sun_* hold a usable grid for (sun_geom, sun_dir_built)
+   bool sun_attempted = false;      // a build for (sun_geom, sun_dir_built) was tried (it may have been refused: sun_why)
+   bool sun_have_pending = false;
+   uint64_t geom_version = 1, sun_geom = 0;
+   float sun_dir_built[3] = {0, 0, 0}, sun_dir_pending[3] = {0, 0, 0};
+   DevBuf<uint32_t> d_sun_cells;
+   DevBuf<SunGridEntry> d_sun_entries;
+   SunGridDev sun_dev{};
+   SunGridLimits sun_limits;
+   std::string sun_why;
+   float sun_build_ms = 0.0f, sun_mean_list = 0.0f;
+   uint32_t sun_cells = 0, sun_entries = 0, sun_max_list = 0;
+   bool sun_this_frame = false;     // set by render_batch for the frame being enqueued
+
    // tile partition
    uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
    DevBuf<uint32_t> owned_pixels;  // ascending pixel ids this rank owns (empty = the whole frame)
@@ -437,6 +455,8 @@ void uh_destroy(uh_ctx* c) {
    c->d_src_shade.release();
    c->d_tex.release();
    c->d_lut.release();
+   c->d_sun_cells.release();
+   c->d_sun_entries.release();
    c->accumulation.release();
    c->gbuffer.release();
    c->output.release();
@@ -680,6 +700,7 @@ int uh_build_acceleration(uh_ctx* c) {
    for (size_t i = 0; i < total; i++) c->packet_keys[i] = tp[i].key;
    c->level_start = bo.level_start;
    c->d_obj_corners.release();  // leaf order changed: the next refit re-creates its inputs
+   c->geom_version++;
    c->topology_valid = true;
    c->built = true;
    c->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -738,6 +759,7 @@ int uh_refit_acceleration(uh_ctx* c) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
    }
    c->built = true;
+   c->geom_version++;
    c->build_ms = c->refit_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
    return UH_OK;
 }
@@ -874,6 +896,7 @@ static int build_on_device(uh_ctx* c) {
    c->bvh_nodes = num_nodes;
    c->bvh_tris = (uint32_t)total;
    c->packet_keys.assign(total, 0u);  // only its size is used once d_obj_corners exists (uh_refit_acceleration)
+   c->geom_version++;
    c->topology_valid = true;
    c->built = true;
    c->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -949,6 +972,71 @@ static int ensure_slot(uh_ctx* c, uint32_t i, uint32_t batch = 1) {
    return UH_OK;
 }
 
+// the sun grid for this frame's direction, if there is (or now should be) one: see uh_ctx::sun_*
+static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
+   c->sun_this_frame = false;
+   if (!c->sun_grid_enabled || c->scene.num_tris == 0) return UH_OK;
+   const bool same_geom = c->sun_geom == c->geom_version;
+   const bool same_dir = std::memcmp(dir, c->sun_dir_built, sizeof(float) * 3) == 0;
+   if (same_geom && c->sun_attempted && same_dir) {
+      c->sun_have_pending = false;
+      c->sun_this_frame = c->sun_valid;
+      return UH_OK;
+   }
+   if (same_geom && c->sun_attempted) {
+      // another direction than the grid's: rebuild once it has been asked for twice in a row, walk the tree meanwhile
+      const bool settled = c->sun_have_pending && std::memcmp(dir, c->sun_dir_pending, sizeof(float) * 3) == 0;
+      std::memcpy(c->sun_dir_pending, dir, sizeof(float) * 3);
+      c->sun_have_pending = true;
+      if (!settled) return UH_OK;
+   }
+   // build: the packets as the device holds them (leaf order; host build, device build and refit all end there)
+   if (int st = sync_all(c)) return st;
+   const auto t0 = std::chrono::steady_clock::now();
+   const uint32_t n = c->scene.num_tris;
+   std::vector<float> packets(12 * (size_t)n);
+   HIP_TRY(c, hipMemcpy2D(packets.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), n, hipMemcpyDeviceToHost));
+   int threads = (int)std::thread::hardware_concurrency();
+   threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+   SunGridHost g;
+   const bool ok = build_sun_grid(packets.data(), n, dir, c->sun_limits, threads, g);
+   c->sun_attempted = true;
+   c->sun_have_pending = false;
+   c->sun_geom = c->geom_version;
+   std::memcpy(c->sun_dir_built, dir, sizeof(float) * 3);
+   c->sun_valid = false;
+   c->sun_why = g.why_not;
+   c->sun_mean_list = (float)g.mean_list;
+   c->sun_max_list = g.max_list;
+   c->sun_cells = c->sun_entries = 0;
+   if (ok) {
+      HIP_TRY(c, c->d_sun_cells.alloc(g.cell_start.size()));
+      HIP_TRY(c, c->d_sun_entries.alloc(g.entries.size() ? g.entries.size() : 1));
+      HIP_TRY(c, hipMemcpy(c->d_sun_cells.p, g.cell_start.data(), g.cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      if (!g.entries.empty()) HIP_TRY(c, hipMemcpy(c->d_sun_entries.p, g.entries.data(), g.entries.size() * sizeof(SunGridEntry), hipMemcpyHostToDevice));
+      SunGridDev& d = c->sun_dev;
+      std::memcpy(d.U, g.U, sizeof(d.U));
+      std::memcpy(d.V, g.V, sizeof(d.V));
+      std::memcpy(d.W, g.W, sizeof(d.W));
+      d.u0 = g.u0;
+      d.v0 = g.v0;
+      d.inv_cell = g.inv_cell;
+      d.nx = g.nx;
+      d.ny = g.ny;
+      d.cell_start = c->d_sun_cells.p;
+      d.entries = c->d_sun_entries.p;
+      c->sun_cells = g.nx * g.ny;
+      c->sun_entries = (uint32_t)g.entries.size();
+      c->sun_valid = true;
+   } else {
+      c->d_sun_cells.release();
+      c->d_sun_entries.release();
+   }
+   c->sun_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+   c->sun_this_frame = c->sun_valid;
+   return UH_OK;
+}
+
 // reference_pt_pass of one frame on one slot (reference.rgen:22-145 as a kernel chain)
 static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
    LaunchCfg lc = cfg(c);
@@ -994,7 +1082,10 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          }
          if (fp.sun_shadow_enabled == 1) {
             begin_timed(c, 1, sh_stream);
-            launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, false);
+            if (c->sun_this_frame)
+               launch_trace_sun_grid(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, c->sun_dev);
+            else
+               launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, false);
             end_timed(c, sh_stream);
          }
          if (fp.lights_enabled == 1) {
@@ -1113,6 +1204,9 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
    for (uint32_t f = 0; f < kMaxBatchFrames; f++) fp.spatial_of[f] = spatial_buf(read_slot[f < batch ? f : 0]);
 
    if (pass_mask & UH_PASS_REFERENCE_PT) {
+      c->sun_this_frame = false;
+      if (fp.sun_shadow_enabled == 1 && fp.num_bounces > 0 && fp.samples_per_frame > 0)
+         if (int st = ensure_sun_grid(c, fp.sun_dir)) return st;
       const uint32_t si = c->next_slot;
       c->next_slot = (c->next_slot + 1) % (c->frames_in_flight ? c->frames_in_flight : 1);
       int st = ensure_slot(c, si, batch);
@@ -1329,6 +1423,10 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->trace_shadow_ms = c->ms_by_kind[1];
    out->shade_ms = c->ms_by_kind[2];
    out->trace_closest_launches = c->trace_closest_launches;
+   out->sun_grid_cells = c->sun_valid ? c->sun_cells : 0;
+   out->sun_grid_entries = c->sun_valid ? c->sun_entries : 0;
+   out->sun_grid_build_ms = c->sun_build_ms;
+   out->sun_grid_mean_list = c->sun_mean_list;
    return UH_OK;
 }
 
@@ -1358,6 +1456,18 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (c->device_build != (value != 0) || (value && c->device_build_kind != (uint32_t)value)) c->built = c->topology_valid = false;
       c->device_build = value != 0;
       if (value) c->device_build_kind = (uint32_t)value;
+   }
+   else if (n == "sun_grid") {
+      // 1 (default): sun shadow rays go through the per-direction grid of sun_grid.h when one can be built; 0: always the tree
+      c->sun_grid_enabled = value != 0;
+   } else if (n == "sun_grid_density") {
+      if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_density (entries per triangle) must be 1..4096");
+      c->sun_limits.entries_per_triangle = (double)value;
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_max_mb") {
+      if (value < 1 || value > 65536) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_mb must be 1..65536");
+      c->sun_limits.max_entries = ((uint64_t)value << 20) / sizeof(SunGridEntry);
+      c->sun_attempted = false;
    }
    else if (n == "time_kernels") {
       if (c->time_kernels && !value) {

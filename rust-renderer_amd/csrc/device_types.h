@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "bvh.h"
+#include "sun_grid.h"
 #include "utopian_hip.h"
 
 namespace uh {
@@ -158,6 +159,9 @@ void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, C
 void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
 void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
                          uint32_t cursor_slot, bool light);
+// sun shadow rays through the per-direction grid (sun_grid.h) instead of the tree
+void launch_trace_sun_grid(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
+                           uint32_t cursor_slot, const SunGridDev&);
 void launch_finish_sample(const LaunchCfg&, const FrameParams&, const PathState&, const Images&, uint32_t sample, bool last);
 void launch_resolve(const LaunchCfg&, const Images&, uint32_t W, uint32_t H, uint32_t total_samples, uint32_t limit);
 // G-buffer + ReSTIR

@@ -669,6 +669,80 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    }
 }
 
+// ------------------------------------------------------------------------------------------
+// trace_sun_grid - the sun shadow rays of reference.rgen:63-79 through the per-direction grid of sun_grid.h instead of the
+// tree: one cell look-up, then the cell's packets front (sun side) to back through the same tri_compute<ANY> until one
+// occludes the ray or the list falls behind the ray's origin. Same predicate as k_trace_shadow<.., false>: occluded <=> some
+// triangle accepts the ray with 0.001 < t < 10000 - bit for bit, the grid only prunes (conservatively) which triangles are asked.
+// Batch form: rays do a handful of steps, and their lengths (0..a few tests) differ little inside a wave.
+// ------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+                                                            uint32_t cursor_slot, SunGridDev g) {
+   const uint32_t lane = lane_id();
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t* __restrict__ queue = ps.queue[(bounce + 1) & 1] + seg;  // a sun ray leaves every scattered path
+   const uint32_t count = ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
+   const float4* __restrict__ tris = sc.tris;
+   const V3 d = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);  // rgen:64
+   const float max_x = (float)(g.nx - 1), max_y = (float)(g.ny - 1);
+   uint32_t n_cells = 0, n_tris = 0;
+   for (;;) {
+      const uint32_t base = next_batch(cursor);
+      if (base >= count) break;
+      const uint32_t i = base + lane;
+      if (i >= count) continue;
+      const uint32_t id = ld_stream(queue + i);
+      const float4 ro = ld_stream(ps.ray_o + id);
+      const V3 o = v3(ro.x, ro.y, ro.z);
+      const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o), pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
+      // the ray's cell; outside the grid (or NaN) it is the border cell, which lists everything that reaches beyond the grid
+      float fx = (pu - g.u0) * g.inv_cell, fy = (pv - g.v0) * g.inv_cell;
+      fx = !(fx >= 0.0f) ? 0.0f : fx;
+      fy = !(fy >= 0.0f) ? 0.0f : fy;
+      fx = fx > max_x ? max_x : fx;
+      fy = fy > max_y ? max_y : fy;
+      const uint32_t cell = (uint32_t)fy * g.nx + (uint32_t)fx;
+      uint32_t e = g.cell_start[cell];
+      const uint32_t end = g.cell_start[cell + 1];
+      if (COUNT) n_cells++;
+      bool occluded = false;
+      Hit best;
+      best.t = 10000.0f;  // tmax (rgen:66)
+      best.u = best.v = 0.0f;
+      best.idx = kEmptyRef;
+      best.key = 0xffffffffu;
+      uint2 en = make_uint2(0u, 0u);
+      if (e < end) en = reinterpret_cast<const uint2*>(g.entries)[e];
+      while (e < end) {
+         // sorted by far depth, descending: from here on every packet ends behind the origin (t < 0 for all of them)
+         if (__uint_as_float(en.y) < pw) break;
+         const uint32_t pk = en.x;
+         uint2 nxt = make_uint2(0u, 0u);
+         if (e + 1 < end) nxt = reinterpret_cast<const uint2*>(g.entries)[e + 1];  // in flight with the packet
+         const float4 a = tris[kTriStride16 * (size_t)pk + 0], b = tris[kTriStride16 * (size_t)pk + 1], c = tris[kTriStride16 * (size_t)pk + 2];
+         if (COUNT) n_tris++;
+         if (tri_compute<true>(a, b, c, pk, o, d, 0.001f, INFINITY, best)) {
+            occluded = true;
+            break;
+         }
+         en = nxt;
+         e++;
+      }
+      if (!occluded) {  // rgen:69-78: radiance += throughput
+         const float4 thr = ld_stream(ps.thr + id), rad = ld_stream(ps.rad + id);
+         st_stream(ps.rad + id, make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w));
+      }
+   }
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[UH_RAY_SUN_SHADOW], (unsigned long long)count);
+   if (COUNT) {
+      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_cells);
+      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
+   }
+}
+
 // stand-alone any-hit query (uh_trace_any): occluded[i] = 1 when some triangle lies in (tmin, tmax) of ray i
 __global__ __launch_bounds__(kBlock) void k_trace_any_raw(SceneDev sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                           uint32_t* __restrict__ occluded, uint32_t count) {
@@ -1369,6 +1443,15 @@ void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneD
       else UH_SHADOW((k_trace_shadow<false, false>));
    }
 #undef UH_SHADOW
+}
+
+void launch_trace_sun_grid(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+                           uint32_t cursor_slot, const SunGridDev& g) {
+   const dim3 grid = sharded_grid(c.num_cus * 8);
+   if (c.count_visits)
+      k_trace_sun_grid<true><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, g);
+   else
+      k_trace_sun_grid<false><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, g);
 }
 
 void launch_finish_sample(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, const Images& im, uint32_t sample, bool last) {

@@ -263,6 +263,12 @@ int uh_mgpu_get_stats(uh_mgpu* m, UhStats* out) {
       if (s.trace_shadow_ms > out->trace_shadow_ms) out->trace_shadow_ms = s.trace_shadow_ms;
       if (s.shade_ms > out->shade_ms) out->shade_ms = s.shade_ms;
       out->trace_closest_launches += s.trace_closest_launches;
+      if (i == 0) {  // every GPU builds the same grid
+         out->sun_grid_cells = s.sun_grid_cells;
+         out->sun_grid_entries = s.sun_grid_entries;
+         out->sun_grid_mean_list = s.sun_grid_mean_list;
+      }
+      if (s.sun_grid_build_ms > out->sun_grid_build_ms) out->sun_grid_build_ms = s.sun_grid_build_ms;
    }
    return UH_OK;
 }

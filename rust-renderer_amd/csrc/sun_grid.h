@@ -1,0 +1,59 @@
+// sun_grid.h — visibility structure for the sun shadow rays of reference.rgen:63-79.
+//
+// Every sun shadow ray of a frame has the SAME direction (normalize(view.sun_dir), rgen:64) - 48 % of all path rays of the
+// headline workload. In a frame whose w axis is that direction such a ray is a point (u, v) plus a start depth w0, so "is
+// any triangle in front of it" needs no tree: the triangles are binned ONCE per sun direction into a uniform 2-D grid over
+// the (u, v) plane - each cell lists the triangle packets whose (conservatively dilated) projection overlaps it, sorted by
+// the packet's far depth, descending - and a ray tests the packets of its one cell, front (sun side) to back, until one
+// occludes it or the list falls behind its origin. The test itself is the very tri_compute<ANY> of the tree walk on the same
+// 48-byte packets, so the result is the same predicate - "some triangle accepts the ray in (tmin, tmax)" - bit for bit;
+// only the set of triangles that gets ASKED shrinks, and it shrinks conservatively (sun_grid.cpp "margins").
+// Replaces, for this ray class, the any-hit tree walk of k_trace_shadow<sun> (12.6 steps per ray) by about one cell
+// look-up and a few triangle tests.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace uh {
+
+struct SunGridEntry {
+   uint32_t packet;  // triangle packet index (TriPacket array, leaf order)
+   float wmax;       // far end of the packet's depth range along the sun direction, padded
+};
+
+// what the kernel reads (device pointers)
+struct SunGridDev {
+   float U[3], V[3], W[3];  // orthonormal frame, W = the sun direction exactly as FrameParams::sun_dir
+   float u0, v0, inv_cell;  // cell (ix, iy) covers u0 + [ix, ix+1) / inv_cell, v0 + [iy, iy+1) / inv_cell
+   uint32_t nx, ny;
+   const uint32_t* cell_start;   // nx * ny + 1 offsets into entries
+   const SunGridEntry* entries;
+};
+
+struct SunGridHost {
+   float U[3], V[3], W[3];
+   float u0 = 0, v0 = 0, inv_cell = 0;
+   uint32_t nx = 0, ny = 0;
+   std::vector<uint32_t> cell_start;
+   std::vector<SunGridEntry> entries;
+   // quality figures (what a ray can expect): entries per non-empty cell, the longest list, cells
+   double mean_list = 0.0;
+   uint32_t max_list = 0;
+   double build_ms = 0.0;
+   std::string why_not;  // non-empty: the grid was not built (degenerate direction, over budget, lists too long)
+};
+
+struct SunGridLimits {
+   uint64_t max_entries = 96ull << 20;  // 8 bytes each
+   uint64_t max_cells = 24ull << 20;
+   double entries_per_triangle = 48.0;  // target density: the cell size is the finest that keeps the estimate under it (MI355X, config 1: 24 / 48 / 96 / 200 = 0.590 / 0.515 / 0.490 / 0.479 ms of sun rays per frame, tree walk 0.632)
+   double max_mean_list = 40.0;         // beyond this a ray's expected work exceeds the tree walk's: use the tree
+};
+
+// packets: n x 12 floats in TriPacket layout (v0.xyz e1.x | e1.yz e2.xy | e2.z key pad pad). sun_dir: the frame's
+// normalised direction (the floats the kernels use). Returns false (and says why in out.why_not) when the direction is not
+// finite, the scene is empty or a limit is exceeded; the caller then keeps the tree walk.
+bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, int num_threads, SunGridHost& out);
+
+}  // namespace uh

@@ -113,6 +113,10 @@ class Stats(C.Structure):
         ("trace_shadow_ms", C.c_float),
         ("shade_ms", C.c_float),
         ("trace_closest_launches", C.c_uint32),
+        ("sun_grid_cells", C.c_uint32),
+        ("sun_grid_entries", C.c_uint32),
+        ("sun_grid_build_ms", C.c_float),
+        ("sun_grid_mean_list", C.c_float),
     ]
 
     @property

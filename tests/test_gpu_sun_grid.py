@@ -1,0 +1,149 @@
+"""-m gpu: the sun-direction visibility grid (csrc/sun_grid.cpp + k_trace_sun_grid) against the any-hit tree walk it replaces
+for the sun shadow rays of reference.rgen:63-79 and against the oracle: same images bit for bit, same ray counts, for every
+octant and for axis-aligned suns (walls edge-on), across direction changes, refits and device-built trees."""
+import numpy as np
+import pytest
+
+import oracle_api as oa
+import rust_renderer_amd as rr
+from util import L2_TOL, make_pair, per_pixel_l2, run_frames, torture_scene
+
+pytestmark = pytest.mark.gpu
+
+SUNS = [(0.0, 0.9, 0.15), (0.3, 0.8, 0.2), (-0.3, -0.8, 0.2), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.7, 0.7, 0.0), (1e-4, 1.0, 0.0), (-0.5, 0.1, 0.85)]
+
+
+@pytest.fixture(scope="module")
+def atrium():
+    return rr.scenes.sponza_class_scene(detail=0.12, tex_size=32, with_spheres=True, num_lights=0, sphere_subdivisions=2)
+
+
+@pytest.fixture(scope="module")
+def cornell():
+    return rr.scenes.cornell_scene(subdivisions=2, tex_size=16)
+
+
+def render(renderer, scene, W, H, sun, frames=2, **flags):
+    loop = rr.FrameLoop(renderer, scene.make_view(W, H, sun_shadow_enabled=1, **flags))
+    loop.view.sun_dir[:] = list(sun)
+    for _ in range(frames):
+        loop.frame(rr.PASS_REFERENCE_PT)
+    return loop
+
+
+@pytest.mark.parametrize("sun", SUNS)
+def test_grid_equals_tree_walk_and_oracle(atrium, sun):
+    W, H = 128, 72
+    grid = atrium.upload(rr.Renderer(W, H))
+    tree = atrium.upload(rr.Renderer(W, H))
+    tree.set_option("sun_grid", 0)
+    cpu = atrium.upload(oa.OracleRenderer(W, H))
+    for r in (grid, tree, cpu):
+        render(r, atrium, W, H, sun, frames=2, sky_enabled=0, lights_enabled=0)
+    g, t = grid.get_stats(), tree.get_stats()
+    assert g.sun_grid_cells > 0 and g.sun_grid_entries > 0 and t.sun_grid_cells == 0, "the first renderer really went through the grid"
+    a = grid.read_accumulation()
+    assert np.array_equal(a.view(np.uint32), tree.read_accumulation().view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), cpu.read_accumulation().view(np.uint32))
+    assert list(g.rays) == list(t.rays) and list(g.rays)[:4] == list(cpu.get_stats().rays)[:4]
+    assert g.rays[rr.RAY_SUN_SHADOW] > 0
+
+
+def test_grid_on_all_scene_kinds_with_sky(atrium, cornell):
+    """the whole path (sky on, every material type, lights) with the grid against the oracle, and against the tree walk bit for bit"""
+    for scene, (W, H) in ((cornell, (96, 64)), (torture_scene(), (24, 24)), (rr.scenes.rtiow_scene(2), (64, 64))):
+        grid, cpu = make_pair(scene, W, H)
+        tree = scene.upload(rr.Renderer(W, H))
+        tree.set_option("sun_grid", 0)
+        for r in (grid, tree, cpu):
+            run_frames(r, scene, W, H, 3, rr.PASS_ALL)
+        assert np.array_equal(grid.read_accumulation().view(np.uint32), tree.read_accumulation().view(np.uint32)), scene.name
+        assert per_pixel_l2(grid.read_accumulation() / 3, cpu.read_accumulation() / 3) <= L2_TOL, scene.name
+        assert list(grid.get_stats().rays) == list(tree.get_stats().rays) == list(cpu.get_stats().rays), scene.name
+
+
+def test_counted_visits_drop(atrium):
+    """what the grid is for: a cell look-up and a few triangle tests per sun ray instead of a tree walk"""
+    W, H = 160, 90
+    out = {}
+    for name, on in (("grid", 1), ("tree", 0)):
+        r = atrium.upload(rr.Renderer(W, H))
+        r.set_option("sun_grid", on)
+        r.set_option("count_visits", 1)
+        render(r, atrium, W, H, SUNS[0], frames=2, sky_enabled=1, lights_enabled=0)
+        s = r.get_stats()
+        out[name] = (s.shadow_nodes_visited / s.rays[rr.RAY_SUN_SHADOW], s.shadow_tris_tested / s.rays[rr.RAY_SUN_SHADOW])
+    assert out["grid"][0] == 1.0, "one cell per ray"
+    assert out["grid"][1] < 6.0 and out["tree"][0] > 5.0, out
+
+
+def test_direction_changes_and_settling(atrium):
+    """frame 1 builds the grid for direction A; a frame with direction B walks the tree (a sun that moves every frame must not
+    rebuild every frame); the second frame in a row with B rebuilds. Every frame equals the oracle's."""
+    W, H = 96, 54
+    gpu, cpu = make_pair(atrium, W, H)
+    A, B, C = (0.0, 0.9, 0.15), (0.4, 0.7, -0.3), (-0.2, 0.5, 0.6)
+    loops = [rr.FrameLoop(r, atrium.make_view(W, H, sun_shadow_enabled=1, sky_enabled=0, lights_enabled=0)) for r in (gpu, cpu)]
+    builds = []
+    for sun in (A, A, B, C, B, B, B, A, A):
+        for loop in loops:
+            loop.view.sun_dir[:] = list(sun)
+            loop.frame(rr.PASS_REFERENCE_PT)
+            loop.reset()  # every frame stands alone
+        s = gpu.get_stats()
+        builds.append(round(s.sun_grid_build_ms, 4))
+        assert np.array_equal(gpu.read_accumulation().view(np.uint32), cpu.read_accumulation().view(np.uint32)), sun
+    # builds happened at frames 0 (A), 5 (B asked twice in a row) and 8 (A again, twice in a row): the timer changes exactly there
+    changed = [i for i in range(1, len(builds)) if builds[i] != builds[i - 1]]
+    assert changed == [5, 8], (changed, builds)
+
+
+def test_refit_and_device_build_invalidate_the_grid(cornell):
+    W, H = 80, 60
+    gpu, cpu = make_pair(cornell, W, H)
+    for r in (gpu, cpu):
+        run_frames(r, cornell, W, H, 1, rr.PASS_REFERENCE_PT)
+    first = gpu.get_stats().sun_grid_entries
+    move = rr.transform3x4((0.3,) * 3, (0.1, 0.9, 0.1))
+    n = cornell.num_meshes
+    for r in (gpu, cpu):
+        r.set_instance_transform(n - 2, move)  # the metal sphere now hangs in the air and casts another shadow
+        r.rebuild_tlas()
+        r.reset_accumulation()
+        run_frames(r, cornell, W, H, 2, rr.PASS_REFERENCE_PT)
+    assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
+    assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays)
+    assert gpu.get_stats().sun_grid_entries > 0 and first > 0
+    for kind in (1, 2):
+        dev = cornell.upload(rr.Renderer(W, H))
+        dev.set_option("device_build", kind)
+        dev.initialize_raytracing()
+        ref = cornell.upload(rr.Renderer(W, H))
+        for r in (dev, ref):
+            run_frames(r, cornell, W, H, 2, rr.PASS_REFERENCE_PT)
+        assert dev.get_stats().sun_grid_cells > 0
+        assert np.array_equal(dev.read_accumulation().view(np.uint32), ref.read_accumulation().view(np.uint32)), kind
+
+
+def test_budget_refusal_falls_back_to_the_tree(atrium):
+    W, H = 64, 36
+    gpu, cpu = make_pair(atrium, W, H)
+    gpu.set_option("sun_grid_max_mb", 1)  # 131,072 entries: far too few for this scene at any useful cell size
+    for r in (gpu, cpu):
+        render(r, atrium, W, H, SUNS[0], frames=1, sky_enabled=0, lights_enabled=0)
+    assert np.array_equal(gpu.read_accumulation().view(np.uint32), cpu.read_accumulation().view(np.uint32))
+
+
+def test_tile_partition_and_batches_with_the_grid(atrium):
+    W, H = 192, 108
+    ref = atrium.upload(rr.Renderer(W, H))
+    ref.set_option("sun_grid", 0)
+    rr.FrameLoop(ref, atrium.make_view(W, H)).frames(6, rr.PASS_REFERENCE_PT)
+    whole = atrium.upload(rr.Renderer(W, H))
+    whole.set_option("batch_frames", 4)
+    rr.FrameLoop(whole, atrium.make_view(W, H)).frames(6, rr.PASS_REFERENCE_PT)
+    assert np.array_equal(ref.read_accumulation().view(np.uint32), whole.read_accumulation().view(np.uint32))
+    group = atrium.upload(rr.MultiGpuRenderer(W, H, devices=[0, 0, 0], tile_size=32))
+    rr.FrameLoop(group, atrium.make_view(W, H)).frames(6, rr.PASS_REFERENCE_PT)
+    assert np.array_equal(ref.read_accumulation().view(np.uint32), group.read_accumulation().view(np.uint32))
+    assert list(ref.get_stats().rays) == list(group.get_stats().rays)

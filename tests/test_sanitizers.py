@@ -21,6 +21,22 @@ def test_bvh_builder_invariants_under_asan_ubsan(tmp_path):
     assert "BVH CHECK OK" in r.stdout
 
 
+def test_sun_grid_builder_under_asan_ubsan_never_hides_an_occluder(tmp_path):
+    """csrc/sun_grid.cpp (product code) under ASan + UBSan: for adversarial soups and nine sun directions the grid walk of
+    k_trace_sun_grid, replayed on the host in the kernel's float arithmetic, gives the verdict of an any-hit over all packets
+    whose padded box the ray meets (tests/cpp/sun_grid_check.cpp)."""
+    exe = str(tmp_path / "sun_grid_check")
+    csrc = os.path.join(ROOT, "rust-renderer_amd", "csrc")
+    subprocess.run(
+        ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-ffp-contract=off", "-mfma", "-Wall",
+         "-Wextra", "-I", csrc, os.path.join(ROOT, "tests", "cpp", "sun_grid_check.cpp"), os.path.join(csrc, "sun_grid.cpp"), "-o", exe, "-pthread"],
+        check=True,
+    )
+    r = subprocess.run([exe, "6", "9"], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "SUN GRID CHECK OK" in r.stdout and "MISMATCH" not in r.stdout
+
+
 def test_oracle_under_asan_ubsan_matches_the_plain_build(tmp_path):
     """the oracle itself, compiled with ASan + UBSan (threads on), renders the Cornell-class scene with
     the ReSTIR chain and all four material types; its image equals the -O2 library's bit for bit.
