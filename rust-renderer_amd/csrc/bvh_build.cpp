@@ -226,6 +226,115 @@ void quantise_node(const NodeW& nd, Node4C& q) {
    }
 }
 
+void split_references(const float* corners, uint32_t count, float threshold, uint32_t max_pieces, std::vector<float>& boxes6, std::vector<uint32_t>& ref_tri) {
+   boxes6.clear();
+   ref_tri.clear();
+   boxes6.reserve(6 * (size_t)count);
+   ref_tri.reserve(count);
+   struct Piece {
+      double p[9][3];  // convex polygon (a triangle clipped by axis-aligned planes has at most 3 + 6 corners)
+      int n;
+   };
+   auto box_of = [](const Piece& q, double* lo, double* hi) {
+      for (int a = 0; a < 3; a++) {
+         lo[a] = INFINITY;
+         hi[a] = -INFINITY;
+      }
+      for (int k = 0; k < q.n; k++)
+         for (int a = 0; a < 3; a++) {
+            lo[a] = std::fmin(lo[a], q.p[k][a]);
+            hi[a] = std::fmax(hi[a], q.p[k][a]);
+         }
+   };
+   // the part of q on the side `keep_below` of the plane x[axis] = pos (Sutherland-Hodgman; corners ON the plane stay in both parts)
+   auto clip = [](const Piece& q, int axis, double pos, bool keep_below) {
+      Piece r;
+      r.n = 0;
+      for (int k = 0; k < q.n; k++) {
+         const double* a = q.p[k];
+         const double* b = q.p[(k + 1) % q.n];
+         const double da = keep_below ? pos - a[axis] : a[axis] - pos, db = keep_below ? pos - b[axis] : b[axis] - pos;
+         if (da >= 0 && r.n < 9) std::memcpy(r.p[r.n++], a, sizeof(double) * 3);
+         if ((da > 0 && db < 0) || (da < 0 && db > 0)) {
+            const double t = da / (da - db);
+            if (r.n < 9) {
+               for (int c = 0; c < 3; c++) r.p[r.n][c] = a[c] + t * (b[c] - a[c]);
+               r.p[r.n][axis] = pos;
+               r.n++;
+            }
+         }
+      }
+      return r;
+   };
+   std::vector<Piece> work;
+   for (uint32_t i = 0; i < count; i++) {
+      const float* c = corners + 9 * (size_t)i;
+      bool finite = true;
+      for (int k = 0; k < 9; k++) finite = finite && std::isfinite(c[k]);
+      Piece whole;
+      whole.n = 3;
+      for (int k = 0; k < 3; k++)
+         for (int a = 0; a < 3; a++) whole.p[k][a] = c[3 * k + a];
+      auto emit = [&](const double* lo, const double* hi) {
+         for (int a = 0; a < 3; a++) {
+            float f = (float)lo[a];
+            if ((double)f > lo[a]) f = std::nextafterf(f, -INFINITY);
+            boxes6.push_back(f);
+         }
+         for (int a = 0; a < 3; a++) {
+            float f = (float)hi[a];
+            if ((double)f < hi[a]) f = std::nextafterf(f, INFINITY);
+            boxes6.push_back(f);
+         }
+         ref_tri.push_back(i);
+      };
+      double lo[3], hi[3];
+      box_of(whole, lo, hi);
+      const double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+      if (!(threshold > 0) || !finite || !(diag > threshold) || max_pieces < 2) {
+         // unsplit: the corners' own box, exactly as the builder would compute it
+         float flo[3], fhi[3];
+         for (int a = 0; a < 3; a++) {
+            flo[a] = std::fmin(c[a], std::fmin(c[3 + a], c[6 + a]));
+            fhi[a] = std::fmax(c[a], std::fmax(c[3 + a], c[6 + a]));
+         }
+         boxes6.insert(boxes6.end(), flo, flo + 3);
+         boxes6.insert(boxes6.end(), fhi, fhi + 3);
+         ref_tri.push_back(i);
+         continue;
+      }
+      // halve the piece with the largest box until every piece is small enough or the budget is spent
+      work.clear();
+      work.push_back(whole);
+      for (;;) {
+         int pick = -1;
+         double worst = threshold;
+         for (size_t k = 0; k < work.size(); k++) {
+            box_of(work[k], lo, hi);
+            const double d = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+            if (d > worst) {
+               worst = d;
+               pick = (int)k;
+            }
+         }
+         if (pick < 0 || work.size() >= max_pieces) break;
+         box_of(work[pick], lo, hi);
+         int axis = 0;
+         for (int a = 1; a < 3; a++)
+            if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+         const double pos = 0.5 * (lo[axis] + hi[axis]);
+         const Piece below = clip(work[pick], axis, pos, true), above = clip(work[pick], axis, pos, false);
+         if (below.n < 3 || above.n < 3) break;  // numerically degenerate cut: keep what there is
+         work[pick] = below;
+         work.push_back(above);
+      }
+      for (const Piece& q : work) {
+         box_of(q, lo, hi);
+         emit(lo, hi);
+      }
+   }
+}
+
 void build_sah_top(const float* boxes6, uint32_t count, std::vector<TopNode>& out) {
    out.clear();
    if (count < 2) return;
@@ -266,17 +375,23 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    std::vector<Box> tb(n);
    std::vector<float> cen(3 * (size_t)n);
    for (uint32_t i = 0; i < n; i++) {
-      const float* c = in.corners + 9 * (size_t)i;
       Box b;
       b.reset();
-      b.grow_pt(c);
-      b.grow_pt(c + 3);
-      b.grow_pt(c + 6);
+      bool finite = true;
+      if (in.boxes6) {
+         b.grow_pt(in.boxes6 + 6 * (size_t)i);
+         b.grow_pt(in.boxes6 + 6 * (size_t)i + 3);
+         for (int k = 0; k < 6; k++) finite = finite && std::isfinite(in.boxes6[6 * (size_t)i + k]);
+      } else {
+         const float* c = in.corners + 9 * (size_t)i;
+         b.grow_pt(c);
+         b.grow_pt(c + 3);
+         b.grow_pt(c + 6);
+         for (int k = 0; k < 9; k++) finite = finite && std::isfinite(c[k]);
+      }
       // a triangle with a non-finite corner can never be hit (NaN fails every comparison of the slab and
       // triangle tests, an infinite edge turns the barycentrics into NaN): it gets a point box at the origin so
       // that the split search below only ever sees finite numbers (NaN breaks the ordering std::nth_element needs)
-      bool finite = true;
-      for (int k = 0; k < 9; k++) finite = finite && std::isfinite(c[k]);
       for (int a = 0; a < 3; a++) finite = finite && std::isfinite(0.5f * (b.lo[a] + b.hi[a]));
       if (!finite)
          for (int a = 0; a < 3; a++) b.lo[a] = b.hi[a] = 0.0f;
@@ -398,8 +513,15 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
                }
             }
             uint32_t mid;
-            if (best_axis < 0) {
+            if (best_axis < 0 || balanced || f.depth > 48) {
+               // median split along the widest centroid axis: what Builder::build does in the same cases, so that the balanced
+               // fallback bounds the depth of the serial top as well (a SAH top over clustered geometry can be a long chain)
+               int a = 0;
+               for (int k = 1; k < 3; k++)
+                  if (cb.hi[k] - cb.lo[k] > cb.hi[a] - cb.lo[a]) a = k;
                mid = f.first + f.count / 2;
+               std::nth_element(out.tri_order.begin() + f.first, out.tri_order.begin() + mid, out.tri_order.begin() + f.first + f.count,
+                                [&](uint32_t x, uint32_t y) { return cen[3 * (size_t)x + a] < cen[3 * (size_t)y + a]; });
             } else {
                float lo = cb.lo[best_axis], scale = (float)NB / (cb.hi[best_axis] - cb.lo[best_axis]);
                auto it = std::partition(out.tri_order.begin() + f.first, out.tri_order.begin() + f.first + f.count, [&](uint32_t t) {

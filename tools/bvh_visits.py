@@ -45,4 +45,5 @@ for name, rs in (("primary", rays), ("bounce", b)):
     with open(path, "wb") as f:
         f.write(np.uint32(len(corners)).tobytes()); f.write(np.uint32(len(rs)).tobytes()); f.write(corners.tobytes()); f.write(rs.tobytes())
     print(f"== {name}: {len(rs)} rays, {len(corners)} triangles", flush=True)
-    subprocess.run([exe, path], check=True)
+    for extra in ([], ["1.0", "16"], ["0.6", "16"], ["0.4", "32"], ["0.25", "64"]):
+        subprocess.run([exe, path] + extra + sys.argv[1:1], check=True)
