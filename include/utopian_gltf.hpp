@@ -9,7 +9,8 @@
 //     (callers override, e.g. prototype/src/scenes.rs:116-121);
 //   * images become RGBA8: RGB8 is expanded with alpha 255, RGBA8 passes, anything else is the reference's
 //     "Unsupported image format!" (gltf_loader.rs:179-198). PNG is decoded here (zlib's inflate + the five scanline
-//     filters; palette images expand to RGB8 / RGBA8 as the `image` crate does). JPEG is not decoded (Error).
+//     filters; palette images expand to RGB8 / RGBA8 as the `image` crate does), JPEG by utopian_jpeg.hpp (baseline,
+//     extended sequential and progressive Huffman JPEGs: 65 of Sponza's 69 images are baseline JPEGs).
 // Buffers and images may be base64 data URIs, files next to the .gltf, or buffer views.
 // The Python twin (rust-renderer_amd/gltf.py + image_decode.py) is what the parity tests use; tests/test_gltf_cpp.py
 // holds the two against each other. Header-only; link with -lz.
@@ -29,6 +30,7 @@
 #include <vector>
 
 #include "utopian_host.hpp"
+#include "utopian_jpeg.hpp"
 
 namespace utopian {
 namespace gltf {
@@ -362,8 +364,17 @@ inline DecodedImage decode_png(const std::vector<uint8_t>& data) {
 
 // gltf_loader.rs:179-198: RGB8 -> RGBA8 with alpha 255, RGBA8 as it is, anything else "Unsupported image format!"
 inline Texture load_image_rgba8(const std::vector<uint8_t>& data) {
-   if (data.size() >= 2 && data[0] == 0xff && data[1] == 0xd8) throw Error(UH_ERR_INVALID_ARGUMENT, "JPEG textures are not decoded by the C++ loader (PNG is)");
-   DecodedImage img = decode_png(data);
+   DecodedImage img;
+   if (data.size() >= 2 && data[0] == 0xff && data[1] == 0xd8) {
+      jpeg::Image j = jpeg::decode(data);
+      img.width = j.width;
+      img.height = j.height;
+      img.channels = j.channels;  // 1 = L8: "Unsupported image format!" below, as in the reference
+      img.depth = 8;
+      img.pixels = std::move(j.pixels);
+   } else {
+      img = decode_png(data);
+   }
    Texture t;
    t.width = img.width;
    t.height = img.height;
@@ -411,8 +422,12 @@ inline void read_accessor(const Document& d, uint32_t index, std::vector<float>*
    if (!acc.has("bufferView")) return;  // all zeros
    const Json& bv = d.json["bufferViews"][acc["bufferView"].index()];
    const std::vector<uint8_t>& raw = d.buffers.at(bv["buffer"].index());
-   const size_t start = (size_t)bv["byteOffset"].number(0) + (size_t)acc["byteOffset"].number(0);
-   size_t stride = (size_t)bv["byteStride"].number(0);
+   auto checked = [](double v, const char* what) {
+      if (!(v >= 0.0) || !(v < 9.0e15)) throw Error(UH_ERR_INVALID_ARGUMENT, std::string("glTF: ") + what + " is negative, not finite or absurdly large");
+      return (size_t)v;
+   };
+   const size_t start = checked(bv["byteOffset"].number(0), "bufferView.byteOffset") + checked(acc["byteOffset"].number(0), "accessor.byteOffset");
+   size_t stride = checked(bv["byteStride"].number(0), "bufferView.byteStride");
    if (!stride) stride = item * n;
    if (count && start + stride * (size_t)(count - 1) + item * n > raw.size()) throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: accessor reaches past its buffer");
    const bool normalized = acc["normalized"].kind == Json::Bool && acc["normalized"].b;
@@ -481,8 +496,9 @@ inline Model load_gltf(const std::string& path, std::vector<std::string>* mesh_n
       } else {
          const Json& bv = d.json["bufferViews"][image["bufferView"].index()];
          const std::vector<uint8_t>& raw = d.buffers.at(bv["buffer"].index());
-         const size_t off = (size_t)bv["byteOffset"].number(0), len = (size_t)bv["byteLength"].number(0);
-         if (off + len > raw.size()) throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: image reaches past its buffer");
+         const double foff = bv["byteOffset"].number(0), flen = bv["byteLength"].number(0);
+         if (!(foff >= 0.0) || !(flen >= 0.0) || !(foff + flen <= (double)raw.size())) throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: image reaches past its buffer");
+         const size_t off = (size_t)foff, len = (size_t)flen;
          data.assign(raw.begin() + (long)off, raw.begin() + (long)(off + len));
       }
       model.textures.push_back(load_image_rgba8(data));
@@ -491,7 +507,14 @@ inline Model load_gltf(const std::string& path, std::vector<std::string>* mesh_n
       const Document& d;
       Model& model;
       std::vector<std::string>* names;
+      int depth = 0;
       void node(uint32_t index, const Mat4& parent) {
+         // a node hierarchy is a forest (glTF 2.0, 3.5.2): a file whose children loop back would recurse for ever
+         if (++depth > 256) throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: node hierarchy deeper than 256 levels (cyclic children?)");
+         struct Leave {
+            int& d;
+            ~Leave() { d--; }
+         } leave{depth};
          const Json& n = d.json["nodes"][index];
          const Mat4 transform = parent * node_matrix(n);
          for (size_t c = 0; c < n["children"].size(); c++) node(n["children"][c].index(), transform);  // children first (gltf_loader.rs:57-63)
@@ -512,6 +535,12 @@ inline Model load_gltf(const std::string& path, std::vector<std::string>* mesh_n
             if (attrs.has("COLOR_0")) read_accessor(d, attrs["COLOR_0"].index(), &col, nullptr, &ncol);
             Mesh mesh;
             const size_t nv = pos.size() / 3;
+            // every attribute accessor must hold one element per POSITION (the reference's reader zips them and would panic)
+            if (n3 != 3 || nrm.size() != 3 * nv || (nuv && uv.size() != (size_t)nuv * nv) || (ntan && tan.size() != (size_t)ntan * nv) ||
+                (ncol && col.size() != (size_t)ncol * nv))
+               throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: attribute accessors of one primitive differ in element count (or NORMAL is not VEC3)");
+            for (uint32_t i : idx)
+               if (i >= nv) throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: index beyond the primitive's vertices");
             mesh.primitive.vertices.resize(nv);
             for (size_t v = 0; v < nv; v++) {
                Vertex& o = mesh.primitive.vertices[v];

@@ -1,8 +1,8 @@
 """In-repo image decoding for glTF ingestion: PNG is decoded here (zlib + the five scanline
 filters, numpy), with the reference loader's format policy on top: RGB8 is expanded to RGBA8 with alpha 255, RGBA8 passes,
 every other pixel format is the reference's `panic!("Unsupported image format!")` (utopian/src/gltf_loader.rs:179-198; the
-`gltf` crate hands 8-bit grey / grey-alpha / 16-bit images over as R8, R8G8, R16...). JPEG needs Pillow (optional; the
-decoder is not restated here - say so loudly when it is missing).
+`gltf` crate hands 8-bit grey / grey-alpha / 16-bit images over as R8, R8G8, R16...). JPEG (65 of Sponza's 69 images) is decoded
+by jpeg_decode.py, the twin of include/utopian_jpeg.hpp.
 """
 import struct
 import zlib
@@ -114,17 +114,13 @@ def load_image_rgba8(data):
     if data[:8] == PNG_MAGIC:
         img, fmt = decode_png(data)
     elif data[:2] == b"\xff\xd8":
-        try:
-            import io
+        from .jpeg_decode import JpegError, decode_jpeg
 
-            from PIL import Image
-        except ImportError as e:
-            raise UnsupportedImage("JPEG textures need Pillow (PNG is decoded in-repo); see INTEGRATION.md") from e
-        im = Image.open(io.BytesIO(data))
-        if im.mode not in ("RGB", "L"):
-            im = im.convert("RGB")
-        img = np.array(im, dtype=np.uint8)
-        img, fmt = (img[:, :, None], "R8") if img.ndim == 2 else (img, "R8G8B8")
+        try:
+            img, _ = decode_jpeg(data)
+        except JpegError as e:
+            raise UnsupportedImage(f"JPEG: {e}") from e
+        fmt = "R8" if img.shape[2] == 1 else "R8G8B8"  # the image crate reports a grey JPEG as L8
     else:
         raise UnsupportedImage("neither PNG nor JPEG")
     if fmt == "R8G8B8":  # "Convert images from rgb8 to rgba8"

@@ -256,3 +256,81 @@ def test_both_loaders_refuse_what_the_reference_refuses(dump_exe, tmp_path, ctyp
 def test_cpp_loader_equals_python_loader_on_the_reference_assets(dump_exe, tmp_path, name):
     meshes, _ = compare(dump_exe, os.path.join(REF, name), tmp_path)
     assert sum(len(m["indices"]) // 3 for m in meshes) == (4512 if name == "sphere.gltf" else 32)
+
+
+def test_both_loaders_read_jpeg_textures(dump_exe, tmp_path):
+    """JPEG images (65 of Sponza's 69): baseline 4:2:0 as a data URI, progressive as a file, a buffer-view image; a grey JPEG is
+    the reference's "Unsupported image format!" like a grey PNG. Textures from the two loaders are compared byte for byte."""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_fixtures.npz"))
+    base, prog, bview = (fx[k].tobytes() for k in ("ref_checker_jpg", "ref_screenshot_jpg", "syn_422_17x9_base_jpg"))
+    open(tmp_path / "prog.jpg", "wb").write(prog)
+    pos = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]])
+    blob = pos.tobytes() + np.uint16([0, 1, 2, 0]).tobytes() + bview
+    doc = {"asset": {"version": "2.0"}, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 0}, "indices": 1, "material": 0}]}],
+           "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 1}}}],
+           "textures": [{"source": 0}, {"source": 1}, {"source": 2}],
+           "images": [{"uri": "data:image/jpeg;base64," + base64.b64encode(base).decode()}, {"uri": "prog.jpg"}, {"bufferView": 2, "mimeType": "image/jpeg"}],
+           "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 6}, {"buffer": 0, "byteOffset": 44, "byteLength": len(bview)}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5123, "count": 3, "type": "SCALAR"}]}
+    path = str(tmp_path / "jpeg.gltf")
+    json.dump(doc, open(path, "w"))
+    _, textures = compare(dump_exe, path, tmp_path)
+    assert [t.shape for t in textures] == [(225, 225, 4), (130, 130, 4), (9, 17, 4)]
+    assert np.array_equal(textures[0][..., :3], fx["ref_checker_rgb"]) and np.array_equal(textures[1][..., :3], fx["ref_screenshot_rgb"])
+    assert all((t[..., 3] == 255).all() for t in textures)
+    doc["images"] = [{"uri": "data:image/jpeg;base64," + base64.b64encode(fx["syn_grey_jpg"].tobytes()).decode()}]
+    doc["textures"], doc["materials"] = [{"source": 0}], [{}]
+    json.dump(doc, open(path, "w"))
+    r = subprocess.run([dump_exe, path, str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unsupported image format" in r.stdout
+    with pytest.raises(UnsupportedImage):
+        gltf.load_gltf(path)
+
+
+def test_cpp_loader_rejects_malformed_files_instead_of_reading_out_of_bounds(tmp_path):
+    """short attribute accessors, indices beyond the vertices, cyclic node children, negative / non-finite offsets: an Error
+    (the reference's loader panics), never an out-of-bounds read - the loader runs under ASan + UBSan here"""
+    exe = str(tmp_path / "gltf_dump_asan")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "gltf_dump.cpp"), "-o", exe, "-lz"], check=True)
+    pos = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]])
+    blob = pos.tobytes() + pos[:2].tobytes() + np.uint16([0, 1, 2, 3, 2, 1]).tobytes()
+
+    def doc(**changes):
+        d = {"asset": {"version": "2.0"}, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+             "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 0}, "indices": 2}]}],
+             "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+             "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 48}, {"buffer": 0, "byteOffset": 48, "byteLength": 24}, {"buffer": 0, "byteOffset": 72, "byteLength": 12}],
+             "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 2, "type": "VEC3"},
+                           {"bufferView": 2, "componentType": 5123, "count": 6, "type": "SCALAR"}]}
+        for k, v in changes.items():
+            d[k] = v
+        return d
+
+    def run(d):
+        path = str(tmp_path / "bad.gltf")
+        json.dump(d, open(path, "w"))
+        return subprocess.run([exe, path, str(tmp_path / "o.bin")], capture_output=True, text=True)
+
+    assert run(doc()).returncode == 0
+    short = doc()
+    short["meshes"][0]["primitives"][0]["attributes"]["NORMAL"] = 1  # two normals for four positions
+    r = run(short)
+    assert r.returncode == 1 and "differ in element count" in r.stdout, r.stdout + r.stderr
+    few = doc()
+    few["accessors"][0]["count"] = 3  # index 3 now points past the vertices
+    few["meshes"][0]["primitives"][0]["attributes"]["NORMAL"] = 0
+    r = run(few)
+    assert r.returncode == 1 and "index beyond" in r.stdout, r.stdout + r.stderr
+    r = run(doc(nodes=[{"mesh": 0, "children": [1]}, {"children": [0]}]))
+    assert r.returncode == 1 and "cyclic" in r.stdout, r.stdout + r.stderr
+    neg = doc()
+    neg["bufferViews"][0]["byteOffset"] = -8
+    r = run(neg)
+    assert r.returncode == 1 and "negative" in r.stdout, r.stdout + r.stderr
+    huge = doc()
+    huge["accessors"][0]["byteOffset"] = 1e300
+    r = run(huge)
+    assert r.returncode == 1, r.stdout + r.stderr
