@@ -306,6 +306,10 @@ int uh_stream(uh_ctx* ctx, void** out);
  * crosses the iso value no mesh is added and *out_mesh_index is 0xffffffff. UH_ERR_CAPACITY above 4 Mi triangles. */
 int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo, float hi, float time, const UhGpuMaterial* material,
                            const float world3x4[12], uint32_t* out_mesh_index, uint32_t* out_triangles);
+/* diagnostics of the extraction: per cell (x fastest, resolution^3 of them) the marching-cubes case index (bit i set when corner i
+ * is outside, marching_cubes.comp:185-190) and the number of triangles the cell contributes (zero-area ones dropped); either
+ * pointer may be NULL. The oracle's restatement of the shader is compared with these cell by cell. */
+int uh_isosurface_cells(uh_ctx* ctx, uint32_t resolution, float lo, float hi, float time, uint8_t* out_cube_index, uint8_t* out_triangle_count);
 /* the context's host copy of a mesh (Model keeps CPU copies, primitive.rs:19-24): sizes, then the data */
 int uh_mesh_info(uh_ctx* ctx, uint32_t mesh_index, uint32_t* num_vertices, uint32_t* num_indices);
 int uh_read_mesh(uh_ctx* ctx, uint32_t mesh_index, UhVertex* vertices, uint32_t* indices);

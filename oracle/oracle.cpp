@@ -1040,6 +1040,38 @@ static void parallel_rows(Oracle& o, F f) {
 // ------------------------------------------------------------------------------------------
 // C interface for ctypes (mirrors include/utopian_hip.h so the parity tests call both the same way)
 // ------------------------------------------------------------------------------------------
+
+// ------------------------------------------------------------------------------------------
+// N3 — marching cubes (utopian/shaders/marching_cubes/marching_cubes.comp), the checker of csrc/isosurface.hip.
+// Runs on the reference's own lookup tables, handed in as data (tests/golden/mc_reference_tables.npz: edgeTable[256],
+// triangleTable[256][16] of shaders/marching_cubes/tables.glsl:4-293). The density field is the shader's (:61-103), with
+// the product's placement of the shapes in a [lo, hi]^3 domain: toOrigin(v) = v + (6, 0, 6), so that the torus sits at
+// (16, 20, 16), the box at (16, 10, 16), the sphere at (16, 26, 16) - the convention of uh_add_isosurface_mesh.
+// ------------------------------------------------------------------------------------------
+namespace mc {
+static inline float sdSphere(V3 p, float s) { return length(p) - s; }                         // marching_cubes.comp:59-62
+static inline float sdTorus(V3 p, float tx, float ty) {                                       // :64-68
+   const float qx = std::sqrt(p.x * p.x + p.z * p.z) - tx, qy = p.y;
+   return std::sqrt(qx * qx + qy * qy) - ty;
+}
+static inline float sdBox(V3 p, V3 b) {                                                       // :77-81
+   const V3 d = v3(std::fabs(p.x) - b.x, std::fabs(p.y) - b.y, std::fabs(p.z) - b.z);
+   const V3 m = v3(std::fmax(d.x, 0.0f), std::fmax(d.y, 0.0f), std::fmax(d.z, 0.0f));
+   return std::fmin(std::fmax(d.x, std::fmax(d.y, d.z)), 0.0f) + length(m);
+}
+// density(vec3) :92-119 = addShapes(pos, -1) :83-90; the noise branches are compiled out (#if 0) in the reference
+static inline float density(V3 pos, float sphere_radius) {
+   float d = std::fmax(-sdTorus(pos - v3(16.0f, 20.0f, 16.0f), 5.0f, 3.0f), -1.0f);
+   d = std::fmax(-sdBox(pos - v3(16.0f, 10.0f, 16.0f), v3(5.0f, 5.0f, 5.0f)), d);
+   d = std::fmax(-sdSphere(pos - v3(16.0f, 26.0f, 16.0f), sphere_radius), d);  // :87 (radius 8 |sin(0.3 time)|, 0 at time 0)
+   return d;
+}
+// marching_cubes.rs:23-32: corner offsets of a voxel (x voxelSize)
+static const int kCorner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+// the corner pairs of vertList[0..11], in the order main() interpolates them (:203-226)
+static const int kEdgeCorners[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+}  // namespace mc
+
 extern "C" {
 
 struct orc_ctx {
@@ -1264,6 +1296,78 @@ int orc_reset_stats(orc_ctx* c) {
    return UH_OK;
 }
 int orc_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
+
+// marching_cubes.comp:179-254 main(), for every voxel of a res^3 grid over [lo, hi]^3, voxels in x-fastest order.
+// Per voxel: cubeIndex (:185-190: bit i set when density(corner i) < 0), the crossed edges from edgeTable (:201-226), their
+// vertices by vertexInterp (:134-137: mix(p1, p2, (iso - v1) / (v2 - v1)) in the order the shader names the corners), the
+// triangles of triangleTable up to the first -1 (:231-251). Nothing is dropped or reordered.
+//   order = 0: the shader's own corner order per edge; 1: the endpoint with the smaller grid index first - what
+//   isosurface.hip does so that the cells sharing an edge produce the same bits (its one arithmetic difference; the two
+//   agree to a rounding of the interpolation).
+// Outputs (each may be null): cube_index[res^3]; tri_count[res^3]; positions: 9 floats per triangle, `cap_triangles` at most.
+// Returns the number of triangles the grid yields (also when it exceeds the capacity: then only the first are written).
+uint64_t orc_marching_cubes(uint32_t res, float lo, float hi, float time, const int32_t* edge_table, const int32_t* triangle_table, int order, uint8_t* cube_index,
+                            uint8_t* tri_count, float* positions, uint64_t cap_triangles) {
+   using namespace mc;
+   const float h = (hi - lo) / (float)res;
+   const float radius = 8.0f * std::fabs(std::sin(time * 0.3f));  // :87
+   uint64_t total = 0;
+   for (uint32_t iz = 0; iz < res; iz++)
+      for (uint32_t iy = 0; iy < res; iy++)
+         for (uint32_t ix = 0; ix < res; ix++) {
+            const uint64_t cell = ((uint64_t)iz * res + iy) * res + ix;
+            V3 p[8];
+            float v[8];
+            int cube = 0;
+            for (int i = 0; i < 8; i++) {
+               p[i] = v3(lo + h * (float)(ix + kCorner[i][0]), lo + h * (float)(iy + kCorner[i][1]), lo + h * (float)(iz + kCorner[i][2]));
+               v[i] = density(p[i], radius);
+               if (v[i] < 0.0f) cube |= 1 << i;  // isoLevel = 0 (:182)
+            }
+            if (cube_index) cube_index[cell] = (uint8_t)cube;
+            uint32_t n = 0;
+            if (edge_table[cube] != 0) {
+               V3 vert[12];
+               for (int e = 0; e < 12; e++) {
+                  if (!(edge_table[cube] & (1 << e))) continue;
+                  int a = kEdgeCorners[e][0], b = kEdgeCorners[e][1];
+                  if (order == 1) {
+                     // smaller grid index first: along the edge's axis the corner with offset 0
+                     const int sa = kCorner[a][0] + kCorner[a][1] + kCorner[a][2], sb = kCorner[b][0] + kCorner[b][1] + kCorner[b][2];
+                     if (sb < sa) std::swap(a, b);
+                  }
+                  const float t = (0.0f - v[a]) / (v[b] - v[a]);                          // vertexInterp :136
+                  vert[e] = v3(p[a].x + t * (p[b].x - p[a].x), p[a].y + t * (p[b].y - p[a].y), p[a].z + t * (p[b].z - p[a].z));  // mix(x, y, a) = x + a (y - x)
+               }
+               for (int i = 0; triangle_table[16 * cube + i] != -1; i += 3, n++) {
+                  if (positions && total + n < cap_triangles) {
+                     float* o = positions + 9 * (total + n);
+                     for (int k = 0; k < 3; k++) {
+                        const V3 q = vert[triangle_table[16 * cube + i + k]];
+                        o[3 * k] = q.x;
+                        o[3 * k + 1] = q.y;
+                        o[3 * k + 2] = q.z;
+                     }
+                  }
+               }
+            }
+            if (tri_count) tri_count[cell] = (uint8_t)n;
+            total += n;
+         }
+   return total;
+}
+// generateNormal (marching_cubes.comp:160-177): central differences of the density at distance d = 1, negated and normalised
+void orc_mc_normal(const float p[3], float time, float out[3]) {
+   const float r = 8.0f * std::fabs(std::sin(time * 0.3f)), d = 1.0f / 1.0f;
+   const V3 q = v3(p[0], p[1], p[2]);
+   const V3 g = v3(mc::density(q + v3(d, 0, 0), r) - mc::density(q + v3(-d, 0, 0), r), mc::density(q + v3(0, d, 0), r) - mc::density(q + v3(0, -d, 0), r),
+                   mc::density(q + v3(0, 0, d), r) - mc::density(q + v3(0, 0, -d), r));
+   const V3 n = neg(normalize(g));
+   out[0] = n.x;
+   out[1] = n.y;
+   out[2] = n.z;
+}
+float orc_mc_density(float x, float y, float z, float time) { return mc::density(v3(x, y, z), 8.0f * std::fabs(std::sin(time * 0.3f))); }
 
 // ---- unit entry points for the known-answer tests ---------------------------------------
 uint32_t orc_jenkins_hash(uint32_t x) { return jenkinsHash(x); }

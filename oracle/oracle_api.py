@@ -61,7 +61,41 @@ def lib():
         L.orc_sample_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.orc_closest_hit_shader.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         L.orc_hardware_threads.restype = C.c_int
+        L.orc_marching_cubes.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_marching_cubes.restype = C.c_uint64
+        L.orc_mc_density.argtypes, L.orc_mc_density.restype = [C.c_float] * 4, C.c_float
+        L.orc_mc_normal.argtypes = [C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]
     return _lib
+
+
+_MC_TABLES = None
+
+
+def mc_reference_tables():
+    """edgeTable[256], triangleTable[256][16] of the reference's tables.glsl, as data (tests/golden/mc_reference_tables.npz)"""
+    global _MC_TABLES
+    if _MC_TABLES is None:
+        t = np.load(os.path.join(_HERE, "..", "tests", "golden", "mc_reference_tables.npz"))
+        _MC_TABLES = (np.ascontiguousarray(t["edge_table"], dtype=np.int32), np.ascontiguousarray(t["triangle_table"], dtype=np.int32))
+    return _MC_TABLES
+
+
+def marching_cubes(resolution, lo, hi, time=0.0, order=0, positions=True):
+    """the oracle's restatement of marching_cubes.comp:179-254 on the reference's tables:
+    -> dict(cube_index (res^3,) uint8, tri_count (res^3,) uint8, positions (T, 3, 3) float32 in voxel order, x fastest)"""
+    edge, tri = mc_reference_tables()
+    cells = int(resolution) ** 3
+    cube, count = np.zeros(cells, dtype=np.uint8), np.zeros(cells, dtype=np.uint8)
+    L = lib()
+    total = L.orc_marching_cubes(resolution, lo, hi, time, edge.ctypes.data, tri.ctypes.data, order, cube.ctypes.data, count.ctypes.data, None, 0)
+    pos = np.zeros((total, 3, 3), dtype=np.float32)
+    if positions and total:
+        L.orc_marching_cubes(resolution, lo, hi, time, edge.ctypes.data, tri.ctypes.data, order, None, None, pos.ctypes.data, total)
+    return dict(cube_index=cube, tri_count=count, positions=pos, triangles=int(total))
+
+
+def mc_density(p, time=0.0):
+    return lib().orc_mc_density(float(p[0]), float(p[1]), float(p[2]), float(time))
 
 
 def _fv(values):
@@ -95,6 +129,28 @@ class OracleRenderer(Renderer):
     def add_gpu_light(self, light):
         self._num_lights += 1
         return super().add_gpu_light(light)
+
+    def add_isosurface_mesh(self, resolution, lo, hi, time=0.0, material=None, world3x4=None):
+        """the counterpart of uh_add_isosurface_mesh on the checker's side: the mesh of the reference's marching cubes as the
+        oracle restates it (marching_cubes.comp:179-254 on the reference's tables, normals by generateNormal :160-177; nothing
+        dropped), added as one mesh. Returns (mesh index or None, triangle count)."""
+        mc = marching_cubes(resolution, lo, hi, time)
+        if mc["triangles"] == 0:
+            return None, 0
+        pos = mc["positions"].reshape(-1, 3)
+        nrm = np.zeros_like(pos)
+        L = lib()
+        fp = C.POINTER(C.c_float)
+        for i in range(len(pos)):  # small grids only: the parity tests hand the oracle the device's own mesh for image comparisons
+            L.orc_mc_normal(pos[i].ctypes.data_as(fp), time, nrm[i].ctypes.data_as(fp))
+        v = np.zeros(len(pos), dtype=rr.types.VERTEX_DTYPE)
+        v["pos"][:, :3], v["pos"][:, 3] = pos, 1.0
+        v["normal"][:, :3] = nrm
+        v["uv"] = pos[:, [0, 2]] / np.float32(hi - lo)
+        v["color"] = 1.0
+        if material is None:
+            material = rr.make_material(base_color=(0.8, 0.8, 0.8, 1.0), diffuse_map=self.default_diffuse_map())
+        return self.add_mesh(v, np.arange(len(pos), dtype=np.uint32), material, world3x4), mc["triangles"]
 
     # unit entry points -------------------------------------------------------------------
     def target_function(self, light_index, p):

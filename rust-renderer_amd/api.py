@@ -270,6 +270,15 @@ class Renderer:
         self._check(fn(self._ctx, int(resolution), float(lo), float(hi), float(time), C.byref(material), w.ctypes.data_as(C.POINTER(C.c_float)), C.byref(mesh), C.byref(tris)))
         return (None if mesh.value == 0xFFFFFFFF else mesh.value), tris.value
 
+    def isosurface_cells(self, resolution, lo, hi, time=0.0):
+        """uh_isosurface_cells: per cell of the extraction grid (x fastest) its marching-cubes case index and the triangles it keeps"""
+        n = int(resolution) ** 3
+        cube, kept = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        fn = self._lib.uh_isosurface_cells
+        fn.argtypes, fn.restype = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p], C.c_int
+        self._check(fn(self._ctx, int(resolution), float(lo), float(hi), float(time), cube.ctypes.data, kept.ctypes.data))
+        return cube, kept
+
     def read_mesh(self, mesh_index):
         """the context's host copy of a mesh: (vertices as VERTEX_DTYPE, indices)"""
         lib = self._lib

@@ -43,14 +43,20 @@ static __global__ __launch_bounds__(kBlock) void k_scan_chunks(uint32_t* __restr
 // one block over the chunk totals (serial over tiles of 2048 when there are more), leaves their exclusive scan and the grand total
 static __global__ __launch_bounds__(kBlock) void k_scan_totals(uint32_t* __restrict__ chunk_totals, uint32_t n_chunks, unsigned long long* __restrict__ grand_total) {
    __shared__ uint32_t scan[kBlock];
+   __shared__ unsigned long long s_total;  // the true sum, in 64 bits: the 32-bit prefixes below wrap silently past 2^32
+   if (threadIdx.x == 0) s_total = 0ull;
+   __syncthreads();
    unsigned long long carry = 0;
    for (uint32_t tile = 0; tile < n_chunks; tile += kChunk) {
       const uint32_t base = tile + threadIdx.x * kPer;
       uint32_t v[kPer], sum = 0;
+      unsigned long long wide = 0ull;
       for (uint32_t k = 0; k < kPer; k++) {
          v[k] = base + k < n_chunks ? chunk_totals[base + k] : 0u;
          sum += v[k];
+         wide += v[k];
       }
+      if (wide) atomicAdd(&s_total, wide);
       uint32_t prefix = block_exclusive_scan(sum, scan) + (uint32_t)carry;
       for (uint32_t k = 0; k < kPer; k++) {
          if (base + k < n_chunks) chunk_totals[base + k] = prefix;
@@ -62,7 +68,8 @@ static __global__ __launch_bounds__(kBlock) void k_scan_totals(uint32_t* __restr
       carry = s_carry;
       __syncthreads();
    }
-   if (threadIdx.x == 0) *grand_total = carry;
+   __syncthreads();
+   if (threadIdx.x == 0) *grand_total = s_total;
 }
 static __global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ chunk_offsets) {
    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -73,8 +80,9 @@ static __global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t* __restrict
 
 inline uint32_t scan_chunk_count(uint32_t n) { return (n + uh_scan::kChunk - 1) / uh_scan::kChunk; }
 
-// data[0..n) -> its exclusive scan, *grand_total (device) = the sum (< 2^32 per value; the total is kept in 64 bits
-// only to tell an overflow apart). chunk_scratch: scan_chunk_count(n) values.
+// data[0..n) -> its exclusive scan, *grand_total (device) = the sum, accumulated in 64 bits from the chunk totals: a caller
+// must refuse a total >= 2^32 (the 32-bit offsets have wrapped by then); a single chunk of 2,048 values must itself sum
+// below 2^32. chunk_scratch: scan_chunk_count(n) values.
 inline void device_exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* chunk_scratch, unsigned long long* grand_total, hipStream_t stream) {
    const uint32_t chunks = scan_chunk_count(n);
    uh_scan::k_scan_chunks<<<chunks ? chunks : 1, uh_scan::kBlock, 0, stream>>>(data, n, chunk_scratch);

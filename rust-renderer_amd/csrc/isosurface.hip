@@ -51,7 +51,7 @@ __device__ __forceinline__ float density(float x, float y, float z, float sphere
    const float sphere = len3(x - 16.0f, y - 26.0f, z - 16.0f) - sphere_r;                      // sdSphere
    float d = fmaxf(-torus, -1.0f);
    d = fmaxf(-box, d);
-   if (sphere_r > 0.0f) d = fmaxf(-sphere, d);
+   d = fmaxf(-sphere, d);  // also at radius 0, as the reference: -|p - c| only wins at the centre point itself (density 0 there)
    return d;
 }
 
@@ -96,7 +96,7 @@ __device__ __forceinline__ bool has_area(const float* a, const float* b, const f
 }
 
 __device__ __forceinline__ void write_vertex(const IsoParams& q, UhVertex* out, const float* p) {
-   const float eps = 1e-3f;
+   const float eps = 1.0f;  // generateNormal: "float d = 1.0f / 1.0f" (marching_cubes.comp:167), whatever the voxel size
    float g[3] = {density(p[0] + eps, p[1], p[2], q.sphere_r) - density(p[0] - eps, p[1], p[2], q.sphere_r),
                  density(p[0], p[1] + eps, p[2], q.sphere_r) - density(p[0], p[1] - eps, p[2], q.sphere_r),
                  density(p[0], p[1], p[2] + eps, q.sphere_r) - density(p[0], p[1], p[2] - eps, q.sphere_r)};
@@ -179,7 +179,58 @@ __global__ __launch_bounds__(kBlock) void k_iso_emit(IsoParams q, const uint32_t
    if (n) cell_triangles<true>(q, c, verts + 3 * ((size_t)block_offsets[blockIdx.x] + before));
 }
 
+// diagnostics (uh_isosurface_cells): what each cell decided - its case index and the triangles it keeps
+__global__ __launch_bounds__(kBlock) void k_iso_cells(IsoParams q, uint8_t* __restrict__ cube_index, uint8_t* __restrict__ tri_count) {
+   const uint64_t cell = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+   if (cell >= (uint64_t)q.res * q.res * q.res) return;
+   Cell c;
+   const bool mixed = load_cell(q, cell, c);
+   if (cube_index) cube_index[cell] = (uint8_t)c.cube_index;
+   if (tri_count) tri_count[cell] = (uint8_t)(mixed ? cell_triangles<false>(q, c, nullptr) : 0u);
+}
+
+static bool load_tables() {
+   static bool tables_loaded[64] = {false};
+   int dev = 0;
+   (void)hipGetDevice(&dev);
+   if (dev >= 0 && dev < 64 && !tables_loaded[dev]) {
+      if (hipMemcpyToSymbol(HIP_SYMBOL(c_edge_mask), kMcEdgeMask, sizeof(kMcEdgeMask)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_tri_count), kMcTriCount, sizeof(kMcTriCount)) != hipSuccess ||
+          hipMemcpyToSymbol(HIP_SYMBOL(c_tris), kMcTris, sizeof(kMcTris)) != hipSuccess)
+         return false;
+      tables_loaded[dev] = true;
+   }
+   return true;
+}
+
 }  // namespace
+
+extern "C" int uh_isosurface_cells(uh_ctx* ctx, uint32_t resolution, float lo, float hi, float time, uint8_t* out_cube_index, uint8_t* out_triangle_count) {
+   if (!ctx || resolution < 1 || resolution > 1024 || !(hi > lo)) return UH_ERR_INVALID_ARGUMENT;
+   void* stream_v = nullptr;
+   if (int st = uh_stream(ctx, &stream_v)) return st;
+   hipStream_t stream = (hipStream_t)stream_v;
+   if (!load_tables()) return UH_ERR_HIP;
+   IsoParams q;
+   q.res = resolution;
+   q.lo = lo;
+   q.h = (hi - lo) / (float)resolution;
+   q.sphere_r = 8.0f * std::fabs(std::sin(time * 0.3f));
+   q.inv_domain = 1.0f / (hi - lo);
+   const uint64_t cells = (uint64_t)resolution * resolution * resolution;
+   uint8_t *d_a = nullptr, *d_b = nullptr;
+   if (hipMalloc(&d_a, cells) != hipSuccess || hipMalloc(&d_b, cells) != hipSuccess) {
+      if (d_a) (void)hipFree(d_a);
+      return UH_ERR_OUT_OF_MEMORY;
+   }
+   k_iso_cells<<<(uint32_t)((cells + kBlock - 1) / kBlock), kBlock, 0, stream>>>(q, d_a, d_b);
+   int st = UH_OK;
+   if (out_cube_index && hipMemcpyAsync(out_cube_index, d_a, cells, hipMemcpyDeviceToHost, stream) != hipSuccess) st = UH_ERR_HIP;
+   if (out_triangle_count && hipMemcpyAsync(out_triangle_count, d_b, cells, hipMemcpyDeviceToHost, stream) != hipSuccess) st = UH_ERR_HIP;
+   if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) st = UH_ERR_HIP;
+   (void)hipFree(d_a);
+   (void)hipFree(d_b);
+   return st;
+}
 
 extern "C" int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo, float hi, float time, const UhGpuMaterial* material, const float world3x4[12],
                                        uint32_t* out_mesh_index, uint32_t* out_triangles) {
@@ -204,15 +255,7 @@ extern "C" int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo
          if (p) (void)hipFree(p);
       return st;
    };
-   static bool tables_loaded[64] = {false};
-   int dev = 0;
-   (void)hipGetDevice(&dev);
-   if (dev >= 0 && dev < 64 && !tables_loaded[dev]) {
-      if (hipMemcpyToSymbol(HIP_SYMBOL(c_edge_mask), kMcEdgeMask, sizeof(kMcEdgeMask)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_tri_count), kMcTriCount, sizeof(kMcTriCount)) != hipSuccess ||
-          hipMemcpyToSymbol(HIP_SYMBOL(c_tris), kMcTris, sizeof(kMcTris)) != hipSuccess)
-         return UH_ERR_HIP;
-      tables_loaded[dev] = true;
-   }
+   if (!load_tables()) return UH_ERR_HIP;
    const uint32_t n_chunks = scan_chunk_count(blocks);
    if (hipMalloc(&d_counts, (size_t)blocks * sizeof(uint32_t)) != hipSuccess || hipMalloc(&d_chunks, (size_t)n_chunks * sizeof(uint32_t)) != hipSuccess ||
        hipMalloc(&d_total, sizeof(unsigned long long)) != hipSuccess)
@@ -223,7 +266,9 @@ extern "C" int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo
    unsigned long long total = 0;
    if (hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, stream) != hipSuccess) return fail(UH_ERR_HIP);
    if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail(UH_ERR_HIP);
-   if (total > (1ull << 22)) return fail(UH_ERR_CAPACITY);  // a mesh holds at most 4 Mi triangles (key = mesh << 22 | primitive)
+   // a mesh holds at most 4 Mi triangles (key = mesh << 22 | primitive); `total` is the true 64-bit sum (device_scan.h), so a
+   // grid whose count would wrap the 32-bit offsets is refused here, before the emit pass sizes anything by it
+   if (total > (1ull << 22)) return fail(UH_ERR_CAPACITY);
    std::vector<UhVertex> verts((size_t)total * 3);
    if (total) {
       if (hipMalloc(&d_verts, verts.size() * sizeof(UhVertex)) != hipSuccess) return fail(UH_ERR_OUT_OF_MEMORY);

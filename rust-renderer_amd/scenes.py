@@ -89,10 +89,12 @@ class Scene:
     lights: list  # [(x, y, z)]
     camera: Camera
     view_flags: dict = field(default_factory=dict)
-    # (resolution, lo, hi, host_fallback): an iso-surface mesh that a HIP renderer extracts on the GPU
-    # (uh_add_isosurface_mesh); other backends get host_fallback() -> Mesh in its place, as mesh 0
+    # (resolution, lo, hi): an iso-surface mesh the renderer extracts itself, as mesh 0 - a HIP renderer on the GPU
+    # (uh_add_isosurface_mesh); the oracle backend with its restatement of the reference's marching cubes, unless the very
+    # triangles a HIP renderer extracted are handed over (device_mesh: image parity needs the same triangulation)
     device_isosurface: tuple = None
     device_triangles: int = 0
+    device_mesh: tuple = None  # (vertices, indices) read back from the last HIP upload
 
     @property
     def num_triangles(self):
@@ -105,13 +107,15 @@ class Scene:
     def upload(self, renderer):
         """Renderer::add_model / add_light for every model and light, then Raytracing::initialize."""
         if self.device_isosurface:
-            res, lo, hi, host_fallback = self.device_isosurface
+            res, lo, hi = self.device_isosurface
             if renderer.backend == "hip":
-                _, self.device_triangles = renderer.add_isosurface_mesh(res, lo, hi)
+                mesh, self.device_triangles = renderer.add_isosurface_mesh(res, lo, hi)
+                self.device_mesh = renderer.read_mesh(mesh) if mesh is not None else None
+            elif self.device_mesh is not None and not renderer.backend.startswith("hip"):
+                v, idx = self.device_mesh
+                renderer.add_mesh(v, idx, make_material(base_color=(0.8, 0.8, 0.8, 1.0), diffuse_map=renderer.default_diffuse_map()), None)
             else:
-                mesh = host_fallback()
-                self.device_triangles = mesh.num_triangles
-                renderer.add_model(Model([mesh], []), None)
+                _, self.device_triangles = renderer.add_isosurface_mesh(res, lo, hi)
         for model, transform in self.models:
             renderer.add_model(model, transform)
         for p in self.lights:
@@ -521,7 +525,6 @@ def scene_for_config(config, **kw):
     if config == 4:
         kw.pop("tex_size", None)
         kw.pop("detail", None)
-        kw.setdefault("device", True)
         return isosurface_scene(**kw)
     raise ValueError(f"config {config} is not defined in BASELINE.json")
 
@@ -529,96 +532,17 @@ def scene_for_config(config, **kw):
 # ---------------------------------------------------------------------------------------------
 # config 5 - isosurface of the reference's marching-cubes density field
 # ---------------------------------------------------------------------------------------------
-def reference_density(p):
-    """marching_cubes.comp:83-103 at view.time = 0 (sphere radius 0): density = max(-1, -sdTorus,
-    -sdBox) with the torus (R 5, r 3, axis y) above the box (half size 5); positive inside."""
-    q = p - np.array([16.0, 20.0, 16.0])
-    torus = np.sqrt((np.sqrt(q[..., 0] ** 2 + q[..., 2] ** 2) - 5.0) ** 2 + q[..., 1] ** 2) - 3.0
-    d = np.abs(p - np.array([16.0, 10.0, 16.0])) - 5.0
-    box = np.minimum(np.maximum(d[..., 0], np.maximum(d[..., 1], d[..., 2])), 0.0) + np.sqrt((np.maximum(d, 0.0) ** 2).sum(-1))
-    return np.maximum(np.maximum(-torus, -box), -1.0)
-
-
-# the 6 tetrahedra of a cube around its 0-6 diagonal (corner numbering of marching_cubes.rs:23-32)
-_CUBE_CORNERS = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]])
-_TETS = np.array([[0, 5, 1, 6], [0, 1, 2, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 7, 4, 6], [0, 4, 5, 6]])
-
-
-def extract_isosurface(density, lo, hi, resolution, slab=16):
-    """triangle soup of {density = 0} on a resolution^3 grid over [lo, hi]^3 by marching tetrahedra
-    (host-side stand-in for the GPU marching-cubes extraction of SURVEY.md section 8f N3)."""
-    h = (hi - lo) / resolution
-    tris = []
-    ax = lo + h * np.arange(resolution + 1)
-    for z0 in range(0, resolution, slab):
-        z1 = min(z0 + slab, resolution)
-        X, Y, Z = np.meshgrid(ax, ax, ax[z0 : z1 + 1], indexing="ij")
-        P = np.stack([X, Y, Z], -1)
-        D = density(P)
-        inside = D > 0
-        c = inside[:-1, :-1, :-1]
-        mixed = np.zeros_like(c)
-        cnt = np.zeros(c.shape, dtype=np.int8)
-        for dx, dy, dz in _CUBE_CORNERS:
-            cnt += inside[dx : dx + resolution, dy : dy + resolution, dz : dz + (z1 - z0)]
-        mixed = (cnt > 0) & (cnt < 8)
-        ix, iy, iz = np.nonzero(mixed)
-        if len(ix) == 0:
-            continue
-        cp = np.stack([P[ix + dx, iy + dy, iz + dz] for dx, dy, dz in _CUBE_CORNERS], 1)  # (n, 8, 3)
-        cv = np.stack([D[ix + dx, iy + dy, iz + dz] for dx, dy, dz in _CUBE_CORNERS], 1)  # (n, 8)
-        for tet in _TETS:
-            p, v = cp[:, tet], cv[:, tet]
-            ins = v > 0
-            k = ins.sum(1)
-            order = np.argsort(~ins, axis=1, kind="stable")  # inside vertices first
-            p = np.take_along_axis(p, order[..., None], 1)
-            v = np.take_along_axis(v, order[:, :], 1)
-
-            def cut(a, b, sel):
-                t = (v[sel, a] / (v[sel, a] - v[sel, b]))[:, None]
-                return p[sel, a] + t * (p[sel, b] - p[sel, a])
-
-            s1, s2, s3 = k == 1, k == 2, k == 3
-            if s1.any():
-                tris.append(np.stack([cut(0, 1, s1), cut(0, 2, s1), cut(0, 3, s1)], 1))
-            if s3.any():
-                tris.append(np.stack([cut(0, 3, s3), cut(1, 3, s3), cut(2, 3, s3)], 1))
-            if s2.any():
-                a, b, c2, d2 = cut(0, 2, s2), cut(0, 3, s2), cut(1, 3, s2), cut(1, 2, s2)
-                tris.append(np.stack([a, b, c2], 1))
-                tris.append(np.stack([a, c2, d2], 1))
-    return np.concatenate(tris) if tris else np.zeros((0, 3, 3))
-
-
-def _isosurface_host_mesh(resolution):
-    T = extract_isosurface(reference_density, 0.0, 32.0, resolution)
-    # drop degenerate slivers (zero area), keep the soup unindexed
-    n = np.cross(T[:, 1] - T[:, 0], T[:, 2] - T[:, 0])
-    T = T[np.linalg.norm(n, axis=1) > 1e-12]
-    pos = T.reshape(-1, 3)
-    eps = 1e-3
-    g = np.stack([reference_density(pos + e) - reference_density(pos - e) for e in (np.array([eps, 0, 0]), np.array([0, eps, 0]), np.array([0, 0, eps]))], -1)
-    nrm = -g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-20)  # density grows inwards
-    uv = pos[:, [0, 2]] / 32.0
-    verts = _pack_vertices(pos.astype(f32), nrm.astype(f32), uv.astype(f32))
-    return Mesh(verts, np.arange(len(pos), dtype=u32), LAMBERTIAN, 0.0, (0.8, 0.8, 0.8, 1.0), None, identity3x4(), "isosurface")
-
-
-def isosurface_scene(resolution=512, device=False):
+def isosurface_scene(resolution=512):
     """BASELINE.json configs[4]: the 512^3 isosurface of the reference's density field (torus above a
-    box, marching_cubes.comp:83-103 scaled to a 32-unit domain), one Lambertian mesh on a ground
-    plane, sky + sun. device=True: a HIP renderer extracts the mesh on the GPU at upload (uh_add_isosurface_mesh:
-    table-driven marching cubes, ~0.8 M triangles at 512^3, milliseconds); otherwise (and for the oracle) the
-    vectorised host marching-tetrahedra pass below builds it (~1.65 M triangles, the better part of a minute)."""
+    box, marching_cubes.comp:83-103 placed in a 32-unit domain), one Lambertian mesh on a ground plane, sky + sun.
+    The mesh is extracted by the renderer the scene is uploaded to (Scene.upload): on the GPU by uh_add_isosurface_mesh
+    (table-driven marching cubes, ~0.75 M triangles at 512^3, milliseconds)."""
     ground = Mesh(*quad((-64, 4.99, -64), (0, 0, 160), (160, 0, 0), 32, 32, uv_scale=(8, 8)), base_color=(0.6, 0.6, 0.6, 1.0), name="ground")
     cam = Camera((27.0, 19.0, 33.0), (16.0, 14.0, 16.0), 60.0, 16.0 / 9.0, 0.01, 1000.0)
     flags = dict(sky_enabled=1, sun_shadow_enabled=1, lights_enabled=0, use_ris_light_sampling=0)
-    if device:
-        sc = Scene("isosurface", [(Model([ground], []), None)], [], cam, flags)
-        sc.device_isosurface = (resolution, 0.0, 32.0, lambda: _isosurface_host_mesh(resolution))
-        return sc
-    return Scene("isosurface", [(Model([_isosurface_host_mesh(resolution), ground], []), None)], [], cam, flags)
+    sc = Scene("isosurface", [(Model([ground], []), None)], [], cam, flags)
+    sc.device_isosurface = (resolution, 0.0, 32.0)
+    return sc
 
 
 BISTRO_SEED = 0x42495354

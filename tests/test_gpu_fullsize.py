@@ -6,7 +6,7 @@ import pytest
 
 import oracle_api as oa
 import rust_renderer_amd as rr
-from util import L2_TOL, per_pixel_l2, run_frames
+from util import L2_TOL, per_pixel_l2, reference_density, run_frames
 
 pytestmark = pytest.mark.gpu
 W, H, TILE = 1920, 1080, 64
@@ -198,7 +198,7 @@ def test_config4_isosurface_512_at_1080p_sampled_tiles():
     assert len(idx) == 3 * ntri
     # every extracted vertex lies on the iso-surface to a fraction of a cell (sampled: 5 M vertices)
     pick = np.arange(0, len(v), 97)
-    assert np.abs(rr.scenes.reference_density(v["pos"][pick, :3].astype(np.float64))).max() < 0.2 * 32.0 / 512
+    assert np.abs(reference_density(v["pos"][pick, :3].astype(np.float64))).max() < 0.2 * 32.0 / 512
     cpu = oa.OracleRenderer(W, H)
     cpu.add_mesh(v, idx, rr.make_material(base_color=(0.8, 0.8, 0.8, 1.0), diffuse_map=cpu.default_diffuse_map()), None)
     for model, transform in scene.models:

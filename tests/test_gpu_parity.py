@@ -7,7 +7,7 @@ import pytest
 
 import oracle_api as oa
 import rust_renderer_amd as rr
-from util import L2_TOL, make_pair, per_pixel_l2, random_rays, run_frames, torture_scene
+from util import L2_TOL, extract_isosurface, make_pair, per_pixel_l2, random_rays, reference_density, run_frames, torture_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -725,7 +725,7 @@ def test_isosurface_extraction_is_marching_cubes_and_renders_like_the_oracle():
     assert np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1).min() > 1e-12
     # every vertex lies on the iso-surface (linear interpolation along cell edges of a distance field with sharp
     # features: within a fraction of a cell); normals point out of the solid and have unit length
-    assert np.abs(rr.scenes.reference_density(pos.astype(np.float64))).max() < 0.2 * cell
+    assert np.abs(reference_density(pos.astype(np.float64))).max() < 0.2 * cell
     n = v["normal"][:, :3].astype(np.float64)
     assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-4)
     # a closed, consistently oriented surface: shared edge vertices are bit-identical between cells (canonical
@@ -736,7 +736,7 @@ def test_isosurface_extraction_is_marching_cubes_and_renders_like_the_oracle():
     matched = np.isin(fwd, rev).mean()
     assert matched > 0.995, matched
     # the same surface as the independent host generator (marching tetrahedra, float64 numpy), at a third to a half of the triangles
-    ref = rr.scenes.extract_isosurface(rr.scenes.reference_density, lo, hi, res)
+    ref = extract_isosurface(reference_density, lo, hi, res)
     ref = ref[np.linalg.norm(np.cross(ref[:, 1] - ref[:, 0], ref[:, 2] - ref[:, 0]), axis=1) > 1e-7]
     assert 0.2 < ntri / len(ref) < 0.65, (ntri, len(ref))
 

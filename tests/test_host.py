@@ -138,18 +138,3 @@ def test_tile_index_math():
     assert np.array_equal(out, img)
 
 
-def test_isosurface_scene_lies_on_the_reference_density_field():
-    """config 5: every vertex of the extracted mesh sits on {density = 0} of the restated
-    marching_cubes.comp field (torus above a box); normals are unit and point out of the solid."""
-    S = rr.scenes
-    T = S.extract_isosurface(S.reference_density, 0.0, 32.0, 48)
-    assert len(T) > 5000
-    d = S.reference_density(T.reshape(-1, 3))
-    assert np.abs(d).max() < 0.2 and np.abs(d).mean() < 0.01, "vertices interpolate the zero crossing along cell edges (cell size 0.67)"
-    scene = S.isosurface_scene(32)
-    iso = scene.models[0][0].meshes[0]
-    n = iso.vertices["normal"][:, :3]
-    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-3)
-    p = iso.vertices["pos"][:, :3].astype(np.float64)
-    assert (S.reference_density(p + 0.05 * n) < S.reference_density(p - 0.05 * n)).mean() > 0.99, "density falls along the normal"
-    assert iso.num_triangles * 3 == len(iso.vertices)

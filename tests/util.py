@@ -74,3 +74,71 @@ def torture_scene():
     ]
     from rust_renderer_amd.camera import Camera
     return Scene("torture", [(Model(meshes, []), None)], [(0.0, 0.0, 5.0)], Camera((0, 0, 6), (0, 0, 0), 60.0, 1.0, 0.01, 1000.0))
+
+
+# ---- independent float64 numpy restatements for the iso-surface checks (test infrastructure; they used to live in the product
+# package as its host fallback): the reference's density field and a marching-TETRAHEDRA extraction of its zero set - a
+# different algorithm than the marching cubes of csrc/isosurface.hip and of the oracle (oracle.cpp orc_marching_cubes), so the
+# three can be held against each other
+def reference_density(p):
+    """marching_cubes.comp:83-103 at view.time = 0: density = max(-1, -sdTorus, -sdBox, -sdSphere(radius 0)) with the torus (R 5, r 3,
+    axis y) above the box (half size 5); positive inside. The zero-radius sphere's term -|p - c| only wins within 1 of its centre
+    and reaches 0 at the centre point alone."""
+    q = p - np.array([16.0, 20.0, 16.0])
+    torus = np.sqrt((np.sqrt(q[..., 0] ** 2 + q[..., 2] ** 2) - 5.0) ** 2 + q[..., 1] ** 2) - 3.0
+    d = np.abs(p - np.array([16.0, 10.0, 16.0])) - 5.0
+    box = np.minimum(np.maximum(d[..., 0], np.maximum(d[..., 1], d[..., 2])), 0.0) + np.sqrt((np.maximum(d, 0.0) ** 2).sum(-1))
+    sphere = np.sqrt(((p - np.array([16.0, 26.0, 16.0])) ** 2).sum(-1))
+    return np.maximum(np.maximum(np.maximum(-torus, -box), -1.0), -sphere)
+
+
+# the 6 tetrahedra of a cube around its 0-6 diagonal (corner numbering of marching_cubes.rs:23-32)
+_CUBE_CORNERS = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]])
+_TETS = np.array([[0, 5, 1, 6], [0, 1, 2, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 7, 4, 6], [0, 4, 5, 6]])
+
+
+def extract_isosurface(density, lo, hi, resolution, slab=16):
+    """triangle soup of {density = 0} on a resolution^3 grid over [lo, hi]^3 by marching tetrahedra
+    (host-side stand-in for the GPU marching-cubes extraction of SURVEY.md section 8f N3)."""
+    h = (hi - lo) / resolution
+    tris = []
+    ax = lo + h * np.arange(resolution + 1)
+    for z0 in range(0, resolution, slab):
+        z1 = min(z0 + slab, resolution)
+        X, Y, Z = np.meshgrid(ax, ax, ax[z0 : z1 + 1], indexing="ij")
+        P = np.stack([X, Y, Z], -1)
+        D = density(P)
+        inside = D > 0
+        c = inside[:-1, :-1, :-1]
+        mixed = np.zeros_like(c)
+        cnt = np.zeros(c.shape, dtype=np.int8)
+        for dx, dy, dz in _CUBE_CORNERS:
+            cnt += inside[dx : dx + resolution, dy : dy + resolution, dz : dz + (z1 - z0)]
+        mixed = (cnt > 0) & (cnt < 8)
+        ix, iy, iz = np.nonzero(mixed)
+        if len(ix) == 0:
+            continue
+        cp = np.stack([P[ix + dx, iy + dy, iz + dz] for dx, dy, dz in _CUBE_CORNERS], 1)  # (n, 8, 3)
+        cv = np.stack([D[ix + dx, iy + dy, iz + dz] for dx, dy, dz in _CUBE_CORNERS], 1)  # (n, 8)
+        for tet in _TETS:
+            p, v = cp[:, tet], cv[:, tet]
+            ins = v > 0
+            k = ins.sum(1)
+            order = np.argsort(~ins, axis=1, kind="stable")  # inside vertices first
+            p = np.take_along_axis(p, order[..., None], 1)
+            v = np.take_along_axis(v, order[:, :], 1)
+
+            def cut(a, b, sel):
+                t = (v[sel, a] / (v[sel, a] - v[sel, b]))[:, None]
+                return p[sel, a] + t * (p[sel, b] - p[sel, a])
+
+            s1, s2, s3 = k == 1, k == 2, k == 3
+            if s1.any():
+                tris.append(np.stack([cut(0, 1, s1), cut(0, 2, s1), cut(0, 3, s1)], 1))
+            if s3.any():
+                tris.append(np.stack([cut(0, 3, s3), cut(1, 3, s3), cut(2, 3, s3)], 1))
+            if s2.any():
+                a, b, c2, d2 = cut(0, 2, s2), cut(0, 3, s2), cut(1, 3, s2), cut(1, 2, s2)
+                tris.append(np.stack([a, b, c2], 1))
+                tris.append(np.stack([a, c2, d2], 1))
+    return np.concatenate(tris) if tris else np.zeros((0, 3, 3))
