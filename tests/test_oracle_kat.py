@@ -162,6 +162,31 @@ def test_sky_is_finite_positive_and_brighter_toward_the_sun():
     assert np.allclose(a, b, rtol=1e-5)
 
 
+def test_sky_matches_the_independent_restatement_of_atmosphere_glsl():
+    """the largest floating-point block of the path (atmosphere.glsl:53-214, ~400 exp per call) pinned by known answers: 48
+    (origin, direction, sun) vectors - ground level, 1 km, inside the ozone layer, above the atmosphere (entry-point branch),
+    toward / away from / below the sun, un-normalised bounce directions - evaluated by a numpy restatement written from the
+    GLSL (tests/golden/make_sky_fixture.py), once with every operation in float32 (what the shader computes) and once in
+    float64. The oracle matches the float32 evaluation to 1e-5 relative; the float64 one within the cancellation error the
+    shader's own AtmosphereHeight carries (+-0.5 m on a 1,200 m scale height)."""
+    import json
+    import os
+
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sky_kat.json")))
+    assert len(kat["vectors"]) >= 32
+    branches = set()
+    for v in kat["vectors"]:
+        sun = np.float32(v["sun"])
+        sun = sun * (np.float32(1.0) / np.sqrt((sun[0] * sun[0] + sun[1] * sun[1]) + sun[2] * sun[2], dtype=np.float32))
+        got = oa.sky(v["origin"], v["direction"], sun)
+        scale = max(float(np.max(np.abs(v["sky_f64"]))), 1e-9)
+        assert np.abs(got - np.float64(v["sky_f32"])).max() <= 1e-5 * scale, v
+        assert np.abs(got - np.float64(v["sky_f64"])).max() <= 5e-4 * scale, v
+        branches.add((max(v["unclamped_f64"]) > 1.0, v["origin"][1] > 100000.0, max(v["sky_f64"]) < 1e-6))
+    # the fixture reaches the clamp of reference.rmiss:22, the "ray starts above the atmosphere" branch and black sky (sun below)
+    assert {b[0] for b in branches} == {True, False} and any(b[1] for b in branches)
+
+
 def test_primary_ray_geometry():
     scene = rr.scenes.cornell_scene(1, 4)
     W, H = 64, 48
