@@ -131,12 +131,17 @@ def main():
         elif i >= 8:
             d = tuple(np.array(d, dtype=np.float64) / np.linalg.norm(d))
         vectors.append((tuple(float(np.float32(x)) for x in o), tuple(float(np.float32(x)) for x in d), tuple(float(np.float32(x)) for x in s)))
+    for s in suns[:4]:  # straight into the sun (Mie forward peak: the clamp of reference.rmiss:22), from the ground and from 1 km
+        n = np.array(s, dtype=np.float64) / np.linalg.norm(s)
+        for o in origins[1], origins[3]:
+            vectors.append((tuple(float(np.float32(x)) for x in o), tuple(float(np.float32(x)) for x in n), tuple(float(np.float32(x)) for x in s)))
     f64, f32 = make(np.float64), make(np.float32)
     out = []
     for o, d, s in vectors:
         raw64, sky64 = f64(o, d, s)
         raw32, sky32 = f32(o, d, s)
-        out.append(dict(origin=o, direction=d, sun=s, unclamped_f64=[float(x) for x in raw64], sky_f64=[float(x) for x in sky64], sky_f32=[float(x) for x in sky32]))
+        out.append(dict(origin=o, direction=d, sun=s, unclamped_f64=[float(x) for x in raw64], unclamped_f32=[float(x) for x in raw32], sky_f64=[float(x) for x in sky64],
+                        sky_f32=[float(x) for x in sky32]))
     json.dump(dict(source="numpy restatement of utopian/shaders/include/atmosphere.glsl:53-214 + reference.rmiss:16-23 (tests/golden/make_sky_fixture.py)", vectors=out),
               open(OUT, "w"), indent=1)
     rel = max(np.abs(np.array(v["sky_f64"]) - np.array(v["sky_f32"])).max() / max(np.abs(np.array(v["sky_f64"])).max(), 1e-9) for v in out)
