@@ -77,8 +77,7 @@ struct Slot {
    hipEvent_t ev_traced = nullptr, ev_missed = nullptr, ev_shaded = nullptr, ev_shadowed = nullptr, ev_side_done = nullptr;
    hipEvent_t ev_acc = nullptr;  // recorded after the frame's accumulate / store tail
    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
-   DevBuf<float4> ray_o, ray_d, hit, thr, rad, pixcol;
-   DevBuf<uint2> rng;
+   DevBuf<float4> rec, rad, pixcol;  // rec: the four path-state planes (device_types.h PathState)
    DevBuf<uint32_t> queues[3];
    DevBuf<Control> control;
    PathState ps{};
@@ -102,26 +101,19 @@ struct Slot {
       SLOT_TRY(hipEventCreate(&frame_start));
       SLOT_TRY(hipEventCreate(&frame_stop));
       const size_t stagger = 4352;  // 4 KiB + 256 B per array slot
-      SLOT_TRY(ray_o.alloc(n, 0 * stagger));
-      SLOT_TRY(ray_d.alloc(n, 1 * stagger));
-      SLOT_TRY(hit.alloc(n, 2 * stagger));
-      SLOT_TRY(thr.alloc(n, 3 * stagger));
-      SLOT_TRY(rad.alloc(n, 4 * stagger));
-      SLOT_TRY(pixcol.alloc(n, 5 * stagger));
-      SLOT_TRY(rng.alloc(n, 6 * stagger));
+      const size_t plane = n + stagger / sizeof(float4);  // planes staggered like the arrays: the same index of two planes must not alias
+      SLOT_TRY(rec.alloc(plane * kRecQuads, 0 * stagger));
+      SLOT_TRY(rad.alloc(n, 1 * stagger));
+      SLOT_TRY(pixcol.alloc(n, 2 * stagger));
       // sharded queues: capacity per shard = the pixels (64-pixel runs) a shard can own
       for (auto& q : queues) SLOT_TRY(q.alloc((size_t)shard_cap * kShards));
       SLOT_TRY(control.alloc(1));
       SLOT_TRY(hipMemsetAsync(control.p, 0, sizeof(Control), stream));
       SLOT_TRY(hipStreamSynchronize(stream));
 #undef SLOT_TRY
-      ps.ray_o = ray_o.p;
-      ps.ray_d = ray_d.p;
-      ps.hit = hit.p;
-      ps.thr = thr.p;
+      ps.rec = PathRecs{rec.p, plane};
       ps.rad = rad.p;
       ps.pixcol = pixcol.p;
-      ps.rng = rng.p;
       for (int i = 0; i < 3; i++) ps.queue[i] = queues[i].p;
       ps.shard_cap = shard_cap;
       ready = true;
@@ -130,13 +122,9 @@ struct Slot {
    void destroy() {
       if (stream) (void)hipStreamSynchronize(stream);
       if (side) (void)hipStreamSynchronize(side);
-      ray_o.release();
-      ray_d.release();
-      hit.release();
-      thr.release();
+      rec.release();
       rad.release();
       pixcol.release();
-      rng.release();
       for (auto& q : queues) q.release();
       control.release();
       for (hipEvent_t ev : {ev_traced, ev_missed, ev_shaded, ev_shadowed, ev_side_done, ev_acc, frame_start, frame_stop})
@@ -908,6 +896,15 @@ static int build_on_device(uh_ctx* c) {
    la.obj_corners = c->d_obj_corners.p;
    uint32_t num_nodes = 1;
    hipError_t e = lbvh_build(la, c->stream, c->level_start, &num_nodes);
+   if (e == hipErrorUnknown) {
+      // the builder gave up on this geometry (a PLOC round that merges nothing: every union area inf / NaN, e.g. coordinates
+      // around 1e19 whose area products overflow): like a tree that came out too deep, such a scene gets the host builder
+      (void)hipGetLastError();
+      c->device_build = false;
+      const int st = uh_build_acceleration(c);
+      c->device_build = true;
+      return st;
+   }
    if (e != hipSuccess) return fail(c, UH_ERR_HIP, std::string("device BVH build: ") + hipGetErrorString(e));
    if (c->level_start.size() - 1 > kMaxTreeLevels) {
       // a Morton tree over clustered geometry can be a long chain; deeper than the traversal stack it would drop
@@ -1219,12 +1216,8 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
                HIP_TRY(c, c->gb_ray_d.alloc(npix));
                HIP_TRY(c, c->gb_hit.alloc(npix));
             }
-            PathState gps;
-            std::memset(&gps, 0, sizeof(gps));
-            gps.ray_o = c->gb_ray_o.p;
-            gps.ray_d = c->gb_ray_d.p;
-            gps.hit = c->gb_hit.p;
-            launch_gbuffer(rc, ff, c->scene, gps, im, nullptr, c->dstats.p);
+            const RawRays gps{c->gb_ray_o.p, c->gb_ray_d.p, c->gb_hit.p};
+            launch_gbuffer(rc, ff, c->scene, gps, im, c->dstats.p);
          }
          if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(rc, ff, im);
          if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(rc, ff, c->scene, im);

@@ -368,6 +368,10 @@ __device__ __forceinline__ void st_stream(uint32_t* p, uint32_t x) {
       *p = x;
 }
 
+// ---- path state planes (device_types.h PathState): streamed like the other per-path arrays -------------------------------
+__device__ __forceinline__ float4 ld_rec(const float4* p) { return ld_stream(p); }
+__device__ __forceinline__ void st_rec(float4* p, float4 x) { st_stream(p, x); }
+
 // ---- wave64 helpers ---------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

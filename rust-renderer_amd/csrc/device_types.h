@@ -117,18 +117,36 @@ struct FrameParams {
    uint32_t n_owned;
 };
 
-// Path / ray state, SoA over pixels (path id == pixel id). 16-byte records so that every lane
-// moves one dwordx4 per access.
+// Path state: four 16-byte quads per path (path id == frame-in-batch * W*H + pixel), each quad in a PLANE of its own (SoA over
+// paths), so that a wave working on consecutive ids moves contiguous kilobytes - the CU's vector-memory pipeline, which bounds
+// this path, handles a coalesced wave access several times faster than 64 scattered sectors. (One 64-byte record per path -
+// one sector per path instead of four - was built and measured: 6.4-6.7 against 7.1 Grays/s, profiles/README.md "path records".)
+// The RNG words ride in the w components the constant ray range (rgen:45-47: 0.001, 10000) does not need:
+//   plane 0  ray origin.xyz            | raygen rngState (bits)            reference.rgen:24,31
+//   plane 1  ray direction.xyz         | rayPayload.randomSeed (bits)      un-normalised direction (rgen:61); seed: rgen:30, rchit:91
+//   plane 2  throughput.rgb            | light weight f                    radiance += throughput * f when the light is visible (rgen:121)
+//   plane 3  hit: t, u, v              | triangle packet index (bits), 0xffffffff = miss
+// so a shaded hit reads four planes and writes three (the round-2 layout: five and four, with a separate RNG array).
+constexpr uint32_t kRecQuads = 4;
+enum { REC_ORIGIN = 0, REC_DIR = 1, REC_THR = 2, REC_HIT = 3 };
+struct PathRecs {
+   float4* base;
+   size_t plane;  // float4 between two planes (the path capacity plus a stagger: the planes must not alias in the caches)
+};
 struct PathState {
-   float4* ray_o;   // origin.xyz, tmin
-   float4* ray_d;   // direction.xyz (un-normalised, reference.rgen:61), tmax
-   float4* hit;     // t, u, v, packet index (bits); miss: index = 0xffffffff
-   float4* thr;     // throughput.rgb, light weight f (radiance += thr * f when the light is visible)
-   float4* rad;     // radiance.rgb, light index (bits)
+   PathRecs rec;
+   float4* rad;     // radiance.rgb, light index (bits): touched only where a path ends or a light / sun sample lands
    float4* pixcol;  // sum over the frame's samples
-   uint2* rng;      // x = raygen rngState, y = rayPayload.randomSeed
    uint32_t* queue[3];  // 0,1 = ray ping-pong; 2 = light; each kShards * shard_cap entries
    uint32_t shard_cap;  // entries per shard segment = pixels a shard can own (multiple of 64)
+};
+__host__ __device__ inline float4* rec_quad(const PathRecs& rec, uint32_t id, int quad) { return rec.base + rec.plane * (size_t)quad + id; }
+
+// rays of the stand-alone queries (uh_trace_closest, the G-buffer cast): record i = ray i, tmin / tmax in the w components
+struct RawRays {
+   float4* ray_o;   // origin.xyz, tmin
+   float4* ray_d;   // direction.xyz, tmax
+   float4* hit;     // t, u, v, packet index (bits)
 };
 
 struct Images {
@@ -165,7 +183,7 @@ void launch_trace_sun_grid(const LaunchCfg&, const FrameParams&, const SceneDev&
 void launch_finish_sample(const LaunchCfg&, const FrameParams&, const PathState&, const Images&, uint32_t sample, bool last);
 void launch_resolve(const LaunchCfg&, const Images&, uint32_t W, uint32_t H, uint32_t total_samples, uint32_t limit);
 // G-buffer + ReSTIR
-void launch_gbuffer(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*);
+void launch_gbuffer(const LaunchCfg&, const FrameParams&, const SceneDev&, const RawRays&, const Images&, DeviceStats*);
 void launch_reset_reservoirs(const LaunchCfg&, const FrameParams&, const Images&);
 void launch_initial_ris(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);
 void launch_temporal_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);

@@ -95,13 +95,13 @@ struct Trav {
    uint32_t cur;
 };
 
-__device__ __forceinline__ void trav_init(Trav& t, float4 ro, float4 rd, float tlimit) {
+__device__ __forceinline__ void trav_init(Trav& t, float4 ro, float4 rd, float tmin, float tmax, float tlimit) {
    t.o = v3(ro.x, ro.y, ro.z);
    t.d = v3(rd.x, rd.y, rd.z);
    t.idir = v3(safe_rcp_dir(t.d.x), safe_rcp_dir(t.d.y), safe_rcp_dir(t.d.z));
-   t.tmin = ro.w;
+   t.tmin = tmin;
    t.tlimit = tlimit;
-   t.best.t = rd.w;
+   t.best.t = tmax;
    t.best.u = t.best.v = 0.0f;
    t.best.idx = kEmptyRef;
    t.best.key = 0xffffffffu;
@@ -243,7 +243,7 @@ template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, float tlimit, Hit& best, uint32_t* lds_col,
                                          uint32_t& n_nodes, uint32_t& n_tris) {
    Trav t;
-   trav_init(t, make_float4(o.x, o.y, o.z, tmin), make_float4(d.x, d.y, d.z, tmax), ANY ? tlimit : INFINITY);
+   trav_init(t, make_float4(o.x, o.y, o.z, tmin), make_float4(d.x, d.y, d.z, tmax), tmin, tmax, ANY ? tlimit : INFINITY);
    uint32_t spill[kSpillStack];
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
@@ -459,10 +459,13 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
 // trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes.
 // Reads the bounce's ray queue, writes hit[path] = (t, u, v, packet) or packet = kEmptyRef.
 // ------------------------------------------------------------------------------------------
+// Path rays (queue_base != null): ray_o / ray_d / hit_out are planes 0 / 1 / 3 of the path state, whose w components carry RNG
+// words: the range is rgen:45-47's constants. Raw rays (queue_base == null, RawRays): the range is in the w components.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const uint32_t* __restrict__ queue_base, const float4* __restrict__ ray_o,
                                                                const float4* __restrict__ ray_d, float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl,
                                                                DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
+   const bool range_in_w = queue_base == nullptr;
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    __shared__ RayPool<2> s_pool[kWavesPerBlock];
    const uint32_t lane = lane_id();
@@ -496,13 +499,14 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
    uint32_t spill[kSpillStack];
    auto take = [&](uint32_t slot) {
       id = pool.id[slot];
-      trav_init(t, pool.v[0][slot], pool.v[1][slot], INFINITY);
+      const float4 ro = pool.v[0][slot], rd = pool.v[1][slot];
+      trav_init(t, ro, rd, range_in_w ? ro.w : 0.001f, range_in_w ? rd.w : 10000.0f, INFINITY);
    };
    while (refill_lanes<2>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
          if (trav_step<false, COUNT>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris))
-            st_stream(hit_out + id, make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx)));
+            st_rec(hit_out + id, make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx)));
       }
    }
    if (COUNT) {
@@ -543,9 +547,9 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
       uint32_t i = base + lane;
       if (i < count) {
          const uint32_t id = queue[i];
-         float4 ro = ray_o[id], rd = ray_d[id];
+         float4 ro = ray_o[id], rd = ray_d[id];  // path state: w = RNG words, range = rgen:45-47's constants
          Hit h;
-         traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
+         traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 0.001f, 10000.0f, 0.0f, h, lds_col, n_nodes, n_tris);
          hit_out[id] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
       }
    }
@@ -609,10 +613,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)src.count);
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
-   const float4* ray_o = ps.ray_o;
-   const float4* thr = ps.thr;
+   const PathRecs rec = ps.rec;
    const float4* rad = ps.rad;
-   auto source_of = [&](int a, uint32_t id) { return (a == 0 ? ray_o : a == 1 ? thr : rad) + id; };
+   auto source_of = [&](int a, uint32_t id) { return a == 2 ? rad + id : (const float4*)rec_quad(rec, id, a == 0 ? REC_ORIGIN : REC_THR); };
    Feeder<3> f;
    Trav t;
    t.cur = kEmptyRef;
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
       id = pool.id[slot];
       const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, pool.v[0][slot], pool.v[1][slot], pool.v[2][slot]);
       lit = s.lit;
-      trav_init(t, s.ro, s.rd, s.tlimit);
+      trav_init(t, s.ro, s.rd, s.ro.w, s.rd.w, s.tlimit);
    };
    while (refill_lanes<3>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
       uint32_t i = base + lane;
       if (i < count) {
          const uint32_t id = queue[i];
-         const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, ps.ray_o[id], ps.thr[id], ps.rad[id]);
+         const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, *rec_quad(ps.rec, id, REC_ORIGIN), *rec_quad(ps.rec, id, REC_THR), ps.rad[id]);
          Hit h;
          if (!traverse<true, COUNT>(sc, xyz(s.ro), xyz(s.rd), s.ro.w, s.rd.w, s.tlimit, h, lds_col, n_nodes, n_tris)) ps.rad[id] = s.lit;
       }
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
       const uint32_t i = base + lane;
       if (i >= count) continue;
       const uint32_t id = ld_stream(queue + i);
-      const float4 ro = ld_stream(ps.ray_o + id);
+      const float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN));
       const V3 o = v3(ro.x, ro.y, ro.z);
       const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o), pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
       // the ray's cell; outside the grid (or NaN) it is the border cell, which lists everything that reaches beyond the grid
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
          e++;
       }
       if (!occluded) {  // rgen:69-78: radiance += throughput
-         const float4 thr = ld_stream(ps.thr + id), rad = ld_stream(ps.rad + id);
+         const float4 thr = ld_rec(rec_quad(ps.rec, id, REC_THR)), rad = ld_stream(ps.rad + id);
          st_stream(ps.rad + id, make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w));
       }
    }
@@ -776,16 +779,16 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
          const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
          id = f * npix + pix;
          uint32_t px = pix % fp.W, py = pix / fp.W;
-         uint32_t rng = sample == 0 ? init_rng(px, py, fp.W, fp.frame_numbers[f]) : ps.rng[id].x;  // rgen:24
+         uint32_t rng = sample == 0 ? init_rng(px, py, fp.W, fp.frame_numbers[f]) : __float_as_uint(rec_quad(ps.rec, id, REC_ORIGIN)->w);  // rgen:24
          uint32_t seed = rng;                                                                   // rgen:30
          float jx = random_float(rng), jy = random_float(rng);                                  // rgen:31
          V3 o, d;
          primary_ray(fp, px, py, jx, jy, o, d);
-         st_stream(ps.ray_o + id, make_float4(o.x, o.y, o.z, 0.001f));
-         st_stream(ps.ray_d + id, make_float4(d.x, d.y, d.z, 10000.0f));
-         // throughput = 1 / radiance = 0 / pixelColor = 0 (rgen:26,39-40) are not materialised: the
-         // bounce-0 shading kernels and the first finish_sample use the constants directly
-         st_stream(ps.rng + id, make_uint2(rng, seed));
+         st_rec(rec_quad(ps.rec, id, REC_ORIGIN), make_float4(o.x, o.y, o.z, __uint_as_float(rng)));
+         st_rec(rec_quad(ps.rec, id, REC_DIR), make_float4(d.x, d.y, d.z, __uint_as_float(seed)));
+         st_rec(rec_quad(ps.rec, id, REC_THR), make_float4(1.0f, 1.0f, 1.0f, 0.0f));  // throughput = 1 (rgen:39)
+         // radiance = 0 / pixelColor = 0 (rgen:26,40) are not materialised: the bounce-0 shading kernels and the first
+         // finish_sample use the constants directly
       }
       // the 64 paths of a wave normally share one run (hence one shard); at tile edges that are not
       // 64-aligned they may not, so append shard by shard
@@ -812,15 +815,13 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
 __device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const PathState& ps, uint32_t id, uint32_t bounce) {
    V3 sky_color = v3(0.0f, 0.0f, 0.0f);
    if (fp.sky_enabled == 1) {
-      float4 ro = ld_stream(ps.ray_o + id), rd = ld_stream(ps.ray_d + id);
+      float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN)), rd = ld_rec(rec_quad(ps.rec, id, REC_DIR));
       V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
       sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
    }
-   float4 thr = make_float4(1.0f, 1.0f, 1.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-   if (bounce != 0) {
-      thr = ld_stream(ps.thr + id);
-      rad = ld_stream(ps.rad + id);
-   }
+   const float4 thr = ld_rec(rec_quad(ps.rec, id, REC_THR));  // 1 at bounce 0 (k_generate)
+   float4 rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+   if (bounce != 0) rad = ld_stream(ps.rad + id);
    V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
    st_stream(ps.rad + id, make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w));   // rgen:55
 }
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState
       uint32_t id = 0;
       if (i < count) {
          id = ld_stream(queue + i);
-         miss = __float_as_uint(ld_stream(ps.hit + id).w) == kEmptyRef;
+         miss = __float_as_uint(ld_rec(rec_quad(ps.rec, id, REC_HIT)).w) == kEmptyRef;
       }
       const unsigned long long mask = __ballot(miss);
       if (mask == 0ull) continue;
@@ -955,11 +956,11 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
       if (valid) {
          // every record of the path is requested up front, together with the shading packet (whose index the
          // classification below already read): one round trip for all of them, then one for the texels
-         const float4 hr = ld_stream(ps.hit + id);
-         float4 ro = ld_stream(ps.ray_o + id), rd = ld_stream(ps.ray_d + id);
-         uint2 rng = ld_stream(ps.rng + id);
-         float4 thr4 = ld_stream(ps.thr + id);  // unconditional (a branch would end the group of loads with a wait); unwritten before bounce 1
-         if (bounce == 0) thr4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+         // the path's state: four planes (the RNG words ride in the rays' w components)
+         const float4 hr = ld_rec(rec_quad(ps.rec, id, REC_HIT));
+         float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN)), rd = ld_rec(rec_quad(ps.rec, id, REC_DIR));
+         uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
+         float4 thr4 = ld_rec(rec_quad(ps.rec, id, REC_THR));
          const V3 ray_dir = v3(rd.x, rd.y, rd.z);
          const float t = hr.x, bu = hr.y, bv = hr.z;
          const float4* sp = sc.shade + 4 * (size_t)pk;  // pk = hr.w, known since the classification: no wait for hr before these
@@ -1029,12 +1030,13 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
             float4 rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (bounce != 0) rad4 = ld_stream(ps.rad + id);
             st_stream(ps.rad + id, make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, rad4.w));
-            st_stream(ps.rng + id, rng);
+            // the RNG words go back into the ray planes: the next sample of the frame starts from them (rgen:28-31)
+            st_rec(rec_quad(ps.rec, id, REC_ORIGIN), make_float4(ro.x, ro.y, ro.z, __uint_as_float(rng.x)));
+            st_rec(rec_quad(ps.rec, id, REC_DIR), make_float4(rd.x, rd.y, rd.z, __uint_as_float(rng.y)));
          } else {
             V3 origin = v3(ro.x, ro.y, ro.z) + t * ray_dir;                            // rgen:59
             origin = offset_ray(origin, world_normal);                                 // rgen:60
-            st_stream(ps.ray_o + id, make_float4(origin.x, origin.y, origin.z, 0.001f));
-            st_stream(ps.ray_d + id, make_float4(scatter.x, scatter.y, scatter.z, 10000.0f));     // rgen:61
+            // (the path's three planes are written below, once the raygen's RNG word is final)
             float f = 0.0f;
             int light_index = 0;
             if (fp.lights_enabled == 1) {                                              // rgen:81-110
@@ -1056,7 +1058,9 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
                   f = target_function(sc.lights, sc.num_lights, light_index, origin) * light_sample_weight;  // rgen:121
                }
             }
-            st_stream(ps.thr + id, make_float4(thr.x, thr.y, thr.z, f));
+            st_rec(rec_quad(ps.rec, id, REC_ORIGIN), make_float4(origin.x, origin.y, origin.z, __uint_as_float(rng.x)));
+            st_rec(rec_quad(ps.rec, id, REC_DIR), make_float4(scatter.x, scatter.y, scatter.z, __uint_as_float(rng.y)));  // rgen:61
+            st_rec(rec_quad(ps.rec, id, REC_THR), make_float4(thr.x, thr.y, thr.z, f));
             if (bounce == 0) {
                // first write of this path's radiance record (generate does not materialise the zero)
                st_stream(ps.rad + id, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)light_index)));
@@ -1064,7 +1068,6 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
                float4 rad4 = ld_stream(ps.rad + id);
                st_stream(ps.rad + id, make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index)));
             }
-            st_stream(ps.rng + id, rng);
          }
       }
       uint32_t slot = wave_append(n_next, scattered);
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
       uint32_t id = 0, pk = kEmptyRef;
       if (i < count) {
          id = ld_stream(queue + i);
-         pk = reinterpret_cast<const uint32_t*>(ps.hit + id)[3];  // a plain load: shade() reads the record again
+         pk = reinterpret_cast<const uint32_t*>(rec_quad(ps.rec, id, REC_HIT))[3];  // a plain load: shade() reads the record again
       }
       const bool is_hit = pk != kEmptyRef;
       const unsigned long long mask = __ballot(is_hit);
@@ -1179,7 +1182,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(Images im, uint32_t n, uint3
 // utopian/src/renderers/gbuffer.rs:11-52, shaders/gbuffer/gbuffer.frag:47; clear colour
 // (1,1,1,0): utopian/src/pass.rs:210-214)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_gbuffer_generate(FrameParams fp, PathState ps) {
+__global__ __launch_bounds__(kBlock) void k_gbuffer_generate(FrameParams fp, RawRays ps) {
    const uint32_t n = fp.W * fp.H;
    for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
       V3 o, d;
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_generate(FrameParams fp, Pat
       ps.ray_d[id] = make_float4(d.x, d.y, d.z, 10000.0f);
    }
 }
-__global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(FrameParams fp, PathState ps, Images im, DeviceStats* stats) {
+__global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(FrameParams fp, RawRays ps, Images im, DeviceStats* stats) {
    const uint32_t n = fp.W * fp.H;
    for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
       float4 h = ps.hit[id];
@@ -1409,7 +1412,8 @@ static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, co
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                           uint32_t cursor_slot, int ray_kind) {
-   launch_closest(c, closest_grid(c), sc, ps.queue[bounce & 1], ps.ray_o, ps.ray_d, ps.hit, ps.shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, 0, false);
+   launch_closest(c, closest_grid(c), sc, ps.queue[bounce & 1], rec_quad(ps.rec, 0, REC_ORIGIN), rec_quad(ps.rec, 0, REC_DIR), rec_quad(ps.rec, 0, REC_HIT), ps.shard_cap, ctl, stats,
+                  bounce, cursor_slot, ray_kind, 0, false);
 }
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
@@ -1462,9 +1466,7 @@ void launch_resolve(const LaunchCfg& c, const Images& im, uint32_t W, uint32_t H
    k_resolve<<<stream_grid(c, W * H), kBlock, 0, c.stream>>>(im, W * H, total_samples, limit);
 }
 
-void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
-                    DeviceStats* stats) {
-   (void)ctl;
+void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const RawRays& ps, const Images& im, DeviceStats* stats) {
    const uint32_t n = fp.W * fp.H;
    k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps);
    launch_closest(c, dim3(c.num_cus * c.closest_blocks_per_cu), sc, nullptr, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n, false);

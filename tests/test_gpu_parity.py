@@ -824,3 +824,27 @@ def test_spatial_splits_keep_every_hit_and_cut_visits():
     cpu = scene.upload(oa.OracleRenderer(W, H))
     run_frames(cpu, scene, W, H, 2, rr.PASS_REFERENCE_PT)
     assert per_pixel_l2(a8, cpu.read_accumulation()) <= L2_TOL and r8[:4] == list(cpu.get_stats().rays)[:4]
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_device_build_falls_back_to_the_host_builder_on_overflowing_geometry(kind):
+    """finite coordinates around 1e19: surface-area products overflow to inf, a PLOC round finds no pair to merge - the device
+    build hands such a scene to the host builder instead of failing (the host tree handles it); hits equal the host build's"""
+    from rust_renderer_amd.camera import Camera
+    from rust_renderer_amd.scenes import Mesh, Model, Scene, _pack_vertices
+    rng = np.random.default_rng(11)
+    c = rng.uniform(-1, 1, (400, 1, 3)) * 3e19
+    pos = (c + rng.uniform(-1, 1, (400, 3, 3)) * 2e18).reshape(-1, 3).astype(np.float32)
+    m = Mesh(_pack_vertices(pos, np.tile(np.float32([0, 0, 1]), (len(pos), 1)), np.zeros((len(pos), 2), np.float32)), np.arange(len(pos), dtype=np.uint32))
+    scene = Scene("huge", [(Model([m], []), None)], [], Camera((0, 0, 4), (0, 0, 0), 60.0, 1.0, 0.01, 100.0))
+    rays = np.empty((4000, 8), dtype=np.float32)
+    rays[:, 0:3] = rng.uniform(-1, 1, (4000, 3)) * 3e19
+    rays[:, 4:7] = pos[rng.integers(0, len(pos), 4000)] - rays[:, 0:3]
+    rays[:, 3], rays[:, 7] = 1e-3, 10.0
+    host = scene.upload(rr.Renderer(8, 8))
+    dev = rr.Renderer(8, 8)
+    dev.set_option("device_build", kind)
+    scene.upload(dev)
+    assert dev.get_stats().bvh_triangles == 400  # built, not refused
+    for a, b in zip(host.trace_closest(rays), dev.trace_closest(rays)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))  # (at this scale the triangle test itself overflows: all miss, on both)
