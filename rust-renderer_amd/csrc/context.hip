@@ -230,6 +230,8 @@ struct uh_ctx {
    // sun shadow rays through a per-direction grid instead of the tree (sun_grid.h; option "sun_grid"). The grid belongs to one
    // (geometry, sun direction) pair: it is built on the first frame that traces sun rays and again when the direction has
    // changed and then stayed put for two consecutive frames - a sun that moves every frame keeps the tree walk.
+   bool primary_tiles = false;      // option "primary_tiles": wave-per-tile traversal (scalar node fetches) for primary rays and the G-buffer cast; measured
+                                    // level with the per-lane kernel (config 1 +1.3 %, config 2 -0.5 %: profiles/README.md), so off by default
    bool sun_grid_enabled = true;
    bool sun_valid = false;          // d_sun_* hold a usable grid for (sun_geom, sun_dir_built)
    bool sun_attempted = false;      // a build for (sun_geom, sun_dir_built) was tried (it may have been refused: sun_why)
@@ -301,7 +303,8 @@ void set_transform(HostMesh& m, const float* w) {
 }
 
 LaunchCfg cfg(uh_ctx* c) {
-   return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->closest_variant, c->shadow_variant, c->raw_visit_counts};
+   return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->closest_variant, c->shadow_variant, c->raw_visit_counts,
+                    c->primary_tiles};
 }
 
 void begin_timed(uh_ctx* c, int kind, hipStream_t stream = nullptr) {
@@ -1093,7 +1096,10 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          // trace_closest(b) refills the miss queue that shade_miss(b-1) reads on the side stream
          if (c->overlap_miss && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_missed, 0));
          begin_timed(c, 0, s.stream);
-         launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
+         if (b == 0 && c->primary_tiles && primary_tiles_apply(fp))
+            launch_trace_primary_tiles(lc, fp, c->scene, s.ps, st);  // coherent: one wave per 8 x 8 pixel tile, nodes through the scalar path
+         else
+            launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
          end_timed(c, s.stream);
          if (c->overlap_miss) {
             // side stream: shade_miss(b) after trace_closest(b); joined before finish_sample
@@ -1499,6 +1505,8 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (c->spatial_split_factor != value) c->built = c->topology_valid = false;
       c->spatial_split_factor = value;
    }
+   else if (n == "primary_tiles")
+      c->primary_tiles = value != 0;
    else if (n == "sun_grid") {
       // 1 (default): sun shadow rays go through the per-direction grid of sun_grid.h when one can be built; 0: always the tree
       c->sun_grid_enabled = value != 0;

@@ -168,11 +168,14 @@ struct LaunchCfg {
    // next ray from an LDS pool (kernels.hip "Ray replacement"), the default
    int closest_variant, shadow_variant;
    bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
+   bool primary_tiles = false;     // primary rays and the G-buffer cast: one wave per 8 x 8 pixel tile (k_trace_closest_tiles)
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);
 void launch_trace_closest(const LaunchCfg&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce, uint32_t cursor_slot,
                           int ray_kind);
+bool primary_tiles_apply(const FrameParams&);
+void launch_trace_primary_tiles(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, DeviceStats*);
 void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, DeviceStats*, uint32_t bounce);
 void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
 void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,

@@ -515,6 +515,138 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
    }
 }
 
+// ------------------------------------------------------------------------------------------
+// trace_closest, one wave per 8 x 8 pixel tile - for rays that leave neighbouring pixels with (nearly) one origin: the primary
+// rays of rgen:36-47 and the G-buffer cast (gbuffer.rs:11-52). The 64 rays of a tile want almost the same nodes, so the wave
+// walks ONE node at a time for all of them: the node (and at a leaf the triangle packet) is fetched through the SCALAR path -
+// three s_load_dwordx4 into SGPRs, off the vector-memory pipeline that bounds the per-lane kernels - every lane slab-tests the
+// four children against ITS ray and ITS best hit, and a child is descended when any lane's test passes (ballot). The wave's
+// stack (LDS, one copy per wave) holds what some lane still wants. A triangle is tested by every lane: testing a triangle a
+// lane's own walk would have culled cannot change that lane's result (boxes are conservative: DESIGN.md "Arithmetic contract"),
+// so hits are those of k_trace_closest bit for bit.
+// ------------------------------------------------------------------------------------------
+struct TileJob {
+   uint32_t W, H, frames;       // rays of frame f, pixel (x, y): record f * W * H + y * W + x
+   uint32_t tp_world, tp_rank, tp_tile, tiles_x;  // tile partition of the path tracer (tp_world <= 1: every pixel); tp_tile % 8 == 0
+   uint32_t range_in_w;         // raw rays: tmin / tmax in the w components; path rays: rgen:45-47's constants
+};
+
+__device__ __forceinline__ void sload48(const uint4* p, uint4& a, uint4& b, uint4& c) {
+   // p is wave-uniform: three scalar loads (the compiler will not prove uniformity of an index that came out of LDS)
+   u4_t x, y, z;
+   asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(x), "=&s"(y), "=&s"(z) : "s"(p) : "memory");
+   a = make_uint4(x.x, x.y, x.z, x.w);
+   b = make_uint4(y.x, y.y, y.z, y.w);
+   c = make_uint4(z.x, z.y, z.z, z.w);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_closest_tiles(SceneDev sc, TileJob job, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                                 float4* __restrict__ hit_out, DeviceStats* stats, int ray_kind) {
+   constexpr uint32_t kTileStack = 3 * kMaxTreeLevels + 4;
+   __shared__ uint32_t s_stack[kWavesPerBlock][kTileStack];
+   const uint32_t lane = lane_id();
+   const uint32_t wave = threadIdx.x >> 6;
+   uint32_t* stack = s_stack[wave];
+   const uint32_t tx8 = (job.W + 7) / 8, ty8 = (job.H + 7) / 8;
+   const uint32_t items = tx8 * ty8 * job.frames;
+   const uint32_t npix = job.W * job.H;
+   uint32_t n_nodes = 0, n_tris = 0, n_rays = 0;
+   for (uint32_t item = blockIdx.x * kWavesPerBlock + wave; item < items; item += gridDim.x * kWavesPerBlock) {
+      const uint32_t f = item / (tx8 * ty8), t = item - f * (tx8 * ty8);
+      const uint32_t px = (t % tx8) * 8 + (lane & 7), py = (t / tx8) * 8 + (lane >> 3);
+      bool live = px < job.W && py < job.H;
+      if (job.tp_world > 1) {
+         // 8 x 8 tiles nest in the partition's tiles: a tile is owned as a whole or not at all (wave-uniform)
+         const uint32_t owner = ((py / job.tp_tile) * job.tiles_x + px / job.tp_tile) % job.tp_world;
+         live = live && owner == job.tp_rank;
+      }
+      if (__ballot(live) == 0ull) continue;
+      const uint32_t id = f * npix + py * job.W + px;
+      float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(1, 0, 0, 0);
+      if (live) {
+         ro = ld_rec(ray_o + id);
+         rd = ld_rec(ray_d + id);
+      }
+      Trav tr;
+      trav_init(tr, ro, rd, job.range_in_w ? ro.w : 0.001f, job.range_in_w ? rd.w : 10000.0f, INFINITY);
+      if (!live) tr.best.t = -1.0f;  // an interval no box meets: the lane votes for nothing
+      const uint32_t n_live = (uint32_t)__popcll(__ballot(live));  // every lane votes: the count is wave-uniform
+      if (lane == 0) n_rays += n_live;
+      uint32_t sp = 0;            // wave-uniform
+      uint32_t cur = 0;           // wave-uniform: node index, or kLeafBit | packet
+      for (uint32_t guard = 0; guard < (1u << 22); guard++) {
+         cur = __builtin_amdgcn_readfirstlane(cur);
+         uint4 w0, w1, w2;
+         if (!(cur & kLeafBit)) {
+            sload48(sc.nodes + kNodeStride16 * (size_t)cur, w0, w1, w2);
+            if (COUNT && live) n_nodes++;  // per ray of the tile, as the per-lane kernels count
+            // the node step of node_compute, with the children's verdicts kept per lane
+            const uint32_t meta = w0.w;
+            const float sx = __uint_as_float((meta & 0xffu) << 23), sy = __uint_as_float((meta << 15) & 0x7f800000u), sz = __uint_as_float((meta << 7) & 0x7f800000u);
+            const float ax = sx * tr.idir.x, ay = sy * tr.idir.y, az = sz * tr.idir.z;
+            const float bx = (__uint_as_float(w0.x) - tr.o.x) * tr.idir.x, by = (__uint_as_float(w0.y) - tr.o.y) * tr.idir.y, bz = (__uint_as_float(w0.z) - tr.o.z) * tr.idir.z;
+            const bool nx = tr.idir.x < 0.0f, ny = tr.idir.y < 0.0f, nz = tr.idir.z < 0.0f;
+            const uint32_t qnx = nx ? w1.w : w1.x, qfx = nx ? w1.x : w1.w;
+            const uint32_t qny = ny ? w2.x : w1.y, qfy = ny ? w1.y : w2.x;
+            const uint32_t qnz = nz ? w2.y : w1.z, qfz = nz ? w1.z : w2.y;
+            const uint32_t n_tri = (meta >> kMetaTriShift) & 7u;
+            const uint32_t tri0 = kLeafBit | w2.w, node0 = w2.z - n_tri;
+            uint32_t want = 0;   // wave-uniform: children some lane's ray meets
+            float centre_t[4];   // entry distance of the tile's centre ray (lane 27), INF when it misses the child
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+               const float t0x = fmaf((float)((qnx >> (8 * k)) & 0xffu), ax, bx), t1x = fmaf((float)((qfx >> (8 * k)) & 0xffu), ax, bx);
+               const float t0y = fmaf((float)((qny >> (8 * k)) & 0xffu), ay, by), t1y = fmaf((float)((qfy >> (8 * k)) & 0xffu), ay, by);
+               const float t0z = fmaf((float)((qnz >> (8 * k)) & 0xffu), az, bz), t1z = fmaf((float)((qfz >> (8 * k)) & 0xffu), az, bz);
+               const float tnear = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, tr.tmin));
+               const float tfar = fminf(fminf(t1x, t1y), fminf(t1z, tr.best.t));
+               const bool hit = tnear <= tfar;
+               if (__ballot(hit) != 0ull) want |= 1u << k;
+               centre_t[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hit ? tnear : INFINITY), 27));
+            }
+            if (want == 0u) {
+               if (sp == 0) break;
+               cur = stack[--sp];
+               continue;
+            }
+            // nearest wanted child (by the centre ray) next, the others pushed - all of it on the scalar side
+            int first = -1;
+            float best_t = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+               if ((want >> k & 1u) && (first < 0 || centre_t[k] < best_t)) {
+                  first = k;
+                  best_t = centre_t[k];
+               }
+#pragma unroll
+            for (int k = 3; k >= 0; k--)
+               if ((want >> k & 1u) && k != first && sp < kTileStack) {
+                  if (lane == 0) stack[sp] = ((uint32_t)k < n_tri ? tri0 : node0) + (uint32_t)k;
+                  sp++;
+               }
+            cur = ((uint32_t)first < n_tri ? tri0 : node0) + (uint32_t)first;
+         } else {
+            const uint32_t packet = cur & ~kLeafBit;
+            sload48((const uint4*)sc.tris + kTriStride16 * (size_t)packet, w0, w1, w2);
+            if (COUNT && live) n_tris++;
+            const float4 ta = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
+            const float4 tb = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
+            const float4 tc = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
+            if (live) tri_compute<false>(ta, tb, tc, packet, tr.o, tr.d, tr.tmin, INFINITY, tr.best);
+            if (sp == 0) break;
+            cur = stack[--sp];
+         }
+      }
+      if (live) st_rec(hit_out + id, make_float4(tr.best.t, tr.best.u, tr.best.v, __uint_as_float(tr.best.idx)));
+   }
+   if (COUNT) {
+      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+   }
+   if (ray_kind >= 0 && lane == 0 && n_rays) atomicAdd(&stats->rays[ray_kind], (unsigned long long)n_rays);
+}
+
 // The plain batch form (option closest_variant = 0): a wave takes 64 rays, every lane walks its ray to the end,
 // then the wave takes the next 64. Kept as the baseline the refill kernels are measured against, and for the
 // per-ray visit counts of the diagnostics (DIAG: u,v of the result carry the ray's node / triangle visits).
@@ -1416,6 +1548,34 @@ void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathStat
                   bounce, cursor_slot, ray_kind, 0, false);
 }
 
+static TileJob tile_job(const FrameParams& fp, uint32_t frames, bool raw) {
+   TileJob j;
+   j.W = fp.W;
+   j.H = fp.H;
+   j.frames = frames;
+   j.tp_world = raw ? 1u : fp.tp_world;
+   j.tp_rank = fp.tp_rank;
+   j.tp_tile = fp.tp_tile;
+   j.tiles_x = fp.tiles_x;
+   j.range_in_w = raw ? 1u : 0u;
+   return j;
+}
+static void launch_tiles(const LaunchCfg& c, const SceneDev& sc, const TileJob& j, const float4* ray_o, const float4* ray_d, float4* hit, DeviceStats* stats, int ray_kind, bool count) {
+   const uint32_t items = ((j.W + 7) / 8) * ((j.H + 7) / 8) * j.frames, need = (items + kWavesPerBlock - 1) / kWavesPerBlock, full = c.num_cus * 8;
+   const dim3 grid(need < full ? (need ? need : 1) : full);
+   if (count)
+      k_trace_closest_tiles<true><<<grid, kBlock, 0, c.stream>>>(sc, j, ray_o, ray_d, hit, stats, ray_kind);
+   else
+      k_trace_closest_tiles<false><<<grid, kBlock, 0, c.stream>>>(sc, j, ray_o, ray_d, hit, stats, ray_kind);
+}
+bool primary_tiles_apply(const FrameParams& fp) { return fp.tp_world <= 1 || fp.tp_tile % 8 == 0; }
+// bounce 0 of the path tracer, wave per 8 x 8 pixel tile (k_trace_closest_tiles): every path of the wavefront is in the bounce's
+// queue, so the tiles are enumerated directly
+void launch_trace_primary_tiles(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, DeviceStats* stats) {
+   launch_tiles(c, sc, tile_job(fp, fp.batch_frames, false), rec_quad(ps.rec, 0, REC_ORIGIN), rec_quad(ps.rec, 0, REC_DIR), rec_quad(ps.rec, 0, REC_HIT), stats, UH_RAY_PRIMARY,
+                c.count_visits);
+}
+
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
    // per-wave compaction leaves one partial batch of misses per wave: a grid of 4 blocks per CU (not one block per 256
    // pixels) gives every wave enough rays that this tail is a small share of its sky integrals
@@ -1469,7 +1629,10 @@ void launch_resolve(const LaunchCfg& c, const Images& im, uint32_t W, uint32_t H
 void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const RawRays& ps, const Images& im, DeviceStats* stats) {
    const uint32_t n = fp.W * fp.H;
    k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps);
-   launch_closest(c, dim3(c.num_cus * c.closest_blocks_per_cu), sc, nullptr, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n, false);
+   if (c.primary_tiles)
+      launch_tiles(c, sc, tile_job(fp, 1, true), ps.ray_o, ps.ray_d, ps.hit, stats, -1, false);
+   else
+      launch_closest(c, dim3(c.num_cus * c.closest_blocks_per_cu), sc, nullptr, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n, false);
    k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats);
 }
 

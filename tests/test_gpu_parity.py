@@ -848,3 +848,22 @@ def test_device_build_falls_back_to_the_host_builder_on_overflowing_geometry(kin
     assert dev.get_stats().bvh_triangles == 400  # built, not refused
     for a, b in zip(host.trace_closest(rays), dev.trace_closest(rays)):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))  # (at this scale the triangle test itself overflows: all miss, on both)
+
+
+@pytest.mark.parametrize("size,world", [((97, 61), 1), ((128, 72), 1), ((192, 128), 3)])
+def test_wave_per_tile_traversal_is_bit_identical(atrium, size, world):
+    """option primary_tiles: primary rays and the G-buffer cast walked one wave per 8 x 8 pixel tile with the nodes fetched through the
+    scalar path (k_trace_closest_tiles) - same hits, reservoirs, images and counts as the per-lane kernel, also on frames whose
+    size is no multiple of 8 and under a tile partition"""
+    W, H = size
+    out = []
+    for tiles in (0, 1):
+        r = atrium.upload(rr.Renderer(W, H))
+        r.set_option("primary_tiles", tiles)
+        if world > 1:
+            r.set_tile_partition(1, world, 64)
+        rr.FrameLoop(r, atrium.make_view(W, H)).frames(5, rr.PASS_ALL)
+        out.append((r.read_accumulation(), r.read_gbuffer_position(), [r.read_reservoirs(k) for k in range(3)], list(r.get_stats().rays)))
+    (a0, g0, r0, c0), (a1, g1, r1, c1) = out
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and np.array_equal(g0.view(np.uint32), g1.view(np.uint32))
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(r0, r1)) and c0 == c1
