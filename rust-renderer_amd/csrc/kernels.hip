@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    const uint32_t n_lds_mesh = sc.num_meshes < kLdsMeshes ? sc.num_meshes : kLdsMeshes;
    const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
    __shared__ uint32_t s_hits;
-   __shared__ uint32_t s_list[kWavesPerBlock][2][128];  // per wave: path ids, and the packet index the classification read with them
+   __shared__ uint32_t s_list[kWavesPerBlock][5][128];  // per wave: path ids, and the hit record (t, u, v, packet) the classification read with them
    if (threadIdx.x == 0) s_hits = 0;
    if (threadIdx.x < n_lds_mesh) s_mesh[threadIdx.x] = sc.meshes[threadIdx.x];
    if (threadIdx.x < n_lds_tex) s_tex[threadIdx.x] = sc.textures[threadIdx.x];
@@ -1083,13 +1083,14 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    const uint32_t rounds = (count + stride - 1) / stride;
    uint32_t n_hits = 0;
    // one path per lane: `valid` lanes shade their hit; every lane of the wave takes part in the queue appends
-   auto shade = [&](uint32_t id, uint32_t pk, bool valid) {
+   auto shade = [&](uint32_t id, float4 hr, bool valid) {
+      const uint32_t pk = __float_as_uint(hr.w);
       bool scattered = false, want_light = false;
       if (valid) {
          // every record of the path is requested up front, together with the shading packet (whose index the
          // classification below already read): one round trip for all of them, then one for the texels
-         // the path's state: four planes (the RNG words ride in the rays' w components)
-         const float4 hr = ld_rec(rec_quad(ps.rec, id, REC_HIT));
+         // the path's state: three more planes (the RNG words ride in the rays' w components); the hit record came with the
+         // classification below
          float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN)), rd = ld_rec(rec_quad(ps.rec, id, REC_DIR));
          uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
          float4 thr4 = ld_rec(rec_quad(ps.rec, id, REC_THR));
@@ -1210,47 +1211,47 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    // The bounce's RAY queue holds hits and misses (the traversal kernels build no hit / miss queues). Shading a wave of
    // queue entries as they come leaves the lanes of the misses idle through the whole material evaluation, so the hits
    // are first compacted inside the wave: their ids collect in a per-wave LDS list and are shaded 64 at a time.
-   uint32_t* list = s_list[threadIdx.x >> 6][0];
-   uint32_t* list_pk = s_list[threadIdx.x >> 6][1];
+   uint32_t(*list)[128] = s_list[threadIdx.x >> 6];  // [0] ids, [1..4] the hit record's four words
    const uint32_t lane = lane_id();
    uint32_t n_list = 0;  // wave-uniform
+   auto entry = [&](uint32_t k) { return make_float4(__uint_as_float(list[1][k]), __uint_as_float(list[2][k]), __uint_as_float(list[3][k]), __uint_as_float(list[4][k])); };
    for (uint32_t r = 0; r < rounds; r++) {
       const uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
-      uint32_t id = 0, pk = kEmptyRef;
+      uint32_t id = 0;
+      float4 hr = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmptyRef));
       if (i < count) {
          id = ld_stream(queue + i);
-         pk = reinterpret_cast<const uint32_t*>(rec_quad(ps.rec, id, REC_HIT))[3];  // a plain load: shade() reads the record again
+         hr = ld_rec(rec_quad(ps.rec, id, REC_HIT));  // the whole record (one 16-byte lane load, as the packet index alone would be): shade() does not read it again
       }
-      const bool is_hit = pk != kEmptyRef;
+      const bool is_hit = __float_as_uint(hr.w) != kEmptyRef;
       const unsigned long long mask = __ballot(is_hit);
       if (mask == 0ull) continue;
       const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
       if (is_hit) {
-         list[n_list + prefix] = id;
-         list_pk[n_list + prefix] = pk;
+         list[0][n_list + prefix] = id;
+         list[1][n_list + prefix] = __float_as_uint(hr.x);
+         list[2][n_list + prefix] = __float_as_uint(hr.y);
+         list[3][n_list + prefix] = __float_as_uint(hr.z);
+         list[4][n_list + prefix] = __float_as_uint(hr.w);
       }
       n_list += (uint32_t)__popcll(mask);
       __builtin_amdgcn_wave_barrier();
       if (n_list >= 64u) {
-         shade(list[lane], list_pk[lane], true);
+         shade(list[0][lane], entry(lane), true);
          n_hits += 64u;
          const uint32_t rest = n_list - 64u;  // move the tail (at most 63 entries) to the front: one wave, LDS operations execute in order
-         uint32_t tmp = 0, tmp_pk = 0;
-         if (lane < rest) {
-            tmp = list[64u + lane];
-            tmp_pk = list_pk[64u + lane];
-         }
+         uint32_t tmp[5] = {0, 0, 0, 0, 0};
+         if (lane < rest)
+            for (int k = 0; k < 5; k++) tmp[k] = list[k][64u + lane];
          __builtin_amdgcn_wave_barrier();
-         if (lane < rest) {
-            list[lane] = tmp;
-            list_pk[lane] = tmp_pk;
-         }
+         if (lane < rest)
+            for (int k = 0; k < 5; k++) list[k][lane] = tmp[k];
          __builtin_amdgcn_wave_barrier();
          n_list = rest;
       }
    }
    if (n_list) {
-      shade(lane < n_list ? list[lane] : 0u, lane < n_list ? list_pk[lane] : 0u, lane < n_list);
+      shade(lane < n_list ? list[0][lane] : 0u, lane < n_list ? entry(lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f), lane < n_list);
       n_hits += n_list;
    }
    // closest_hits: per-block sum, one atomic per block (n_hits is wave-uniform)
