@@ -78,7 +78,7 @@ struct Slot {
    hipEvent_t ev_acc = nullptr;  // recorded after the frame's accumulate / store tail
    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
    DevBuf<float4> rec, rad, pixcol;  // rec: the four path-state planes (device_types.h PathState)
-   DevBuf<uint32_t> queues[3];
+   DevBuf<uint32_t> queues[4];
    DevBuf<Control> control;
    PathState ps{};
    bool ready = false;
@@ -114,7 +114,7 @@ struct Slot {
       ps.rec = PathRecs{rec.p, plane};
       ps.rad = rad.p;
       ps.pixcol = pixcol.p;
-      for (int i = 0; i < 3; i++) ps.queue[i] = queues[i].p;
+      for (int i = 0; i < 4; i++) ps.queue[i] = queues[i].p;
       ps.shard_cap = shard_cap;
       ready = true;
       return hipSuccess;
@@ -1067,6 +1067,7 @@ static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
       d.inv_cell = g.inv_cell;
       d.nx = g.nx;
       d.ny = g.ny;
+      d.max_walk = c->sun_limits.max_walk;
       d.cell_start = c->d_sun_cells.p;
       d.entries = c->d_sun_entries.p;
       c->sun_cells = g.nx * g.ny;
@@ -1129,9 +1130,10 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          }
          if (fp.sun_shadow_enabled == 1) {
             begin_timed(c, 1, sh_stream);
-            if (c->sun_this_frame)
+            if (c->sun_this_frame) {
                launch_trace_sun_grid(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, c->sun_dev);
-            else
+               launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, false, true);  // the rays the grid handed over (border cells, long lists)
+            } else
                launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, false);
             end_timed(c, sh_stream);
          }

@@ -15,9 +15,9 @@ namespace uh {
 constexpr uint32_t kMaxBounces = 64;
 // per bounce: RAY (paths whose ray the bounce traces; the shading kernels tell hits from misses by the hit
 // record, so no hit / miss queues exist) and LIGHT (scattered paths that carry a light sample)
-constexpr uint32_t kQueueKinds = 2;
-enum { Q_RAY = 0, Q_LIGHT = 1 };
-constexpr uint32_t kLaunchSlots = kMaxBounces * 3 + 4;
+constexpr uint32_t kQueueKinds = 3;
+enum { Q_RAY = 0, Q_LIGHT = 1, Q_SUN_TREE = 2 };  // Q_SUN_TREE: sun rays the grid kernel hands to the tree walk (border cells, long lists)
+constexpr uint32_t kLaunchSlots = kMaxBounces * 4 + 4;  // per bounce: closest, sun (grid), sun leftovers (tree), light
 
 // Queues are sharded: path p lives in shard shard_of_run(p / 64) for its whole life, every queue
 // has one segment (capacity PathState::shard_cap) and one counter per shard, and the blocks of a
@@ -137,7 +137,7 @@ struct PathState {
    PathRecs rec;
    float4* rad;     // radiance.rgb, light index (bits): touched only where a path ends or a light / sun sample lands
    float4* pixcol;  // sum over the frame's samples
-   uint32_t* queue[3];  // 0,1 = ray ping-pong; 2 = light; each kShards * shard_cap entries
+   uint32_t* queue[4];  // 0,1 = ray ping-pong; 2 = light; 3 = sun rays for the tree walk; each kShards * shard_cap entries
    uint32_t shard_cap;  // entries per shard segment = pixels a shard can own (multiple of 64)
 };
 __host__ __device__ inline float4* rec_quad(const PathRecs& rec, uint32_t id, int quad) { return rec.base + rec.plane * (size_t)quad + id; }
@@ -179,7 +179,7 @@ void launch_trace_primary_tiles(const LaunchCfg&, const FrameParams&, const Scen
 void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, DeviceStats*, uint32_t bounce);
 void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
 void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
-                         uint32_t cursor_slot, bool light);
+                         uint32_t cursor_slot, bool light, bool sun_leftovers = false);
 // sun shadow rays through the per-direction grid (sun_grid.h) instead of the tree
 void launch_trace_sun_grid(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
                            uint32_t cursor_slot, const SunGridDev&);

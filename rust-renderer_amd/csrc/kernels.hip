@@ -725,9 +725,10 @@ __device__ __forceinline__ ShadowRay make_shadow_ray(const SceneDev& sc, const F
    return s;
 }
 
+// leftovers (sun rays only): the rays k_trace_sun_grid could not serve from its grid (queue 3); they are already counted
 template <bool COUNT, bool LIGHT>
 __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
-                                                              uint32_t cursor_slot) {
+                                                              uint32_t cursor_slot, bool leftovers) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    __shared__ RayPool<3> s_pool[kWavesPerBlock];
    const uint32_t lane = lane_id();
@@ -738,11 +739,11 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    const uint32_t seg = sx.shard * ps.shard_cap;
    RaySource src;
    // sun rays leave from every scattered path = the next bounce's ray queue; light rays from the light queue
-   src.queue = (LIGHT ? ps.queue[2] : ps.queue[(bounce + 1) & 1]) + seg;
-   src.count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   src.queue = (LIGHT ? ps.queue[2] : leftovers ? ps.queue[3] : ps.queue[(bounce + 1) & 1]) + seg;
+   src.count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : leftovers ? ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    src.wave_index = src.num_waves = 0;
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)src.count);
+   if (sx.lb == 0 && threadIdx.x == 0 && !leftovers) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)src.count);
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
    const PathRecs rec = ps.rec;
@@ -824,51 +825,67 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
    const V3 d = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);  // rgen:64
    const float max_x = (float)(g.nx - 1), max_y = (float)(g.ny - 1);
    uint32_t n_cells = 0, n_tris = 0;
+   uint32_t* q_tree = ps.queue[3] + seg;
+   uint32_t* n_tree = &ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)];
    for (;;) {
       const uint32_t base = next_batch(cursor);
       if (base >= count) break;
       const uint32_t i = base + lane;
-      if (i >= count) continue;
-      const uint32_t id = ld_stream(queue + i);
-      const float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN));
-      const V3 o = v3(ro.x, ro.y, ro.z);
-      const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o), pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
-      // the ray's cell; outside the grid (or NaN) it is the border cell, which lists everything that reaches beyond the grid
-      float fx = (pu - g.u0) * g.inv_cell, fy = (pv - g.v0) * g.inv_cell;
-      fx = !(fx >= 0.0f) ? 0.0f : fx;
-      fy = !(fy >= 0.0f) ? 0.0f : fy;
-      fx = fx > max_x ? max_x : fx;
-      fy = fy > max_y ? max_y : fy;
-      const uint32_t cell = (uint32_t)fy * g.nx + (uint32_t)fx;
-      uint32_t e = g.cell_start[cell];
-      const uint32_t end = g.cell_start[cell + 1];
-      if (COUNT) n_cells++;
-      bool occluded = false;
-      Hit best;
-      best.t = 10000.0f;  // tmax (rgen:66)
-      best.u = best.v = 0.0f;
-      best.idx = kEmptyRef;
-      best.key = 0xffffffffu;
-      uint2 en = make_uint2(0u, 0u);
-      if (e < end) en = reinterpret_cast<const uint2*>(g.entries)[e];
-      while (e < end) {
-         // sorted by far depth, descending: from here on every packet ends behind the origin (t < 0 for all of them)
-         if (__uint_as_float(en.y) < pw) break;
-         const uint32_t pk = en.x;
-         uint2 nxt = make_uint2(0u, 0u);
-         if (e + 1 < end) nxt = reinterpret_cast<const uint2*>(g.entries)[e + 1];  // in flight with the packet
-         const float4 a = tris[kTriStride16 * (size_t)pk + 0], b = tris[kTriStride16 * (size_t)pk + 1], c = tris[kTriStride16 * (size_t)pk + 2];
-         if (COUNT) n_tris++;
-         if (tri_compute<true>(a, b, c, pk, o, d, 0.001f, INFINITY, best)) {
-            occluded = true;
-            break;
+      const bool valid = i < count;
+      uint32_t id = 0;
+      bool defer = false;
+      if (valid) {
+         id = ld_stream(queue + i);
+         const float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN));
+         const V3 o = v3(ro.x, ro.y, ro.z);
+         const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o), pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
+         // the ray's cell; outside the grid (or NaN) it is a border cell
+         float fx = (pu - g.u0) * g.inv_cell, fy = (pv - g.v0) * g.inv_cell;
+         fx = !(fx >= 0.0f) ? 0.0f : fx;
+         fy = !(fy >= 0.0f) ? 0.0f : fy;
+         fx = fx > max_x ? max_x : fx;
+         fy = fy > max_y ? max_y : fy;
+         const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy;
+         const uint32_t cell = cy * g.nx + cx;
+         uint32_t e = g.cell_start[cell];
+         const uint32_t end = g.cell_start[cell + 1];
+         // a border cell stands for everything beyond the dense part of the scene, and some interior cells list a great many
+         // packets (walls edge-on to the sun): such a ray is cheaper in the tree - k_trace_shadow takes it from queue 3
+         defer = cx == 0 || cy == 0 || cx + 1 == g.nx || cy + 1 == g.ny || end - e > g.max_walk;
+         if (COUNT) n_cells++;
+         if (!defer) {
+            bool occluded = false;
+            Hit best;
+            best.t = 10000.0f;  // tmax (rgen:66)
+            best.u = best.v = 0.0f;
+            best.idx = kEmptyRef;
+            best.key = 0xffffffffu;
+            uint2 en = make_uint2(0u, 0u);
+            if (e < end) en = reinterpret_cast<const uint2*>(g.entries)[e];
+            while (e < end) {
+               // sorted by far depth, descending: from here on every packet ends behind the origin (t < 0 for all of them)
+               if (__uint_as_float(en.y) < pw) break;
+               const uint32_t pk = en.x;
+               uint2 nxt = make_uint2(0u, 0u);
+               if (e + 1 < end) nxt = reinterpret_cast<const uint2*>(g.entries)[e + 1];  // in flight with the packet
+               const float4 a = tris[kTriStride16 * (size_t)pk + 0], b = tris[kTriStride16 * (size_t)pk + 1], c = tris[kTriStride16 * (size_t)pk + 2];
+               if (COUNT) n_tris++;
+               if (tri_compute<true>(a, b, c, pk, o, d, 0.001f, INFINITY, best)) {
+                  occluded = true;
+                  break;
+               }
+               en = nxt;
+               e++;
+            }
+            if (!occluded) {  // rgen:69-78: radiance += throughput
+               const float4 thr = ld_rec(rec_quad(ps.rec, id, REC_THR)), rad = ld_stream(ps.rad + id);
+               st_stream(ps.rad + id, make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w));
+            }
          }
-         en = nxt;
-         e++;
       }
-      if (!occluded) {  // rgen:69-78: radiance += throughput
-         const float4 thr = ld_rec(rec_quad(ps.rec, id, REC_THR)), rad = ld_stream(ps.rad + id);
-         st_stream(ps.rad + id, make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w));
+      if (__ballot(defer) != 0ull) {  // wave-uniform: every lane of the wave takes part in the append
+         const uint32_t slot = wave_append(n_tree, defer);
+         if (defer) st_stream(q_tree + slot, id);
       }
    }
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[UH_RAY_SUN_SHADOW], (unsigned long long)count);
@@ -1590,7 +1607,14 @@ void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev&
 }
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
-                         uint32_t bounce, uint32_t cursor_slot, bool light) {
+                         uint32_t bounce, uint32_t cursor_slot, bool light, bool sun_leftovers) {
+   if (sun_leftovers) {  // what the sun grid handed to the tree (queue 3): always the refill kernel
+      if (c.count_visits)
+         k_trace_shadow<true, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, true);
+      else
+         k_trace_shadow<false, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, true);
+      return;
+   }
 #define UH_SHADOW(KERNEL) KERNEL<<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot)
    if (c.shadow_variant == 0) {
       if (light) {
@@ -1601,11 +1625,11 @@ void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneD
          else UH_SHADOW((k_trace_shadow_batch<false, false>));
       }
    } else if (light) {
-      if (c.count_visits) UH_SHADOW((k_trace_shadow<true, true>));
-      else UH_SHADOW((k_trace_shadow<false, true>));
+      if (c.count_visits) k_trace_shadow<true, true><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, false);
+      else k_trace_shadow<false, true><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, false);
    } else {
-      if (c.count_visits) UH_SHADOW((k_trace_shadow<true, false>));
-      else UH_SHADOW((k_trace_shadow<false, false>));
+      if (c.count_visits) k_trace_shadow<true, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, false);
+      else k_trace_shadow<false, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, false);
    }
 #undef UH_SHADOW
 }

@@ -329,8 +329,36 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
       }
    });
    out.mean_list = nonempty ? (double)total / (double)nonempty : 0.0;
+   // Where do sun rays start? On surfaces - so weigh every triangle by its area and ask whether the cell under its centre would
+   // serve a ray well (an interior cell with a short list) or hand it to the tree (a border cell: everything beyond the dense
+   // part of the scene, e.g. a ground plane around a detailed object; or a long list: walls seen edge-on). A grid that sends a
+   // large share of the surface to the tree only adds its look-up to the tree walk: refused as a whole.
+   {
+      double area_all = 0.0, area_bad = 0.0;
+      const double inv = out.inv_cell;
+      for (uint32_t i = 0; i < n; i++) {
+         const Proj& p = pr[i];
+         if (!p.use) continue;
+         const float* q = packets12 + 12 * (size_t)i;
+         const double e1[3] = {q[3], q[4], q[5]}, e2[3] = {q[6], q[7], q[8]};
+         const double cx3 = e1[1] * e2[2] - e1[2] * e2[1], cy3 = e1[2] * e2[0] - e1[0] * e2[2], cz3 = e1[0] * e2[1] - e1[1] * e2[0];
+         const double area = 0.5 * std::sqrt(cx3 * cx3 + cy3 * cy3 + cz3 * cz3);
+         if (!std::isfinite(area)) continue;
+         double fx = std::floor(((p.px[0] + p.px[1] + p.px[2]) / 3.0 - out.u0) * inv), fy = std::floor(((p.py[0] + p.py[1] + p.py[2]) / 3.0 - out.v0) * inv);
+         fx = !(fx >= 0) ? 0 : (fx > out.nx - 1 ? out.nx - 1 : fx);
+         fy = !(fy >= 0) ? 0 : (fy > out.ny - 1 ? out.ny - 1 : fy);
+         const uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy;
+         const size_t c = (size_t)iy * out.nx + ix;
+         const bool border = ix == 0 || iy == 0 || ix == out.nx - 1 || iy == out.ny - 1;
+         area_all += area;
+         if (border || out.cell_start[c + 1] - out.cell_start[c] > lim.max_walk) area_bad += area;
+      }
+      out.fallback_area = area_all > 0 ? area_bad / area_all : 0.0;
+   }
    out.max_list = longest;
    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+   if (out.fallback_area > lim.max_fallback_area)
+      return refuse("too much of the scene's surface (" + std::to_string(out.fallback_area) + ") lies beyond the dense extent or in cells with long lists: its rays would walk the tree anyway");
    if (out.mean_list > lim.max_mean_list) return refuse("lists too long for this direction (mean " + std::to_string(out.mean_list) + " entries per occupied cell)");
    return true;
 }

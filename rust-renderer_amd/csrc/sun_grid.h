@@ -27,6 +27,7 @@ struct SunGridDev {
    float U[3], V[3], W[3];  // orthonormal frame, W = the sun direction exactly as FrameParams::sun_dir
    float u0, v0, inv_cell;  // cell (ix, iy) covers u0 + [ix, ix+1) / inv_cell, v0 + [iy, iy+1) / inv_cell
    uint32_t nx, ny;
+   uint32_t max_walk;            // cells with a longer list, and the border cells, hand their rays to the tree walk
    const uint32_t* cell_start;   // nx * ny + 1 offsets into entries
    const SunGridEntry* entries;
 };
@@ -40,6 +41,7 @@ struct SunGridHost {
    // quality figures (what a ray can expect): entries per non-empty cell, the longest list, cells
    double mean_list = 0.0;
    uint32_t max_list = 0;
+   double fallback_area = 0.0;  // share of the triangles' surface area whose cell sends its rays to the tree (border or long list)
    double build_ms = 0.0;
    std::string why_not;  // non-empty: the grid was not built (degenerate direction, over budget, lists too long)
 };
@@ -49,6 +51,8 @@ struct SunGridLimits {
    uint64_t max_cells = 24ull << 20;
    double entries_per_triangle = 48.0;  // target density: the cell size is the finest that keeps the estimate under it (MI355X, config 1: 24 / 48 / 96 / 200 = 0.590 / 0.515 / 0.490 / 0.479 ms of sun rays per frame, tree walk 0.632)
    double max_mean_list = 40.0;         // beyond this a ray's expected work exceeds the tree walk's: use the tree
+   uint32_t max_walk = 32;              // a ray whose cell lists more than this (or is a border cell) walks the tree instead (k_trace_sun_grid's fallback queue)
+   double max_fallback_area = 0.2;      // share of the scene's surface area that may lie in such cells; above it the grid is refused as a whole
 };
 
 // packets: n x 12 floats in TriPacket layout (v0.xyz e1.x | e1.yz e2.xy | e2.z key pad pad). sun_dir: the frame's

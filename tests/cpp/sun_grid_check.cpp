@@ -123,6 +123,7 @@ static void check_scene(const char* name, const std::vector<float>& pk, F3 sun, 
    const float dir[3] = {d.x, d.y, d.z};
    SunGridHost g;
    SunGridLimits lim;
+   lim.max_fallback_area = 1.0;  // this check is about what the walk finds, not about when the grid is worth building (checked at the end)
    const bool ok = build_sun_grid(pk.data(), n, dir, lim, 3, g);
    if (!ok) {
       std::printf("%-34s grid refused: %s%s\n", name, g.why_not.c_str(), expect_grid ? "   <-- UNEXPECTED" : "");
@@ -286,6 +287,7 @@ int main(int argc, char** argv) {
          std::printf("a degenerate request was not refused\n");
          failures++;
       }
+      lim.max_fallback_area = 1.0;
       if (!build_sun_grid(one.data(), 1, ok, lim, 1, g)) {
          std::printf("single triangle refused: %s\n", g.why_not.c_str());
          failures++;
@@ -295,6 +297,28 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 500; i++) add_tri(soup, F3{rnd(), rnd(), rnd()}, F3{rnd(), rnd(), rnd()}, F3{rnd(), rnd(), rnd()});
       if (build_sun_grid(soup.data(), 500, ok, lim, 2, g) && g.entries.size() > 4) {
          std::printf("entry budget ignored\n");
+         failures++;
+      }
+   }
+   {
+      // when is the grid refused as a whole? A detailed object on a ground plane far larger than it: most of the surface (by area)
+      // lies beyond the dense extent, its rays would all be handed to the tree. A uniformly tessellated room: accepted.
+      std::vector<float> object, room;
+      add_patch(object, F3{-200, 0, -200}, F3{400, 0, 0}, F3{0, 0, 400}, 8, 8, 0.0f);
+      for (int k = 0; k < 6; k++) add_patch(object, F3{-1.0f + 0.3f * k, 0.2f, -1}, F3{0.25f, 0, 0}, F3{0, 1.5f, 2}, 24, 24, 0.02f);
+      add_patch(room, F3{-4, 0, -3}, F3{8, 0, 0}, F3{0, 0, 6}, 40, 30, 0.01f);
+      add_patch(room, F3{-4, 3, -3}, F3{8, 0, 0}, F3{0, 0, 6}, 40, 30, 0.01f);
+      add_patch(room, F3{-4, 0, -3}, F3{8, 0, 0}, F3{0, 3, 0}, 40, 15, 0.01f);
+      SunGridHost g;
+      SunGridLimits lim;
+      const F3 d = normalised(F3{0.0f, 0.9f, 0.15f});
+      const float dir[3] = {d.x, d.y, d.z};
+      const bool small_on_huge = build_sun_grid(object.data(), (uint32_t)(object.size() / 12), dir, lim, 2, g);
+      std::printf("object on a huge ground plane: %s (surface beyond the grid's reach: %.2f)\n", small_on_huge ? "grid built" : g.why_not.c_str(), g.fallback_area);
+      const bool uniform = build_sun_grid(room.data(), (uint32_t)(room.size() / 12), dir, lim, 2, g);
+      std::printf("uniform room: %s (surface beyond the grid's reach: %.2f)\n", uniform ? "grid built" : g.why_not.c_str(), g.fallback_area);
+      if (small_on_huge || !uniform) {
+         std::printf("the refusal heuristic misjudged a scene\n");
          failures++;
       }
    }

@@ -2,7 +2,7 @@
 # the round's committed evidence: default bench line, kernel trace + counter passes of the same command line, the other BASELINE configs
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
-tag=${1:-r02}
+tag=${1:-r03}
 timeout -k 10 300 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tools/profile_bench.sh $tag
 # the other configs carry their own bounded CPU-oracle sample

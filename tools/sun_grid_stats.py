@@ -3,9 +3,10 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import rust_renderer_amd as rr
-scene = rr.scenes.scene_for_config(1, tex_size=64)
-W, H = 1920, 1080
-for opts in ([("sun_grid", 0)], [], [("sun_grid_density", 48)], [("sun_grid_density", 96)], [("sun_grid_density", 200), ("sun_grid_max_mb", 2048)]):
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+scene = rr.scenes.scene_for_config(cfg, tex_size=64)
+W, H = (256, 256) if cfg == 0 else (1920, 1080)
+for opts in ([("sun_grid", 0)], [], [("sun_grid_density", 12)], [("sun_grid_density", 200), ("sun_grid_max_mb", 2048)]):
     r = rr.Renderer(W, H)
     for k, v in opts: r.set_option(k, v)
     scene.upload(r)
