@@ -321,9 +321,12 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     achieved = traffic / (serial_ms * 1e-3) / 1e9 if (traffic and serial_ms) else None
     overlapped = traffic / (avg_ms * 1e-3) / 1e9 if (traffic and avg_ms > 0) else None
     frame_bytes = (prof or {}).get("frame_hbm_bytes")
+    frame_bytes_lo = (prof or {}).get("frame_hbm_bytes_uncorrected")
     if frame_bytes and k.get("closest_rays_per_launch"):
         frame_bytes *= rays_per_launch / k["closest_rays_per_launch"]  # same rays-per-frame normalisation
+        frame_bytes_lo = frame_bytes_lo * rays_per_launch / k["closest_rays_per_launch"] if frame_bytes_lo else None
     ms_per_step = elapsed / args.steps * 1e3
+    uncorrected = (k.get("hbm_bytes_per_launch_uncorrected") or 0.0) / k["hbm_bytes_per_launch"] if traffic else None  # share of `traffic` the raw counters report
     # vector-memory issue: every per-lane load or store of <= 16 B takes one slot of the CU's texture addresser / data path, and
     # that path retires about one lane per clock (profiles/r02_microbench_rates.txt). Lane operations of one closest-hit ray: 3
     # per node visit (48-B node), 3 per triangle tested (48-B packet), 4 for queue id + ray (2 LDS-DMA) + hit.
@@ -347,6 +350,10 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
                        "note": "timed region: launches of up to four wavefronts overlap on two streams each, so a launch's duration includes time the chip gave to other kernels"},
         "frame_hbm_frac": (frame_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)) if frame_bytes else None,
         "frame_hbm_bytes": frame_bytes,
+        # the x2 FETCH_SIZE correction is calibrated for coalesced wide reads; these kernels gather 16-B lanes from 48/64-byte
+        # records, for which it may overstate by up to 2x. The same fractions from the counters AS REPORTED are the lower bounds.
+        "uncorrected": {"frac": (achieved / HBM_PEAK_GBS * uncorrected) if (achieved is not None and uncorrected) else None,
+                        "frame_hbm_frac": (frame_bytes_lo / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)) if frame_bytes_lo else None},
         "launches": st.trace_closest_launches,
         "rays_per_launch": rays_per_launch,
         "nodes_per_ray": nodes_per_ray,

@@ -6,7 +6,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 [ -z "$GRAFT_REPO_ROOT" ] && out=/root/repo/gpurun_out/pmc_$tag
-mkdir -p $out
+rm -rf $out; mkdir -p $out  # a tag profiled twice must not keep the earlier run's files
 k=0
 while IFS= read -r counters; do
   [ -z "$counters" ] && continue

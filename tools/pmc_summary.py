@@ -26,7 +26,14 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
     durations = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> pass file -> dispatch durations (ns)
+    # one file per pass directory - the newest: gpurun merges every call's output into gpurun_out/, so a tag that was profiled
+    # twice holds both runs' files side by side, and mixing them double-counts every dispatch
+    newest = {}
     for f in glob.glob(os.path.join(src, "**", "*_counter_collection.csv"), recursive=True):
+        d = os.path.relpath(f, src).split(os.sep)[0]
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+            newest[d] = f
+    for f in sorted(newest.values()):
         per_dispatch = collections.defaultdict(float)
         span = {}
         for r in csv.DictReader(open(f)):
@@ -86,14 +93,17 @@ def main():
             pass
         # HBM-side bytes of the WHOLE profiled run, every kernel and every dispatch (sum, not median x count), per frame the run
         # rendered: bench.py's roofline.frame_hbm_frac = this / ms_per_step / 8 TB/s
-        total_bytes = 0.0
+        total_bytes = uncorrected = 0.0
         for k, v in out["kernels"].items():
             c = v["counters"]
-            total_bytes += 2048.0 * c.get("FETCH_SIZE", {}).get("mean", 0.0) * c.get("FETCH_SIZE", {}).get("n", 0)
-            total_bytes += 1024.0 * c.get("WRITE_SIZE", {}).get("mean", 0.0) * c.get("WRITE_SIZE", {}).get("n", 0)
+            fetch = 1024.0 * c.get("FETCH_SIZE", {}).get("mean", 0.0) * c.get("FETCH_SIZE", {}).get("n", 0)
+            write = 1024.0 * c.get("WRITE_SIZE", {}).get("mean", 0.0) * c.get("WRITE_SIZE", {}).get("n", 0)
+            total_bytes += 2.0 * fetch + write
+            uncorrected += fetch + write
         bench["run_hbm_bytes_total"] = total_bytes
         if sig.get("frames_total"):
             bench["frame_hbm_bytes"] = total_bytes / sig["frames_total"]
+            bench["frame_hbm_bytes_uncorrected"] = uncorrected / sig["frames_total"]  # FETCH_SIZE as reported (64 B per TCC_EA0_RDREQ): the lower bound
             bench["frames_profiled"] = sig["frames_total"]
         bench["signature"] = {a: b for a, b in sig.items() if a != "frames_total"}
         for k, v in out["kernels"].items():
@@ -106,6 +116,7 @@ def main():
             if "FETCH_SIZE" in m or "WRITE_SIZE" in m:
                 e["fetch_kib_per_launch"], e["write_kib_per_launch"] = m.get("FETCH_SIZE"), m.get("WRITE_SIZE")
                 e["hbm_bytes_per_launch"] = 2048.0 * m.get("FETCH_SIZE", 0.0) + 1024.0 * m.get("WRITE_SIZE", 0.0)
+                e["hbm_bytes_per_launch_uncorrected"] = 1024.0 * m.get("FETCH_SIZE", 0.0) + 1024.0 * m.get("WRITE_SIZE", 0.0)
             if m.get("SQ_INSTS_VALU"):
                 e["wave_instr_per_launch"] = m["SQ_INSTS_VALU"]
             d = v["derived"]
