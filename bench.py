@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--emulate-rank", type=int, default=0, help="the rank --emulate-world stands in for")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=0")
+    ap.add_argument("--full-frame-reservoir-passes", action="store_true", help="N > 1: every rank runs the G-buffer cast and the reservoir passes for the whole frame (rounds 1-2) instead of its band of rows + one all-gather per frame")
     ap.add_argument("--spp", type=int, default=1, help="samples_per_frame (reference default 1, UI maximum 10); SURVEY 8d also asks for 64 spp as 8 frames x 8")
     ap.add_argument("--cook-torrance", action="store_true", help="extension (SURVEY 8f N2): the diffuse materials of configs 1-3 become Cook-Torrance (material type 4)")
     ap.add_argument("--cpu-sample", type=str, default="1920x1080x8", help="WxHx(max frames) rendered by the CPU oracle")
@@ -112,11 +113,17 @@ def main():
         k, v = kv.split("=")
         renderer.set_option(k, int(v))
     scene.upload(renderer)
+    pass_mask = rr.PASS_ALL if args.config == 2 else rr.PASS_REFERENCE_PT
+    restir = bool(pass_mask & rr.PASS_RESTIR) and not args.full_frame_reservoir_passes
     if use_dist:
         renderer.set_tile_partition(rank, world, args.tile)
+        if restir and args.backend == "nccl":
+            # the reservoir passes by bands of rows, their all-gather by RCCL inside the library (one broadcast of the id here)
+            rr.distributed.partition_reservoir_passes(renderer, rank, world, dist, torch)
     elif args.emulate_world > 1:
         renderer.set_tile_partition(args.emulate_rank % args.emulate_world, args.emulate_world, args.tile)
-    pass_mask = rr.PASS_ALL if args.config == 2 else rr.PASS_REFERENCE_PT
+        if restir:
+            renderer.set_restir_partition(args.emulate_rank % args.emulate_world, args.emulate_world)  # one rank's rows, no exchange: its share of the work
     view = scene.make_view(W, H, samples_per_frame=args.spp) if args.spp != 1 else scene.make_view(W, H)
     loop = rr.FrameLoop(renderer, view)
 

@@ -24,6 +24,10 @@
  *   uh_pack_tiles, uh_unpack_tiles, uh_resolve_output
  *                             multi-GPU framebuffer tile partition; no reference counterpart
  *                             (the reference is single-device, utopian/src/device.rs:45)
+ *   uh_set_restir_partition, uh_rccl_attach
+ *                             multi-GPU partition of the reservoir passes by bands of rows with one
+ *                             all-gather of spatial_reuse_reservoirs per frame (temporal_reuse.rgen:90-99,
+ *                             spatial_reuse.rgen:40-60 read across any pixel partition)
  *
  * Contract: plain C, POD in / status out, no exceptions cross the boundary. One context per
  * GPU; all calls on one context are serialised by the caller (the reference has a single render
@@ -280,7 +284,7 @@ int uh_set_option(uh_ctx* ctx, const char* name, int value);
 
 /* ---- multi-GPU framebuffer tile partition (one process per GPU) ------------------------ */
 /* After this call uh_render_frame path-traces only pixels of tiles t with t % world == rank
- * (tile_size x tile_size tiles, row-major tile ids). ReSTIR passes stay full-frame. */
+ * (tile_size x tile_size tiles, row-major tile ids). ReSTIR passes stay full-frame unless uh_set_restir_partition says otherwise. */
 int uh_set_tile_partition(uh_ctx* ctx, uint32_t rank, uint32_t world, uint32_t tile_size);
 /* number of float4 pixels uh_pack_tiles writes for `rank` (padded: whole tiles) */
 int uh_tile_pack_count(uh_ctx* ctx, uint32_t rank, uint64_t* out_pixels);
@@ -290,6 +294,38 @@ int uh_pack_tiles(uh_ctx* ctx, void* device_out, uint64_t capacity_pixels);
 int uh_unpack_tiles(uh_ctx* ctx, uint32_t from_rank, const void* device_in, uint64_t num_pixels);
 /* recompute pt_output_image from the accumulation image (after uh_unpack_tiles on the root) */
 int uh_resolve_output(uh_ctx* ctx, uint32_t total_samples, uint32_t accumulation_limit);
+/* ---- multi-GPU, the reservoir passes: a band of rows per rank + one exchange per frame ------ */
+/* The path tracer needs spatial_reuse_reservoirs only at its own pixels, but temporal_reuse reads last frame's buffer at a
+ * reprojected pixel (restir/temporal_reuse.rgen:90-99) and spatial_reuse gathers from a 30-pixel neighbourhood
+ * (restir/spatial_reuse.rgen:40-60), so run full-frame on every rank these passes do not scale (alternative).
+ * After uh_set_restir_partition(rank, world) the G-buffer cast and the reservoir passes of this context cover
+ *   spatial_reuse      rows [rank * B, min(H, (rank + 1) * B)),  B = ceil(H / world)        (the band)
+ *   reset / initial / temporal   the band +- 30 rows, plus row H - 1 for the first band (spatial_reuse.rgen:54: a row
+ *                      offset below zero wraps and is clamped to the last row)
+ *   G-buffer cast      those rows and the row above each (the 2 x 2 corner filter of initial_ris.rgen:22-23)
+ * and every spatial pass is followed by ONE call of `exchange`, which must enqueue on `hip_stream` whatever makes
+ * spatial_base[k * band_bytes, (k + 1) * band_bytes) hold rank k's band for every k (an in-place all-gather: this rank's band
+ * is already where it belongs). It is called while the frame is ENQUEUED, not when it runs: it must not wait for the GPU.
+ * Each spatial_reuse buffer is world * B rows long (the frame, padded to equal bands). With the exchange in place every
+ * rank holds the whole spatial_reuse_reservoirs of every frame - bit for bit the single-GPU buffer - while buffers 0 and 1
+ * (uh_read_reservoirs) are valid on the rank's own rows only. world = 1 (the default) restores full-frame passes.
+ * exchange == NULL with world > 1 leaves the other bands stale: for timing one rank's share only. */
+typedef int (*UhRestirExchangeFn)(void* user, void* hip_stream, void* spatial_base, uint64_t band_bytes, uint32_t rank, uint32_t world);
+int uh_set_restir_partition(uh_ctx* ctx, uint32_t rank, uint32_t world, UhRestirExchangeFn exchange, void* user);
+/* the rows of this context's band and of its reservoir / G-buffer passes (counts of rows; *_extra_row0 is the first row of the second interval or 0 with *_extra_rows 0) */
+typedef struct UhRestirRows {
+   uint32_t band_row0, band_rows;        /* spatial_reuse */
+   uint32_t reuse_row0, reuse_rows, reuse_extra_row0, reuse_extra_rows;   /* reset, initial_ris, temporal_reuse */
+   uint32_t cast_row0, cast_rows, cast_extra_row0, cast_extra_rows;       /* G-buffer cast */
+   uint32_t rows_per_band;               /* B */
+} UhRestirRows;
+int uh_get_restir_rows(uh_ctx* ctx, UhRestirRows* out);
+/* The exchange over RCCL, built in (one process per GPU): librccl is opened at run time (the library does not link it).
+ * Rank 0 makes an id, the job's launcher hands the 128 bytes to every rank (bench.py: one torch.distributed broadcast),
+ * every rank attaches: ncclCommInitRank + uh_set_restir_partition(rank, world, <ncclAllGather on the reservoir stream>). */
+int uh_rccl_unique_id(uint8_t out_id[128]);
+int uh_rccl_attach(uh_ctx* ctx, uint32_t rank, uint32_t world, const uint8_t id[128]);
+int uh_rccl_detach(uh_ctx* ctx);
 /* raw device pointers (zero-copy wrap by the caller, e.g. for RCCL): 0 accumulation RGBA32F,
  * 1 output BGRA8 */
 int uh_device_pointer(uh_ctx* ctx, int which, void** out);
@@ -345,8 +381,13 @@ int uh_mgpu_synchronize(uh_mgpu* group);
 int uh_mgpu_compose(uh_mgpu* group);             /* gather tiles to GPU 0 + resolve; a no-op until the next frame */
 int uh_mgpu_read_accumulation(uh_mgpu* group, float* rgba32f /* W*H*4 */);  /* compose, then read GPU 0 */
 int uh_mgpu_read_output_bgra8(uh_mgpu* group, uint8_t* bgra /* W*H*4 */);
+/* reservoir buffers of the whole frame (0 initial, 1 temporal: each GPU's band of rows; 2 spatial: complete on every GPU) */
+int uh_mgpu_read_reservoirs(uh_mgpu* group, int which, UhReservoir* out /* W*H */);
 int uh_mgpu_get_stats(uh_mgpu* group, UhStats* out); /* counters summed over GPUs, times = slowest GPU */
 int uh_mgpu_reset_stats(uh_mgpu* group);
+/* every context's options, plus "restir_partition" (default 1 for more than one GPU): the G-buffer cast and the reservoir
+ * passes by bands of rows, one band per GPU (uh_set_restir_partition), the bands exchanged by peer copies after every
+ * spatial pass; 0 = every GPU runs them for the whole frame */
 int uh_mgpu_set_option(uh_mgpu* group, const char* name, int value);
 
 #ifdef __cplusplus

@@ -333,6 +333,10 @@ struct Oracle {
    std::vector<UhReservoir> reservoirs[3];
    // tile partition
    uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
+   // reservoir passes by bands of rows (orc_set_restir_partition: the checker's twin of uh_set_restir_partition)
+   uint32_t rp_rank = 0, rp_world = 1;
+   UhRestirExchangeFn rp_exchange = nullptr;
+   void* rp_user = nullptr;
    Counters ctr;
    std::string err;
 };
@@ -876,10 +880,10 @@ static void raygen_pixel(Oracle& o, const UhViewUniformData& view, uint32_t px, 
 // world position of the primary-visible surface at each pixel centre, clear colour (1,1,1,0)
 // (pass.rs:210-214). Produced here by an un-jittered primary ray instead of rasterisation.
 // ------------------------------------------------------------------------------------------
-static void gbuffer_pixel(Oracle& o, const UhViewUniformData& view, uint32_t px, uint32_t py) {
+static void gbuffer_pixel(Oracle& o, const UhViewUniformData& view, uint32_t px, uint32_t py, bool counted = true) {
    V3 org, dir;
    primary_ray(view, o.W, o.H, px, py, 0.5f, 0.5f, org, dir);
-   tl_ctr.rays[UH_RAY_GBUFFER]++;
+   if (counted) tl_ctr.rays[UH_RAY_GBUFFER]++;  // a rank counts the rays of its own band, not the rows it casts again for its neighbourhood
    Hit h = trace_closest(o, org, dir, 0.001f, 10000.0f, false);
    float* g = &o.gbuffer_pos[((size_t)py * o.W + px) * 4];
    if (h.mesh != 0xffffffffu) {
@@ -1014,7 +1018,7 @@ static int default_threads() {
 }
 
 template <typename F>
-static void parallel_rows(Oracle& o, F f) {
+static void parallel_rows(Oracle& o, F f, const std::vector<uint8_t>* rows = nullptr) {
    int nt = o.num_threads > 0 ? o.num_threads : default_threads();
    if (nt < 1) nt = 1;
    std::atomic<uint32_t> next(0);
@@ -1022,6 +1026,7 @@ static void parallel_rows(Oracle& o, F f) {
       for (;;) {
          uint32_t y = next.fetch_add(1);
          if (y >= o.H) break;
+         if (rows && !(*rows)[y]) continue;
          for (uint32_t x = 0; x < o.W; x++) f(x, y);
          flush_counters(o);
       }
@@ -1189,6 +1194,68 @@ int orc_set_tile_partition(orc_ctx* c, uint32_t rank, uint32_t world, uint32_t t
    return UH_OK;
 }
 
+// The reservoir passes of one rank of a job that partitions them by rows (the product's uh_set_restir_partition, restated from
+// what the shaders read rather than from the product's interval arithmetic): the spatial pass runs on the rank's band; it
+// gathers temporal reservoirs from rows y + dy, |dy| < 30, a negative row wrapping to the last one (spatial_reuse.rgen:48-56
+// with the uvec2 conversion pinned in DESIGN.md section 2); temporal, initial and reset run on those rows; each of them reads
+// the G-buffer at its row and the one above (initial_ris.rgen:22-23 through the LINEAR sampler).
+int orc_set_restir_partition(orc_ctx* c, uint32_t rank, uint32_t world, UhRestirExchangeFn exchange, void* user) {
+   if (!c || world == 0 || rank >= world) return UH_ERR_INVALID_ARGUMENT;
+   Oracle& o = c->o;
+   o.rp_rank = rank;
+   o.rp_world = world;
+   o.rp_exchange = world > 1 ? exchange : nullptr;
+   o.rp_user = user;
+   const uint32_t band = (o.H + world - 1) / world;
+   const size_t need = std::max((size_t)o.W * o.H, (size_t)band * world * o.W);  // the frame padded to equal bands: what an in-place all-gather addresses
+   if (o.reservoirs[2].size() < need) o.reservoirs[2].resize(need, UhReservoir{0, 0.0f, 0.0f, 0});
+   return UH_OK;
+}
+struct RestirRowMasks {
+   std::vector<uint8_t> band, reuse, cast;
+   uint32_t rows_per_band = 0;
+};
+static RestirRowMasks restir_row_masks(const Oracle& o) {
+   RestirRowMasks m;
+   const uint32_t H = o.H;
+   m.rows_per_band = (H + o.rp_world - 1) / o.rp_world;
+   m.band.assign(H, 0);
+   m.reuse.assign(H, 0);
+   m.cast.assign(H, 0);
+   for (uint32_t y = 0; y < H; y++) {
+      if (y / m.rows_per_band != o.rp_rank) continue;
+      m.band[y] = 1;
+      for (int dy = -30; dy <= 30; dy++) {
+         const int64_t ny = (int64_t)y + dy;
+         m.reuse[ny < 0 || ny > (int64_t)H - 1 ? H - 1 : (uint32_t)ny] = 1;
+      }
+   }
+   for (uint32_t y = 0; y < H; y++)
+      if (m.reuse[y]) m.cast[y] = m.cast[y ? y - 1 : 0] = 1;
+   return m;
+}
+int orc_get_restir_rows(orc_ctx* c, UhRestirRows* out) {
+   if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
+   const Oracle& o = c->o;
+   const RestirRowMasks m = restir_row_masks(o);
+   *out = UhRestirRows{};
+   out->rows_per_band = o.rp_world > 1 ? m.rows_per_band : o.H;
+   auto interval = [&](const std::vector<uint8_t>& rows, uint32_t& r0, uint32_t& n, uint32_t& e0, uint32_t& en) {
+      uint32_t y = 0;
+      while (y < o.H && !rows[y]) y++;
+      r0 = y < o.H ? y : 0;
+      while (y < o.H && rows[y]) y++, n++;
+      while (y < o.H && !rows[y]) y++;
+      e0 = y < o.H ? y : 0;
+      while (y < o.H && rows[y]) y++, en++;
+   };
+   uint32_t none0 = 0, none = 0;
+   interval(m.band, out->band_row0, out->band_rows, none0, none);
+   interval(m.reuse, out->reuse_row0, out->reuse_rows, out->reuse_extra_row0, out->reuse_extra_rows);
+   interval(m.cast, out->cast_row0, out->cast_rows, out->cast_extra_row0, out->cast_extra_rows);
+   return UH_OK;
+}
+
 // renderers/mod.rs:246-358 pass order; frame protocol of prototype/src/main.rs:460-471
 int orc_render_frame(orc_ctx* c, const UhViewUniformData* view, uint32_t pass_mask) {
    if (!c || !view) return UH_ERR_INVALID_ARGUMENT;
@@ -1196,13 +1263,25 @@ int orc_render_frame(orc_ctx* c, const UhViewUniformData* view, uint32_t pass_ma
    if (!o.built && o.ever_built && view->rebuild_tlas == 1) orc_build_acceleration(c);  // main.rs:392,526
    if (!o.built) return UH_ERR_NOT_BUILT;
    const UhViewUniformData v = *view;
-   if (pass_mask & UH_PASS_GBUFFER) parallel_rows(o, [&](uint32_t x, uint32_t y) { gbuffer_pixel(o, v, x, y); });
-   if (pass_mask & UH_PASS_RESET_RESERVOIRS) parallel_rows(o, [&](uint32_t x, uint32_t y) { reset_pixel(o, x, y); });
-   if (pass_mask & UH_PASS_INITIAL_RIS) parallel_rows(o, [&](uint32_t x, uint32_t y) { initial_ris_pixel(o, v, x, y); });
-   if (pass_mask & UH_PASS_TEMPORAL_REUSE) parallel_rows(o, [&](uint32_t x, uint32_t y) { temporal_pixel(o, v, x, y); });
-   if (pass_mask & UH_PASS_SPATIAL_REUSE) {
-      // the pass reads temporal_reuse_reservoirs and writes spatial_reuse_reservoirs: no hazard
-      parallel_rows(o, [&](uint32_t x, uint32_t y) { spatial_pixel(o, v, x, y); });
+   if (o.rp_world > 1 && (pass_mask & UH_PASS_RESTIR)) {
+      const RestirRowMasks m = restir_row_masks(o);
+      if (pass_mask & UH_PASS_GBUFFER) parallel_rows(o, [&](uint32_t x, uint32_t y) { gbuffer_pixel(o, v, x, y, m.band[y] != 0); }, &m.cast);
+      if (pass_mask & UH_PASS_RESET_RESERVOIRS) parallel_rows(o, [&](uint32_t x, uint32_t y) { reset_pixel(o, x, y); }, &m.reuse);
+      if (pass_mask & UH_PASS_INITIAL_RIS) parallel_rows(o, [&](uint32_t x, uint32_t y) { initial_ris_pixel(o, v, x, y); }, &m.reuse);
+      if (pass_mask & UH_PASS_TEMPORAL_REUSE) parallel_rows(o, [&](uint32_t x, uint32_t y) { temporal_pixel(o, v, x, y); }, &m.reuse);
+      if (pass_mask & UH_PASS_SPATIAL_REUSE) {
+         parallel_rows(o, [&](uint32_t x, uint32_t y) { spatial_pixel(o, v, x, y); }, &m.band);
+         // the other ranks' bands: an in-place all-gather over equal bands, done by the caller (synchronously: there is no stream here)
+         if (o.rp_exchange)
+            if (o.rp_exchange(o.rp_user, nullptr, o.reservoirs[2].data(), (uint64_t)m.rows_per_band * o.W * sizeof(UhReservoir), o.rp_rank, o.rp_world) != 0) return UH_ERR_HIP;
+      }
+   } else {
+      if (pass_mask & UH_PASS_GBUFFER) parallel_rows(o, [&](uint32_t x, uint32_t y) { gbuffer_pixel(o, v, x, y); });
+      if (pass_mask & UH_PASS_RESET_RESERVOIRS) parallel_rows(o, [&](uint32_t x, uint32_t y) { reset_pixel(o, x, y); });
+      if (pass_mask & UH_PASS_INITIAL_RIS) parallel_rows(o, [&](uint32_t x, uint32_t y) { initial_ris_pixel(o, v, x, y); });
+      if (pass_mask & UH_PASS_TEMPORAL_REUSE) parallel_rows(o, [&](uint32_t x, uint32_t y) { temporal_pixel(o, v, x, y); });
+      // the spatial pass reads temporal_reuse_reservoirs and writes spatial_reuse_reservoirs: no hazard
+      if (pass_mask & UH_PASS_SPATIAL_REUSE) parallel_rows(o, [&](uint32_t x, uint32_t y) { spatial_pixel(o, v, x, y); });
    }
    if (pass_mask & UH_PASS_REFERENCE_PT)
       parallel_rows(o, [&](uint32_t x, uint32_t y) {
@@ -1226,12 +1305,12 @@ int orc_read_output_bgra8(orc_ctx* c, uint8_t* out) {
 }
 int orc_read_reservoirs(orc_ctx* c, int which, UhReservoir* out) {
    if (which < 0 || which > 2) return UH_ERR_INVALID_ARGUMENT;
-   std::memcpy(out, c->o.reservoirs[which].data(), c->o.reservoirs[which].size() * sizeof(UhReservoir));
+   std::memcpy(out, c->o.reservoirs[which].data(), (size_t)c->o.W * c->o.H * sizeof(UhReservoir));
    return UH_OK;
 }
 int orc_write_reservoirs(orc_ctx* c, int which, const UhReservoir* in) {
    if (which < 0 || which > 2) return UH_ERR_INVALID_ARGUMENT;
-   std::memcpy(c->o.reservoirs[which].data(), in, c->o.reservoirs[which].size() * sizeof(UhReservoir));
+   std::memcpy(c->o.reservoirs[which].data(), in, (size_t)c->o.W * c->o.H * sizeof(UhReservoir));
    return UH_OK;
 }
 int orc_read_gbuffer_position(orc_ctx* c, float* out) {

@@ -19,10 +19,12 @@ from .types import (
     ERR_NAMES,
     PASS_ALL,
     RESERVOIR_DTYPE,
+    RESTIR_EXCHANGE_FN,
     VERTEX_DTYPE,
     GpuLight,
     GpuMaterial,
     Reservoir,
+    RestirRows,
     Stats,
     ViewUniformData,
 )
@@ -62,6 +64,8 @@ class CApi:
             "reset_stats": [vp],
             "set_option": [vp, C.c_char_p, C.c_int],
             "set_tile_partition": [vp, u32, u32, u32],
+            "set_restir_partition": [vp, u32, u32, vp, vp],
+            "get_restir_rows": [vp, p(RestirRows)],
             "resolve_output": [vp, u32, u32],
         }
         for name, argtypes in sig.items():
@@ -407,6 +411,43 @@ class Renderer:
 
     def resolve_output(self, total_samples, accumulation_limit=999999):
         self._check(self._api.resolve_output(self._ctx, total_samples, accumulation_limit))
+
+    # -- multi-GPU, the reservoir passes by bands of rows (uh_set_restir_partition) --------
+    def set_restir_partition(self, rank, world, exchange=None):
+        """`exchange(stream, spatial_base, band_bytes, rank, world) -> int`: called after every spatial pass, while the frame is
+        enqueued; it must enqueue on `stream` (a hipStream_t as int; None on the CPU oracle, which calls it synchronously)
+        whatever fills the other ranks' bands of the buffer at `spatial_base`. None with world > 1: the other bands stay stale."""
+        fn = None
+        if exchange is not None:
+            fn = RESTIR_EXCHANGE_FN(lambda user, stream, base, band_bytes, r, w: int(exchange(stream, base, band_bytes, r, w) or 0))
+        self._check(self._api.set_restir_partition(self._ctx, rank, world, C.cast(fn, C.c_void_p) if fn else None, None))
+        self._restir_exchange = fn  # the library keeps the pointer: the trampoline must live as long as the partition
+
+    def restir_rows(self):
+        out = RestirRows()
+        self._check(self._api.get_restir_rows(self._ctx, C.byref(out)))
+        return out
+
+    @staticmethod
+    def rccl_unique_id():
+        lib = load_library()
+        lib.uh_rccl_unique_id.argtypes, lib.uh_rccl_unique_id.restype = [C.c_void_p], C.c_int
+        buf = (C.c_uint8 * 128)()
+        st = lib.uh_rccl_unique_id(buf)
+        if st != 0:
+            raise UtopianError(f"uh_rccl_unique_id failed: {ERR_NAMES.get(st, st)} (is librccl loadable?)")
+        return bytes(buf)
+
+    def rccl_attach(self, rank, world, unique_id):
+        """ncclCommInitRank on this context's device + the band partition with ncclAllGather as its exchange (collective:
+        every rank of the job calls it with the id rank 0 made)"""
+        self._lib.uh_rccl_attach.argtypes, self._lib.uh_rccl_attach.restype = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p], C.c_int
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.uh_rccl_attach(self._ctx, rank, world, buf))
+
+    def rccl_detach(self):
+        self._lib.uh_rccl_detach.argtypes, self._lib.uh_rccl_detach.restype = [C.c_void_p], C.c_int
+        self._check(self._lib.uh_rccl_detach(self._ctx))
 
     def tile_pack_count(self, rank):
         out = C.c_uint64()

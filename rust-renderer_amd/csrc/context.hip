@@ -3,6 +3,8 @@
 // utopian::Renderer (utopian/src/renderer.rs), utopian::Raytracing (utopian/src/raytracing.rs) and
 // build_path_tracing_render_graph (utopian/src/renderers/mod.rs:189-375) for this path only.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library opens librccl at run time (uh_rccl_attach)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -160,6 +162,13 @@ struct uh_ctx {
    bool restir_recorded = false;
    int spatial_cur = 0;
    hipEvent_t spatial_reader[kSpatialRing] = {};
+   // the reservoir passes by bands of rows over the ranks of a job (uh_set_restir_partition)
+   uint32_t rp_rank = 0, rp_world = 1, rp_band_rows = 0;
+   size_t res_stride = 0;  // reservoirs per spatial_reuse buffer: the frame, padded to rp_world equal bands
+   UhRestirExchangeFn rp_exchange = nullptr;
+   void* rp_user = nullptr;
+   hipEvent_t ev_band[kSpatialRing] = {};  // "this context's band of ring slot k is written" (in-process groups pull on it)
+   void* rccl = nullptr;                   // RcclLink (uh_rccl_attach)
    hipEvent_t t_start = nullptr, t_stop = nullptr;  // bracket of the last uh_render_frame call (last_frame_ms)
    Slot* last_slot = nullptr;
    hipStream_t& stream = slots[0].stream;  // slot 0 also serves every non-frame operation
@@ -403,6 +412,8 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    c->im.gbuffer_pos = c->gbuffer.p;
    for (int i = 0; i < 3; i++) c->im.reservoirs[i] = c->reservoirs[i].p;
    c->im.prev_spatial = c->reservoirs[2].p;
+   c->res_stride = n;
+   c->rp_band_rows = height;
    *out = c;
    return UH_OK;
 }
@@ -416,6 +427,9 @@ void uh_destroy(uh_ctx* c) {
          if (ev) (void)hipEventDestroy(ev);
       (void)hipStreamDestroy(c->restir_stream);
    }
+   uh_rccl_detach(c);
+   for (hipEvent_t ev : c->ev_band)
+      if (ev) (void)hipEventDestroy(ev);
    c->spatial_ring.release();
    c->gb_ray_o.release();
    c->gb_ray_d.release();
@@ -1164,7 +1178,50 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
    return UH_OK;
 }
 
-static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t batch) {
+// ---- one batch of frames, in phases: begin | per frame: reservoir chain, exchange | end (the path-tracing wavefront).
+// uh_render_frame(s) runs the phases back to back; an in-process group (mgpu.hip) interleaves them over its contexts,
+// because frame f + 1's temporal pass of one GPU reads the bands every other GPU wrote in frame f.
+struct uh_batch {
+   FrameParams fp;
+   uint32_t pass_mask = 0, batch = 0;
+   bool restir_frame = false, reads_reservoirs = false;
+   int read_slot[kMaxBatchFrames];
+   LaunchCfg rc;
+};
+
+static UhReservoir* spatial_buf(uh_ctx* c, int slot) { return slot ? c->spatial_ring.p + (size_t)(slot - 1) * c->res_stride : c->reservoirs[2].p; }
+
+// rows of this context's reservoir passes (uh_set_restir_partition): its band, the band's 30-row neighbourhood (plus the last
+// row for the first band: spatial_reuse.rgen:54's wrapped offset is clamped to size - 1), and for the G-buffer cast the row
+// above each of those (the 2 x 2 corner filter)
+static void restir_rows(const uh_ctx* c, UhRestirRows& r) {
+   const uint32_t H = c->H, B = c->rp_world > 1 ? c->rp_band_rows : H;
+   r = UhRestirRows{};
+   r.rows_per_band = B;
+   const uint32_t b0 = std::min<uint64_t>((uint64_t)c->rp_rank * B, H), b1 = std::min<uint64_t>((uint64_t)b0 + B, H);
+   r.band_row0 = b0;
+   r.band_rows = b1 - b0;
+   if (b1 == b0) return;  // more ranks than bands: nothing to do here
+   const uint32_t halo = 30;
+   const uint32_t t0 = b0 > halo ? b0 - halo : 0, t1 = std::min<uint64_t>((uint64_t)b1 + halo, H);
+   r.reuse_row0 = t0;
+   r.reuse_rows = t1 - t0;
+   if (b0 < halo && t1 < H) {
+      r.reuse_extra_row0 = H - 1;
+      r.reuse_extra_rows = 1;
+   }
+   const uint32_t g0 = t0 > 0 ? t0 - 1 : 0;
+   r.cast_row0 = g0;
+   r.cast_rows = t1 - g0;
+   if (r.reuse_extra_rows) {
+      const uint32_t e0 = std::max(H >= 2 ? H - 2 : 0u, t1);  // rows H - 2 and H - 1, without what the first interval already holds
+      r.cast_extra_row0 = e0;
+      r.cast_extra_rows = H - e0;
+   }
+}
+static RowSpans spans_of(const uh_ctx* c, uint32_t row0, uint32_t rows, uint32_t extra0, uint32_t extra_rows) { return RowSpans{{row0, extra0}, {rows, extra_rows}, c->W}; }
+
+static int batch_begin(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t batch, uh_batch& bs) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (!view) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frame: null view");
    if (!c->built && c->topology_valid && view->rebuild_tlas == 1) {
@@ -1177,7 +1234,8 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
    if (view->num_lights > c->lights.size() && (view->lights_enabled == 1 || (pass_mask & UH_PASS_RESTIR)))
       return fail(c, UH_ERR_INVALID_ARGUMENT, "view.num_lights exceeds the lights added with uh_add_light");
    HIP_TRY(c, hipSetDevice(c->device));
-   FrameParams fp = make_params(c, *view);
+   FrameParams& fp = bs.fp;
+   fp = make_params(c, *view);
    fp.batch_frames = batch;
    for (uint32_t f = 0; f < batch; f++) {
       // frame f of the batch: total_samples advanced by the application once per frame (main.rs:467-469)
@@ -1185,70 +1243,110 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
       fp.total_samples_of[f] = total;
       fp.frame_numbers[f] = (uint32_t)(int32_t)((float)total + view->time * 10000.0f);
    }
-   const bool restir_frame = (pass_mask & UH_PASS_RESTIR) != 0;
+   bs.pass_mask = pass_mask;
+   bs.batch = batch;
+   bs.restir_frame = (pass_mask & UH_PASS_RESTIR) != 0;
    // the path tracer reads spatial_reuse_reservoirs when it samples lights from them (rgen:98)
-   const bool reads_reservoirs = (pass_mask & UH_PASS_REFERENCE_PT) && fp.lights_enabled == 1 && fp.use_ris == 1;
+   bs.reads_reservoirs = (pass_mask & UH_PASS_REFERENCE_PT) && fp.lights_enabled == 1 && fp.use_ris == 1;
 
    if (batch > 1 && !(pass_mask & UH_PASS_REFERENCE_PT)) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: a batch needs the path-tracing pass");
-   if (batch > kRestirBatch && restir_frame) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: more reservoir-pass frames in one batch than the spatial ring holds");
-   const size_t npix = (size_t)c->W * c->H;
-   auto spatial_buf = [&](int slot) { return slot ? c->spatial_ring.p + (size_t)(slot - 1) * npix : c->reservoirs[2].p; };
+   if (batch > kRestirBatch && bs.restir_frame) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: more reservoir-pass frames in one batch than the spatial ring holds");
    c->t_start = c->t_stop = nullptr;
    // the slot each frame of the batch samples lights from (rgen:98): without reservoir passes in this call, the current one
-   int read_slot[kMaxBatchFrames];
-   for (uint32_t f = 0; f < batch; f++) read_slot[f] = c->spatial_cur;
+   for (uint32_t f = 0; f < kMaxBatchFrames; f++) bs.read_slot[f] = c->spatial_cur;
 
-   if (restir_frame) {
+   if (bs.restir_frame) {
       if (!c->restir_stream) {
          HIP_TRY(c, hipStreamCreateWithFlags(&c->restir_stream, hipStreamNonBlocking));
          HIP_TRY(c, hipEventCreateWithFlags(&c->ev_restir, hipEventDisableTiming));
          HIP_TRY(c, hipEventCreate(&c->rs_start));
          HIP_TRY(c, hipEventCreate(&c->rs_stop));
-         HIP_TRY(c, c->spatial_ring.alloc((size_t)(kSpatialRing - 1) * npix));  // every slot is written before it is read
+      }
+      if (!c->spatial_ring.p) {
+         HIP_TRY(c, c->spatial_ring.alloc((size_t)(kSpatialRing - 1) * c->res_stride));
+         // every slot is written before it is read - by this context's passes; under a row partition other ranks' bands arrive by
+         // the exchange, and a caller that times one rank without one (exchange == NULL) must still read defined reservoirs
+         if (c->rp_world > 1) HIP_TRY(c, hipMemsetAsync(c->spatial_ring.p, 0, c->spatial_ring.n * sizeof(UhReservoir), c->restir_stream));
          HIP_TRY(c, hipStreamSynchronize(c->stream));  // slot 0 (zeroed at creation or uh_write_reservoirs) is the history
       }
-      LaunchCfg rc = cfg(c);
-      rc.stream = c->restir_stream;
+      bs.rc = cfg(c);
+      bs.rc.stream = c->restir_stream;
       HIP_TRY(c, hipEventRecord(c->rs_start, c->restir_stream));
       c->t_start = c->rs_start;
-      for (uint32_t f = 0; f < batch; f++) {
-         FrameParams ff = fp;  // frame f of the batch: its own RNG frame number (the reservoir kernels read nothing else per frame)
-         ff.frame_number = fp.frame_numbers[f];
-         ff.total_samples = fp.total_samples_of[f];
-         Images im = c->im;
-         im.prev_spatial = spatial_buf(c->spatial_cur);
-         im.reservoirs[2] = spatial_buf(c->spatial_cur);
-         if (pass_mask & UH_PASS_GBUFFER) {
-            if (!c->gb_hit.p) {
-               HIP_TRY(c, c->gb_ray_o.alloc(npix));
-               HIP_TRY(c, c->gb_ray_d.alloc(npix));
-               HIP_TRY(c, c->gb_hit.alloc(npix));
-            }
-            const RawRays gps{c->gb_ray_o.p, c->gb_ray_d.p, c->gb_hit.p};
-            launch_gbuffer(rc, ff, c->scene, gps, im, c->dstats.p);
-         }
-         if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(rc, ff, im);
-         if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(rc, ff, c->scene, im);
-         if (pass_mask & UH_PASS_TEMPORAL_REUSE) launch_temporal_reuse(rc, ff, c->scene, im);
-         if (pass_mask & UH_PASS_SPATIAL_REUSE) {
-            // writes the NEXT slot of the ring: the path-tracing wavefronts that still read the current one keep going
-            const int nxt = (c->spatial_cur + 1) % kSpatialRing;
-            if (c->spatial_reader[nxt]) HIP_TRY(c, hipStreamWaitEvent(c->restir_stream, c->spatial_reader[nxt], 0));
-            im.reservoirs[2] = spatial_buf(nxt);
-            launch_spatial_reuse(rc, ff, c->scene, im);
-            c->spatial_cur = nxt;
-            c->im.reservoirs[2] = spatial_buf(nxt);
-         }
-         read_slot[f] = c->spatial_cur;
+   }
+   return UH_OK;
+}
+
+// G-buffer cast and reservoir chain of frame f of the batch, on the reservoir stream
+static int batch_restir_frame(uh_ctx* c, uh_batch& bs, uint32_t f) {
+   if (!bs.restir_frame) return UH_OK;
+   HIP_TRY(c, hipSetDevice(c->device));
+   const uint32_t pass_mask = bs.pass_mask;
+   const size_t npix = (size_t)c->W * c->H;
+   FrameParams ff = bs.fp;  // frame f of the batch: its own RNG frame number (the reservoir kernels read nothing else per frame)
+   ff.frame_number = bs.fp.frame_numbers[f];
+   ff.total_samples = bs.fp.total_samples_of[f];
+   UhRestirRows rows;
+   restir_rows(c, rows);
+   const RowSpans band = spans_of(c, rows.band_row0, rows.band_rows, 0, 0);
+   const RowSpans reuse = spans_of(c, rows.reuse_row0, rows.reuse_rows, rows.reuse_extra_row0, rows.reuse_extra_rows);
+   const RowSpans cast = spans_of(c, rows.cast_row0, rows.cast_rows, rows.cast_extra_row0, rows.cast_extra_rows);
+   Images im = c->im;
+   im.prev_spatial = spatial_buf(c, c->spatial_cur);
+   im.reservoirs[2] = spatial_buf(c, c->spatial_cur);
+   if (pass_mask & UH_PASS_GBUFFER) {
+      if (!c->gb_hit.p) {
+         HIP_TRY(c, c->gb_ray_o.alloc(npix));
+         HIP_TRY(c, c->gb_ray_d.alloc(npix));
+         HIP_TRY(c, c->gb_hit.alloc(npix));
       }
+      const RawRays gps{c->gb_ray_o.p, c->gb_ray_d.p, c->gb_hit.p};
+      launch_gbuffer(bs.rc, ff, c->scene, gps, im, c->dstats.p, cast, band.total());
+   }
+   if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(bs.rc, ff, im, reuse);
+   if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(bs.rc, ff, c->scene, im, reuse);
+   if (pass_mask & UH_PASS_TEMPORAL_REUSE) launch_temporal_reuse(bs.rc, ff, c->scene, im, reuse);
+   if (pass_mask & UH_PASS_SPATIAL_REUSE) {
+      // writes the NEXT slot of the ring: the path-tracing wavefronts that still read the current one keep going
+      const int nxt = (c->spatial_cur + 1) % kSpatialRing;
+      if (c->spatial_reader[nxt]) HIP_TRY(c, hipStreamWaitEvent(c->restir_stream, c->spatial_reader[nxt], 0));
+      im.reservoirs[2] = spatial_buf(c, nxt);
+      launch_spatial_reuse(bs.rc, ff, c->scene, im, band);
+      c->spatial_cur = nxt;
+      c->im.reservoirs[2] = spatial_buf(c, nxt);
+      if (c->rp_world > 1) {
+         if (!c->ev_band[nxt]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_band[nxt], hipEventDisableTiming));
+         HIP_TRY(c, hipEventRecord(c->ev_band[nxt], c->restir_stream));
+      }
+   }
+   bs.read_slot[f] = c->spatial_cur;
+   return UH_OK;
+}
+
+// the other ranks' bands of the buffer frame f's spatial pass wrote (uh_set_restir_partition)
+static int batch_exchange(uh_ctx* c, uh_batch& bs, uint32_t f) {
+   (void)f;
+   if (!bs.restir_frame || !c->rp_exchange || !(bs.pass_mask & UH_PASS_SPATIAL_REUSE)) return UH_OK;  // world 1 with an exchange: a one-rank all-gather (rehearsals)
+   HIP_TRY(c, hipSetDevice(c->device));
+   const uint64_t band_bytes = (uint64_t)c->rp_band_rows * c->W * sizeof(UhReservoir);
+   if (int st = c->rp_exchange(c->rp_user, (void*)c->restir_stream, (void*)c->im.reservoirs[2], band_bytes, c->rp_rank, c->rp_world))
+      return fail(c, UH_ERR_HIP, std::string("the reservoir exchange reported error ") + std::to_string(st));
+   return UH_OK;
+}
+
+static int batch_end(uh_ctx* c, uh_batch& bs) {
+   HIP_TRY(c, hipSetDevice(c->device));
+   FrameParams& fp = bs.fp;
+   const uint32_t batch = bs.batch;
+   if (bs.restir_frame) {
       HIP_TRY(c, hipEventRecord(c->ev_restir, c->restir_stream));
       c->restir_recorded = true;
       HIP_TRY(c, hipEventRecord(c->rs_stop, c->restir_stream));
       c->t_stop = c->rs_stop;
    }
-   for (uint32_t f = 0; f < kMaxBatchFrames; f++) fp.spatial_of[f] = spatial_buf(read_slot[f < batch ? f : 0]);
+   for (uint32_t f = 0; f < kMaxBatchFrames; f++) fp.spatial_of[f] = spatial_buf(c, bs.read_slot[f < batch ? f : 0]);
 
-   if (pass_mask & UH_PASS_REFERENCE_PT) {
+   if (bs.pass_mask & UH_PASS_REFERENCE_PT) {
       c->sun_this_frame = false;
       if (fp.sun_shadow_enabled == 1 && fp.num_bounces > 0 && fp.samples_per_frame > 0)
          if (int st = ensure_sun_grid(c, fp.sun_dir)) return st;
@@ -1258,13 +1356,13 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
       if (st != UH_OK) return st;
       Slot& s = c->slots[si];
       // rgen:98 reads this frame's spatial_reuse_reservoirs
-      if (reads_reservoirs && c->restir_recorded) HIP_TRY(c, hipStreamWaitEvent(s.stream, c->ev_restir, 0));
+      if (bs.reads_reservoirs && c->restir_recorded) HIP_TRY(c, hipStreamWaitEvent(s.stream, c->ev_restir, 0));
       HIP_TRY(c, hipEventRecord(s.frame_start, s.stream));
       if (!c->t_start) c->t_start = s.frame_start;
       st = enqueue_path_trace(c, s, fp);
       if (st != UH_OK) return st;
-      if (reads_reservoirs)
-         for (uint32_t f = 0; f < batch; f++) c->spatial_reader[read_slot[f]] = s.ev_acc;
+      if (bs.reads_reservoirs)
+         for (uint32_t f = 0; f < batch; f++) c->spatial_reader[bs.read_slot[f]] = s.ev_acc;
       HIP_TRY(c, hipEventRecord(s.frame_stop, s.stream));
       c->t_stop = s.frame_stop;
       c->last_slot = &s;
@@ -1275,21 +1373,24 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
    return UH_OK;
 }
 
-int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask) { return render_batch(c, view, pass_mask, 1); }
+static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t batch) {
+   uh_batch bs;
+   if (int st = batch_begin(c, view, pass_mask, batch, bs)) return st;
+   for (uint32_t f = 0; f < batch; f++) {
+      if (int st = batch_restir_frame(c, bs, f)) return st;
+      if (int st = batch_exchange(c, bs, f)) return st;
+   }
+   return batch_end(c, bs);
+}
 
-int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t count) {
-   if (!c) return UH_ERR_INVALID_ARGUMENT;
-   if (!view || count == 0) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: null view or zero frames");
-   UhViewUniformData v = *view;
-   uint32_t done = 0;
-   // auto: about four frames' worth of paths per wavefront - 4 frames on a whole frame, 4 x world frames on a rank's 1 / world
-   // share of it (swept on MI355X for 1, 4 and 8 ranks' shares: tools/sweep_world8.sh, profiles/README.md)
+// frames one wavefront carries for this pass mask (option "batch_frames", 0 = auto), and the slots it will rotate through
+static int plan_batch(uh_ctx* c, uint32_t pass_mask, uint32_t* out_batch) {
    uint32_t batch = c->batch_frames;
    if (!batch) {
       // auto: about 32 M paths per wavefront (1080p: 16 frames, 4K: 4, a rank's eighth of 1080p: 16, 256 x 256: 32) - what
       // the launches need to fill the chip and amortise their tails; 1080p 4 / 8 / 12 / 16 frames = 6,271 / 6,341 / 6,388 /
       // 6,398 Mrays/s, the short paths of the iso-surface scene 4,974 / 5,393 / - / 6,223 (tools/sweep_batch.sh,
-      // profiles/README.md) - within 33 M path-state records per slot (3.9 GB; path ids run over the whole frame even
+      // profiles/README.md) - within 33 M path-state records per slot (3.7 GB; path ids run over the whole frame even
       // when a rank owns a part of it)
       const uint64_t pixels = (uint64_t)c->W * c->H, owned = c->n_owned ? c->n_owned : pixels;
       uint64_t b = (32u << 20) / (owned ? owned : 1), cap = (33u << 20) / (pixels ? pixels : 1);
@@ -1304,6 +1405,54 @@ int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mas
    if (pass_mask & UH_PASS_REFERENCE_PT)
       for (uint32_t i = 0; i < (c->frames_in_flight ? c->frames_in_flight : 1); i++)
          if (int st = ensure_slot(c, i, batch)) return st;
+   *out_batch = batch;
+   return UH_OK;
+}
+
+// ---- the phases for an in-process group (csrc/context_internal.h; mgpu.hip) ----
+int uhi_plan_batch(uh_ctx* c, uint32_t pass_mask, uint32_t* out_batch) {
+   if (!c || !out_batch) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));
+   return plan_batch(c, pass_mask, out_batch);
+}
+int uhi_batch_begin(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t batch, uh_batch** out) {
+   if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
+   uh_batch* bs = new uh_batch();
+   int st = batch_begin(c, view, pass_mask, batch, *bs);
+   if (st != UH_OK) {
+      delete bs;
+      bs = nullptr;
+   }
+   *out = bs;
+   return st;
+}
+int uhi_batch_restir_frame(uh_ctx* c, uh_batch* bs, uint32_t f) { return (c && bs) ? batch_restir_frame(c, *bs, f) : UH_ERR_INVALID_ARGUMENT; }
+int uhi_batch_end(uh_ctx* c, uh_batch* bs) {
+   if (!c || !bs) return UH_ERR_INVALID_ARGUMENT;
+   int st = batch_end(c, *bs);
+   delete bs;
+   return st;
+}
+void uhi_batch_abandon(uh_batch* bs) { delete bs; }
+// what a peer pulls a band from / into: the buffer the last spatial pass wrote, the event recorded behind that pass, the
+// stream the passes run on
+int uhi_exchange_endpoints(uh_ctx* c, void** spatial_base, void** band_event, void** stream, uint64_t* band_bytes) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (spatial_base) *spatial_base = (void*)c->im.reservoirs[2];
+   if (band_event) *band_event = (void*)c->ev_band[c->spatial_cur];
+   if (stream) *stream = (void*)c->restir_stream;
+   if (band_bytes) *band_bytes = (uint64_t)c->rp_band_rows * c->W * sizeof(UhReservoir);
+   return UH_OK;
+}
+
+int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask) { return render_batch(c, view, pass_mask, 1); }
+
+int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t count) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!view || count == 0) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_render_frames: null view or zero frames");
+   UhViewUniformData v = *view;
+   uint32_t done = 0, batch = 1;
+   if (int st = plan_batch(c, pass_mask, &batch)) return st;
    while (done < count) {
       uint32_t b = count - done < batch ? count - done : batch;
       int st = render_batch(c, &v, pass_mask, b);
@@ -1347,7 +1496,7 @@ int uh_read_reservoirs(uh_ctx* c, int which, UhReservoir* out) {
    if (which < 0 || which > 2) return fail(c, UH_ERR_INVALID_ARGUMENT, "reservoir buffer index must be 0..2");
    // spatial_reuse_reservoirs is double-buffered (render_batch): the current one is what the reference's single buffer holds
    const UhReservoir* src = which == 2 ? c->im.reservoirs[2] : c->reservoirs[which].p;
-   return read_back(c, out, src, c->reservoirs[which].n * sizeof(UhReservoir));
+   return read_back(c, out, src, (size_t)c->W * c->H * sizeof(UhReservoir));
 }
 int uh_write_reservoirs(uh_ctx* c, int which, const UhReservoir* in) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
@@ -1355,7 +1504,7 @@ int uh_write_reservoirs(uh_ctx* c, int which, const UhReservoir* in) {
    HIP_TRY(c, hipSetDevice(c->device));
    if (int st = sync_all(c)) return st;
    UhReservoir* dst = which == 2 ? c->im.reservoirs[2] : c->reservoirs[which].p;
-   HIP_TRY(c, hipMemcpyAsync(dst, in, c->reservoirs[which].n * sizeof(UhReservoir), hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(c, hipMemcpyAsync(dst, in, (size_t)c->W * c->H * sizeof(UhReservoir), hipMemcpyHostToDevice, c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    return UH_OK;
 }
@@ -1583,6 +1732,143 @@ int uh_set_tile_partition(uh_ctx* c, uint32_t rank, uint32_t world, uint32_t til
       c->n_owned = (uint32_t)own.size();
       HIP_TRY(c, c->owned_pixels.alloc(own.size() ? own.size() : 1));
       if (!own.empty()) HIP_TRY(c, hipMemcpy(c->owned_pixels.p, own.data(), own.size() * 4, hipMemcpyHostToDevice));
+   }
+   return UH_OK;
+}
+
+int uh_set_restir_partition(uh_ctx* c, uint32_t rank, uint32_t world, UhRestirExchangeFn exchange, void* user) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (world == 0 || rank >= world) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_set_restir_partition: need rank < world");
+   HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
+   const size_t npix = (size_t)c->W * c->H;
+   const uint32_t band_rows = (c->H + world - 1) / world;
+   const size_t stride = std::max(npix, (size_t)band_rows * world * c->W);
+   if (stride != c->res_stride) {
+      // the history (the current slot of the ring) moves into a buffer of the new length, which becomes slot 0
+      DevBuf<UhReservoir> fresh;
+      HIP_TRY(c, fresh.alloc(stride));
+      HIP_TRY(c, hipMemsetAsync(fresh.p, 0, stride * sizeof(UhReservoir), c->stream));
+      HIP_TRY(c, hipMemcpyAsync(fresh.p, c->im.reservoirs[2], npix * sizeof(UhReservoir), hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      c->reservoirs[2].release();
+      c->reservoirs[2] = fresh;
+      fresh.p = nullptr;
+      fresh.n = 0;
+      c->spatial_ring.release();
+      c->res_stride = stride;
+   } else if (c->spatial_cur != 0) {
+      HIP_TRY(c, hipMemcpyAsync(c->reservoirs[2].p, c->im.reservoirs[2], npix * sizeof(UhReservoir), hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+   }
+   c->spatial_cur = 0;
+   for (auto& r : c->spatial_reader) r = nullptr;
+   c->im.reservoirs[2] = c->reservoirs[2].p;
+   c->im.prev_spatial = c->reservoirs[2].p;
+   c->rp_rank = rank;
+   c->rp_world = world;
+   c->rp_band_rows = world > 1 ? band_rows : c->H;
+   c->rp_exchange = exchange;
+   c->rp_user = user;
+   return UH_OK;
+}
+
+int uh_get_restir_rows(uh_ctx* c, UhRestirRows* out) {
+   if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
+   restir_rows(c, *out);
+   return UH_OK;
+}
+
+// ---- the exchange over RCCL. librccl is opened at run time (types from its header, no link dependency): a process that
+// never attaches needs no RCCL at all, and one that has torch's copy loaded gets that same copy (same soname). ----
+namespace {
+struct RcclApi {
+   void* so = nullptr;
+   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+   decltype(&ncclCommInitRank) CommInitRank = nullptr;
+   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+   decltype(&ncclAllGather) AllGather = nullptr;
+   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+   std::string why;
+};
+RcclApi* rccl_api() {
+   static RcclApi api;
+   static bool tried = false;
+   if (tried) return &api;
+   tried = true;
+   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.so) break;
+   }
+   if (!api.so) {
+      api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+      return &api;
+   }
+   api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.so, "ncclGetUniqueId");
+   api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.so, "ncclCommInitRank");
+   api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.so, "ncclCommDestroy");
+   api.AllGather = (decltype(api.AllGather))dlsym(api.so, "ncclAllGather");
+   api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.so, "ncclGetErrorString");
+   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
+      api.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+      api.so = nullptr;
+   }
+   return &api;
+}
+struct RcclLink {
+   ncclComm_t comm = nullptr;
+   int last = 0;
+};
+// UhRestirExchangeFn: in-place all-gather of the bands, enqueued on the reservoir stream
+int rccl_exchange(void* user, void* stream, void* base, uint64_t band_bytes, uint32_t rank, uint32_t) {
+   RcclLink* l = (RcclLink*)user;
+   l->last = (int)rccl_api()->AllGather((const char*)base + (size_t)rank * band_bytes, base, (size_t)band_bytes, ncclInt8, l->comm, (hipStream_t)stream);
+   return l->last;
+}
+}  // namespace
+
+int uh_rccl_unique_id(uint8_t out_id[128]) {
+   static_assert(sizeof(ncclUniqueId) == 128, "the C ABI hands the id over as 128 bytes");
+   if (!out_id) return UH_ERR_INVALID_ARGUMENT;
+   RcclApi* api = rccl_api();
+   if (!api->so) return UH_ERR_HIP;
+   ncclUniqueId id;
+   if (api->GetUniqueId(&id) != ncclSuccess) return UH_ERR_HIP;
+   memcpy(out_id, &id, 128);
+   return UH_OK;
+}
+
+int uh_rccl_attach(uh_ctx* c, uint32_t rank, uint32_t world, const uint8_t id[128]) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!id || world == 0 || rank >= world) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_rccl_attach: need an id and rank < world");
+   RcclApi* api = rccl_api();
+   if (!api->so) return fail(c, UH_ERR_HIP, "uh_rccl_attach: " + api->why);
+   HIP_TRY(c, hipSetDevice(c->device));
+   uh_rccl_detach(c);
+   RcclLink* l = new RcclLink();
+   ncclUniqueId nid;
+   memcpy(&nid, id, 128);
+   const ncclResult_t r = api->CommInitRank(&l->comm, (int)world, nid, (int)rank);
+   if (r != ncclSuccess) {
+      delete l;
+      return fail(c, UH_ERR_HIP, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(r) : "failed"));
+   }
+   c->rccl = l;
+   return uh_set_restir_partition(c, rank, world, rccl_exchange, l);
+}
+
+int uh_rccl_detach(uh_ctx* c) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!c->rccl) return UH_OK;
+   (void)hipSetDevice(c->device);
+   (void)sync_all(c);
+   RcclLink* l = (RcclLink*)c->rccl;
+   if (l->comm) (void)rccl_api()->CommDestroy(l->comm);
+   delete l;
+   c->rccl = nullptr;
+   if (c->rp_exchange == rccl_exchange) {
+      c->rp_exchange = nullptr;
+      c->rp_user = nullptr;
    }
    return UH_OK;
 }

@@ -1,0 +1,20 @@
+// context_internal.h — the phases of one batch of frames, for the in-process group (mgpu.hip). Not part of the C ABI
+// (include/utopian_hip.h): uh_render_frame(s) runs these back to back on one context; a group interleaves them over its
+// contexts because, with the reservoir passes partitioned by rows (uh_set_restir_partition), frame f + 1's temporal pass on
+// one GPU reads the bands every other GPU wrote in frame f.
+#pragma once
+#include <cstdint>
+
+#include "utopian_hip.h"
+
+struct uh_batch;
+extern "C" {
+int uhi_plan_batch(uh_ctx*, uint32_t pass_mask, uint32_t* out_batch);  // frames per wavefront for this pass mask; creates the slots
+int uhi_batch_begin(uh_ctx*, const UhViewUniformData*, uint32_t pass_mask, uint32_t batch, uh_batch** out);
+int uhi_batch_restir_frame(uh_ctx*, uh_batch*, uint32_t f);  // G-buffer cast + reservoir chain of frame f (this context's rows)
+int uhi_batch_end(uh_ctx*, uh_batch*);                       // the path-tracing wavefront; frees the batch
+void uhi_batch_abandon(uh_batch*);
+// what a peer pulls a band from / into after uhi_batch_restir_frame: the buffer the spatial pass wrote, the event recorded
+// behind it (hipEvent_t), the stream the passes run on (hipStream_t), bytes per band
+int uhi_exchange_endpoints(uh_ctx*, void** spatial_base, void** band_event, void** stream, uint64_t* band_bytes);
+}

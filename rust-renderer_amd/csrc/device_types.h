@@ -157,6 +157,20 @@ struct Images {
    const UhReservoir* prev_spatial;     // last frame's spatial_reuse_reservoirs, read by the temporal pass (renderers/mod.rs:294)
 };
 
+// Rows of the frame a reservoir-pass launch covers: the whole frame on one GPU; on a rank of an N-rank job (DESIGN.md
+// section 5, "band partition") the rank's band of rows plus what its spatial pass gathers from - at most two row intervals
+// (spatial_reuse.rgen:54's uvec2 wrap sends the first 30 rows to row H - 1). Work item j of a launch is pixel pixel_of(j).
+struct RowSpans {
+   uint32_t row0[2], rows[2];  // interval k covers rows [row0[k], row0[k] + rows[k]); rows[1] == 0: one interval
+   uint32_t W;
+   __host__ __device__ uint32_t total() const { return (rows[0] + rows[1]) * W; }
+   __host__ __device__ uint32_t pixel_of(uint32_t j) const {
+      const uint32_t first = rows[0] * W;
+      return j < first ? row0[0] * W + j : row0[1] * W + (j - first);
+   }
+};
+inline RowSpans whole_frame(uint32_t W, uint32_t H) { return RowSpans{{0, 0}, {H, 0}, W}; }
+
 // launch wrappers implemented in kernels.hip --------------------------------------------------
 struct LaunchCfg {
    hipStream_t stream;
@@ -186,11 +200,13 @@ void launch_trace_sun_grid(const LaunchCfg&, const FrameParams&, const SceneDev&
 void launch_finish_sample(const LaunchCfg&, const FrameParams&, const PathState&, const Images&, uint32_t sample, bool last);
 void launch_resolve(const LaunchCfg&, const Images&, uint32_t W, uint32_t H, uint32_t total_samples, uint32_t limit);
 // G-buffer + ReSTIR
-void launch_gbuffer(const LaunchCfg&, const FrameParams&, const SceneDev&, const RawRays&, const Images&, DeviceStats*);
-void launch_reset_reservoirs(const LaunchCfg&, const FrameParams&, const Images&);
-void launch_initial_ris(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);
-void launch_temporal_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);
-void launch_spatial_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&);
+// the reservoir passes and the G-buffer cast over the rows of `spans`; `counted` = the G-buffer rays this launch adds to the
+// statistics (a rank counts its own band, not the halo it casts again)
+void launch_gbuffer(const LaunchCfg&, const FrameParams&, const SceneDev&, const RawRays&, const Images&, DeviceStats*, const RowSpans& spans, uint32_t counted);
+void launch_reset_reservoirs(const LaunchCfg&, const FrameParams&, const Images&, const RowSpans& spans);
+void launch_initial_ris(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&, const RowSpans& spans);
+void launch_temporal_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&, const RowSpans& spans);
+void launch_spatial_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&, const RowSpans& spans);
 // stand-alone queries (n rays in ray_o/ray_d[0..n), identity queue)
 void launch_trace_closest_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n);
 void launch_trace_any_raw(const LaunchCfg&, const SceneDev&, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n);

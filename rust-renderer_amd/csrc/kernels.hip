@@ -1332,28 +1332,31 @@ __global__ __launch_bounds__(kBlock) void k_resolve(Images im, uint32_t n, uint3
 // utopian/src/renderers/gbuffer.rs:11-52, shaders/gbuffer/gbuffer.frag:47; clear colour
 // (1,1,1,0): utopian/src/pass.rs:210-214)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_gbuffer_generate(FrameParams fp, RawRays ps) {
-   const uint32_t n = fp.W * fp.H;
-   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+// ray j of the cast is the primary ray of pixel spans.pixel_of(j): the rays of a rank's rows lie densely in the ray arrays
+__global__ __launch_bounds__(kBlock) void k_gbuffer_generate(FrameParams fp, RawRays ps, RowSpans spans) {
+   const uint32_t n = spans.total();
+   for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+      const uint32_t id = spans.pixel_of(j);
       V3 o, d;
       primary_ray(fp, id % fp.W, id / fp.W, 0.5f, 0.5f, o, d);
-      ps.ray_o[id] = make_float4(o.x, o.y, o.z, 0.001f);
-      ps.ray_d[id] = make_float4(d.x, d.y, d.z, 10000.0f);
+      ps.ray_o[j] = make_float4(o.x, o.y, o.z, 0.001f);
+      ps.ray_d[j] = make_float4(d.x, d.y, d.z, 10000.0f);
    }
 }
-__global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(FrameParams fp, RawRays ps, Images im, DeviceStats* stats) {
-   const uint32_t n = fp.W * fp.H;
-   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
-      float4 h = ps.hit[id];
+__global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(FrameParams fp, RawRays ps, Images im, DeviceStats* stats, RowSpans spans, uint32_t counted) {
+   const uint32_t n = spans.total();
+   for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+      const uint32_t id = spans.pixel_of(j);
+      float4 h = ps.hit[j];
       if (__float_as_uint(h.w) != kEmptyRef) {
-         float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
+         float4 ro = ps.ray_o[j], rd = ps.ray_d[j];
          V3 p = v3(ro.x, ro.y, ro.z) + h.x * v3(rd.x, rd.y, rd.z);
          im.gbuffer_pos[id] = make_float4(p.x, p.y, p.z, 1.0f);
       } else {
          im.gbuffer_pos[id] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
       }
    }
-   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[UH_RAY_GBUFFER], (unsigned long long)n);
+   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[UH_RAY_GBUFFER], (unsigned long long)counted);
 }
 
 // texture(in_gbuffer_position, vec2(px) / vec2(size)) through the LINEAR + MIRRORED_REPEAT sampler
@@ -1375,8 +1378,10 @@ __device__ __forceinline__ void stage_lights(float4* s_lights, const SceneDev& s
 }
 
 // restir/reset_reservoirs.comp:24-45
-__global__ __launch_bounds__(kBlock) void k_reset_reservoirs(Images im, uint32_t n) {
-   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+__global__ __launch_bounds__(kBlock) void k_reset_reservoirs(Images im, RowSpans spans) {
+   const uint32_t n = spans.total();
+   for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+      const uint32_t id = spans.pixel_of(j);
       UhReservoir z = {-1, 0.0f, 0.0f, 0};
       im.reservoirs[0][id] = z;
       im.reservoirs[1][id] = z;
@@ -1384,11 +1389,12 @@ __global__ __launch_bounds__(kBlock) void k_reset_reservoirs(Images im, uint32_t
 }
 
 // restir/initial_ris.rgen:19-39 + restir_sampling.glsl:96-131 (resample, 32 candidates)
-__global__ __launch_bounds__(kBlock) void k_initial_ris(FrameParams fp, SceneDev sc, Images im) {
+__global__ __launch_bounds__(kBlock) void k_initial_ris(FrameParams fp, SceneDev sc, Images im, RowSpans spans) {
    __shared__ float4 s_lights[2 * kMaxLdsLights];
    stage_lights(s_lights, sc);
-   const uint32_t n = fp.W * fp.H;
-   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+   const uint32_t work = spans.total();
+   for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < work; j += gridDim.x * kBlock) {
+      const uint32_t id = spans.pixel_of(j);
       uint32_t px = id % fp.W, py = id / fp.W;
       uint32_t rng = init_rng(px, py, fp.W, fp.frame_number);
       V3 hit_position = gbuffer_fetch(im.gbuffer_pos, fp.W, px, py);
@@ -1413,11 +1419,12 @@ __global__ __launch_bounds__(kBlock) void k_initial_ris(FrameParams fp, SceneDev
 }
 
 // restir/temporal_reuse.rgen:35-119
-__global__ __launch_bounds__(kBlock) void k_temporal_reuse(FrameParams fp, SceneDev sc, Images im) {
+__global__ __launch_bounds__(kBlock) void k_temporal_reuse(FrameParams fp, SceneDev sc, Images im, RowSpans spans) {
    __shared__ float4 s_lights[2 * kMaxLdsLights];
    stage_lights(s_lights, sc);
-   const uint32_t n = fp.W * fp.H;
-   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+   const uint32_t n = fp.W * fp.H, work = spans.total();
+   for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < work; j += gridDim.x * kBlock) {
+      const uint32_t id = spans.pixel_of(j);
       if (fp.temporal_enabled == 0) {
          im.reservoirs[1][id] = im.reservoirs[0][id];
          continue;
@@ -1450,12 +1457,13 @@ __global__ __launch_bounds__(kBlock) void k_temporal_reuse(FrameParams fp, Scene
 }
 
 // restir/spatial_reuse.rgen:23-73
-__global__ __launch_bounds__(kBlock) void k_spatial_reuse(FrameParams fp, SceneDev sc, Images im) {
+__global__ __launch_bounds__(kBlock) void k_spatial_reuse(FrameParams fp, SceneDev sc, Images im, RowSpans spans) {
    __shared__ float4 s_lights[2 * kMaxLdsLights];
    stage_lights(s_lights, sc);
-   const uint32_t n = fp.W * fp.H;
+   const uint32_t work = spans.total();
    const UhReservoir* __restrict__ temporal = im.reservoirs[1];
-   for (uint32_t id = blockIdx.x * kBlock + threadIdx.x; id < n; id += gridDim.x * kBlock) {
+   for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < work; j += gridDim.x * kBlock) {
+      const uint32_t id = spans.pixel_of(j);
       if (fp.spatial_enabled == 0) {
          im.reservoirs[2][id] = temporal[id];
          continue;
@@ -1651,27 +1659,36 @@ void launch_resolve(const LaunchCfg& c, const Images& im, uint32_t W, uint32_t H
    k_resolve<<<stream_grid(c, W * H), kBlock, 0, c.stream>>>(im, W * H, total_samples, limit);
 }
 
-void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const RawRays& ps, const Images& im, DeviceStats* stats) {
-   const uint32_t n = fp.W * fp.H;
-   k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps);
-   if (c.primary_tiles)
+void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const RawRays& ps, const Images& im, DeviceStats* stats, const RowSpans& spans, uint32_t counted) {
+   const uint32_t n = spans.total();
+   if (n == 0) return;
+   const bool whole = n == fp.W * fp.H;
+   k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, spans);
+   if (c.primary_tiles && whole)  // the tile kernel addresses rays by pixel: whole frames only
       launch_tiles(c, sc, tile_job(fp, 1, true), ps.ray_o, ps.ray_d, ps.hit, stats, -1, false);
-   else
-      launch_closest(c, dim3(c.num_cus * c.closest_blocks_per_cu), sc, nullptr, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n, false);
-   k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats);
+   else {
+      const uint32_t full = c.num_cus * c.closest_blocks_per_cu, need = (n + kBlock - 1) / kBlock;
+      launch_closest(c, dim3(need < full ? need : full), sc, nullptr, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n, false);
+   }
+   k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats, spans, counted);
 }
 
-void launch_reset_reservoirs(const LaunchCfg& c, const FrameParams& fp, const Images& im) {
-   k_reset_reservoirs<<<stream_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(im, fp.W * fp.H);
+// the reservoir kernels stage the light table per block: no more blocks than the rows at hand can feed
+static inline dim3 reservoir_grid(const LaunchCfg& c, const RowSpans& spans) {
+   const uint32_t full = c.num_cus * 4, need = (spans.total() + kBlock - 1) / kBlock;
+   return dim3(need < full ? (need ? need : 1) : full);
 }
-void launch_initial_ris(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const Images& im) {
-   k_initial_ris<<<dim3(c.num_cus * 4), kBlock, 0, c.stream>>>(fp, sc, im);
+void launch_reset_reservoirs(const LaunchCfg& c, const FrameParams& fp, const Images& im, const RowSpans& spans) {
+   if (spans.total()) k_reset_reservoirs<<<stream_grid(c, spans.total()), kBlock, 0, c.stream>>>(im, spans);
 }
-void launch_temporal_reuse(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const Images& im) {
-   k_temporal_reuse<<<dim3(c.num_cus * 4), kBlock, 0, c.stream>>>(fp, sc, im);
+void launch_initial_ris(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const Images& im, const RowSpans& spans) {
+   if (spans.total()) k_initial_ris<<<reservoir_grid(c, spans), kBlock, 0, c.stream>>>(fp, sc, im, spans);
 }
-void launch_spatial_reuse(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const Images& im) {
-   k_spatial_reuse<<<dim3(c.num_cus * 4), kBlock, 0, c.stream>>>(fp, sc, im);
+void launch_temporal_reuse(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const Images& im, const RowSpans& spans) {
+   if (spans.total()) k_temporal_reuse<<<reservoir_grid(c, spans), kBlock, 0, c.stream>>>(fp, sc, im, spans);
+}
+void launch_spatial_reuse(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const Images& im, const RowSpans& spans) {
+   if (spans.total()) k_spatial_reuse<<<reservoir_grid(c, spans), kBlock, 0, c.stream>>>(fp, sc, im, spans);
 }
 
 void launch_trace_closest_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n) {

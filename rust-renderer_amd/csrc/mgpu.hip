@@ -8,11 +8,13 @@
 // the same partition, distributed.py.)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include "context_internal.h"
 #include "utopian_hip.h"
 
 struct uh_mgpu {
@@ -24,6 +26,9 @@ struct uh_mgpu {
    uint32_t W = 0, H = 0, tile = 0;
    uint32_t total_samples = 1, accumulation_limit = 999999;  // of the last frame, for the resolve
    bool composed = false;
+   // the G-buffer cast and the reservoir passes by bands of rows, one band per GPU, the bands exchanged by peer copies after
+   // every spatial pass (uh_set_restir_partition; option "restir_partition", on by default for more than one GPU)
+   bool restir_partition = false;
    std::string error;
 };
 
@@ -74,6 +79,7 @@ int uh_mgpu_create(int ngpus, const int* device_ordinals, uint32_t width, uint32
       uh_ctx* c = nullptr;
       int st = uh_create(dev, width, height, &c);
       if (st == UH_OK) st = uh_set_tile_partition(c, (uint32_t)i, (uint32_t)ngpus, tile_size);
+      if (st == UH_OK && ngpus > 1) st = uh_set_restir_partition(c, (uint32_t)i, (uint32_t)ngpus, nullptr, nullptr);  // the group moves the bands itself
       if (st != UH_OK) {
          const char* e = uh_last_error(c);
          g_create_error = std::string("uh_mgpu_create: GPU ") + std::to_string(dev) + ": " + (e ? e : "");
@@ -85,6 +91,7 @@ int uh_mgpu_create(int ngpus, const int* device_ordinals, uint32_t width, uint32
       m->ctx.push_back(c);
       m->device.push_back(dev);
    }
+   m->restir_partition = ngpus > 1;
    m->packed.assign(ngpus, nullptr);
    m->staged.assign(ngpus, nullptr);
    m->pack_pixels.assign(ngpus, 0);
@@ -170,16 +177,95 @@ int uh_mgpu_refit_acceleration(uh_mgpu* m) {
 }
 int uh_mgpu_set_option(uh_mgpu* m, const char* name, int value) {
    if (!m) return UH_ERR_INVALID_ARGUMENT;
+   if (name && std::string(name) == "restir_partition") {
+      // 1 (default for more than one GPU): reservoir passes by bands of rows; 0: every GPU runs them for the whole frame
+      const uint32_t n = (uint32_t)m->ctx.size();
+      const bool on = value != 0 && n > 1;
+      for (uint32_t i = 0; i < n; i++)
+         if (int st = uh_set_restir_partition(m->ctx[i], on ? i : 0, on ? n : 1, nullptr, nullptr)) return fail(m, st, "uh_mgpu_set_option", m->ctx[i]);
+      m->restir_partition = on;
+      return UH_OK;
+   }
    for (uh_ctx* c : m->ctx)
       if (int st = uh_set_option(c, name, value)) return fail(m, st, "uh_mgpu_set_option", c);
    return UH_OK;
 }
 
 // ---- frames: every GPU enqueues its tiles of the frame; the calls return without waiting ----
+namespace {
+// after every GPU's spatial pass of one frame: GPU i pulls band j from GPU j, on its own reservoir stream, behind the event
+// GPU j recorded after writing it. Nothing waits on the host; frame f + 1's temporal pass of GPU i follows on the same stream.
+int exchange_bands(uh_mgpu* m) {
+   const size_t n = m->ctx.size();
+   std::vector<void*> base(n), ev(n), stream(n);
+   std::vector<UhRestirRows> rows(n);
+   uint64_t band_bytes = 0;
+   for (size_t i = 0; i < n; i++) {
+      if (int st = uhi_exchange_endpoints(m->ctx[i], &base[i], &ev[i], &stream[i], &band_bytes)) return fail(m, st, "exchange endpoints", m->ctx[i]);
+      uh_get_restir_rows(m->ctx[i], &rows[i]);
+   }
+   for (size_t i = 0; i < n; i++) {
+      hipError_t e = hipSetDevice(m->device[i]);
+      for (size_t j = 0; j < n && e == hipSuccess; j++) {
+         const size_t bytes = (size_t)rows[j].band_rows * m->W * sizeof(UhReservoir);
+         if (j == i || bytes == 0) continue;
+         e = hipStreamWaitEvent((hipStream_t)stream[i], (hipEvent_t)ev[j], 0);
+         if (e == hipSuccess)
+            e = hipMemcpyPeerAsync((char*)base[i] + j * band_bytes, m->device[i], (const char*)base[j] + j * band_bytes, m->device[j], bytes, (hipStream_t)stream[i]);
+      }
+      if (e != hipSuccess) return fail(m, UH_ERR_HIP, std::string("band exchange: ") + hipGetErrorString(e));
+   }
+   return UH_OK;
+}
+
+int group_frames(uh_mgpu* m, const UhViewUniformData* view, uint32_t pass_mask, uint32_t count, bool batched) {
+   const size_t n = m->ctx.size();
+   const bool interleave = m->restir_partition && n > 1 && (pass_mask & UH_PASS_RESTIR);
+   if (!interleave) {
+      for (uh_ctx* c : m->ctx)
+         if (int st = batched ? uh_render_frames(c, view, pass_mask, count) : uh_render_frame(c, view, pass_mask)) return fail(m, st, "uh_mgpu_render_frame(s)", c);
+      return UH_OK;
+   }
+   UhViewUniformData v = *view;
+   uint32_t batch = 1;
+   if (batched)
+      for (size_t i = 0; i < n; i++) {
+         uint32_t b = 1;
+         if (int st = uhi_plan_batch(m->ctx[i], pass_mask, &b)) return fail(m, st, "uh_mgpu_render_frames", m->ctx[i]);
+         batch = i == 0 ? b : std::min(batch, b);
+      }
+   std::vector<uh_batch*> bs(n, nullptr);
+   auto abandon = [&]() {
+      for (uh_batch*& b : bs) {
+         if (b) uhi_batch_abandon(b);
+         b = nullptr;
+      }
+   };
+   for (uint32_t done = 0; done < count;) {
+      const uint32_t b = std::min(batch, count - done);
+      for (size_t i = 0; i < n; i++)
+         if (int st = uhi_batch_begin(m->ctx[i], &v, pass_mask, b, &bs[i])) return abandon(), fail(m, st, "uh_mgpu_render_frames", m->ctx[i]);
+      for (uint32_t f = 0; f < b; f++) {
+         for (size_t i = 0; i < n; i++)
+            if (int st = uhi_batch_restir_frame(m->ctx[i], bs[i], f)) return abandon(), fail(m, st, "uh_mgpu_render_frames", m->ctx[i]);
+         if (pass_mask & UH_PASS_SPATIAL_REUSE)
+            if (int st = exchange_bands(m)) return abandon(), st;
+      }
+      for (size_t i = 0; i < n; i++) {
+         uh_batch* mine = bs[i];
+         bs[i] = nullptr;  // uhi_batch_end frees it
+         if (int st = uhi_batch_end(m->ctx[i], mine)) return abandon(), fail(m, st, "uh_mgpu_render_frames", m->ctx[i]);
+      }
+      done += b;
+      v.total_samples += b * v.samples_per_frame;
+   }
+   return UH_OK;
+}
+}  // namespace
+
 int uh_mgpu_render_frame(uh_mgpu* m, const UhViewUniformData* view, uint32_t pass_mask) {
    if (!m || !view) return UH_ERR_INVALID_ARGUMENT;
-   for (uh_ctx* c : m->ctx)
-      if (int st = uh_render_frame(c, view, pass_mask)) return fail(m, st, "uh_mgpu_render_frame", c);
+   if (int st = group_frames(m, view, pass_mask, 1, false)) return st;
    m->total_samples = view->total_samples;
    m->accumulation_limit = view->accumulation_limit;
    m->composed = false;
@@ -187,8 +273,7 @@ int uh_mgpu_render_frame(uh_mgpu* m, const UhViewUniformData* view, uint32_t pas
 }
 int uh_mgpu_render_frames(uh_mgpu* m, const UhViewUniformData* view, uint32_t pass_mask, uint32_t count) {
    if (!m || !view || count == 0) return UH_ERR_INVALID_ARGUMENT;
-   for (uh_ctx* c : m->ctx)
-      if (int st = uh_render_frames(c, view, pass_mask, count)) return fail(m, st, "uh_mgpu_render_frames", c);
+   if (int st = group_frames(m, view, pass_mask, count, true)) return st;
    m->total_samples = view->total_samples + (count - 1) * view->samples_per_frame;
    m->accumulation_limit = view->accumulation_limit;
    m->composed = false;
@@ -241,13 +326,31 @@ int uh_mgpu_read_output_bgra8(uh_mgpu* m, uint8_t* bgra) {
 }
 
 // counters summed over the GPUs (each traces only its tiles); times are the slowest GPU's
+// reservoir buffers of the whole frame: spatial_reuse_reservoirs (2) is complete on every GPU after the exchange; the
+// initial (0) and temporal (1) buffers are assembled from the rows each GPU's band covers
+int uh_mgpu_read_reservoirs(uh_mgpu* m, int which, UhReservoir* out) {
+   if (!m || !out || which < 0 || which > 2) return UH_ERR_INVALID_ARGUMENT;
+   if (!m->restir_partition || which == 2) {
+      if (int st = uh_read_reservoirs(m->ctx[0], which, out)) return fail(m, st, "uh_mgpu_read_reservoirs", m->ctx[0]);
+      return UH_OK;
+   }
+   std::vector<UhReservoir> tmp((size_t)m->W * m->H);
+   for (uh_ctx* c : m->ctx) {
+      UhRestirRows r;
+      uh_get_restir_rows(c, &r);
+      if (r.band_rows == 0) continue;
+      if (int st = uh_read_reservoirs(c, which, tmp.data())) return fail(m, st, "uh_mgpu_read_reservoirs", c);
+      memcpy(out + (size_t)r.band_row0 * m->W, tmp.data() + (size_t)r.band_row0 * m->W, (size_t)r.band_rows * m->W * sizeof(UhReservoir));
+   }
+   return UH_OK;
+}
 int uh_mgpu_get_stats(uh_mgpu* m, UhStats* out) {
    if (!m || !out) return UH_ERR_INVALID_ARGUMENT;
    std::memset(out, 0, sizeof(*out));
    for (size_t i = 0; i < m->ctx.size(); i++) {
       UhStats s;
       if (int st = uh_get_stats(m->ctx[i], &s)) return fail(m, st, "uh_mgpu_get_stats", m->ctx[i]);
-      for (int k = 0; k < UH_RAY_KINDS; k++) out->rays[k] += (k == UH_RAY_GBUFFER && i > 0) ? 0 : s.rays[k];  // the G-buffer cast is replicated
+      for (int k = 0; k < UH_RAY_KINDS; k++) out->rays[k] += (k == UH_RAY_GBUFFER && i > 0 && !m->restir_partition) ? 0 : s.rays[k];  // without the row partition the G-buffer cast is replicated: counted once
       out->nodes_visited += s.nodes_visited;
       out->tris_tested += s.tris_tested;
       out->shadow_nodes_visited += s.shadow_nodes_visited;

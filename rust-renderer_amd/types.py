@@ -95,6 +95,16 @@ RAY_KINDS = 5
 RAY_PRIMARY, RAY_BOUNCE, RAY_SUN_SHADOW, RAY_LIGHT_SHADOW, RAY_GBUFFER = range(5)
 
 
+class RestirRows(C.Structure):
+    """UhRestirRows: the rows a context's reservoir passes cover under uh_set_restir_partition"""
+    _fields_ = [(n, C.c_uint32) for n in ("band_row0", "band_rows", "reuse_row0", "reuse_rows", "reuse_extra_row0", "reuse_extra_rows",
+                                          "cast_row0", "cast_rows", "cast_extra_row0", "cast_extra_rows", "rows_per_band")]
+
+
+# int exchange(void* user, void* hip_stream, void* spatial_base, uint64_t band_bytes, uint32_t rank, uint32_t world)
+RESTIR_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32)
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("rays", C.c_uint64 * RAY_KINDS),
