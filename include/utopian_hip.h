@@ -308,8 +308,10 @@ int uh_resolve_output(uh_ctx* ctx, uint32_t total_samples, uint32_t accumulation
  * is already where it belongs). It is called while the frame is ENQUEUED, not when it runs: it must not wait for the GPU.
  * Each spatial_reuse buffer is world * B rows long (the frame, padded to equal bands). With the exchange in place every
  * rank holds the whole spatial_reuse_reservoirs of every frame - bit for bit the single-GPU buffer - while buffers 0 and 1
- * (uh_read_reservoirs) are valid on the rank's own rows only. world = 1 (the default) restores full-frame passes.
- * exchange == NULL with world > 1 leaves the other bands stale: for timing one rank's share only. */
+ * (uh_read_reservoirs) are valid on the rank's own rows only. world = 1 (the default) restores full-frame passes (an
+ * exchange given with world = 1 is still called: a one-rank all-gather, for rehearsals). exchange == NULL with world > 1
+ * leaves the other bands stale: for timing one rank's share only. The call waits for the frames in flight and keeps the
+ * temporal history. */
 typedef int (*UhRestirExchangeFn)(void* user, void* hip_stream, void* spatial_base, uint64_t band_bytes, uint32_t rank, uint32_t world);
 int uh_set_restir_partition(uh_ctx* ctx, uint32_t rank, uint32_t world, UhRestirExchangeFn exchange, void* user);
 /* the rows of this context's band and of its reservoir / G-buffer passes (counts of rows; *_extra_row0 is the first row of the second interval or 0 with *_extra_rows 0) */
