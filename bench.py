@@ -179,7 +179,7 @@ def main():
 
     # ---- untimed: what an interactive caller sees with the library's defaults - uh_render_frame, then a synchronisation
     # (a present) after every frame: side-stream overlap inside the frame, but no second frame in flight and no batching
-    interactive_frame_ms = None
+    interactive_frame_ms = pipelined_frame_ms = None
     if not args.no_alone:
         for _ in range(4):  # every frames-in-flight slot exists before the clock starts
             loop.frame(pass_mask)
@@ -189,7 +189,14 @@ def main():
             loop.frame(pass_mask)
             renderer.synchronize()
         interactive_frame_ms = (time.perf_counter() - t_int) / 8 * 1e3
-        frames_rendered += 12
+        # ... and with a swapchain's worth of frames in flight: uh_render_frame per frame (every frame may carry another
+        # camera), no wait in between - the library rotates its four slots; no batching
+        t_pipe = time.perf_counter()
+        for _ in range(32):
+            loop.frame(pass_mask)
+        renderer.synchronize()
+        pipelined_frame_ms = (time.perf_counter() - t_pipe) / 32 * 1e3
+        frames_rendered += 44
 
     # ---- untimed priming, independent of --warmup: the first multi-frame call makes the library create its
     # frames-in-flight slots (streams, ~1 GB of path state each at 1080p; ~14 ms) - with --warmup 0 or 1 that
@@ -260,6 +267,7 @@ def main():
                 "partition": f"{args.tile}x{args.tile} tiles round-robin over {world} rank(s), 1 RCCL gather" if world > 1 else "single GPU",
                 "frame_by_frame_ms": frame_by_frame_ms,      # fully serial: one stream, one frame, per-kernel event timing on
                 "interactive_frame_ms": interactive_frame_ms,  # default options, a synchronisation after every frame
+                "pipelined_frame_ms": pipelined_frame_ms,      # one uh_render_frame per frame, four frames in flight, no batching: a moving camera
                 "serial_kernel_ms_per_frame": serial_ms_per_frame,  # HIP-event time by kernel kind, one 16-frame wavefront alone on the GPU, nothing overlapped
             },
             "roofline": roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, signature(args, scene, W, H)),

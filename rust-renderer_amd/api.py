@@ -577,7 +577,7 @@ class FrameLoop:
     def frames(self, count, pass_mask=PASS_ALL):
         """`count` frames of the loop with the camera at rest. Everything that includes the path-tracing pass is handed to
         uh_render_frames in one call (the library batches frames into shared wavefronts of about 32 M paths: 16 frames at
-        1080p, at most 8 when the reservoir passes run too). The first frame of a run that includes the temporal pass goes alone:
+        1080p, at most 16 when the reservoir passes run too). The first frame of a run that includes the temporal pass goes alone:
         it is the one that may still see another prev_frame_projection_view."""
         from .types import PASS_REFERENCE_PT, PASS_TEMPORAL_REUSE
 

@@ -140,7 +140,7 @@ struct Slot {
 
 // frames of the reservoir passes one uh_render_frames wavefront carries at most, and the ring of spatial buffers that
 // lets the next batch's chains run beside the current wavefront (two batches + the history slot)
-constexpr uint32_t kRestirBatch = 8;
+constexpr uint32_t kRestirBatch = 16;
 constexpr int kSpatialRing = 2 * (int)kRestirBatch + 1;
 
 struct uh_ctx {

@@ -29,8 +29,8 @@ def test_group_with_band_partition_equals_single_context_and_oracle(atrium, ngpu
     one, cpu = make_pair(atrium, W, H)
     group = atrium.upload(rr.MultiGpuRenderer(W, H, devices=[0] * ngpu, tile_size=16))
     for r in (one, group):
-        rr.FrameLoop(r, atrium.make_view(W, H)).frames(11, rr.PASS_ALL)  # batches of 8 + 3: the exchange runs inside batched chains
-    run_frames(cpu, atrium, W, H, 11, rr.PASS_ALL)
+        rr.FrameLoop(r, atrium.make_view(W, H)).frames(21, rr.PASS_ALL)  # the first frame alone, then batches of 16 + 4: the exchange runs inside batched chains
+    run_frames(cpu, atrium, W, H, 21, rr.PASS_ALL)
     assert np.array_equal(group.read_accumulation().view(np.uint32), one.read_accumulation().view(np.uint32))
     for which in range(3):
         got = group.read_reservoirs(which)
