@@ -237,15 +237,16 @@ struct uh_ctx {
    uint32_t bvh_nodes = 0, bvh_tris = 0;
 
    // sun shadow rays through a per-direction grid instead of the tree (sun_grid.h; option "sun_grid"). The grid belongs to one
-   // (geometry, sun direction) pair: it is built on the first frame that traces sun rays and again when the direction has
-   // changed and then stayed put for two consecutive frames - a sun that moves every frame keeps the tree walk.
+   // (geometry, sun direction) pair: it is built on the first frame that traces sun rays and again when the direction or the
+   // geometry has changed and then stayed put for two consecutive frames - a sun or an instance that moves every frame keeps
+   // the tree walk.
    bool primary_tiles = false;      // option "primary_tiles": wave-per-tile traversal (scalar node fetches) for primary rays and the G-buffer cast; measured
                                     // level with the per-lane kernel (config 1 +1.3 %, config 2 -0.5 %: profiles/README.md), so off by default
    bool sun_grid_enabled = true;
    bool sun_valid = false;          // d_sun_* hold a usable grid for (sun_geom, sun_dir_built)
    bool sun_attempted = false;      // a build for (sun_geom, sun_dir_built) was tried (it may have been refused: sun_why)
    bool sun_have_pending = false;
-   uint64_t geom_version = 1, sun_geom = 0;
+   uint64_t geom_version = 1, sun_geom = 0, sun_geom_pending = 0;
    float sun_dir_built[3] = {0, 0, 0}, sun_dir_pending[3] = {0, 0, 0};
    DevBuf<uint32_t> d_sun_cells;
    DevBuf<SunGridEntry> d_sun_entries;
@@ -1041,10 +1042,13 @@ static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
       c->sun_this_frame = c->sun_valid;
       return UH_OK;
    }
-   if (same_geom && c->sun_attempted) {
-      // another direction than the grid's: rebuild once it has been asked for twice in a row, walk the tree meanwhile
-      const bool settled = c->sun_have_pending && std::memcmp(dir, c->sun_dir_pending, sizeof(float) * 3) == 0;
+   if (c->sun_attempted) {
+      // another direction or other geometry than the grid's (a sun dragged in the UI, instances moved with rebuild_tlas every
+      // frame): rebuild once the same pair has been asked for twice in a row, walk the tree meanwhile - a build costs as much
+      // as a thousand frames' worth of what the grid saves
+      const bool settled = c->sun_have_pending && c->sun_geom_pending == c->geom_version && std::memcmp(dir, c->sun_dir_pending, sizeof(float) * 3) == 0;
       std::memcpy(c->sun_dir_pending, dir, sizeof(float) * 3);
+      c->sun_geom_pending = c->geom_version;
       c->sun_have_pending = true;
       if (!settled) return UH_OK;
    }

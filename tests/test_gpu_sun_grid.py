@@ -126,6 +126,29 @@ def test_refit_and_device_build_invalidate_the_grid(cornell):
         assert np.array_equal(dev.read_accumulation().view(np.uint32), ref.read_accumulation().view(np.uint32)), kind
 
 
+def test_instances_moving_every_frame_never_rebuild_the_grid(cornell):
+    """rebuild_tlas = 1 with an instance that moves every frame (main.rs:392,526): every frame refits, none builds a grid
+    (a build costs a thousand frames' saving); the first frame at rest brings the grid back. Every frame equals the oracle's."""
+    W, H = 80, 60
+    gpu, cpu = make_pair(cornell, W, H)
+    loops = [rr.FrameLoop(r, cornell.make_view(W, H, sun_shadow_enabled=1, lights_enabled=0)) for r in (gpu, cpu)]
+    n = cornell.num_meshes
+    builds = []
+    for k in range(8):
+        moved = k in (2, 3, 4, 5)
+        for r, loop in zip((gpu, cpu), loops):
+            if moved:
+                r.set_instance_transform(n - 2, rr.transform3x4((0.3,) * 3, (0.1 + 0.05 * k, 0.9, 0.1)))
+            loop.view.rebuild_tlas = 1 if moved else 0
+            loop.frame(rr.PASS_REFERENCE_PT)
+            loop.reset()
+        builds.append(round(gpu.get_stats().sun_grid_build_ms, 4))
+        assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL, k
+        assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays), k
+    changed = [i for i in range(1, len(builds)) if builds[i] != builds[i - 1]]
+    assert changed == [6], (changed, builds)  # frames 2-5 move; frame 6 is the second in a row with frame 5's geometry: the rebuild
+
+
 def test_rays_beyond_the_dense_extent_walk_the_tree(atrium):
     """a long strip of ground that leaves the atrium through its end wall (two triangles, little area: the grid is not refused as
     a whole): rays that start out there land in border cells and are handed to the tree walk (queue 3); the image equals the
