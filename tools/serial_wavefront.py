@@ -24,7 +24,8 @@ def report(d):
         ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         total += ns
         print("%-34s %9.3f ms   grid %s" % (r["Kernel_Name"].split("(")[0].replace("void ", "").replace("uh::", "")[:34], ns / 1e6, r.get("Grid_Size", "")))
-    print("sum %.3f ms per wavefront" % (total / 1e6))
+    span = int(rows[-1]["End_Timestamp"]) - int(rows[start]["Start_Timestamp"])
+    print("sum %.3f ms per wavefront; first start to last end %.3f ms (the difference is what the GPU idles between launches)" % (total / 1e6, span / 1e6))
 
 
 def main():
