@@ -1013,7 +1013,7 @@ static int sync_all(uh_ctx* c) {
 
 // slot i exists and can hold `batch` frames worth of paths
 static int ensure_slot(uh_ctx* c, uint32_t i, uint32_t batch = 1) {
-   const size_t need = (size_t)c->W * c->H * batch;
+   const size_t need = (size_t)(c->tp_world > 1 ? c->n_owned : c->W * c->H) * batch;  // path ids are dense over the rank's owned pixels
    Slot& s = c->slots[i];
    if (s.ready && s.capacity >= need) return UH_OK;
    if (s.ready) {
@@ -1391,13 +1391,13 @@ static int render_batch(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_
 static int plan_batch(uh_ctx* c, uint32_t pass_mask, uint32_t* out_batch) {
    uint32_t batch = c->batch_frames;
    if (!batch) {
-      // auto: about 32 M paths per wavefront (1080p: 16 frames, 4K: 4, a rank's eighth of 1080p: 16, 256 x 256: 32) - what
+      // auto: about 32 M paths per wavefront (1080p: 16 frames, 4K: 4, a rank's eighth of 1080p: 32, 256 x 256: 32) - what
       // the launches need to fill the chip and amortise their tails; 1080p 4 / 8 / 12 / 16 frames = 6,271 / 6,341 / 6,388 /
       // 6,398 Mrays/s, the short paths of the iso-surface scene 4,974 / 5,393 / - / 6,223 (tools/sweep_batch.sh,
-      // profiles/README.md) - within 33 M path-state records per slot (3.7 GB; path ids run over the whole frame even
-      // when a rank owns a part of it)
+      // profiles/README.md) - within 33 M path-state records per slot (3.7 GB; path ids are dense over the pixels a rank
+      // owns, so its wavefronts carry more frames than a whole frame's would)
       const uint64_t pixels = (uint64_t)c->W * c->H, owned = c->n_owned ? c->n_owned : pixels;
-      uint64_t b = (32u << 20) / (owned ? owned : 1), cap = (33u << 20) / (pixels ? pixels : 1);
+      uint64_t b = (32u << 20) / (owned ? owned : 1), cap = (33u << 20) / (owned ? owned : 1);
       if (b > cap) b = cap;
       batch = (uint32_t)(b < 1 ? 1 : b);
    }

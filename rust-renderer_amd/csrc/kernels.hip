@@ -912,7 +912,6 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_raw(SceneDev sc, const flo
 // generate — reference.rgen:24-40: RNG init, payload seed copy, jitter, primary ray
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState ps, Control* ctl, uint32_t sample) {
-   const uint32_t npix = fp.W * fp.H;
    const uint32_t n = fp.n_owned * fp.batch_frames;  // owned pixels x frames of the batch
    const uint32_t lane = lane_id();
    const uint32_t groups = (n + 63) / 64;
@@ -924,9 +923,11 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
       bool own = q < n;
       uint32_t id = 0;
       if (own) {
+         // path id = frame of the batch x owned pixels + index into the rank's owned-pixel list: dense, so a rank's wavefront
+         // carries as many frames as its share of the frame allows (on one GPU: frame x W x H + pixel)
          const uint32_t f = q / fp.n_owned, k = q - f * fp.n_owned;
          const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
-         id = f * npix + pix;
+         id = q;
          uint32_t px = pix % fp.W, py = pix / fp.W;
          uint32_t rng = sample == 0 ? init_rng(px, py, fp.W, fp.frame_numbers[f]) : __float_as_uint(rec_quad(ps.rec, id, REC_ORIGIN)->w);  // rgen:24
          uint32_t seed = rng;                                                                   // rgen:30
@@ -939,8 +940,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
          // radiance = 0 / pixelColor = 0 (rgen:26,40) are not materialised: the bounce-0 shading kernels and the first
          // finish_sample use the constants directly
       }
-      // the 64 paths of a wave normally share one run (hence one shard); at tile edges that are not
-      // 64-aligned they may not, so append shard by shard
+      // the 64 paths of a wave are one run of ids (hence one shard); the loop below is kept for the general case
       uint32_t shard = own ? shard_of_run(id >> 6) : 0xffffffffu;
       unsigned long long todo = __ballot(own);
       while (todo) {
@@ -1191,11 +1191,12 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
             int light_index = 0;
             if (fp.lights_enabled == 1) {                                              // rgen:81-110
                float light_sample_weight = 0.0f, total_weights = 1.0f;
-               const uint32_t pix = id % (fp.W * fp.H);
+               const uint32_t k = id % fp.n_owned;
+               const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
                uint32_t px = pix % fp.W;
                bool use_reservoir = (px > fp.W / 2 || fp.full_frame_restir) && fp.use_ris == 1;  // rgen:87
                if (use_reservoir) {
-                  UhReservoir rs = fp.spatial_of[id / (fp.W * fp.H)][pix];             // rgen:98 (the path's own frame of the batch)
+                  UhReservoir rs = fp.spatial_of[id / fp.n_owned][pix];                // rgen:98 (the path's own frame of the batch)
                   light_sample_weight = rs.W_X;
                   total_weights = rs.W_sum;
                   light_index = rs.Y;
@@ -1289,7 +1290,6 @@ __device__ __forceinline__ uchar4 resolve_color(float4 acc, uint32_t total_sampl
 }
 
 __global__ __launch_bounds__(kBlock) void k_finish_sample(FrameParams fp, PathState ps, Images im, uint32_t sample, bool last) {
-   const uint32_t npix = fp.W * fp.H;
    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < fp.n_owned; k += gridDim.x * kBlock) {
       const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
       float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(kBlock) void k_finish_sample(FrameParams fp, PathSt
       uint32_t total = fp.total_samples;
       // frames of the batch in order: each applies the reference's accumulate tail with ITS total_samples
       for (uint32_t f = 0; f < fp.batch_frames; f++) {
-         const uint32_t id = f * npix + pix;
+         const uint32_t id = f * fp.n_owned + k;
          float4 pc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
          if (sample != 0) pc = ps.pixcol[id];
          if (fp.num_bounces != 0) rad = ps.rad[id];  // with zero bounces no kernel ever wrote a radiance
@@ -1594,7 +1594,7 @@ static void launch_tiles(const LaunchCfg& c, const SceneDev& sc, const TileJob& 
    else
       k_trace_closest_tiles<false><<<grid, kBlock, 0, c.stream>>>(sc, j, ray_o, ray_d, hit, stats, ray_kind);
 }
-bool primary_tiles_apply(const FrameParams& fp) { return fp.tp_world <= 1 || fp.tp_tile % 8 == 0; }
+bool primary_tiles_apply(const FrameParams& fp) { return fp.tp_world <= 1; }  // the tile kernel derives path ids from pixel coordinates: whole frames only
 // bounce 0 of the path tracer, wave per 8 x 8 pixel tile (k_trace_closest_tiles): every path of the wavefront is in the bounce's
 // queue, so the tiles are enumerated directly
 void launch_trace_primary_tiles(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, DeviceStats* stats) {

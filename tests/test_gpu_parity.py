@@ -854,7 +854,8 @@ def test_device_build_falls_back_to_the_host_builder_on_overflowing_geometry(kin
 def test_wave_per_tile_traversal_is_bit_identical(atrium, size, world):
     """option primary_tiles: primary rays and the G-buffer cast walked one wave per 8 x 8 pixel tile with the nodes fetched through the
     scalar path (k_trace_closest_tiles) - same hits, reservoirs, images and counts as the per-lane kernel, also on frames whose
-    size is no multiple of 8 and under a tile partition"""
+    size is no multiple of 8; under a tile partition (dense path ids) the path tracer's rays stay with the per-lane kernel and
+    only the full-frame G-buffer cast goes through the tiles"""
     W, H = size
     out = []
     for tiles in (0, 1):

@@ -12,6 +12,14 @@ timeout -k 10 300 python bench.py --config 4 --steps 64 --cpu-sample 1920x1080x8
 timeout -k 10 300 python bench.py --config 0 --width 256 --height 256 --steps 64 --cpu-sample 256x256x64 > gpurun_out/${tag}_bench_config0_rtiow.json 2>/dev/null
 for w in 2 4 8; do timeout -k 10 200 python bench.py --emulate-world $w --no-cpu-baseline > gpurun_out/${tag}_bench_emulated_world$w.json 2>/dev/null; done
 timeout -k 10 200 python bench.py --force-dist --no-cpu-baseline --steps 16 > gpurun_out/${tag}_bench_force_dist.json 2> gpurun_out/${tag}_bench_force_dist.err
+# SURVEY 8d's second reporting forms; config 2 on N ranks (reservoir passes by bands of rows against full-frame passes on every rank); RCCL link with one rank
+timeout -k 10 300 python bench.py --spp 8 --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_8x8spp.json 2>/dev/null
+timeout -k 10 300 python bench.py --config 2 --steps 32 --no-cpu-baseline --opt full_frame_restir=1 > gpurun_out/${tag}_bench_config2_full_frame_restir.json 2>/dev/null
+for w in 2 4 8; do
+  timeout -k 10 300 python bench.py --config 2 --steps 32 --emulate-world $w --no-cpu-baseline > gpurun_out/${tag}_bench_config2_emulated_world$w.json 2>/dev/null
+  timeout -k 10 300 python bench.py --config 2 --steps 32 --emulate-world $w --no-cpu-baseline --full-frame-reservoir-passes > gpurun_out/${tag}_bench_config2_emulated_world${w}_full_frame_passes.json 2>/dev/null
+done
+timeout -k 10 300 python bench.py --config 2 --steps 32 --force-dist --no-cpu-baseline > gpurun_out/${tag}_bench_config2_force_dist.json 2> gpurun_out/${tag}_bench_config2_force_dist.err
 for f in gpurun_out/${tag}_bench*.json; do python - "$f" <<'PY'
 import json, sys
 try:
