@@ -208,9 +208,7 @@ def main():
     if use_dist:
         # warm the composition path too (RCCL connects its send/recv channels on first use, the
         # caching allocator takes its first staging buffers): one untimed gather + resolve
-        rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}")
-        if rank == 0:
-            renderer.resolve_output(max(view.total_samples, 1), view.accumulation_limit)
+        rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}", resolve=(max(view.total_samples, 1), view.accumulation_limit))
     loop.reset()
     renderer.reset_stats()
     renderer.set_option("time_kernels", 1)
@@ -224,9 +222,8 @@ def main():
         print(f"[debug] frames done at {time.perf_counter() - t0:.4f} s", file=sys.stderr)
     if use_dist:
         # the ONE collective of the data path: RCCL gather of the packed accumulation tiles to rank 0
-        rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}")
-        if rank == 0:
-            renderer.resolve_output(view.total_samples, view.accumulation_limit)
+        # (rank 0 scatters the tiles and recomputes pt_output_image in one launch: uh_compose_tiles)
+        rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}", resolve=(view.total_samples, view.accumulation_limit))
     if os.environ.get("UH_BENCH_DEBUG"):
         renderer.synchronize()
         print(f"[debug] composition done at {time.perf_counter() - t0:.4f} s", file=sys.stderr)

@@ -292,6 +292,10 @@ int uh_tile_pack_count(uh_ctx* ctx, uint32_t rank, uint64_t* out_pixels);
 int uh_pack_tiles(uh_ctx* ctx, void* device_out, uint64_t capacity_pixels);
 /* scatter `from_rank`'s packed tiles (DEVICE buffer) into this context's accumulation image */
 int uh_unpack_tiles(uh_ctx* ctx, uint32_t from_rank, const void* device_in, uint64_t num_pixels);
+/* the root's whole composition in one launch: `device_all` holds `world` packed buffers (rank r's at r * stride_pixels
+ * float4 pixels, as uh_pack_tiles wrote them; the root's own slot is not read); scatters every other rank's tiles into the
+ * accumulation image and recomputes pt_output_image (= uh_unpack_tiles for every rank + uh_resolve_output) */
+int uh_compose_tiles(uh_ctx* ctx, const void* device_all, uint64_t stride_pixels, uint32_t total_samples, uint32_t accumulation_limit);
 /* recompute pt_output_image from the accumulation image (after uh_unpack_tiles on the root) */
 int uh_resolve_output(uh_ctx* ctx, uint32_t total_samples, uint32_t accumulation_limit);
 /* ---- multi-GPU, the reservoir passes: a band of rows per rank + one exchange per frame ------ */

@@ -117,6 +117,7 @@ def load_library(path=LIB_PATH):
         ("uh_tile_pack_count", [C.c_uint32, C.POINTER(C.c_uint64)]),
         ("uh_pack_tiles", [C.c_void_p, C.c_uint64]),
         ("uh_unpack_tiles", [C.c_uint32, C.c_void_p, C.c_uint64]),
+        ("uh_compose_tiles", [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]),
         ("uh_device_pointer", [C.c_int, C.POINTER(C.c_void_p)]),
         ("uh_stream", [C.POINTER(C.c_void_p)]),
     ):
@@ -459,6 +460,10 @@ class Renderer:
 
     def unpack_tiles(self, from_rank, device_ptr, num_pixels):
         self._check(self._lib.uh_unpack_tiles(self._ctx, from_rank, C.c_void_p(device_ptr), num_pixels))
+
+    def compose_tiles(self, device_ptr_all, stride_pixels, total_samples, accumulation_limit=999999):
+        """every other rank's packed tiles (world buffers of stride_pixels each) into the accumulation image + the output resolve, one launch"""
+        self._check(self._lib.uh_compose_tiles(self._ctx, C.c_void_p(device_ptr_all), stride_pixels, total_samples, accumulation_limit))
 
     def device_pointer(self, which):
         out = C.c_void_p()

@@ -1898,6 +1898,22 @@ int uh_pack_tiles(uh_ctx* c, void* device_out, uint64_t capacity_pixels) {
    return UH_OK;
 }
 
+int uh_compose_tiles(uh_ctx* c, const void* device_all, uint64_t stride_pixels, uint32_t total_samples, uint32_t accumulation_limit) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   uint64_t need = 0;
+   for (uint32_t r = 0; r < c->tp_world; r++) {
+      uint64_t n = 0;
+      uh_tile_pack_count(c, r, &n);
+      need = n > need ? n : need;
+   }
+   if (!device_all || stride_pixels < need) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_compose_tiles: stride smaller than a rank's packed tiles");
+   HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
+   launch_compose_tiles(cfg(c), c->im, (const float4*)device_all, stride_pixels, c->W, c->H, c->tp_rank, c->tp_world, c->tp_tile, total_samples, accumulation_limit);
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   return UH_OK;
+}
+
 int uh_unpack_tiles(uh_ctx* c, uint32_t from_rank, const void* device_in, uint64_t num_pixels) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    uint64_t need = 0;

@@ -251,6 +251,8 @@ hipError_t lbvh_build(const LbvhArgs&, hipStream_t, std::vector<uint32_t>& level
 
 void launch_pack_tiles(const LaunchCfg&, const float4* acc, float4* out, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);
 void launch_unpack_tiles(const LaunchCfg&, float4* acc, const float4* in, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile);
+void launch_compose_tiles(const LaunchCfg&, const Images&, const float4* all, uint64_t stride, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile,
+                          uint32_t total_samples, uint32_t limit);
 uint32_t query_trace_occupancy();
 
 }  // namespace uh

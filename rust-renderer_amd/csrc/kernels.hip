@@ -1700,6 +1700,30 @@ void launch_trace_any_raw(const LaunchCfg& c, const SceneDev& sc, const float4* 
    k_trace_any_raw<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, occluded, n);
 }
 
+// the root's composition in one pass over the frame: a pixel of another rank's tile comes out of that rank's packed buffer
+// (`all` holds world buffers of `stride` pixels each, rank r's at r * stride, laid out as k_tiles<true> packs them), the
+// root's own pixels stay, and pt_output_image is recomputed for every pixel (rgen:140-144)
+__global__ __launch_bounds__(kBlock) void k_compose_tiles(Images im, const float4* __restrict__ all, uint64_t stride, uint32_t W, uint32_t H, uint32_t rank, uint32_t world,
+                                                           uint32_t tile, uint32_t total_samples, uint32_t limit) {
+   const uint32_t tiles_x = (W + tile - 1) / tile, n = W * H;
+   for (uint32_t pix = blockIdx.x * kBlock + threadIdx.x; pix < n; pix += gridDim.x * kBlock) {
+      const uint32_t x = pix % W, y = pix / W;
+      const uint32_t t = (y / tile) * tiles_x + x / tile, owner = t % world;
+      float4 acc;
+      if (owner == rank)
+         acc = im.accumulation[pix];
+      else {
+         acc = all[owner * stride + (uint64_t)(t / world) * tile * tile + (y % tile) * tile + x % tile];
+         im.accumulation[pix] = acc;
+      }
+      im.output[pix] = resolve_color(acc, total_samples, limit);
+   }
+}
+void launch_compose_tiles(const LaunchCfg& c, const Images& im, const float4* all, uint64_t stride, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile,
+                          uint32_t total_samples, uint32_t limit) {
+   k_compose_tiles<<<stream_grid(c, W * H), kBlock, 0, c.stream>>>(im, all, stride, W, H, rank, world, tile, total_samples, limit);
+}
+
 void launch_pack_tiles(const LaunchCfg& c, const float4* acc, float4* out, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t tile) {
    k_tiles<true><<<stream_grid(c, W * H), kBlock, 0, c.stream>>>(const_cast<float4*>(acc), out, W, H, rank, world, tile);
 }

@@ -54,21 +54,25 @@ def unpack_tiles_host(acc, packed, tile, rank, world):
     return acc
 
 
-def gather_and_compose(renderer, rank, world, tile, dist, torch, device):
+def gather_and_compose(renderer, rank, world, tile, dist, torch, device, resolve=None):
     """One collective per composed frame. HIP renderers pack on the device and hand RCCL a device
     buffer; CPU (oracle / gloo) renderers go through the numpy restatement. Returns, on rank 0, the
     composed (H, W, 4) accumulation as numpy for CPU renderers, or None after composing in place
-    on the device for HIP renderers."""
+    on the device for HIP renderers. `resolve` = (total_samples, accumulation_limit): the root also recomputes
+    pt_output_image, in the same launch that scatters the tiles (uh_compose_tiles)."""
     counts = [c * tile * tile for c in tile_counts(renderer.width, renderer.height, tile, world)]
     if renderer.backend == "hip":
         buf = torch.empty((max(counts), 4), dtype=torch.float32, device=device)
         renderer.pack_tiles(buf.data_ptr(), buf.shape[0])
-        parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, parts, dst=0)
+        every = torch.empty((world, max(counts), 4), dtype=torch.float32, device=device) if rank == 0 else None
+        dist.gather(buf, list(every.unbind(0)) if rank == 0 else None, dst=0)
         if rank == 0:
             torch.cuda.synchronize()
-            for r in range(1, world):
-                renderer.unpack_tiles(r, parts[r].data_ptr(), counts[r])
+            if resolve is not None:
+                renderer.compose_tiles(every.data_ptr(), max(counts), resolve[0], resolve[1])
+            else:
+                for r in range(1, world):
+                    renderer.unpack_tiles(r, every[r].data_ptr(), counts[r])
         return None
     acc = renderer.read_accumulation()
     buf = torch.zeros((max(counts), 4), dtype=torch.float32)

@@ -166,9 +166,23 @@ def test_tile_partition_composes_to_full_frame(cornell):
             root = r
     for rank, buf in parts[1:]:
         root.unpack_tiles(rank, buf.data_ptr(), buf.shape[0])
+    # the same composition in one launch (uh_compose_tiles: what bench.py's rank 0 does after the RCCL gather), on rank 1 as the root
+    stride = max(buf.shape[0] for _, buf in parts)
+    every = torch.zeros((world, stride, 4), dtype=torch.float32, device="cuda:0")
+    for rank, buf in parts:
+        every[rank, : buf.shape[0]] = buf
+    other = cornell.upload(rr.Renderer(W, H))
+    other.set_tile_partition(1, world, tile)
+    run_frames(other, cornell, W, H, 2, rr.PASS_REFERENCE_PT)
+    every[1].zero_()  # the root's own slot is not read
+    torch.cuda.synchronize()
+    other.compose_tiles(every.data_ptr(), stride, 2)
     root.resolve_output(2)
-    assert np.array_equal(root.read_accumulation().view(np.uint32), ref.view(np.uint32)), "tile-partitioned frame must be bit-identical"
-    assert np.array_equal(root.read_output_bgra8(), full.read_output_bgra8())
+    for r in (root, other):
+        assert np.array_equal(r.read_accumulation().view(np.uint32), ref.view(np.uint32)), "tile-partitioned frame must be bit-identical"
+        assert np.array_equal(r.read_output_bgra8(), full.read_output_bgra8())
+    with pytest.raises(rr.UtopianError):
+        other.compose_tiles(every.data_ptr(), 16, 2)  # stride smaller than a rank's tiles
 
 
 def test_error_paths():
