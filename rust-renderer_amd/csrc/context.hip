@@ -80,7 +80,7 @@ struct Slot {
    hipEvent_t ev_acc = nullptr;  // recorded after the frame's accumulate / store tail
    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
    DevBuf<float4> rec, rad, pixcol;  // rec: the four path-state planes (device_types.h PathState)
-   DevBuf<uint32_t> queues[4];
+   DevBuf<uint32_t> queues[5];
    DevBuf<Control> control;
    PathState ps{};
    bool ready = false;
@@ -116,7 +116,7 @@ struct Slot {
       ps.rec = PathRecs{rec.p, plane};
       ps.rad = rad.p;
       ps.pixcol = pixcol.p;
-      for (int i = 0; i < 4; i++) ps.queue[i] = queues[i].p;
+      for (int i = 0; i < 5; i++) ps.queue[i] = queues[i].p;
       ps.shard_cap = shard_cap;
       ready = true;
       return hipSuccess;
@@ -1112,37 +1112,37 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       uint32_t slot = 0;
       launch_generate(lc, fp, s.ps, ctl, smp);
       for (uint32_t b = 0; b < fp.num_bounces; b++) {
-         // trace_closest(b) refills the miss queue that shade_miss(b-1) reads on the side stream
-         if (c->overlap_miss && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_missed, 0));
          begin_timed(c, 0, s.stream);
          if (b == 0 && c->primary_tiles && primary_tiles_apply(fp))
             launch_trace_primary_tiles(lc, fp, c->scene, s.ps, st);  // coherent: one wave per 8 x 8 pixel tile, nodes through the scalar path
          else
             launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
          end_timed(c, s.stream);
-         if (c->overlap_miss) {
-            // side stream: shade_miss(b) after trace_closest(b); joined before finish_sample
-            HIP_TRY(c, hipEventRecord(s.ev_traced, s.stream));
-            HIP_TRY(c, hipStreamWaitEvent(s.side, s.ev_traced, 0));
-            LaunchCfg ls = lc;
-            ls.stream = s.side;
-            launch_shade_miss(ls, fp, s.ps, ctl, st, b);
-            HIP_TRY(c, hipEventRecord(s.ev_missed, s.side));
-         }
          const bool side_shadow = c->overlap_shadow && (fp.sun_shadow_enabled == 1 || fp.lights_enabled == 1);
-         // shade_hit(b) rewrites ray_o / thr / rad of the paths shadow(b-1) still reads on the side stream
-         if (side_shadow && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_shadowed, 0));
+         const bool side_used = side_shadow || c->overlap_miss;
+         // shade_hit(b) rewrites ray_o / thr / rad of the paths shadow(b-1) still reads on the side stream, and refills the
+         // miss queue shade_miss(b-1) reads there
+         if (side_used && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_shadowed, 0));
          begin_timed(c, 2, s.stream);
+         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b);  // also hands the bounce's misses to shade_miss (Q_MISS)
          if (!c->overlap_miss) launch_shade_miss(lc, fp, s.ps, ctl, st, b);
-         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b);
          end_timed(c, s.stream);
-         // shadow traversals of bounce b are independent of trace_closest(b+1) (both only read what
+         // shade_miss(b) and the shadow queries of bounce b are independent of trace_closest(b+1) (they only read what
          // shade_hit(b) wrote): on the side stream their blocks fill the tail of the other kernel
          LaunchCfg lsh = lc;
          hipStream_t sh_stream = s.stream;
-         if (side_shadow) {
+         if (side_used) {
             HIP_TRY(c, hipEventRecord(s.ev_shaded, s.stream));
             HIP_TRY(c, hipStreamWaitEvent(s.side, s.ev_shaded, 0));
+         }
+         if (c->overlap_miss) {
+            LaunchCfg ls = lc;
+            ls.stream = s.side;
+            begin_timed(c, 2, s.side);
+            launch_shade_miss(ls, fp, s.ps, ctl, st, b);
+            end_timed(c, s.side);
+         }
+         if (side_shadow) {
             lsh.stream = s.side;
             sh_stream = s.side;
          }
@@ -1160,7 +1160,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
             launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, true);
             end_timed(c, sh_stream);
          }
-         if (side_shadow) HIP_TRY(c, hipEventRecord(s.ev_shadowed, s.side));
+         if (side_used) HIP_TRY(c, hipEventRecord(s.ev_shadowed, s.side));
       }
       if ((c->overlap_miss || c->overlap_shadow) && fp.num_bounces > 0) {
          HIP_TRY(c, hipEventRecord(s.ev_side_done, s.side));

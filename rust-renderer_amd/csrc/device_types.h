@@ -15,8 +15,10 @@ namespace uh {
 constexpr uint32_t kMaxBounces = 64;
 // per bounce: RAY (paths whose ray the bounce traces; the shading kernels tell hits from misses by the hit
 // record, so no hit / miss queues exist) and LIGHT (scattered paths that carry a light sample)
-constexpr uint32_t kQueueKinds = 3;
-enum { Q_RAY = 0, Q_LIGHT = 1, Q_SUN_TREE = 2 };  // Q_SUN_TREE: sun rays the grid kernel hands to the tree walk (border cells, long lists)
+constexpr uint32_t kQueueKinds = 4;
+// Q_SUN_TREE: sun rays the grid kernel hands to the tree walk (border cells, long lists). Q_MISS: the paths of a bounce whose ray
+// left the scene - k_shade_hit meets them while it classifies the bounce's RAY queue and hands their ids to k_shade_miss
+enum { Q_RAY = 0, Q_LIGHT = 1, Q_SUN_TREE = 2, Q_MISS = 3 };
 constexpr uint32_t kLaunchSlots = kMaxBounces * 4 + 4;  // per bounce: closest, sun (grid), sun leftovers (tree), light
 
 // Queues are sharded: path p lives in shard shard_of_run(p / 64) for its whole life, every queue
@@ -137,7 +139,7 @@ struct PathState {
    PathRecs rec;
    float4* rad;     // radiance.rgb, light index (bits): touched only where a path ends or a light / sun sample lands
    float4* pixcol;  // sum over the frame's samples
-   uint32_t* queue[4];  // 0,1 = ray ping-pong; 2 = light; 3 = sun rays for the tree walk; each kShards * shard_cap entries
+   uint32_t* queue[5];  // 0,1 = ray ping-pong; 2 = light; 3 = sun rays for the tree walk; 4 = misses; each kShards * shard_cap entries
    uint32_t shard_cap;  // entries per shard segment = pixels a shard can own (multiple of 64)
 };
 __host__ __device__ inline float4* rec_quad(const PathRecs& rec, uint32_t id, int quad) { return rec.base + rec.plane * (size_t)quad + id; }

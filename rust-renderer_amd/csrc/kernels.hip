@@ -975,51 +975,15 @@ __device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const Pat
    st_stream(ps.rad + id, make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w));   // rgen:55
 }
 
+// The bounce's misses arrive as a queue of their own (Q_MISS), written by k_shade_hit while it classifies the bounce's RAY
+// queue: every lane has a path, no hit record is read here, and nothing but the sky integral (~600 VALU instructions per
+// path) and four 16-byte records per path is left in the kernel.
 __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
-   __shared__ uint32_t s_list[kWavesPerBlock][128];
-   __shared__ uint32_t s_total;
-   if (threadIdx.x == 0) s_total = 0;
-   __syncthreads();
-   const uint32_t lane = lane_id();
-   uint32_t* list = s_list[threadIdx.x >> 6];
    const ShardCtx sx = shard_ctx();
-   const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + sx.shard * ps.shard_cap;
-   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
-   const uint32_t stride = sx.nb * kBlock;
-   const uint32_t rounds = (count + stride - 1) / stride;
-   uint32_t n_list = 0, n_total = 0;  // wave-uniform
-   for (uint32_t r = 0; r < rounds; r++) {
-      const uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
-      bool miss = false;
-      uint32_t id = 0;
-      if (i < count) {
-         id = ld_stream(queue + i);
-         miss = __float_as_uint(ld_rec(rec_quad(ps.rec, id, REC_HIT)).w) == kEmptyRef;
-      }
-      const unsigned long long mask = __ballot(miss);
-      if (mask == 0ull) continue;
-      const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      if (miss) list[n_list + prefix] = id;
-      n_list += (uint32_t)__popcll(mask);
-      __builtin_amdgcn_wave_barrier();
-      if (n_list >= 64u) {
-         shade_miss_path(fp, ps, list[lane], bounce);
-         n_total += 64u;
-         // move the tail (at most 63 ids) to the front: one wave, LDS operations execute in order
-         const uint32_t rest = n_list - 64u;
-         uint32_t tmp = 0;
-         if (lane < rest) tmp = list[64u + lane];
-         __builtin_amdgcn_wave_barrier();
-         if (lane < rest) list[lane] = tmp;
-         __builtin_amdgcn_wave_barrier();
-         n_list = rest;
-      }
-   }
-   if (lane < n_list) shade_miss_path(fp, ps, list[lane], bounce);
-   n_total += n_list;
-   if (lane == 0 && n_total) atomicAdd(&s_total, n_total);
-   __syncthreads();
-   if (threadIdx.x == 0 && s_total) atomicAdd(&stats->misses, (unsigned long long)s_total);
+   const uint32_t* __restrict__ queue = ps.queue[4] + sx.shard * ps.shard_cap;
+   const uint32_t count = ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
+   for (uint32_t i = sx.lb * kBlock + threadIdx.x; i < count; i += sx.nb * kBlock) shade_miss_path(fp, ps, ld_stream(queue + i), bounce);
+   if (sx.lb == 0 && threadIdx.x == 0 && count) atomicAdd(&stats->misses, (unsigned long long)count);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1083,6 +1047,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
    __shared__ uint32_t s_hits;
    __shared__ uint32_t s_list[kWavesPerBlock][5][128];  // per wave: path ids, and the hit record (t, u, v, packet) the classification read with them
+   __shared__ uint32_t s_miss[kWavesPerBlock][128];     // per wave: ids of the paths that missed, handed to k_shade_miss 64 at a time
    if (threadIdx.x == 0) s_hits = 0;
    if (threadIdx.x < n_lds_mesh) s_mesh[threadIdx.x] = sc.meshes[threadIdx.x];
    if (threadIdx.x < n_lds_tex) s_tex[threadIdx.x] = sc.textures[threadIdx.x];
@@ -1096,6 +1061,8 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    uint32_t* n_next = &ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    uint32_t* q_light = ps.queue[2] + seg;
    uint32_t* n_light = &ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)];
+   uint32_t* q_miss = ps.queue[4] + seg;
+   uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
    const uint32_t stride = sx.nb * kBlock;
    const uint32_t rounds = (count + stride - 1) / stride;
    uint32_t n_hits = 0;
@@ -1230,8 +1197,16 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    // queue entries as they come leaves the lanes of the misses idle through the whole material evaluation, so the hits
    // are first compacted inside the wave: their ids collect in a per-wave LDS list and are shaded 64 at a time.
    uint32_t(*list)[128] = s_list[threadIdx.x >> 6];  // [0] ids, [1..4] the hit record's four words
+   uint32_t* missed = s_miss[threadIdx.x >> 6];
    const uint32_t lane = lane_id();
-   uint32_t n_list = 0;  // wave-uniform
+   uint32_t n_list = 0, n_missed = 0;  // wave-uniform
+   // `n` ids from the front of the wave's miss list go to the bounce's miss queue (one atomic per call)
+   auto flush_misses = [&](uint32_t n) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(n_miss, n);
+      base = __shfl(base, 0);
+      if (lane < n) st_stream(q_miss + base + lane, missed[lane]);
+   };
    auto entry = [&](uint32_t k) { return make_float4(__uint_as_float(list[1][k]), __uint_as_float(list[2][k]), __uint_as_float(list[3][k]), __uint_as_float(list[4][k])); };
    for (uint32_t r = 0; r < rounds; r++) {
       const uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
@@ -1243,6 +1218,23 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
       }
       const bool is_hit = __float_as_uint(hr.w) != kEmptyRef;
       const unsigned long long mask = __ballot(is_hit);
+      const unsigned long long mmask = __ballot(i < count && !is_hit);
+      if (mmask) {
+         const uint32_t mp = __builtin_amdgcn_mbcnt_hi((uint32_t)(mmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mmask, 0u));
+         if (i < count && !is_hit) missed[n_missed + mp] = id;
+         n_missed += (uint32_t)__popcll(mmask);
+         __builtin_amdgcn_wave_barrier();
+         if (n_missed >= 64u) {
+            flush_misses(64u);
+            const uint32_t rest = n_missed - 64u;  // at most 63: to the front (one wave, LDS operations execute in order)
+            uint32_t tmp = 0;
+            if (lane < rest) tmp = missed[64u + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) missed[lane] = tmp;
+            __builtin_amdgcn_wave_barrier();
+            n_missed = rest;
+         }
+      }
       if (mask == 0ull) continue;
       const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
       if (is_hit) {
@@ -1272,6 +1264,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
       shade(lane < n_list ? list[0][lane] : 0u, lane < n_list ? entry(lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f), lane < n_list);
       n_hits += n_list;
    }
+   if (n_missed) flush_misses(n_missed);
    // closest_hits: per-block sum, one atomic per block (n_hits is wave-uniform)
    if (lane_id() == 0 && n_hits) atomicAdd(&s_hits, n_hits);
    __syncthreads();
@@ -1603,9 +1596,9 @@ void launch_trace_primary_tiles(const LaunchCfg& c, const FrameParams& fp, const
 }
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
-   // per-wave compaction leaves one partial batch of misses per wave: a grid of 4 blocks per CU (not one block per 256
-   // pixels) gives every wave enough rays that this tail is a small share of its sky integrals
-   const dim3 full = shade_grid(c, fp.W * fp.H * fp.batch_frames), lean = sharded_grid(c.num_cus * 4);
+   // the bounce's misses are a dense queue (Q_MISS, written by k_shade_hit): every lane shades one; the count is on the
+   // device, so the grid is sized for the paths the wavefront started with
+   const dim3 full = shade_grid(c, fp.n_owned * fp.batch_frames), lean = sharded_grid(c.num_cus * 4);
    k_shade_miss<<<full.x < lean.x ? full : lean, kBlock, 0, c.stream>>>(fp, ps, ctl, stats, bounce);
 }
 
