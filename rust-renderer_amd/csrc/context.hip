@@ -1669,6 +1669,10 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_density (entries per triangle) must be 1..4096");
       c->sun_limits.entries_per_triangle = (double)value;
       c->sun_attempted = false;
+   } else if (n == "sun_grid_max_walk") {
+      if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_walk (longest list a ray tests itself) must be 1..4096");
+      c->sun_limits.max_walk = (uint32_t)value;
+      c->sun_attempted = false;
    } else if (n == "sun_grid_max_mb") {
       if (value < 1 || value > 65536) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_mb must be 1..65536");
       c->sun_limits.max_entries = ((uint64_t)value << 20) / sizeof(SunGridEntry);

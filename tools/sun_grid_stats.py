@@ -6,7 +6,10 @@ import rust_renderer_amd as rr
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 scene = rr.scenes.scene_for_config(cfg, tex_size=64)
 W, H = (256, 256) if cfg == 0 else (1920, 1080)
-for opts in ([("sun_grid", 0)], [], [("sun_grid_density", 12)], [("sun_grid_density", 200), ("sun_grid_max_mb", 2048)]):
+sweeps = ([("sun_grid", 0)], [], [("sun_grid_density", 12)], [("sun_grid_density", 200), ("sun_grid_max_mb", 2048)])
+if len(sys.argv) > 2 and sys.argv[2] == "walk":
+    sweeps = [[("sun_grid_max_walk", w)] for w in (8, 16, 32, 64, 128)]
+for opts in sweeps:
     r = rr.Renderer(W, H)
     for k, v in opts: r.set_option(k, v)
     scene.upload(r)
