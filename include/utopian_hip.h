@@ -212,6 +212,7 @@ typedef struct UhStats {
    uint32_t sun_grid_entries;   /* (triangle, cell) pairs it holds */
    float sun_grid_build_ms;     /* host time of its last build (once per sun direction and geometry) */
    float sun_grid_mean_list;    /* entries per occupied cell */
+   uint64_t sun_tree_rays;      /* sun shadow rays the grid handed to the tree walk (border cells, long lists); part of rays[UH_RAY_SUN_SHADOW] */
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;

@@ -1625,6 +1625,7 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->sun_grid_entries = c->sun_valid ? c->sun_entries : 0;
    out->sun_grid_build_ms = c->sun_build_ms;
    out->sun_grid_mean_list = c->sun_mean_list;
+   out->sun_tree_rays = ds.sun_tree_rays;
    return UH_OK;
 }
 

@@ -56,6 +56,7 @@ struct DeviceStats {
    unsigned long long rays[UH_RAY_KINDS];
    unsigned long long nodes_visited, tris_tested, shadow_nodes_visited, shadow_tris_tested;
    unsigned long long closest_hits, misses;
+   unsigned long long sun_tree_rays;  // sun rays k_trace_sun_grid handed to the tree walk
 };
 
 // per-mesh shading record (80 B): inverse instance rotation/scale + the material fields the

@@ -743,7 +743,10 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    src.count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : leftovers ? ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    src.wave_index = src.num_waves = 0;
-   if (sx.lb == 0 && threadIdx.x == 0 && !leftovers) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)src.count);
+   if (sx.lb == 0 && threadIdx.x == 0) {
+      if (!leftovers) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)src.count);
+      else if (src.count) atomicAdd(&stats->sun_tree_rays, (unsigned long long)src.count);  // counted as sun rays by the grid kernel already
+   }
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
    const PathRecs rec = ps.rec;

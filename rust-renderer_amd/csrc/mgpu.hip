@@ -357,6 +357,7 @@ int uh_mgpu_get_stats(uh_mgpu* m, UhStats* out) {
       out->shadow_tris_tested += s.shadow_tris_tested;
       out->closest_hits += s.closest_hits;
       out->misses += s.misses;
+      out->sun_tree_rays += s.sun_tree_rays;
       out->frames = s.frames;
       out->bvh_nodes = s.bvh_nodes;
       out->bvh_triangles = s.bvh_triangles;

@@ -127,6 +127,7 @@ class Stats(C.Structure):
         ("sun_grid_entries", C.c_uint32),
         ("sun_grid_build_ms", C.c_float),
         ("sun_grid_mean_list", C.c_float),
+        ("sun_tree_rays", C.c_uint64),
     ]
 
     @property

@@ -18,7 +18,7 @@ for opts in sweeps:
     loop.frame(rr.PASS_REFERENCE_PT)
     s = r.get_stats()
     print(opts, "cells", s.sun_grid_cells, "entries", s.sun_grid_entries, "build ms", s.sun_grid_build_ms, "mean list", s.sun_grid_mean_list,
-          "tests/ray", s.shadow_tris_tested / s.rays[2], "rays", s.rays[2])
+          "tests/ray", s.shadow_tris_tested / s.rays[2], "rays", s.rays[2], "handed to the tree", s.sun_tree_rays)
     r.set_option("count_visits", 0)
     r.set_option("time_kernels", 1)
     for k, v in (("frames_in_flight", 1), ("overlap_miss", 0), ("overlap_shadow", 0)): r.set_option(k, v)
