@@ -103,7 +103,10 @@ struct Slot {
       SLOT_TRY(hipEventCreate(&frame_start));
       SLOT_TRY(hipEventCreate(&frame_stop));
       const size_t stagger = 4352;  // 4 KiB + 256 B per array slot
-      const size_t plane = n + stagger / sizeof(float4);  // planes staggered like the arrays: the same index of two planes must not alias
+      // planes staggered like the arrays: the same index of two planes must not alias. The hit plane is indexed by queue position
+      // (shard segment + position in the shard's queue), which runs to kShards * shard_cap >= n
+      const size_t cap_q = (size_t)shard_cap * kShards;
+      const size_t plane = (n > cap_q ? n : cap_q) + stagger / sizeof(float4);
       SLOT_TRY(rec.alloc(plane * kRecQuads, 0 * stagger));
       SLOT_TRY(rad.alloc(n, 1 * stagger));
       SLOT_TRY(pixcol.alloc(n, 2 * stagger));
@@ -1113,7 +1116,8 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       launch_generate(lc, fp, s.ps, ctl, smp);
       for (uint32_t b = 0; b < fp.num_bounces; b++) {
          begin_timed(c, 0, s.stream);
-         if (b == 0 && c->primary_tiles && primary_tiles_apply(fp))
+         const bool tiles = b == 0 && c->primary_tiles && primary_tiles_apply(fp);
+         if (tiles)
             launch_trace_primary_tiles(lc, fp, c->scene, s.ps, st);  // coherent: one wave per 8 x 8 pixel tile, nodes through the scalar path
          else
             launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
@@ -1124,7 +1128,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          // miss queue shade_miss(b-1) reads there
          if (side_used && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_shadowed, 0));
          begin_timed(c, 2, s.stream);
-         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b);  // also hands the bounce's misses to shade_miss (Q_MISS)
+         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b, tiles);  // also hands the bounce's misses to shade_miss (Q_MISS)
          if (!c->overlap_miss) launch_shade_miss(lc, fp, s.ps, ctl, st, b);
          end_timed(c, s.stream);
          // shade_miss(b) and the shadow queries of bounce b are independent of trace_closest(b+1) (they only read what

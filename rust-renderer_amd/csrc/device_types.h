@@ -194,7 +194,7 @@ void launch_trace_closest(const LaunchCfg&, const SceneDev&, const PathState&, C
 bool primary_tiles_apply(const FrameParams&);
 void launch_trace_primary_tiles(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, DeviceStats*);
 void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, DeviceStats*, uint32_t bounce);
-void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
+void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce, bool hits_by_path);
 void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
                          uint32_t cursor_slot, bool light, bool sun_leftovers = false);
 // sun shadow rays through the per-direction grid (sun_grid.h) instead of the tree

@@ -339,6 +339,7 @@ struct Feeder {
    uint32_t q_n = 0;            // valid lanes of q_id
    uint32_t static_k = 0;
    uint32_t iterations = 0;
+   uint32_t q_base = 0, load_base = 0, pool_base = 0;  // first queue position of the chunk in q_id / in flight / in the pool
    bool loading = false, have_base = false, drained = false;
    // per-lane pipeline registers
    uint32_t r_base = 0;         // lane 0: what the newest cursor atomic returned
@@ -352,6 +353,7 @@ struct Feeder {
          wait_vm0();
          pos = 0;
          n = load_n;
+         pool_base = load_base;
          loading = false;
       }
    }
@@ -368,6 +370,7 @@ struct Feeder {
             pool.id[lane] = q_id;
          }
          load_n = q_n;
+         load_base = q_base;
          loading = true;
          q_n = 0;
       }
@@ -375,6 +378,7 @@ struct Feeder {
          const uint32_t b = __builtin_amdgcn_readfirstlane(r_base);
          have_base = false;
          if (b < src.count) {
+            q_base = b;
             q_n = src.count - b < kPool ? src.count - b : kPool;
             if (lane < q_n) q_id = src.queue ? ld_stream(src.queue + b + lane) : b + lane;
          } else {
@@ -457,7 +461,9 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
 
 // ------------------------------------------------------------------------------------------
 // trace_closest — reference.rgen:47 traceRayEXT(..., payload 0) minus the shaders it invokes.
-// Reads the bounce's ray queue, writes hit[path] = (t, u, v, packet) or packet = kEmptyRef.
+// Reads the bounce's ray queue, writes hit[queue position] = (t, u, v, packet) or packet = kEmptyRef: the shading kernel walks
+// the same queue and reads the records back as one contiguous stream (a record per path id was a 64-byte sector per 16-byte
+// record there).
 // ------------------------------------------------------------------------------------------
 // Path rays (queue_base != null): ray_o / ray_d / hit_out are planes 0 / 1 / 3 of the path state, whose w components carry RNG
 // words: the range is rgen:45-47's constants. Raw rays (queue_base == null, RawRays): the range is in the w components.
@@ -473,9 +479,11 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
    uint32_t* lds_col = &s_stack[wave][0][lane];
    RayPool<2>& pool = s_pool[wave];
    RaySource src;
+   uint32_t seg = 0;  // first record of this block's results: its shard's segment (path rays) or 0 (raw rays: record i = ray i)
    if (queue_base) {  // path tracer: this block's shard of the bounce's ray queue, chunks from the shard's cursor
       const ShardCtx sx = shard_ctx();
-      src.queue = queue_base + sx.shard * shard_cap;
+      seg = sx.shard * shard_cap;
+      src.queue = queue_base + seg;
       src.count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
       src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
       src.wave_index = src.num_waves = 0;
@@ -495,10 +503,10 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
    Trav t;
    t.cur = kEmptyRef;
    t.sp = 0;
-   uint32_t id = 0, n_nodes = 0, n_tris = 0;
+   uint32_t where = 0, n_nodes = 0, n_tris = 0;
    uint32_t spill[kSpillStack];
    auto take = [&](uint32_t slot) {
-      id = pool.id[slot];
+      where = seg + f.pool_base + slot;  // the ray's position in the queue (the pool holds one chunk: positions pool_base ..)
       const float4 ro = pool.v[0][slot], rd = pool.v[1][slot];
       trav_init(t, ro, rd, range_in_w ? ro.w : 0.001f, range_in_w ? rd.w : 10000.0f, INFINITY);
    };
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
       if (t.cur != kEmptyRef) {
          bool occluded = false;
          if (trav_step<false, COUNT>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris))
-            st_rec(hit_out + id, make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx)));
+            st_rec(hit_out + where, make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx)));
       }
    }
    if (COUNT) {
@@ -682,7 +690,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
          float4 ro = ray_o[id], rd = ray_d[id];  // path state: w = RNG words, range = rgen:45-47's constants
          Hit h;
          traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 0.001f, 10000.0f, 0.0f, h, lds_col, n_nodes, n_tris);
-         hit_out[id] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
+         hit_out[sx.shard * shard_cap + i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));  // by queue position, as the refill kernel
       }
    }
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
@@ -1036,7 +1044,8 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
    return I * eta - N * (eta * dn + sqrtf(k));
 }
 
-__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
+// hits_by_path: the hit records lie by path id (the wave-per-tile kernel wrote them), not by queue position
+__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce, bool hits_by_path) {
    // c / 255.0f table in LDS: the 12 per-fetch table gathers were texture-addresser traffic (the
    // kernel ran 86 % TA-busy at 2 % VALU, profiles/r01c_*); LDS serves them at no TA cost
    __shared__ float s_lut[256];
@@ -1217,7 +1226,9 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
       float4 hr = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmptyRef));
       if (i < count) {
          id = ld_stream(queue + i);
-         hr = ld_rec(rec_quad(ps.rec, id, REC_HIT));  // the whole record (one 16-byte lane load, as the packet index alone would be): shade() does not read it again
+         // the whole record (one 16-byte lane load, as the packet index alone would be): shade() does not read it again. The
+         // traversal kernel left it at the ray's queue position: the wave reads 1 KiB in one piece
+         hr = ld_rec(rec_quad(ps.rec, hits_by_path ? id : seg + i, REC_HIT));
       }
       const bool is_hit = __float_as_uint(hr.w) != kEmptyRef;
       const unsigned long long mask = __ballot(is_hit);
@@ -1606,8 +1617,8 @@ void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathStat
 }
 
 void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
-                      DeviceStats* stats, uint32_t bounce) {
-   k_shade_hit<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce);
+                      DeviceStats* stats, uint32_t bounce, bool hits_by_path) {
+   k_shade_hit<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce, hits_by_path);
 }
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
