@@ -181,6 +181,7 @@ struct uh_ctx {
    uint32_t W = 0, H = 0;
    uint32_t num_cus = 256;
    uint32_t closest_blocks_per_cu = 6, shadow_blocks_per_cu = 5;  // what the refill kernels' LDS (stacks + ray pool) admits
+   uint32_t miss_blocks_per_cu = 8;  // 2 / 4 / 6 / 8: 7,599 / 7,613-7,656 / 7,699 / 7,676-7,678 Mrays/s
    std::string err;
 
    // host scene
@@ -317,7 +318,7 @@ void set_transform(HostMesh& m, const float* w) {
 
 LaunchCfg cfg(uh_ctx* c) {
    return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->closest_variant, c->shadow_variant, c->raw_visit_counts,
-                    c->primary_tiles};
+                    c->primary_tiles, c->miss_blocks_per_cu};
 }
 
 void begin_timed(uh_ctx* c, int kind, hipStream_t stream = nullptr) {
@@ -1716,6 +1717,9 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 0 || value > 1) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0 (batch kernels) or 1 (refill kernels)");
       if (n != "shadow_variant") c->closest_variant = value;
       if (n != "closest_variant") c->shadow_variant = value;
+   } else if (n == "miss_blocks_per_cu") {
+      if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, "miss_blocks_per_cu must be 1..8");
+      c->miss_blocks_per_cu = (uint32_t)value;
    } else if (n == "trace_blocks_per_cu" || n == "closest_blocks_per_cu" || n == "shadow_blocks_per_cu") {
       if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 1..8");
       if (n != "shadow_blocks_per_cu") c->closest_blocks_per_cu = (uint32_t)value;

@@ -186,6 +186,7 @@ struct LaunchCfg {
    int closest_variant, shadow_variant;
    bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
    bool primary_tiles = false;     // primary rays and the G-buffer cast: one wave per 8 x 8 pixel tile (k_trace_closest_tiles)
+   uint32_t miss_blocks_per_cu = 8; // k_shade_miss (dense miss queue, VALU-bound sky integral): option "miss_blocks_per_cu"
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);

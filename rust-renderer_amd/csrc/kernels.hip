@@ -1612,7 +1612,7 @@ void launch_trace_primary_tiles(const LaunchCfg& c, const FrameParams& fp, const
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
    // the bounce's misses are a dense queue (Q_MISS, written by k_shade_hit): every lane shades one; the count is on the
    // device, so the grid is sized for the paths the wavefront started with
-   const dim3 full = shade_grid(c, fp.n_owned * fp.batch_frames), lean = sharded_grid(c.num_cus * 4);
+   const dim3 full = shade_grid(c, fp.n_owned * fp.batch_frames), lean = sharded_grid(c.num_cus * c.miss_blocks_per_cu);
    k_shade_miss<<<full.x < lean.x ? full : lean, kBlock, 0, c.stream>>>(fp, ps, ctl, stats, bounce);
 }
 
