@@ -50,12 +50,14 @@ static_assert(sizeof(Node4C) == 48, "device node = three 16-byte loads");
 constexpr uint32_t kMetaTriShift = 24, kMetaChildShift = 28;
 // Stride of the device arrays in 16-byte units. A 48-byte record at a 48-byte stride straddles two 64-byte cache
 // sectors half of the time; at a 64-byte stride (the last 16 bytes unused) every record is one sector - more bytes of
-// working set against fewer sector fetches per record (measured: profiles/README.md "record stride").
+// working set against fewer sector fetches per record. Measured (profiles/README.md "record stride"): neutral for both
+// arrays in round 2; with the sun grid, whose rays fetch packets and nothing else of the tree, triangle packets at 64 bytes
+// are worth +3 % (config 1 7,620 -> 7,841 Mrays/s, 4K Bistro-class 6,230 -> 6,429, config 2 +1.9 %), nodes at 64 bytes -3 %.
 #ifndef UH_NODE_STRIDE16
 #define UH_NODE_STRIDE16 3
 #endif
 #ifndef UH_TRI_STRIDE16
-#define UH_TRI_STRIDE16 3
+#define UH_TRI_STRIDE16 4
 #endif
 constexpr uint32_t kNodeStride16 = UH_NODE_STRIDE16, kTriStride16 = UH_TRI_STRIDE16;
 
