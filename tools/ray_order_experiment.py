@@ -72,6 +72,34 @@ timed(b, "bounce, pixel order")
 timed(b[rng.permutation(len(b))], "bounce, random shuffle")
 timed(b[np.argsort(octant, kind='stable')], "bounce, octant bins (stable)")
 timed(b[np.argsort(mc, kind='stable')], "bounce, morton(origin)")
+
+
+def per_xcd(key8, label, chunk=64, blocks=256 * 6, waves_per_block=4):
+    """chunks of 64 rays whose 3-bit key equals the XCD their wave runs on: raw rays are handed out statically, chunk c to wave
+    c % num_waves, block = wave // 4, XCD = block % 8 (round-robin dispatch)"""
+    num_waves = blocks * waves_per_block
+    pools = [list(np.flatnonzero(key8 == k)) for k in range(8)]
+    pos = [0] * 8
+    order = np.empty(len(b), np.int64)
+    nchunks = (len(b) + chunk - 1) // chunk
+    at = 0
+    for c in range(nchunks):
+        want = ((c % num_waves) // waves_per_block) % 8
+        need = min(chunk, len(b) - at)
+        while need:
+            k = want if pos[want] < len(pools[want]) else max(range(8), key=lambda q: len(pools[q]) - pos[q])
+            take = min(need, len(pools[k]) - pos[k])
+            order[at:at + take] = pools[k][pos[k]:pos[k] + take]
+            pos[k] += take
+            at += take
+            need -= take
+    timed(b[order], label)
+
+
+per_xcd(octant.astype(np.int64), "bounce, octant = XCD, 64-ray chunks")
+per_xcd((rng.integers(0, 8, len(b))).astype(np.int64), "bounce, random key = XCD (control)")
+zq = np.minimum(((b[:, 0] - b[:, 0].min()) / (np.ptp(b[:, 0]) + 1e-9) * 8).astype(np.int64), 7)
+per_xcd(zq, "bounce, origin x slab = XCD")
 timed(b[np.argsort((octant << np.uint64(30)) | mc, kind='stable')], "bounce, octant then morton")
 timed(b[np.argsort((mc >> np.uint64(15) << np.uint64(3)) | octant, kind='stable')], "bounce, morton15 then octant")
 # direction-only fine sort: octahedral-ish quantisation of direction, 6 bits per axis
