@@ -288,6 +288,15 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
       cell *= 1.3;
    }
 
+   {  // lists too long to beat the tree walk: known after the count pass - no fill, no sort
+      uint64_t occupied = 0;
+      for (size_t c = 0; c < (size_t)out.nx * out.ny; c++) occupied += counts[c] ? 1 : 0;
+      out.mean_list = occupied ? (double)total / (double)occupied : 0.0;
+      if (out.mean_list > lim.max_mean_list) {
+         out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+         return refuse("lists too long for this direction (mean " + std::to_string(out.mean_list) + " entries per occupied cell)");
+      }
+   }
    // ---- offsets, fill, sort
    const size_t ncell = (size_t)out.nx * out.ny;
    out.cell_start.resize(ncell + 1);
