@@ -141,3 +141,31 @@ def test_partition_change_keeps_the_history(atrium):
         for _ in range(n):
             loop.frame(rr.PASS_RESTIR)
     assert same_reservoirs(a.read_reservoirs(2), b.read_reservoirs(2))
+
+
+def test_error_paths_of_the_partition_verbs():
+    import ctypes as C
+
+    r = rr.Renderer(32, 24)
+    with pytest.raises(rr.UtopianError):
+        r.set_restir_partition(3, 3)       # rank < world
+    with pytest.raises(rr.UtopianError):
+        r.set_restir_partition(0, 0)
+    lib = r._lib
+    lib.uh_rccl_attach.argtypes, lib.uh_rccl_attach.restype = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p], C.c_int
+    assert lib.uh_rccl_attach(r._ctx, 0, 1, None) != 0, "no id"
+    assert lib.uh_rccl_attach(r._ctx, 2, 2, (C.c_uint8 * 128)()) != 0, "rank < world"
+    lib.uh_rccl_detach.argtypes, lib.uh_rccl_detach.restype = [C.c_void_p], C.c_int
+    assert lib.uh_rccl_detach(r._ctx) == 0, "detaching what was never attached is not an error"
+    lib.uh_get_restir_rows.argtypes, lib.uh_get_restir_rows.restype = [C.c_void_p, C.c_void_p], C.c_int
+    assert lib.uh_get_restir_rows(r._ctx, None) != 0
+    # more ranks than rows: the ranks beyond the frame get an empty band and launch nothing
+    scene = rr.scenes.cornell_scene(subdivisions=1, tex_size=8)
+    tiny = scene.upload(rr.Renderer(16, 3))
+    tiny.set_restir_partition(5, 8)
+    rows = tiny.restir_rows()
+    assert rows.band_rows == 0 and rows.reuse_rows == 0 and rows.cast_rows == 0
+    run_frames(tiny, scene, 16, 3, 2, rr.PASS_ALL, use_ris_light_sampling=1)
+    assert tiny.get_stats().rays[rr.RAY_GBUFFER] == 0
+    r.close()
+    tiny.close()
