@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
@@ -260,6 +261,8 @@ struct uh_ctx {
    float sun_build_ms = 0.0f, sun_mean_list = 0.0f;
    uint32_t sun_cells = 0, sun_entries = 0, sun_max_list = 0;
    bool sun_this_frame = false;     // set by render_batch for the frame being enqueued
+   bool sun_async = false;          // option "sun_grid_async": build on a host thread, walk the tree until it is done
+   struct SunJob* sun_job = nullptr;
 
    // tile partition
    uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
@@ -423,6 +426,8 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    return UH_OK;
 }
 
+static void drop_sun_job(uh_ctx* c);
+
 void uh_destroy(uh_ctx* c) {
    if (!c) return;
    (void)hipSetDevice(c->device);
@@ -433,6 +438,7 @@ void uh_destroy(uh_ctx* c) {
       (void)hipStreamDestroy(c->restir_stream);
    }
    uh_rccl_detach(c);
+   drop_sun_job(c);
    for (hipEvent_t ev : c->ev_band)
       if (ev) (void)hipEventDestroy(ev);
    c->spatial_ring.release();
@@ -1035,40 +1041,24 @@ static int ensure_slot(uh_ctx* c, uint32_t i, uint32_t batch = 1) {
    return UH_OK;
 }
 
-// the sun grid for this frame's direction, if there is (or now should be) one: see uh_ctx::sun_*
-static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
-   c->sun_this_frame = false;
-   if (!c->sun_grid_enabled || c->scene.num_tris == 0) return UH_OK;
-   const bool same_geom = c->sun_geom == c->geom_version;
-   const bool same_dir = std::memcmp(dir, c->sun_dir_built, sizeof(float) * 3) == 0;
-   if (same_geom && c->sun_attempted && same_dir) {
-      c->sun_have_pending = false;
-      c->sun_this_frame = c->sun_valid;
-      return UH_OK;
-   }
-   if (c->sun_attempted) {
-      // another direction or other geometry than the grid's (a sun dragged in the UI, instances moved with rebuild_tlas every
-      // frame): rebuild once the same pair has been asked for twice in a row, walk the tree meanwhile - a build costs as much
-      // as a thousand frames' worth of what the grid saves
-      const bool settled = c->sun_have_pending && c->sun_geom_pending == c->geom_version && std::memcmp(dir, c->sun_dir_pending, sizeof(float) * 3) == 0;
-      std::memcpy(c->sun_dir_pending, dir, sizeof(float) * 3);
-      c->sun_geom_pending = c->geom_version;
-      c->sun_have_pending = true;
-      if (!settled) return UH_OK;
-   }
-   // build: the packets as the device holds them (leaf order; host build, device build and refit all end there)
+// a grid built on a host thread while frames go on with the tree walk (option "sun_grid_async")
+struct SunJob {
+   std::thread worker;
+   std::atomic<bool> done{false};
+   std::vector<float> packets;
+   SunGridHost grid;
+   bool ok = false;
+   uint64_t geom = 0;
+   float dir[3] = {0, 0, 0};
+   double ms = 0.0;
+};
+
+// the grid `g` (or its refusal) becomes the context's grid for (geom, dir). Frames in flight may still read the old buffers.
+static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float dir[3], uint64_t geom, float build_ms) {
    if (int st = sync_all(c)) return st;
-   const auto t0 = std::chrono::steady_clock::now();
-   const uint32_t n = c->scene.num_tris;
-   std::vector<float> packets(12 * (size_t)n);
-   HIP_TRY(c, hipMemcpy2D(packets.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), n, hipMemcpyDeviceToHost));
-   int threads = (int)std::thread::hardware_concurrency();
-   threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
-   SunGridHost g;
-   const bool ok = build_sun_grid(packets.data(), n, dir, c->sun_limits, threads, g);
    c->sun_attempted = true;
    c->sun_have_pending = false;
-   c->sun_geom = c->geom_version;
+   c->sun_geom = geom;
    std::memcpy(c->sun_dir_built, dir, sizeof(float) * 3);
    c->sun_valid = false;
    c->sun_why = g.why_not;
@@ -1099,6 +1089,82 @@ static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
       c->d_sun_cells.release();
       c->d_sun_entries.release();
    }
+   c->sun_build_ms = build_ms;
+   return UH_OK;
+}
+
+static void drop_sun_job(uh_ctx* c) {
+   if (!c->sun_job) return;
+   if (c->sun_job->worker.joinable()) c->sun_job->worker.join();
+   delete c->sun_job;
+   c->sun_job = nullptr;
+}
+
+// the sun grid for this frame's direction, if there is (or now should be) one: see uh_ctx::sun_*
+static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
+   c->sun_this_frame = false;
+   if (!c->sun_grid_enabled || c->scene.num_tris == 0) return UH_OK;
+   if (c->sun_job && c->sun_job->done.load(std::memory_order_acquire)) {
+      // a background build has finished: it becomes the grid if it is still what this frame asks for
+      SunJob* j = c->sun_job;
+      j->worker.join();
+      int st = UH_OK;
+      if (j->geom == c->geom_version && std::memcmp(dir, j->dir, sizeof(float) * 3) == 0) st = adopt_sun_grid(c, j->grid, j->ok, j->dir, j->geom, (float)j->ms);
+      delete j;
+      c->sun_job = nullptr;
+      if (st != UH_OK) return st;
+   }
+   const bool same_geom = c->sun_geom == c->geom_version;
+   const bool same_dir = std::memcmp(dir, c->sun_dir_built, sizeof(float) * 3) == 0;
+   if (same_geom && c->sun_attempted && same_dir) {
+      c->sun_have_pending = false;
+      c->sun_this_frame = c->sun_valid;
+      return UH_OK;
+   }
+   if (c->sun_attempted) {
+      // another direction or other geometry than the grid's (a sun dragged in the UI, instances moved with rebuild_tlas every
+      // frame): rebuild once the same pair has been asked for twice in a row, walk the tree meanwhile - a build costs as much
+      // as a thousand frames' worth of what the grid saves
+      const bool settled = c->sun_have_pending && c->sun_geom_pending == c->geom_version && std::memcmp(dir, c->sun_dir_pending, sizeof(float) * 3) == 0;
+      std::memcpy(c->sun_dir_pending, dir, sizeof(float) * 3);
+      c->sun_geom_pending = c->geom_version;
+      c->sun_have_pending = true;
+      if (!settled) return UH_OK;
+   }
+   // build: the packets as the device holds them (leaf order; host build, device build and refit all end there)
+   const uint32_t n = c->scene.num_tris;
+   int threads = (int)std::thread::hardware_concurrency();
+   threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+   if (c->sun_async) {
+      // on a host thread: this frame and the next ones walk the tree; the grid is adopted by the first frame that finds it done
+      if (c->sun_job) return UH_OK;  // one at a time; a job for another (geometry, direction) is dropped when it ends
+      SunJob* j = new SunJob();
+      j->packets.resize(12 * (size_t)n);
+      hipError_t e = hipMemcpy2D(j->packets.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), n, hipMemcpyDeviceToHost);  // packets change only under sync_all
+      if (e != hipSuccess) {
+         delete j;
+         return fail(c, UH_ERR_HIP, std::string("sun grid: ") + hipGetErrorString(e));
+      }
+      j->geom = c->geom_version;
+      std::memcpy(j->dir, dir, sizeof(float) * 3);
+      const SunGridLimits lim = c->sun_limits;
+      j->worker = std::thread([j, n, lim, threads]() {
+         const auto t0 = std::chrono::steady_clock::now();
+         j->ok = build_sun_grid(j->packets.data(), n, j->dir, lim, threads > 2 ? threads / 2 : 1, j->grid);  // half the cores: the render thread keeps going
+         j->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+         j->packets = std::vector<float>();
+         j->done.store(true, std::memory_order_release);
+      });
+      c->sun_job = j;
+      return UH_OK;
+   }
+   if (int st = sync_all(c)) return st;
+   const auto t0 = std::chrono::steady_clock::now();
+   std::vector<float> packets(12 * (size_t)n);
+   HIP_TRY(c, hipMemcpy2D(packets.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), n, hipMemcpyDeviceToHost));
+   SunGridHost g;
+   const bool ok = build_sun_grid(packets.data(), n, dir, c->sun_limits, threads, g);
+   if (int st = adopt_sun_grid(c, g, ok, dir, c->geom_version, 0.0f)) return st;
    c->sun_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
    c->sun_this_frame = c->sun_valid;
    return UH_OK;
@@ -1675,6 +1741,10 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_density (entries per triangle) must be 1..4096");
       c->sun_limits.entries_per_triangle = (double)value;
       c->sun_attempted = false;
+   } else if (n == "sun_grid_async") {
+      // 1: a grid is built on a host thread while frames go on with the tree walk (no 130 ms stall when the sun or the geometry
+      // comes to rest; images are the same either way); 0 (default): built inside the frame call that asks for it
+      c->sun_async = value != 0;
    } else if (n == "sun_grid_max_walk") {
       if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_walk (longest list a ray tests itself) must be 1..4096");
       c->sun_limits.max_walk = (uint32_t)value;

@@ -149,6 +149,43 @@ def test_instances_moving_every_frame_never_rebuild_the_grid(cornell):
     assert changed == [6], (changed, builds)  # frames 2-5 move; frame 6 is the second in a row with frame 5's geometry: the rebuild
 
 
+def test_grid_built_on_a_host_thread(atrium):
+    """option sun_grid_async: the frame that asks for a grid starts a host thread and walks the tree; the grid is adopted by the
+    first frame that finds it done; a job overtaken by a change of direction is dropped. Every frame equals the oracle's."""
+    import time
+
+    W, H = 96, 54
+    gpu, cpu = make_pair(atrium, W, H)
+    gpu.set_option("sun_grid_async", 1)
+    loops = [rr.FrameLoop(r, atrium.make_view(W, H, sun_shadow_enabled=1, sky_enabled=0, lights_enabled=0)) for r in (gpu, cpu)]
+
+    def frame(sun):
+        for loop in loops:
+            loop.view.sun_dir[:] = list(sun)
+            loop.frame(rr.PASS_REFERENCE_PT)
+            loop.reset()
+        assert np.array_equal(gpu.read_accumulation().view(np.uint32), cpu.read_accumulation().view(np.uint32)), sun
+        return gpu.get_stats().sun_grid_cells
+
+    A, B = (0.0, 0.9, 0.15), (0.4, 0.7, -0.3)
+    assert frame(A) == 0, "the first frame does not wait for the build"
+    cells, tries = 0, 0
+    while cells == 0 and tries < 400:  # the build takes some tens of milliseconds on this scene
+        time.sleep(0.01)
+        cells = frame(A)
+        tries += 1
+    assert cells > 0, "the grid arrives"
+    first = cells
+    # B asked twice starts a job for B; going back to A before it is done drops it: A's grid is still there and used
+    frame(B)
+    frame(B)
+    assert frame(A) == first
+    for _ in range(30):
+        time.sleep(0.01)
+        assert frame(A) == first
+    gpu.close()
+
+
 def test_rays_beyond_the_dense_extent_walk_the_tree(atrium):
     """a long strip of ground that leaves the atrium through its end wall (two triangles, little area: the grid is not refused as
     a whole): rays that start out there land in border cells and are handed to the tree walk (queue 3); the image equals the
