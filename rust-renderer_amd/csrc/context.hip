@@ -1023,7 +1023,8 @@ static int sync_all(uh_ctx* c) {
 
 // slot i exists and can hold `batch` frames worth of paths
 static int ensure_slot(uh_ctx* c, uint32_t i, uint32_t batch = 1) {
-   const size_t need = (size_t)(c->tp_world > 1 ? c->n_owned : c->W * c->H) * batch;  // path ids are dense over the rank's owned pixels
+   size_t need = (size_t)(c->tp_world > 1 ? c->n_owned : c->W * c->H) * batch;  // path ids are dense over the rank's owned pixels
+   if (need < 64) need = 64;  // a rank that owns no pixel (more ranks than tiles) still gets a well-formed, empty slot
    Slot& s = c->slots[i];
    if (s.ready && s.capacity >= need) return UH_OK;
    if (s.ready) {

@@ -169,3 +169,20 @@ def test_error_paths_of_the_partition_verbs():
     assert tiny.get_stats().rays[rr.RAY_GBUFFER] == 0
     r.close()
     tiny.close()
+
+
+def test_rank_that_owns_no_tile(atrium):
+    """more ranks than tiles: a rank without pixels renders nothing and does not fall over (dense path ids: its slot is empty)"""
+    W, H = 64, 64
+    r = atrium.upload(rr.Renderer(W, H))
+    r.set_tile_partition(5, 8, 64)  # one 64 x 64 tile in all: rank 0 owns it
+    rr.FrameLoop(r, atrium.make_view(W, H)).frames(5, rr.PASS_ALL)
+    s = r.get_stats()
+    assert s.rays[rr.RAY_PRIMARY] == 0 and s.rays[rr.RAY_BOUNCE] == 0 and s.rays[rr.RAY_SUN_SHADOW] == 0
+    assert not r.read_accumulation().any()
+    owner = atrium.upload(rr.Renderer(W, H))
+    owner.set_tile_partition(0, 8, 64)
+    whole = atrium.upload(rr.Renderer(W, H))
+    for x in (owner, whole):
+        rr.FrameLoop(x, atrium.make_view(W, H)).frames(5, rr.PASS_ALL)
+    assert np.array_equal(owner.read_accumulation().view(np.uint32), whole.read_accumulation().view(np.uint32))
