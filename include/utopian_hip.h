@@ -277,10 +277,15 @@ int uh_get_stats(uh_ctx* ctx, UhStats* out);
 int uh_reset_stats(uh_ctx* ctx);
 /* options: "count_visits" (0/1), "time_kernels" (0/1), "full_frame_restir" (0/1; 1 = documented
  * divergence: use the reservoir for every pixel instead of the reference's x > W/2 split),
- * "device_build" (0/1; 1 = uh_build_acceleration builds a Morton-order tree ON THE DEVICE in a few ms instead
- * of the host SAH tree in tens to hundreds: same hits bit for bit, about 30 % more traversal work per ray -
- * for geometry that changes every few frames), tuning knobs documented in DESIGN.md ("frames_in_flight",
- * "batch_frames", "closest_variant", "shadow_variant", "*_blocks_per_cu", "device_build", "full_frame_restir") */
+ * "device_build" (0/1/2; 1 or 2 = uh_build_acceleration builds the tree ON THE DEVICE in a few ms instead of the host SAH
+ * tree in tens to hundreds: same hits bit for bit, about 10 % (1: clusters under a SAH top) or 30 % (2: radix tree) more
+ * traversal work per ray - for geometry that changes every few frames),
+ * "sun_grid" (0/1, default 1: sun shadow rays through a per-direction visibility grid once the direction has settled; same
+ * images), "sun_grid_async" (0/1: that grid is built on a host thread and no frame call waits for it - for interactive
+ * callers), "sun_grid_density", "sun_grid_max_mb", "sun_grid_max_walk",
+ * tuning knobs documented in DESIGN.md section 7 ("frames_in_flight", "batch_frames", "closest_variant", "shadow_variant",
+ * "*_blocks_per_cu", "overlap_miss", "overlap_shadow", "spatial_splits", "primary_tiles", "ploc_radius", "ploc_sah_top").
+ * Unknown names return UH_ERR_INVALID_ARGUMENT. */
 int uh_set_option(uh_ctx* ctx, const char* name, int value);
 
 /* ---- multi-GPU framebuffer tile partition (one process per GPU) ------------------------ */
