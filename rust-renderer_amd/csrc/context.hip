@@ -1742,6 +1742,10 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_density (entries per triangle) must be 1..4096");
       c->sun_limits.entries_per_triangle = (double)value;
       c->sun_attempted = false;
+   } else if (n == "sun_grid_max_fallback_pct") {
+      if (value < 0 || value > 100) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_fallback_pct must be 0..100");
+      c->sun_limits.max_fallback_area = value / 100.0;  // share of the scene's surface whose sun rays may go on to the tree before the grid is refused
+      c->sun_attempted = false;
    } else if (n == "sun_grid_async") {
       // 1: a grid is built on a host thread while frames go on with the tree walk (no 130 ms stall when the sun or the geometry
       // comes to rest; images are the same either way); 0 (default): built inside the frame call that asks for it
