@@ -316,6 +316,23 @@ class Renderer {
       check(uh_add_isosurface_mesh(ctx_, resolution, lo, hi, time, &m, w.data(), &mesh, &tris), "add_isosurface_mesh");
       return tris;
    }
+   // ---- one process per GPU (the reference is single-device: utopian/src/device.rs:45) ----
+   // path tracing: tiles t % world == rank; reservoir passes: this rank's band of rows, exchanged over RCCL inside the library
+   // (rank 0 makes the id, the launcher hands the 128 bytes to every rank); composition on the root: compose_tiles
+   void set_tile_partition(uint32_t rank, uint32_t world, uint32_t tile_size = 64) { check(uh_set_tile_partition(ctx_, rank, world, tile_size), "set_tile_partition"); }
+   static std::array<uint8_t, 128> rccl_unique_id() {
+      std::array<uint8_t, 128> id{};
+      if (uh_rccl_unique_id(id.data()) != UH_OK) throw Error(UH_ERR_HIP, "uh_rccl_unique_id: librccl is not loadable");
+      return id;
+   }
+   void rccl_attach(uint32_t rank, uint32_t world, const std::array<uint8_t, 128>& id) { check(uh_rccl_attach(ctx_, rank, world, id.data()), "rccl_attach"); }
+   void set_restir_partition(uint32_t rank, uint32_t world, UhRestirExchangeFn exchange = nullptr, void* user = nullptr) {
+      check(uh_set_restir_partition(ctx_, rank, world, exchange, user), "set_restir_partition");
+   }
+   void pack_tiles(void* device_out, uint64_t capacity_pixels) { check(uh_pack_tiles(ctx_, device_out, capacity_pixels), "pack_tiles"); }
+   void compose_tiles(const void* device_all, uint64_t stride_pixels, uint32_t total_samples, uint32_t accumulation_limit = 999999) {
+      check(uh_compose_tiles(ctx_, device_all, stride_pixels, total_samples, accumulation_limit), "compose_tiles");
+   }
    uh_ctx* handle() { return ctx_; }
    uint32_t width() const { return width_; }
    uint32_t height() const { return height_; }
