@@ -186,6 +186,43 @@ def test_grid_built_on_a_host_thread(atrium):
     gpu.close()
 
 
+def test_background_build_overtaken_by_a_moved_instance(cornell):
+    """sun_grid_async + geometry that changes while a grid is being built: the finished grid belongs to packets that no longer
+    exist and is dropped; frames stay equal to the oracle's throughout; a grid for the new geometry follows once it rests"""
+    import time
+
+    W, H = 80, 60
+    gpu, cpu = make_pair(cornell, W, H)
+    gpu.set_option("sun_grid_async", 1)
+    loops = [rr.FrameLoop(r, cornell.make_view(W, H, sun_shadow_enabled=1, lights_enabled=0)) for r in (gpu, cpu)]
+    n = cornell.num_meshes
+
+    def frame(move=None):
+        for r, loop in zip((gpu, cpu), loops):
+            if move is not None:
+                r.set_instance_transform(n - 2, rr.transform3x4((0.3,) * 3, move))
+                r.rebuild_tlas()
+            loop.frame(rr.PASS_REFERENCE_PT)
+            loop.reset()
+        assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
+        assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays)
+        return gpu.get_stats().sun_grid_cells
+
+    frame()                      # starts the first build
+    frame(move=(0.2, 0.9, 0.1))  # the geometry changes under it
+    for k in range(3):
+        frame(move=(0.2 + 0.05 * k, 0.9, 0.1))
+    cells, tries = 0, 0
+    while cells == 0 and tries < 400:
+        time.sleep(0.01)
+        cells = frame()
+        tries += 1
+    assert cells > 0, "a grid for the geometry at rest arrives"
+    for _ in range(5):
+        assert frame() == cells
+    gpu.close()
+
+
 def test_rays_beyond_the_dense_extent_walk_the_tree(atrium):
     """a long strip of ground that leaves the atrium through its end wall (two triangles, little area: the grid is not refused as
     a whole): rays that start out there land in border cells and are handed to the tree walk (queue 3); the image equals the
