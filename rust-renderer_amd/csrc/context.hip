@@ -1067,9 +1067,16 @@ static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float 
    c->sun_max_list = g.max_list;
    c->sun_cells = c->sun_entries = 0;
    if (ok) {
-      HIP_TRY(c, c->d_sun_cells.alloc(g.cell_start.size()));
+      // per cell two words: offset into the entries | cover depth (sun_grid.h)
+      std::vector<uint32_t> cells(2 * g.cell_start.size());
+      for (size_t k = 0; k < g.cell_start.size(); k++) {
+         const float cover = k < g.cell_cover.size() ? g.cell_cover[k] : -INFINITY;
+         cells[2 * k] = g.cell_start[k];
+         std::memcpy(&cells[2 * k + 1], &cover, 4);
+      }
+      HIP_TRY(c, c->d_sun_cells.alloc(cells.size()));
       HIP_TRY(c, c->d_sun_entries.alloc(g.entries.size() ? g.entries.size() : 1));
-      HIP_TRY(c, hipMemcpy(c->d_sun_cells.p, g.cell_start.data(), g.cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(c->d_sun_cells.p, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       if (!g.entries.empty()) HIP_TRY(c, hipMemcpy(c->d_sun_entries.p, g.entries.data(), g.entries.size() * sizeof(SunGridEntry), hipMemcpyHostToDevice));
       SunGridDev& d = c->sun_dev;
       std::memcpy(d.U, g.U, sizeof(d.U));

@@ -858,13 +858,17 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
          fy = fy > max_y ? max_y : fy;
          const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy;
          const uint32_t cell = cy * g.nx + cx;
-         uint32_t e = g.cell_start[cell];
-         const uint32_t end = g.cell_start[cell + 1];
+         const uint2 cs = reinterpret_cast<const uint2*>(g.cell_start)[cell];  // offset into the entries | cover depth
+         uint32_t e = cs.x;
+         const uint32_t end = reinterpret_cast<const uint2*>(g.cell_start)[cell + 1].x;
+         // the cell's cover: some packet spans the whole cell (with the margins to spare) and every ray that starts below this
+         // depth has it in front, further than tmin away - occluded, and the tree walk would have said so too
+         const bool covered = pw < __uint_as_float(cs.y);
          // a border cell stands for everything beyond the dense part of the scene, and some interior cells list a great many
          // packets (walls edge-on to the sun): such a ray is cheaper in the tree - k_trace_shadow takes it from queue 3
-         defer = cx == 0 || cy == 0 || cx + 1 == g.nx || cy + 1 == g.ny || end - e > g.max_walk;
+         defer = !covered && (cx == 0 || cy == 0 || cx + 1 == g.nx || cy + 1 == g.ny || end - e > g.max_walk);
          if (COUNT) n_cells++;
-         if (!defer) {
+         if (!defer && !covered) {
             bool occluded = false;
             Hit best;
             best.t = 10000.0f;  // tmax (rgen:66)

@@ -33,6 +33,10 @@ struct Proj {
    double x0, x1, y0, y1;  // padded bounding box
    float wmax;
    bool use;
+   // the packet's plane over the (u, v) plane, w = pa * u + pb * v + pc, when it faces the sun steeply enough to serve as a
+   // cover (|normal . W| >= 0.1: its depth is well conditioned), else can_cover = false
+   double pa, pb, pc;
+   bool can_cover;
 };
 
 inline float dot_fma_h(const float* a, const float* b) { return std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])); }
@@ -69,7 +73,7 @@ inline void for_cells(const Proj& p, double u0, double v0, double inv, uint32_t 
    };
    const uint32_t ix0 = cell(p.x0, u0, inv, nx), ix1 = cell(p.x1, u0, inv, nx), iy0 = cell(p.y0, v0, inv, ny), iy1 = cell(p.y1, v0, inv, ny);
    // outward normals of the projected edges (orientation from the signed area); a degenerate projection keeps only its box
-   double nxe[3], nye[3], off[3];
+   double nxe[3], nye[3], off[3], epad[3];
    int ne = 0;
    const double area2 = (p.px[1] - p.px[0]) * (p.py[2] - p.py[0]) - (p.py[1] - p.py[0]) * (p.px[2] - p.px[0]);
    if (std::fabs(area2) > 1e-300) {
@@ -81,6 +85,7 @@ inline void for_cells(const Proj& p, double u0, double v0, double inv, uint32_t 
          nxe[ne] = s * dy / len;
          nye[ne] = -s * dx / len;
          off[ne] = nxe[ne] * p.px[k] + nye[ne] * p.py[k] + p.pad[k];
+         epad[ne] = p.pad[k];
          ne++;
       }
    }
@@ -91,15 +96,24 @@ inline void for_cells(const Proj& p, double u0, double v0, double inv, uint32_t 
       for (uint32_t ix = ix0; ix <= ix1; ix++) {
          const bool border = by || ix == 0 || ix == nx - 1;
          bool in = true;
+         double cover = -INFINITY;
          if (!border) {
             const double cx0 = u0 + ix * cs, cx1 = cx0 + cs;
+            bool inside = ne == 3 && p.can_cover;  // the whole cell inside the projection ERODED by twice the margins
             for (int e = 0; e < ne && in; e++) {
                // the cell's corner deepest inside the half-plane n . x <= off
                const double m = std::min(nxe[e] * cx0, nxe[e] * cx1) + std::min(nye[e] * cy0, nye[e] * cy1);
                in = m <= off[e];
+               const double M = std::max(nxe[e] * cx0, nxe[e] * cx1) + std::max(nye[e] * cy0, nye[e] * cy1);  // the corner farthest out
+               inside = inside && M <= off[e] - 3.0 * epad[e];
+            }
+            if (in && inside) {
+               // the packet's nearest depth over the cell (its plane at the four corners, pushed out by the margin)
+               const double wa = std::min(p.pa * cx0, p.pa * cx1), wb = std::min(p.pb * cy0, p.pb * cy1);
+               cover = wa + wb + p.pc - (std::fabs(p.pa) + std::fabs(p.pb)) * p.padmax;
             }
          }
-         if (in) emit(iy * (size_t)nx + ix);
+         if (in) emit(iy * (size_t)nx + ix, cover);
       }
    }
 }
@@ -112,6 +126,7 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
    auto refuse = [&](const std::string& why) {
       out.why_not = why;
       out.cell_start.clear();
+      out.cell_cover.clear();
       out.entries.clear();
       return false;
    };
@@ -207,6 +222,24 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
          if ((double)wf < wm) wf = std::nextafterf(wf, INFINITY);
          p.wmax = wf;
          p.use = std::isfinite(p.x0) && std::isfinite(p.x1) && std::isfinite(p.y0) && std::isfinite(p.y1);
+         // cover candidate: the plane w(u, v) through the three projected corners
+         p.can_cover = false;
+         {
+            double pw[3];
+            for (int k = 0; k < 3; k++) pw[k] = W[0] * c[k][0] + W[1] * c[k][1] + W[2] * c[k][2];
+            const double ax = p.px[1] - p.px[0], ay = p.py[1] - p.py[0], bx = p.px[2] - p.px[0], by = p.py[2] - p.py[0];
+            const double det2 = ax * by - ay * bx;
+            // |normal . W| = projected area / true area
+            const double nx3 = (double)q[4] * q[8] - (double)q[5] * q[7], ny3 = (double)q[5] * q[6] - (double)q[3] * q[8], nz3 = (double)q[3] * q[7] - (double)q[4] * q[6];
+            const double area3 = std::sqrt(nx3 * nx3 + ny3 * ny3 + nz3 * nz3);
+            if (p.use && area3 > 0 && std::fabs(det2) >= 0.1 * area3) {
+               const double dw1 = pw[1] - pw[0], dw2 = pw[2] - pw[0];
+               p.pa = (dw1 * by - dw2 * ay) / det2;
+               p.pb = (dw2 * ax - dw1 * bx) / det2;
+               p.pc = pw[0] - p.pa * p.px[0] - p.pb * p.py[0];
+               p.can_cover = std::isfinite(p.pa) && std::isfinite(p.pb) && std::isfinite(p.pc);
+            }
+         }
       }
    });
 
@@ -279,7 +312,7 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
       counts.assign(ncell + 1, 0u);
       parallel_for(n, num_threads, [&](size_t a, size_t b) {
          for (size_t i = a; i < b; i++)
-            if (pr[i].use) for_cells(pr[i], out.u0, out.v0, inv, out.nx, out.ny, [&](size_t c) { __atomic_fetch_add(&counts[c], 1u, __ATOMIC_RELAXED); });
+            if (pr[i].use) for_cells(pr[i], out.u0, out.v0, inv, out.nx, out.ny, [&](size_t c, double) { __atomic_fetch_add(&counts[c], 1u, __ATOMIC_RELAXED); });
       });
       total = 0;
       for (size_t c = 0; c < ncell; c++) total += counts[c];
@@ -311,14 +344,28 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
    }
    out.entries.resize(total);
    std::vector<uint32_t> cursor(out.cell_start.begin(), out.cell_start.end() - 1);
+   std::vector<uint32_t> cover_key(ncell, 0u);  // key 0 = below every float: no cover
    {
       const double inv = out.inv_cell;
       parallel_for(n, num_threads, [&](size_t a, size_t b) {
          for (size_t i = a; i < b; i++)
             if (pr[i].use)
-               for_cells(pr[i], out.u0, out.v0, inv, out.nx, out.ny, [&](size_t c) {
+               for_cells(pr[i], out.u0, out.v0, inv, out.nx, out.ny, [&](size_t c, double cover) {
                   const uint32_t at = __atomic_fetch_add(&cursor[c], 1u, __ATOMIC_RELAXED);
                   out.entries[at] = SunGridEntry{(uint32_t)i, pr[i].wmax};
+                  if (cover > -INFINITY) {
+                     // a ray of this cell that starts below `cover` (less the ray's tmin and the margins) is occluded by this packet
+                     // whatever else the cell lists: keep the highest such depth (atomic max on order-preserving keys)
+                     double cw = cover - 1.01e-3 - 4.0 * base;
+                     float cf = (float)cw;
+                     if ((double)cf > cw) cf = std::nextafterf(cf, -INFINITY);
+                     uint32_t bits;
+                     std::memcpy(&bits, &cf, 4);
+                     const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+                     uint32_t seen = __atomic_load_n(&cover_key[c], __ATOMIC_RELAXED);
+                     while (key > seen && !__atomic_compare_exchange_n(&cover_key[c], &seen, key, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                     }
+                  }
                });
       });
    }
@@ -338,6 +385,19 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
       }
    });
    out.mean_list = nonempty ? (double)total / (double)nonempty : 0.0;
+   out.cell_cover.resize(ncell);
+   uint64_t covered = 0;
+   for (size_t c = 0; c < ncell; c++) {
+      const uint32_t key = cover_key[c];
+      float f = -INFINITY;
+      if (key) {
+         const uint32_t bits = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+         std::memcpy(&f, &bits, 4);
+         covered++;
+      }
+      out.cell_cover[c] = f;
+   }
+   out.covered_cells = covered;
    // Where do sun rays start? On surfaces - so weigh every triangle by its area and ask whether the cell under its centre would
    // serve a ray well (an interior cell with a short list) or hand it to the tree (a border cell: everything beyond the dense
    // part of the scene, e.g. a ground plane around a detailed object; or a long list: walls seen edge-on). A grid that sends a

@@ -28,7 +28,8 @@ struct SunGridDev {
    float u0, v0, inv_cell;  // cell (ix, iy) covers u0 + [ix, ix+1) / inv_cell, v0 + [iy, iy+1) / inv_cell
    uint32_t nx, ny;
    uint32_t max_walk;            // cells with a longer list, and the border cells, hand their rays to the tree walk
-   const uint32_t* cell_start;   // nx * ny + 1 offsets into entries
+   const uint32_t* cell_start;   // nx * ny + 1 records of two words: offset into entries | cover depth (float bits): a ray of the
+                                 // cell that starts below the cover depth is occluded - some packet spans the whole cell in front of it
    const SunGridEntry* entries;
 };
 
@@ -37,6 +38,10 @@ struct SunGridHost {
    float u0 = 0, v0 = 0, inv_cell = 0;
    uint32_t nx = 0, ny = 0;
    std::vector<uint32_t> cell_start;
+   // per cell: the depth below which every ray of the cell is occluded (some packet whose projection, eroded by twice the
+   // margins, contains the whole cell lies in front of it by more than the rays' tmin); -inf: no such packet
+   std::vector<float> cell_cover;
+   uint64_t covered_cells = 0;
    std::vector<SunGridEntry> entries;
    // quality figures (what a ray can expect): entries per non-empty cell, the longest list, cells
    double mean_list = 0.0;

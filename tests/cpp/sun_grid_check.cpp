@@ -87,6 +87,7 @@ static bool grid_occluded(const SunGridHost& g, const std::vector<float>& pk, F3
    fx = fx > max_x ? max_x : fx;
    fy = fy > max_y ? max_y : fy;
    const uint32_t cell = (uint32_t)fy * g.nx + (uint32_t)fx;
+   if (pw < g.cell_cover[cell]) return true;  // the cell's cover: no packet is asked (k_trace_sun_grid does the same)
    for (uint32_t e = g.cell_start[cell]; e < g.cell_start[cell + 1]; e++) {
       if (g.entries[e].wmax < pw) break;
       (*tests)++;
