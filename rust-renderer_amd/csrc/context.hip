@@ -1749,6 +1749,10 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_density (entries per triangle) must be 1..4096");
       c->sun_limits.entries_per_triangle = (double)value;
       c->sun_attempted = false;
+   } else if (n == "sun_grid_max_mean_list_x10") {
+      if (value < 1 || value > 10000) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_mean_list_x10 must be 1..10000");
+      c->sun_limits.max_mean_list = value / 10.0;  // entries per occupied cell beyond which the grid is refused (sun_grid.h)
+      c->sun_attempted = false;
    } else if (n == "sun_grid_max_fallback_pct") {
       if (value < 0 || value > 100) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_fallback_pct must be 0..100");
       c->sun_limits.max_fallback_area = value / 100.0;  // share of the scene's surface whose sun rays may go on to the tree before the grid is refused

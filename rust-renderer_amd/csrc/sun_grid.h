@@ -55,9 +55,9 @@ struct SunGridLimits {
    uint64_t max_entries = 96ull << 20;  // 8 bytes each
    uint64_t max_cells = 24ull << 20;
    double entries_per_triangle = 48.0;  // target density: the cell size is the finest that keeps the estimate under it (MI355X, config 1: 24 / 48 / 96 / 200 = 0.590 / 0.515 / 0.490 / 0.479 ms of sun rays per frame, tree walk 0.632)
-   // beyond this the grid does not beat the tree walk: Sponza-class atrium 4.5 entries per occupied cell, sun rays -17 %;
-   // Bistro-class street 7.4, -2 % for 462 ms of build and 340 MB (5.4 at four times the memory: -5 %): refused
-   double max_mean_list = 6.5;
+   // beyond this the grid does not beat the tree walk. With the cover depth: Sponza-class atrium 4.5 entries per occupied cell,
+   // sun rays -37 %; Bistro-class street 7.4, -9 % (555 ms of build, 340 MB); without the cover depth that street gained 2 %
+   double max_mean_list = 8.0;
    uint32_t max_walk = 32;              // a ray whose cell lists more than this (or is a border cell) walks the tree instead (k_trace_sun_grid's fallback queue)
    double max_fallback_area = 0.2;      // share of the scene's surface area that may lie in such cells; above it the grid is refused as a whole
 };
