@@ -1713,7 +1713,10 @@ int uh_reset_stats(uh_ctx* c) {
    HIP_TRY(c, hipSetDevice(c->device));
    if (int st = sync_all(c)) return st;
    drain_timed(c);
-   HIP_TRY(c, hipMemset(c->dstats.p, 0, sizeof(DeviceStats)));
+   // on the context's stream and waited for: a hipMemset on the null stream may still be in flight when the call returns, and
+   // the frames' non-blocking streams do not wait for it - the next frame's first counters could be wiped
+   HIP_TRY(c, hipMemsetAsync(c->dstats.p, 0, sizeof(DeviceStats), c->stream));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
    c->frames = 0;
    c->ms_by_kind[0] = c->ms_by_kind[1] = c->ms_by_kind[2] = 0.0f;
    c->trace_closest_launches = 0;
