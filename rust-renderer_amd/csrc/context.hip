@@ -1552,6 +1552,7 @@ int uh_reset_accumulation(uh_ctx* c) {
    if (int st = sync_all(c)) return st;
    HIP_TRY(c, hipMemsetAsync(c->accumulation.p, 0, c->accumulation.n * sizeof(float4), c->stream));
    HIP_TRY(c, hipMemsetAsync(c->output.p, 0, c->output.n * sizeof(uchar4), c->stream));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the next frame may run on another slot's stream, which does not wait for this one
    return UH_OK;
 }
 
