@@ -349,7 +349,7 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     r = {
         "kernel": "k_trace_closest",
         "bound": "vmem-issue/valu",
-        "bound_note": "counter passes: texture addresser / data units 0.9 busy, VALU issue 0.5 at 2 clk per instruction (~0.8 at the node step's real mix), HBM-side bytes well under the peak: the CU's vector-memory pipeline and VALU issue bound this kernel, HBM does not",
+        "bound_note": "counter passes (profiles/bench_counters.json, `valu` below): texture addresser / data units 0.92 / 0.96 busy, VALU issue 0.57 at 2 clk per instruction (~0.9 at the node step's real mix), HBM-side bytes under half the peak: the CU's vector-memory pipeline and VALU issue bound this kernel, HBM does not",
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
