@@ -100,6 +100,12 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         print(f"[bench] rank {rank}/{world} joined the {args.backend} group", file=sys.stderr, flush=True)
+    rccl_ranks = None
+    if use_dist and args.backend == "nccl":
+        # what RCCL itself saw: every rank contributes a one through the communicator the tile gather uses
+        ones = torch.ones(1, dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
 
     W, H = args.width, args.height
     kw = dict(tex_size=args.tex_size)
@@ -141,6 +147,16 @@ def main():
     closest_rays = cs.rays[rr.RAY_PRIMARY] + cs.rays[rr.RAY_BOUNCE]
     nodes_per_ray = cs.nodes_visited / max(closest_rays, 1)
     tris_per_ray = cs.tris_tested / max(closest_rays, 1)
+    sun_rays_counted = max(cs.rays[rr.RAY_SUN_SHADOW], 1)
+    sun_grid = {
+        "in_use": bool(cs.sun_grid_cells),
+        "build_ms": cs.sun_grid_build_ms,          # once per (geometry, sun direction), OUTSIDE the timed region: see value_with_sun_grid_build
+        "cells": cs.sun_grid_cells,
+        "entries": cs.sun_grid_entries,
+        "mean_list": cs.sun_grid_mean_list,
+        "tests_per_ray": cs.shadow_tris_tested / sun_rays_counted,   # triangle tests per sun shadow ray (grid walk + the tree walk of the handed-over rays)
+        "handed_to_tree": cs.sun_tree_rays / sun_rays_counted,       # share of the sun rays the grid gives back to the tree (border cells, long lists)
+    }
     renderer.set_option("count_visits", 0)
 
     # ---- untimed: the dominant kernel alone on the GPU (no frame overlap, no second stream), in launches of the SAME size as
@@ -233,27 +249,55 @@ def main():
     st = renderer.get_stats()
     my_rays = float(st.path_rays)
     my_closest = float(st.rays[rr.RAY_PRIMARY] + st.rays[rr.RAY_BOUNCE])
+
+    # ---- the same K steps once more with the sun grid off (every sun shadow ray walks the tree): the figure that owes nothing
+    # to a structure built outside the timed region. Same protocol: priming wavefront, barrier, K frames (+ composition), barrier.
+    renderer.set_option("time_kernels", 0)
+    renderer.set_option("sun_grid", 0)
+    loop.frames(16, pass_mask)
+    loop.reset()
+    renderer.reset_stats()
+    sync_all()
+    t1 = time.perf_counter()
+    loop.frames(args.steps, pass_mask)
     if use_dist:
-        t = torch.tensor([elapsed, my_rays, my_closest, st.trace_closest_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}", resolve=(view.total_samples, view.accumulation_limit))
+    sync_all()
+    elapsed_tree = time.perf_counter() - t1
+    tree_rays = float(renderer.get_stats().path_rays)
+    renderer.set_option("sun_grid", 1)
+    if use_dist:
+        t = torch.tensor([elapsed, my_rays, my_closest, st.trace_closest_ms, elapsed_tree, tree_rays], dtype=torch.float64, device=f"cuda:{local_rank}")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, total_rays = float(tmax[0]), float(t[1])
+        elapsed_tree, tree_rays = float(tmax[4]), float(t[5])
     else:
         total_rays = my_rays
 
     if rank == 0:
         out = {
-            "metric": "Mrays/s (path rays: primary + bounce + sun-shadow + light-shadow) at 1080p, 64 spp = 64 frames x 1 spp",
+            "metric": f"Mrays/s (path rays: primary + bounce + sun-shadow + light-shadow) at {W}x{H}, {args.steps * args.spp} spp = {args.steps} frames x {args.spp} spp",
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
+            # ranks counted THROUGH RCCL (an all-reduce of ones over the tile gather's communicator), and the size of the library's own
+            # communicator for the reservoir all-gather (ncclCommCount; config 2 only); null = no RCCL in this run (single process)
+            "rccl_ranks": rccl_ranks,
+            "rccl_library_comm_ranks": (renderer.rccl_comm_count() or None) if use_dist and args.backend == "nccl" else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
+            # the same steps with option sun_grid = 0 (tree walk for the sun shadow rays), and with the grid's one-off build charged
+            # to THIS run's K frames: the grid is built once per (geometry, sun direction), before the timed region
+            "value_tree_walk": tree_rays / elapsed_tree / 1e6,
+            "ms_per_step_tree_walk": elapsed_tree / args.steps * 1e3,
+            "value_with_sun_grid_build": total_rays / (elapsed + sun_grid["build_ms"] * 1e-3) / 1e6 if sun_grid["in_use"] else None,
+            "sun_grid": sun_grid,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
@@ -267,7 +311,7 @@ def main():
                 "pipelined_frame_ms": pipelined_frame_ms,      # one uh_render_frame per frame, four frames in flight, no batching: a moving camera
                 "serial_kernel_ms_per_frame": serial_ms_per_frame,  # HIP-event time by kernel kind, one 16-frame wavefront alone on the GPU, nothing overlapped
             },
-            "roofline": roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, signature(args, scene, W, H)),
+            "roofline": roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, signature(args, scene, W, H), rays_per_frame=total_rays / args.steps),
         }
         if os.environ.get("UH_BENCH_SIGNATURE"):  # tools/pmc_summary.py stamps counter profiles with it
             json.dump(dict(signature(args, scene, W, H), frames_total=frames_rendered), open(os.environ["UH_BENCH_SIGNATURE"], "w"))
@@ -305,7 +349,33 @@ def load_profile(sig):
     return prof if prof.get("signature") == sig else None
 
 
-def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, sig):
+def classify_bound(k, hbm_frac, hbm_frac_raw):
+    """What limits the dominant kernel, read from the counter profile (never a literal): the busiest of the resources the
+    passes measured. `hbm` = HBM-side bytes / serialised launch time / 8 TB/s (corrected; raw in the note), `vmem-issue` = the
+    CU's texture addresser busy fraction (every <= 16-byte lane load or store takes a slot), `valu` = VALU issue fraction at
+    the nominal 2 clk per wave instruction. Returns (bound, note); without a matching profile the bound is unknown."""
+    if not k:
+        return None, "no counter profile matches this run's configuration: the bound is not asserted"
+    cand = {"hbm": hbm_frac, "vmem-issue": k.get("ta_busy_frac"), "valu": k.get("issue_frac")}
+    cand = {a: b for a, b in cand.items() if b is not None}
+    if not cand:
+        return None, "the matching counter profile carries no busy fractions"
+    order = sorted(cand, key=cand.get, reverse=True)
+    bound = order[0]
+    # two resources within 0.1 of each other share the name: the kernel sits on both
+    if len(order) > 1 and cand[order[0]] - cand[order[1]] < 0.1:
+        bound = f"{order[0]}/{order[1]}"
+
+    def fmt(x):
+        return "n/a" if x is None else f"{x:.2f}"
+
+    note = (f"counter passes (profiles/bench_counters.json): texture addresser busy {fmt(k.get('ta_busy_frac'))}, texture data unit busy {fmt(k.get('td_busy_frac'))}, "
+            f"VALU issue {fmt(k.get('issue_frac'))} at 2 clk per wave instruction, lane utilisation {fmt(k.get('lane_utilisation'))}, "
+            f"HBM-side bytes {fmt(hbm_frac)} of the 8 TB/s peak ({fmt(hbm_frac_raw)} as the counters report them): the busiest resource names the bound")
+    return bound, note
+
+
+def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, sig, rays_per_frame=None, prof=False):
     """Roofline block of the dominant kernel, k_trace_closest - every figure physical and <= 1 by construction.
     traffic   HBM-side bytes per launch from the rocprofv3 counter passes of this command line (profiles/bench_counters.json:
               2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; an upper bound for 48-byte gathers),
@@ -313,20 +383,24 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     achieved  traffic / the kernel's SERIALISED launch duration, measured live with HIP events on the library's stream with
               the kernel alone on the GPU in launches of the timed size (frac = achieved / 8 TB/s)
     overlapped  the same bytes over the timed region's average launch duration, during which other frames' kernels share the chip
-    frame_hbm_frac  HBM-side bytes of ALL kernels per frame (counter passes, summed over every dispatch) / ms_per_step / 8 TB/s
+    frame_hbm_frac  HBM-side bytes of ALL kernels PER FRAME (counter passes, summed over every dispatch, divided by the frames the
+              profiled run rendered) / ms_per_step / 8 TB/s. Per frame: it does not depend on how many frames a launch carries
+              (--steps 20 = a 16-frame and a 4-frame wavefront); it is scaled only by rays per frame when the profile records its own
     algorithmic  SURVEY 8d's work metric at its contract price (128 B per node visit) and at the real record size (48 B): bytes the
               caches serve, not a roofline fraction
-    bound     what the counters show limits the kernel (not HBM: see `limiter`)"""
+    bound     the busiest resource in the counter profile (classify_bound), not a literal
+    prof      the counter profile (tests hand one in); False = profiles/bench_counters.json when its signature matches"""
     launches = max(st.trace_closest_launches, 1)
     avg_ms = st.trace_closest_ms / launches
     rays_per_launch = my_closest / launches
     per_ray_128 = 48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0  # SURVEY.md 8d
     per_ray_48 = 48.0 + nodes_per_ray * 48.0 + tris_per_ray * 48.0    # nodes are 48-byte records (csrc/bvh.h)
-    prof = load_profile(sig)
+    if prof is False:
+        prof = load_profile(sig)
     k = (prof or {}).get("kernels", {}).get("k_trace_closest", {})
     traffic = k.get("hbm_bytes_per_launch")
     if traffic and k.get("closest_rays_per_launch"):
-        # the profiled run's launches may carry another number of frames than this run's: traffic goes with the rays
+        # the profiled run's launches may carry another number of frames than this run's: a LAUNCH's traffic goes with its rays
         traffic *= rays_per_launch / k["closest_rays_per_launch"]
     # serialised duration of a launch of the timed size: the calibration launches are the same wavefronts, alone
     serial_ms = alone_ms * (rays_per_launch / alone_rays) if (alone_ms > 0 and alone_rays > 0) else None
@@ -334,9 +408,11 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     overlapped = traffic / (avg_ms * 1e-3) / 1e9 if (traffic and avg_ms > 0) else None
     frame_bytes = (prof or {}).get("frame_hbm_bytes")
     frame_bytes_lo = (prof or {}).get("frame_hbm_bytes_uncorrected")
-    if frame_bytes and k.get("closest_rays_per_launch"):
-        frame_bytes *= rays_per_launch / k["closest_rays_per_launch"]  # same rays-per-frame normalisation
-        frame_bytes_lo = frame_bytes_lo * rays_per_launch / k["closest_rays_per_launch"] if frame_bytes_lo else None
+    prof_rpf = (prof or {}).get("rays_per_frame")
+    if frame_bytes and prof_rpf and rays_per_frame:
+        # a FRAME's bytes go with the rays of a frame (same scene and camera by the signature: a factor of 1 up to the frame numbers)
+        frame_bytes *= rays_per_frame / prof_rpf
+        frame_bytes_lo = frame_bytes_lo * rays_per_frame / prof_rpf if frame_bytes_lo else None
     ms_per_step = elapsed / args.steps * 1e3
     uncorrected = (k.get("hbm_bytes_per_launch_uncorrected") or 0.0) / k["hbm_bytes_per_launch"] if traffic else None  # share of `traffic` the raw counters report
     # vector-memory issue: every per-lane load or store of <= 16 B takes one slot of the CU's texture addresser / data path, and
@@ -346,14 +422,19 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     peak_lane_rate = 256 * 2.4e9  # CUs x max clock (MI355X_MICROARCH.md); the clock under load is lower
     alone_rate = alone_rays * lane_ops / (alone_ms * 1e-3) if alone_ms > 0 else 0.0
     ref = serial_ms or avg_ms
+    frac = (achieved / HBM_PEAK_GBS) if achieved is not None else None
+    # the bound is classified on the profile's own serialised launch (bytes and duration from the same counter pass)
+    prof_frac = (k["hbm_bytes_per_launch"] / (k["launch_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9)) if (k.get("hbm_bytes_per_launch") and k.get("launch_ns")) else frac
+    prof_frac_raw = (k["hbm_bytes_per_launch_uncorrected"] / (k["launch_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9)) if (k.get("hbm_bytes_per_launch_uncorrected") and k.get("launch_ns")) else None
+    bound, bound_note = classify_bound(k, prof_frac, prof_frac_raw)
     r = {
         "kernel": "k_trace_closest",
-        "bound": "vmem-issue/valu",
-        "bound_note": "counter passes (profiles/bench_counters.json, `valu` below): texture addresser / data units 0.92 / 0.96 busy, VALU issue 0.57 at 2 clk per instruction (~0.9 at the node step's real mix), HBM-side bytes under half the peak: the CU's vector-memory pipeline and VALU issue bound this kernel, HBM does not",
+        "bound": bound,
+        "bound_note": bound_note,
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
+        "frac": frac,
         "traffic": traffic,
         "traffic_source": ((prof or {}).get("source", "") + " - signature-matched to this command line, scaled by rays per launch; not collected in this run") if traffic
         else "no committed counter profile matches this run's configuration: traffic is null rather than borrowed",

@@ -338,6 +338,8 @@ int uh_get_restir_rows(uh_ctx* ctx, UhRestirRows* out);
 int uh_rccl_unique_id(uint8_t out_id[128]);
 int uh_rccl_attach(uh_ctx* ctx, uint32_t rank, uint32_t world, const uint8_t id[128]);
 int uh_rccl_detach(uh_ctx* ctx);
+/* ranks of the communicator uh_rccl_attach made, as RCCL itself counts them (ncclCommCount); 0 when none is attached */
+int uh_rccl_comm_count(uh_ctx* ctx, uint32_t* out_ranks);
 /* raw device pointers (zero-copy wrap by the caller, e.g. for RCCL): 0 accumulation RGBA32F,
  * 1 output BGRA8 */
 int uh_device_pointer(uh_ctx* ctx, int which, void** out);

@@ -446,6 +446,13 @@ class Renderer:
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self._check(self._lib.uh_rccl_attach(self._ctx, rank, world, buf))
 
+    def rccl_comm_count(self):
+        """ranks of the attached RCCL communicator as ncclCommCount reports them (0: none attached)"""
+        n = C.c_uint32(0)
+        self._lib.uh_rccl_comm_count.argtypes, self._lib.uh_rccl_comm_count.restype = [C.c_void_p, C.POINTER(C.c_uint32)], C.c_int
+        self._check(self._lib.uh_rccl_comm_count(self._ctx, C.byref(n)))
+        return n.value
+
     def rccl_detach(self):
         self._lib.uh_rccl_detach.argtypes, self._lib.uh_rccl_detach.restype = [C.c_void_p], C.c_int
         self._check(self._lib.uh_rccl_detach(self._ctx))

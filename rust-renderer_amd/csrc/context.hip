@@ -1895,6 +1895,7 @@ struct RcclApi {
    decltype(&ncclCommInitRank) CommInitRank = nullptr;
    decltype(&ncclCommDestroy) CommDestroy = nullptr;
    decltype(&ncclAllGather) AllGather = nullptr;
+   decltype(&ncclCommCount) CommCount = nullptr;
    decltype(&ncclGetErrorString) GetErrorString = nullptr;
    std::string why;
 };
@@ -1915,6 +1916,7 @@ RcclApi* rccl_api() {
    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.so, "ncclCommInitRank");
    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.so, "ncclCommDestroy");
    api.AllGather = (decltype(api.AllGather))dlsym(api.so, "ncclAllGather");
+   api.CommCount = (decltype(api.CommCount))dlsym(api.so, "ncclCommCount");
    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.so, "ncclGetErrorString");
    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
       api.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
@@ -1977,6 +1979,17 @@ int uh_rccl_detach(uh_ctx* c) {
       c->rp_exchange = nullptr;
       c->rp_user = nullptr;
    }
+   return UH_OK;
+}
+
+int uh_rccl_comm_count(uh_ctx* c, uint32_t* out_ranks) {
+   if (!c || !out_ranks) return UH_ERR_INVALID_ARGUMENT;
+   *out_ranks = 0;
+   if (!c->rccl) return UH_OK;
+   RcclLink* l = (RcclLink*)c->rccl;
+   int n = 0;
+   if (!rccl_api()->CommCount || rccl_api()->CommCount(l->comm, &n) != ncclSuccess) return fail(c, UH_ERR_HIP, "ncclCommCount failed");
+   *out_ranks = (uint32_t)n;
    return UH_OK;
 }
 

@@ -84,11 +84,13 @@ def main():
                          "so hbm_bytes is an upper bound there); Infinity-Cache hits are counted in", "kernels": {}}
         # rays per k_trace_closest launch of the profiled run (the bench line its first pass printed): bench.py scales the
         # per-launch traffic by its own rays per launch
-        profiled_rays = None
+        profiled_rays = profiled_rays_per_frame = None
         try:
             for line in open(os.path.join(src, "pass1.log")):
                 if line.startswith("{") and '"roofline"' in line:
-                    profiled_rays = json.loads(line)["roofline"]["rays_per_launch"]
+                    bl = json.loads(line)
+                    profiled_rays = bl["roofline"]["rays_per_launch"]
+                    profiled_rays_per_frame = bl.get("config", {}).get("rays_per_frame")
         except OSError:
             pass
         # HBM-side bytes of the WHOLE profiled run, every kernel and every dispatch (sum, not median x count), per frame the run
@@ -105,6 +107,8 @@ def main():
             bench["frame_hbm_bytes"] = total_bytes / sig["frames_total"]
             bench["frame_hbm_bytes_uncorrected"] = uncorrected / sig["frames_total"]  # FETCH_SIZE as reported (64 B per TCC_EA0_RDREQ): the lower bound
             bench["frames_profiled"] = sig["frames_total"]
+        if profiled_rays_per_frame:
+            bench["rays_per_frame"] = profiled_rays_per_frame  # path rays per frame of the profiled run: bench.py scales frame_hbm_bytes by its own
         bench["signature"] = {a: b for a, b in sig.items() if a != "frames_total"}
         for k, v in out["kernels"].items():
             m = {c: x["median"] for c, x in v["counters"].items()}
