@@ -277,6 +277,9 @@ int uh_get_stats(uh_ctx* ctx, UhStats* out);
 int uh_reset_stats(uh_ctx* ctx);
 /* options: "count_visits" (0/1), "time_kernels" (0/1), "full_frame_restir" (0/1; 1 = documented
  * divergence: use the reservoir for every pixel instead of the reference's x > W/2 split),
+ * "furnace" (0/1: the reference's FURNACE_TEST build of the miss shader, reference.rmiss:14-28 - a path ray that leaves the
+ * scene returns white whatever view->sky_enabled says; with albedo-1 materials, sun and lights off every sample is exactly 1 or,
+ * for a path still inside the scene after view->num_bounces hits, 0),
  * "device_build" (0/1/2; 1 or 2 = uh_build_acceleration builds the tree ON THE DEVICE in a few ms instead of the host SAH
  * tree in tens to hundreds: same hits bit for bit, about 10 % (1: clusters under a SAH top) or 30 % (2: radix tree) more
  * traversal work per ray - for geometry that changes every few frames),

@@ -325,6 +325,7 @@ struct Oracle {
    bool built = false, ever_built = false;
    bool brute_force = false;
    bool full_frame_restir = false;
+   bool furnace = false;  // reference.rmiss built with FURNACE_TEST (rmiss:14-28 compiled out): a miss returns white
    int num_threads = 0;
    // graph resources (renderers/mod.rs:199-244)
    std::vector<float> accumulation;  // RGBA32F
@@ -678,9 +679,11 @@ static void closest_hit_shader(Oracle& o, const Hit& h, V3 rayDir, Payload& pl) 
 
 // A4 — miss shader (pathtrace_reference/reference.rmiss:10-31). `want_color` = false for shadow
 // rays: the raygen only reads .w == -1 from them (rgen:69,118-119), so the sky integral is dead.
-static void miss_shader(const UhViewUniformData& view, V3 org, V3 dir, bool want_color, Payload& pl) {
-   V3 sky_color = v3(1, 1, 1);
-   if (view.sky_enabled == 1) {
+static void miss_shader(const UhViewUniformData& view, V3 org, V3 dir, bool want_color, bool furnace, Payload& pl) {
+   V3 sky_color = v3(1, 1, 1);  // rmiss:12
+   if (furnace) {
+      // #ifndef FURNACE_TEST (rmiss:14-28) compiled out: white stays
+   } else if (view.sky_enabled == 1) {
       if (want_color) {
          V3 light_dir = normalize(v3(view.sun_dir[0], view.sun_dir[1], view.sun_dir[2]));
          sky_color = sky::IntegrateScattering(org, dir, 999999999.0f, light_dir, v3(1, 1, 1));
@@ -710,7 +713,7 @@ static void trace_ray(Oracle& o, const UhViewUniformData& view, V3 org, V3 dir, 
       }
    } else {
       if (path_ray) tl_ctr.misses++;
-      miss_shader(view, org, dir, path_ray, pl);
+      miss_shader(view, org, dir, path_ray, o.furnace, pl);
    }
 }
 
@@ -1170,7 +1173,7 @@ int orc_refit_acceleration(orc_ctx* c) {
    if (!c->o.ever_built) return UH_ERR_NOT_BUILT;
    return orc_build_acceleration(c);
 }
-// option names: "brute_force", "threads", "full_frame_restir"
+// option names: "brute_force", "threads", "full_frame_restir", "furnace"
 int orc_set_option(orc_ctx* c, const char* name, int value) {
    if (!c || !name) return UH_ERR_INVALID_ARGUMENT;
    std::string n(name);
@@ -1180,6 +1183,8 @@ int orc_set_option(orc_ctx* c, const char* name, int value) {
       c->o.num_threads = value;
    else if (n == "full_frame_restir")
       c->o.full_frame_restir = value != 0;
+   else if (n == "furnace")
+      c->o.furnace = value != 0;
    else if (n == "count_visits" || n == "time_kernels")
       ;
    else

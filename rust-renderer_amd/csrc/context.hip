@@ -231,6 +231,7 @@ struct uh_ctx {
 
    // options / stats
    bool count_visits = false, time_kernels = false, full_frame_restir = false, raw_visit_counts = false;
+   bool furnace = false;  // option "furnace": reference.rmiss compiled with FURNACE_TEST (a miss returns white whatever view.sky_enabled says)
    int spatial_split_factor = 0;  // option "spatial_splits": 0 = off, k = split triangles whose box diagonal exceeds k x the median
    int closest_variant = 1, shadow_variant = 1;  // refill kernels (0 = batch kernels)
    uint64_t frames = 0;
@@ -998,6 +999,7 @@ static FrameParams make_params(uh_ctx* c, const UhViewUniformData& v) {
    fp.lights_enabled = v.lights_enabled;
    fp.use_ris = v.use_ris_light_sampling;
    fp.full_frame_restir = c->full_frame_restir ? 1u : 0u;
+   fp.furnace = c->furnace ? 1u : 0u;
    fp.num_lights_used = v.num_lights < v.max_num_lights_used ? v.num_lights : v.max_num_lights_used;
    fp.temporal_enabled = v.temporal_reuse_enabled;
    fp.spatial_enabled = v.spatial_reuse_enabled;
@@ -1782,6 +1784,8 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->time_kernels = value != 0;
    } else if (n == "full_frame_restir")
       c->full_frame_restir = value != 0;
+   else if (n == "furnace")
+      c->furnace = value != 0;  // applies to the frames enqueued from now on
    else if (n == "ploc_sah_top") {
       if (value < 0 || value > (1 << 20)) return fail(c, UH_ERR_INVALID_ARGUMENT, "ploc_sah_top must be 0..1048576");
       if (c->ploc_sah_top != (uint32_t)value && c->device_build) c->built = c->topology_valid = false;

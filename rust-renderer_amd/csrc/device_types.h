@@ -111,6 +111,7 @@ struct FrameParams {
    uint32_t W, H, frame_number;
    uint32_t samples_per_frame, total_samples, num_bounces, accumulation_limit;
    uint32_t sky_enabled, sun_shadow_enabled, lights_enabled, use_ris, full_frame_restir;
+   uint32_t furnace;  // option "furnace": the reference's FURNACE_TEST build of the miss shader (reference.rmiss:14-28): a miss returns white
    uint32_t num_lights_used;  // min(view.num_lights, view.max_num_lights_used)
    uint32_t temporal_enabled, spatial_enabled;
    uint32_t tp_rank, tp_world, tp_tile, tiles_x;

@@ -978,7 +978,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const PathState& ps, uint32_t id, uint32_t bounce) {
    V3 sky_color = v3(0.0f, 0.0f, 0.0f);
-   if (fp.sky_enabled == 1) {
+   if (fp.furnace) {
+      sky_color = v3(1.0f, 1.0f, 1.0f);  // rmiss:12 with FURNACE_TEST defined: the #ifndef block (rmiss:14-28) is compiled out
+   } else if (fp.sky_enabled == 1) {
       float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN)), rd = ld_rec(rec_quad(ps.rec, id, REC_DIR));
       V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
       sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
