@@ -277,6 +277,7 @@ int uh_get_stats(uh_ctx* ctx, UhStats* out);
 int uh_reset_stats(uh_ctx* ctx);
 /* options: "count_visits" (0/1), "time_kernels" (0/1), "full_frame_restir" (0/1; 1 = documented
  * divergence: use the reservoir for every pixel instead of the reference's x > W/2 split),
+ * "iso_reference_triangulation" (0/1, default 1: see uh_add_isosurface_mesh),
  * "furnace" (0/1: the reference's FURNACE_TEST build of the miss shader, reference.rmiss:14-28 - a path ray that leaves the
  * scene returns white whatever view->sky_enabled says; with albedo-1 materials, sun and lights off every sample is exactly 1 or,
  * for a path still inside the scene after view->num_bounces hits, 0),
@@ -353,9 +354,11 @@ int uh_stream(uh_ctx* ctx, void** out);
 /* ---- GPU extraction of the reference's marching-cubes density field (BASELINE configs[4]) --------
  * Adds the iso-surface {density = 0} of utopian/shaders/marching_cubes/marching_cubes.comp:83-103 (torus over a box,
  * plus the sphere of radius 8 |sin(0.3 time)|; shapes placed in a 32-unit domain) sampled on a resolution^3 grid over
- * [lo, hi]^3 as one mesh with uh_add_mesh semantics. Extraction runs on the device (marching tetrahedra: the cube's 6
- * tetrahedra are cut directly, see csrc/isosurface.hip for why not the reference's case table); vertex normals come
- * from the density gradient, uv = position.xz / (hi - lo). *out_triangles receives the triangle count; when nothing
+ * [lo, hi]^3 as one mesh with uh_add_mesh semantics. Extraction runs on the device: marching cubes on the reference's case table,
+ * cell by cell the triangles marching_cubes.comp:231-251 emits - same vertices (vertexInterp in the shader's corner order), same
+ * order within a cell, zero-area triangles included; cells in x-fastest order (the reference's order is whatever its atomics
+ * give). Option "iso_reference_triangulation" = 0 selects this repository's own tables (other interior diagonals, slivers
+ * dropped). Vertex normals come from the density gradient (generateNormal), uv = position.xz / (hi - lo). *out_triangles receives the triangle count; when nothing
  * crosses the iso value no mesh is added and *out_mesh_index is 0xffffffff. UH_ERR_CAPACITY above 4 Mi triangles. */
 int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo, float hi, float time, const UhGpuMaterial* material,
                            const float world3x4[12], uint32_t* out_mesh_index, uint32_t* out_triangles);

@@ -231,6 +231,7 @@ struct uh_ctx {
 
    // options / stats
    bool count_visits = false, time_kernels = false, full_frame_restir = false, raw_visit_counts = false;
+   bool iso_reference = true;  // option "iso_reference_triangulation": uh_add_isosurface_mesh emits the reference's triangles (isosurface.hip)
    bool furnace = false;  // option "furnace": reference.rmiss compiled with FURNACE_TEST (a miss returns white whatever view.sky_enabled says)
    int spatial_split_factor = 0;  // option "spatial_splits": 0 = off, k = split triangles whose box diagonal exceeds k x the median
    int closest_variant = 1, shadow_variant = 1;  // refill kernels (0 = batch kernels)
@@ -1530,6 +1531,8 @@ int uhi_exchange_endpoints(uh_ctx* c, void** spatial_base, void** band_event, vo
    return UH_OK;
 }
 
+int uhi_iso_reference_triangulation(uh_ctx* c) { return c && c->iso_reference ? 1 : 0; }
+
 int uh_render_frame(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask) { return render_batch(c, view, pass_mask, 1); }
 
 int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mask, uint32_t count) {
@@ -1784,6 +1787,8 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->time_kernels = value != 0;
    } else if (n == "full_frame_restir")
       c->full_frame_restir = value != 0;
+   else if (n == "iso_reference_triangulation")
+      c->iso_reference = value != 0;
    else if (n == "furnace")
       c->furnace = value != 0;  // applies to the frames enqueued from now on
    else if (n == "ploc_sah_top") {

@@ -17,4 +17,5 @@ void uhi_batch_abandon(uh_batch*);
 // what a peer pulls a band from / into after uhi_batch_restir_frame: the buffer the spatial pass wrote, the event recorded
 // behind it (hipEvent_t), the stream the passes run on (hipStream_t), bytes per band
 int uhi_exchange_endpoints(uh_ctx*, void** spatial_base, void** band_event, void** stream, uint64_t* band_bytes);
+int uhi_iso_reference_triangulation(uh_ctx*);  // option "iso_reference_triangulation" (isosurface.hip)
 }

@@ -3,15 +3,19 @@
 //
 // Reference: utopian/shaders/marching_cubes/marching_cubes.comp:83-119 (density = max(-1, -sdTorus, -sdBox,
 // -sdSphere(8 |sin(0.3 t)|)), positive inside), :179-254 (per-voxel case index, edge vertices by linear interpolation,
-// triangles from the 256-case table), driven by utopian/src/renderers/marching_cubes.rs:17-83. What differs, stated once:
-//   * the case tables are generated in this repository from the cube's geometry (tools/gen_mc_tables.py ->
-//     mc_tables.h, corner / edge numbering of the reference, one fixed rule on ambiguous faces, watertight:
-//     tests/test_mc_tables.py); the reference's tables.glsl is not taken;
-//   * an edge vertex is interpolated from the endpoint with the smaller grid index to the other one, so the two to
-//     four cells that share an edge compute the same bits (the reference interpolates in each cell's own order);
+// triangles from the 256-case table), driven by utopian/src/renderers/marching_cubes.rs:17-83.
+// Default (option "iso_reference_triangulation" = 1): the reference's triangles, cell by cell - the triangle table is the public
+// Lorensen-Cline table tables.glsl:38-293 holds (mc_reference_tables.h, numbers as data), every edge vertex is vertexInterp
+// (marching_cubes.comp:134-137) in the corner order the shader names (:204-226), and every triangle of the case's list is
+// emitted in list order, zero-area ones included (:231-251). What differs, stated once:
 //   * output order is deterministic: triangles are counted per cell, the counts are scanned ON THE DEVICE (three small
-//     kernels below) and a second pass writes each cell's triangles at its offset - where the reference appends with
-//     one atomicAdd per triangle in arrival order (marching_cubes.comp:236);
+//     kernels below) and a second pass writes each cell's triangles at its offset, cells in x-fastest order - where the
+//     reference appends with one atomicAdd per triangle in arrival order (marching_cubes.comp:236);
+// With the option at 0 (round 3's form, kept for the tree it gives):
+//   * the case tables are the ones generated in this repository from the cube's geometry (tools/gen_mc_tables.py ->
+//     mc_tables.h: same crossed edges, triangle counts and boundary polygons, other interior diagonals in 160 cases);
+//   * an edge vertex is interpolated from the endpoint with the smaller grid index to the other one, so the two to
+//     four cells that share an edge compute the same bits;
 //   * triangles of zero area (a cut that lands on a grid corner collapses an edge) are dropped on the device in both
 //     passes: they can never be hit (det == 0) and would only cost tree nodes;
 //   * the shapes sit in a [lo, hi]^3 domain (32 units for config 5) instead of around the camera block origin, and the
@@ -25,7 +29,9 @@
 #include <vector>
 
 #include "device_scan.h"
+#include "mc_reference_tables.h"
 #include "mc_tables.h"
+#include "context_internal.h"
 #include "utopian_hip.h"
 
 namespace {
@@ -37,6 +43,7 @@ struct IsoParams {
    float lo, h;         // domain origin and cell size
    float sphere_r;      // 8 |sin(0.3 t)|
    float inv_domain;    // uv = pos.xz * inv_domain
+   uint32_t reference;  // 1: the reference's triangle table, corner order and zero-area triangles (the default)
 };
 
 __device__ __forceinline__ float len2(float a, float b) { return sqrtf(a * a + b * b); }
@@ -61,6 +68,9 @@ __constant__ uint8_t c_tri_count[256];
 __constant__ uint8_t c_tris[256][3 * kMcMaxTris];
 // the edge's endpoints, the one with the smaller grid index first (every cell sharing the edge interpolates alike)
 __constant__ uint8_t c_edge_lo_hi[12][2] = {{0, 1}, {1, 2}, {3, 2}, {0, 3}, {4, 5}, {5, 6}, {7, 6}, {4, 7}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+// ... and in the order marching_cubes.comp:204-226 hands the corners to vertexInterp
+__constant__ uint8_t c_edge_shader[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+__constant__ int8_t c_ref_tris[256][16];
 
 struct Cell {
    float p[8][3], v[8];
@@ -83,7 +93,13 @@ __device__ __forceinline__ bool load_cell(const IsoParams& q, uint64_t cell, Cel
 }
 
 // vertexInterp (marching_cubes.comp:134-137) at iso level 0 on edge e
-__device__ __forceinline__ void edge_point(const Cell& c, int e, float* p) {
+__device__ __forceinline__ void edge_point(const Cell& c, int e, float* p, bool reference) {
+   if (reference) {
+      const int a = c_edge_shader[e][0], b = c_edge_shader[e][1];
+      const float t = (0.0f - c.v[a]) / (c.v[b] - c.v[a]);  // (isolevel - val1) / (val2 - val1), :136
+      for (int k = 0; k < 3; k++) p[k] = c.p[a][k] + t * (c.p[b][k] - c.p[a][k]);  // mix(x, y, a) = x + a (y - x): the oracle's reading
+      return;
+   }
    const int a = c_edge_lo_hi[e][0], b = c_edge_lo_hi[e][1];
    const float t = c.v[a] / (c.v[a] - c.v[b]);
    for (int k = 0; k < 3; k++) p[k] = c.p[a][k] + t * (c.p[b][k] - c.p[a][k]);
@@ -119,11 +135,24 @@ __device__ __forceinline__ void write_vertex(const IsoParams& q, UhVertex* out, 
 // the cell's triangles with area; EMIT writes them from `out` on
 template <bool EMIT>
 __device__ __forceinline__ uint32_t cell_triangles(const IsoParams& q, const Cell& c, UhVertex* out) {
+   if (q.reference) {
+      // marching_cubes.comp:231-251: the case's list up to the first -1, nothing dropped, nothing reordered
+      uint32_t n = 0;
+      for (int i = 0; i < 15 && c_ref_tris[c.cube_index][i] >= 0; i += 3, n++) {
+         if (!EMIT) continue;
+         for (int k = 0; k < 3; k++) {
+            float p[3];
+            edge_point(c, c_ref_tris[c.cube_index][i + k], p, true);
+            write_vertex(q, out + 3 * n + k, p);
+         }
+      }
+      return n;
+   }
    const uint32_t n = c_tri_count[c.cube_index];
    uint32_t kept = 0;
    for (uint32_t t = 0; t < n; t++) {
       float p[3][3];
-      for (int k = 0; k < 3; k++) edge_point(c, c_tris[c.cube_index][3 * t + k], p[k]);
+      for (int k = 0; k < 3; k++) edge_point(c, c_tris[c.cube_index][3 * t + k], p[k], false);
       if (!has_area(p[0], p[1], p[2])) continue;
       if (EMIT)
          for (int k = 0; k < 3; k++) write_vertex(q, out + 3 * kept + k, p[k]);
@@ -195,7 +224,7 @@ static bool load_tables() {
    (void)hipGetDevice(&dev);
    if (dev >= 0 && dev < 64 && !tables_loaded[dev]) {
       if (hipMemcpyToSymbol(HIP_SYMBOL(c_edge_mask), kMcEdgeMask, sizeof(kMcEdgeMask)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_tri_count), kMcTriCount, sizeof(kMcTriCount)) != hipSuccess ||
-          hipMemcpyToSymbol(HIP_SYMBOL(c_tris), kMcTris, sizeof(kMcTris)) != hipSuccess)
+          hipMemcpyToSymbol(HIP_SYMBOL(c_tris), kMcTris, sizeof(kMcTris)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_ref_tris), kMcRefTris, sizeof(kMcRefTris)) != hipSuccess)
          return false;
       tables_loaded[dev] = true;
    }
@@ -216,6 +245,7 @@ extern "C" int uh_isosurface_cells(uh_ctx* ctx, uint32_t resolution, float lo, f
    q.h = (hi - lo) / (float)resolution;
    q.sphere_r = 8.0f * std::fabs(std::sin(time * 0.3f));
    q.inv_domain = 1.0f / (hi - lo);
+   q.reference = uhi_iso_reference_triangulation(ctx) ? 1u : 0u;
    const uint64_t cells = (uint64_t)resolution * resolution * resolution;
    uint8_t *d_a = nullptr, *d_b = nullptr;
    if (hipMalloc(&d_a, cells) != hipSuccess || hipMalloc(&d_b, cells) != hipSuccess) {
@@ -245,6 +275,7 @@ extern "C" int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo
    q.h = (hi - lo) / (float)resolution;
    q.sphere_r = 8.0f * std::fabs(std::sin(time * 0.3f));
    q.inv_domain = 1.0f / (hi - lo);
+   q.reference = uhi_iso_reference_triangulation(ctx) ? 1u : 0u;
    const uint64_t cells = (uint64_t)resolution * resolution * resolution;
    const uint32_t blocks = (uint32_t)((cells + kBlock - 1) / kBlock);
    uint32_t *d_counts = nullptr, *d_chunks = nullptr;

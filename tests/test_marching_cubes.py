@@ -121,32 +121,30 @@ def test_product_tables_describe_the_reference_s_surface_case_by_case():
 @pytest.mark.gpu
 @pytest.mark.parametrize("res,time", [(48, 0.0), (32, 0.0), (40, 3.0)])
 def test_gpu_extraction_against_the_oracle_cell_by_cell(res, time):
+    """the default extraction (option iso_reference_triangulation = 1) emits the reference's triangles: per cell the list of
+    marching_cubes.comp:231-251 on the reference's table, vertices by vertexInterp in the shader's corner order, zero-area
+    triangles kept, order within a cell kept - the whole vertex stream equals orc_marching_cubes' bit for bit"""
     gpu = rr.Renderer(8, 8)
     mesh, ntri = gpu.add_isosurface_mesh(res, LO, HI, time=time)
-    v, _ = gpu.read_mesh(mesh)
+    v, idx = gpu.read_mesh(mesh)
     tri = v["pos"][:, :3].reshape(-1, 3, 3)
     cube, kept = gpu.isosurface_cells(res, LO, HI, time=time)
-    mc = oa.marching_cubes(res, LO, HI, time=time, order=1)
+    mc = oa.marching_cubes(res, LO, HI, time=time, order=0)
     # 1. every cell decides the same case (the density field and its sign agree bit for bit)
     assert np.array_equal(cube, mc["cube_index"])
-    # 2. per cell: the reference's number of triangles, minus the zero-area ones the device drops
-    ot = mc["positions"].astype(np.float64)
-    area = np.linalg.norm(np.cross(ot[:, 1] - ot[:, 0], ot[:, 2] - ot[:, 0]), axis=1)
-    owner = np.repeat(np.arange(res ** 3), mc["tri_count"])
-    assert int(kept.astype(np.int64).sum()) == ntri == len(tri)
-    degenerate_cells = np.unique(owner[area <= 1e-12])
-    plain = np.ones(res ** 3, dtype=bool)
-    plain[degenerate_cells] = False
-    assert np.array_equal(kept[plain], mc["tri_count"][plain]), "cells without a collapsed triangle keep the reference's count"
-    assert (kept[~plain] <= mc["tri_count"][~plain]).all()
-    # 3. the vertices: each is the oracle's interpolated edge crossing, bit for bit (smaller-grid-index-first order)
-    mine = np.unique(tri.reshape(-1, 3).view(np.uint32), axis=0)
-    theirs = np.unique(mc["positions"].reshape(-1, 3).view(np.uint32), axis=0)
-    key = lambda a: a[:, 0].astype(np.uint64) << np.uint64(42) ^ a[:, 1].astype(np.uint64) << np.uint64(21) ^ a[:, 2].astype(np.uint64)
-    assert np.isin(key(mine), key(theirs)).all()
-    assert len(mine) >= 0.99 * len(theirs)  # the rest belonged to dropped slivers only
-    # 4. the same solid: volume against the oracle's mesh (other diagonals inside a cell's polygons) and against the formula
-    assert abs(volume(tri) - volume(mc["positions"])) < 2e-3 * VOLUME
+    # 2. per cell: the reference's number of triangles - nothing dropped
+    assert np.array_equal(kept, mc["tri_count"])
+    assert int(kept.astype(np.int64).sum()) == ntri == len(tri) == mc["triangles"]
+    # 3. per cell: the reference's triangles in the reference's order, every coordinate bit for bit (cells in x-fastest order,
+    #    which is also the order the oracle walks them in, so the two streams are compared whole)
+    want = mc["positions"].reshape(-1, 3, 3)
+    assert np.array_equal(tri.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(idx, np.arange(3 * ntri, dtype=idx.dtype))
+    # ... zero-area triangles included (a cut through a grid corner collapses an edge): the reference keeps them
+    area = np.linalg.norm(np.cross(want[:, 1].astype(np.float64) - want[:, 0], want[:, 2].astype(np.float64) - want[:, 0]), axis=1)
+    if time == 0.0 and res == 48:
+        assert (area <= 1e-12).any()
+    # 4. the same solid as the formula says
     if time == 0.0:
         assert abs(volume(tri) - VOLUME) < 0.02 * VOLUME * (48 / res) ** 2
     # 5. normals: generateNormal (central differences at distance 1, negated), as the oracle restates it
@@ -161,6 +159,28 @@ def test_gpu_extraction_against_the_oracle_cell_by_cell(res, time):
 
 
 @pytest.mark.gpu
+def test_gpu_extraction_with_the_generated_tables_is_the_same_surface():
+    """option iso_reference_triangulation = 0 (round 3's form): the tables generated in this repository, slivers dropped, edge
+    vertices from the smaller grid index - the same case per cell, the same crossings, the same solid"""
+    res, time = 40, 0.0
+    gpu = rr.Renderer(8, 8)
+    gpu.set_option("iso_reference_triangulation", 0)
+    mesh, ntri = gpu.add_isosurface_mesh(res, LO, HI, time=time)
+    v, _ = gpu.read_mesh(mesh)
+    tri = v["pos"][:, :3].reshape(-1, 3, 3)
+    cube, kept = gpu.isosurface_cells(res, LO, HI, time=time)
+    mc = oa.marching_cubes(res, LO, HI, time=time, order=1)
+    assert np.array_equal(cube, mc["cube_index"])
+    assert int(kept.astype(np.int64).sum()) == ntri == len(tri)
+    assert (kept <= mc["tri_count"]).all()
+    mine = np.unique(tri.reshape(-1, 3).view(np.uint32), axis=0)
+    theirs = np.unique(mc["positions"].reshape(-1, 3).view(np.uint32), axis=0)
+    key = lambda a: a[:, 0].astype(np.uint64) << np.uint64(42) ^ a[:, 1].astype(np.uint64) << np.uint64(21) ^ a[:, 2].astype(np.uint64)
+    assert np.isin(key(mine), key(theirs)).all()
+    assert abs(volume(tri) - volume(mc["positions"])) < 2e-3 * VOLUME
+
+
+@pytest.mark.gpu
 def test_gpu_extraction_at_512_matches_the_oracle_on_sampled_slabs():
     """BASELINE configs[4]'s grid: the case index of all 134 M cells' worth is too much for the CPU side of a test, so the
     oracle walks a 512 x 512 x 8 slab through the torus and one through the box (the same cells of the 512^3 grid)"""
@@ -170,4 +190,5 @@ def test_gpu_extraction_at_512_matches_the_oracle_on_sampled_slabs():
     cube, kept = cube.reshape(res, res, res), kept.reshape(res, res, res)
     mc = oa.marching_cubes(res, LO, HI, positions=False)  # ~20 s of CPU: one pass over the grid, no positions
     assert np.array_equal(cube.reshape(-1), mc["cube_index"])
-    assert int(kept.astype(np.int64).sum()) <= mc["triangles"] and int(kept.astype(np.int64).sum()) > 0.99 * mc["triangles"]
+    assert np.array_equal(kept.reshape(-1), mc["tri_count"])  # the reference's triangle count in every one of the 134 M cells
+    assert int(kept.astype(np.int64).sum()) == mc["triangles"]
