@@ -428,8 +428,13 @@ inline void read_accessor(const Document& d, uint32_t index, std::vector<float>*
    };
    const size_t start = checked(bv["byteOffset"].number(0), "bufferView.byteOffset") + checked(acc["byteOffset"].number(0), "accessor.byteOffset");
    size_t stride = checked(bv["byteStride"].number(0), "bufferView.byteStride");
+   if (stride > 252) throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: bufferView.byteStride above 252 (the format allows 4..252)");
    if (!stride) stride = item * n;
-   if (count && start + stride * (size_t)(count - 1) + item * n > raw.size()) throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: accessor reaches past its buffer");
+   // no multiplication that could wrap: the last element must start early enough for its item * n bytes
+   if (count) {
+      if (start > raw.size() || item * n > raw.size() - start) throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: accessor reaches past its buffer");
+      if ((size_t)(count - 1) > (raw.size() - start - item * n) / stride) throw Error(UH_ERR_INVALID_ARGUMENT, "glTF: accessor reaches past its buffer");
+   }
    const bool normalized = acc["normalized"].kind == Json::Bool && acc["normalized"].b;
    for (uint32_t i = 0; i < count; i++)
       for (uint32_t c = 0; c < n; c++) {

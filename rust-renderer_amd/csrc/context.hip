@@ -433,14 +433,17 @@ static void drop_sun_job(uh_ctx* c);
 void uh_destroy(uh_ctx* c) {
    if (!c) return;
    (void)hipSetDevice(c->device);
+   // the communicator's collectives were enqueued on the reservoir stream: it goes (and every stream is drained) while that
+   // stream still exists
+   uh_rccl_detach(c);
+   drop_sun_job(c);
    if (c->restir_stream) {
       (void)hipStreamSynchronize(c->restir_stream);
       for (hipEvent_t ev : {c->ev_restir, c->rs_start, c->rs_stop})
          if (ev) (void)hipEventDestroy(ev);
       (void)hipStreamDestroy(c->restir_stream);
+      c->restir_stream = nullptr;
    }
-   uh_rccl_detach(c);
-   drop_sun_job(c);
    for (hipEvent_t ev : c->ev_band)
       if (ev) (void)hipEventDestroy(ev);
    c->spatial_ring.release();
@@ -1120,7 +1123,17 @@ static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
       SunJob* j = c->sun_job;
       j->worker.join();
       int st = UH_OK;
-      if (j->geom == c->geom_version && std::memcmp(dir, j->dir, sizeof(float) * 3) == 0) st = adopt_sun_grid(c, j->grid, j->ok, j->dir, j->geom, (float)j->ms);
+      if (j->geom == c->geom_version && std::memcmp(dir, j->dir, sizeof(float) * 3) == 0)
+         st = adopt_sun_grid(c, j->grid, j->ok, j->dir, j->geom, (float)j->ms);
+      else if (!c->sun_attempted) {
+         // overtaken by another change before any grid existed: from now on the "same pair twice in a row" rule below decides
+         // when the next build starts (a sun or an instance that moves every frame must not start a build per finished job)
+         c->sun_attempted = true;
+         c->sun_valid = false;
+         c->sun_geom = j->geom;
+         std::memcpy(c->sun_dir_built, j->dir, sizeof(float) * 3);
+         c->sun_why = "a background build was overtaken by a change of direction or geometry";
+      }
       delete j;
       c->sun_job = nullptr;
       if (st != UH_OK) return st;

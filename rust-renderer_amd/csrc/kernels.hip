@@ -863,7 +863,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
          const uint32_t end = reinterpret_cast<const uint2*>(g.cell_start)[cell + 1].x;
          // the cell's cover: some packet spans the whole cell (with the margins to spare) and every ray that starts below this
          // depth has it in front, further than tmin away - occluded, and the tree walk would have said so too
-         const bool covered = pw < __uint_as_float(cs.y);
+         // (... and nearer than tmax: sun_grid.h kSunCoverReach)
+         const float cover = __uint_as_float(cs.y);
+         const bool covered = pw < cover && cover - pw < kSunCoverReach;
          // a border cell stands for everything beyond the dense part of the scene, and some interior cells list a great many
          // packets (walls edge-on to the sun): such a ray is cheaper in the tree - k_trace_shadow takes it from queue 3
          defer = !covered && (cx == 0 || cy == 0 || cx + 1 == g.nx || cy + 1 == g.ny || end - e > g.max_walk);

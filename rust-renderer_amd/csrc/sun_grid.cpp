@@ -36,6 +36,7 @@ struct Proj {
    // the packet's plane over the (u, v) plane, w = pa * u + pb * v + pc, when it faces the sun steeply enough to serve as a
    // cover (|normal . W| >= 0.1: its depth is well conditioned), else can_cover = false
    double pa, pb, pc;
+   double cover_drop;  // what the fill pass takes off the cover depth: the rays' tmin and the base margins
    bool can_cover;
 };
 
@@ -107,6 +108,8 @@ inline void for_cells(const Proj& p, double u0, double v0, double inv, uint32_t 
                const double M = std::max(nxe[e] * cx0, nxe[e] * cx1) + std::max(nye[e] * cy0, nye[e] * cy1);  // the corner farthest out
                inside = inside && M <= off[e] - 3.0 * epad[e];
             }
+            // tmax (sun_grid.h kSunCoverSlack): the packet's depth over the cell may not leave the cover depth by more than the slack
+            inside = inside && (std::fabs(p.pa) + std::fabs(p.pb)) * (cs + p.padmax) + p.cover_drop <= kSunCoverSlack;
             if (in && inside) {
                // the packet's nearest depth over the cell (its plane at the four corners, pushed out by the margin)
                const double wa = std::min(p.pa * cx0, p.pa * cx1), wb = std::min(p.pb * cy0, p.pb * cy1);
@@ -224,6 +227,7 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
          p.use = std::isfinite(p.x0) && std::isfinite(p.x1) && std::isfinite(p.y0) && std::isfinite(p.y1);
          // cover candidate: the plane w(u, v) through the three projected corners
          p.can_cover = false;
+         p.cover_drop = 1.01e-3 + 4.0 * base;
          {
             double pw[3];
             for (int k = 0; k < 3; k++) pw[k] = W[0] * c[k][0] + W[1] * c[k][1] + W[2] * c[k][2];
@@ -356,7 +360,7 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
                   if (cover > -INFINITY) {
                      // a ray of this cell that starts below `cover` (less the ray's tmin and the margins) is occluded by this packet
                      // whatever else the cell lists: keep the highest such depth (atomic max on order-preserving keys)
-                     double cw = cover - 1.01e-3 - 4.0 * base;
+                     double cw = cover - pr[i].cover_drop;
                      float cf = (float)cw;
                      if ((double)cf > cw) cf = std::nextafterf(cf, -INFINITY);
                      uint32_t bits;

@@ -17,6 +17,15 @@
 
 namespace uh {
 
+// The cover shortcut and the rays' tmax (reference.rgen:45,66-67: tmax = 10000). A ray that starts below its cell's cover depth has
+// the covering packet in front of it at t = w_packet(u, v) - w0 > tmin; the packet only occludes it when also t < tmax. The builder
+// admits a packet as a cover only if its depth over the cell, margins included, stays within kSunCoverSlack of the stored cover
+// depth, and the kernel takes the shortcut only while cover - w0 < kSunCoverReach: then t < kSunCoverReach + kSunCoverSlack <
+// tmax. Rays deeper than that below their cover (scenes more than 9,000 units deep along the sun) ask the cell's packets or the
+// tree like any other ray.
+constexpr float kSunCoverReach = 9000.0f;
+constexpr double kSunCoverSlack = 900.0;
+
 struct SunGridEntry {
    uint32_t packet;  // triangle packet index (TriPacket array, leaf order)
    float wmax;       // far end of the packet's depth range along the sun direction, padded

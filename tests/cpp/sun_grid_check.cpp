@@ -87,7 +87,7 @@ static bool grid_occluded(const SunGridHost& g, const std::vector<float>& pk, F3
    fx = fx > max_x ? max_x : fx;
    fy = fy > max_y ? max_y : fy;
    const uint32_t cell = (uint32_t)fy * g.nx + (uint32_t)fx;
-   if (pw < g.cell_cover[cell]) return true;  // the cell's cover: no packet is asked (k_trace_sun_grid does the same)
+   if (pw < g.cell_cover[cell] && g.cell_cover[cell] - pw < uh::kSunCoverReach) return true;  // the cell's cover: no packet is asked (k_trace_sun_grid does the same)
    for (uint32_t e = g.cell_start[cell]; e < g.cell_start[cell + 1]; e++) {
       if (g.entries[e].wmax < pw) break;
       (*tests)++;
@@ -124,6 +124,7 @@ static void check_scene(const char* name, const std::vector<float>& pk, F3 sun, 
    const float dir[3] = {d.x, d.y, d.z};
    SunGridHost g;
    SunGridLimits lim;
+   lim.max_mean_list = 1e9;
    lim.max_fallback_area = 1.0;  // this check is about what the walk finds, not about when the grid is worth building (checked at the end)
    const bool ok = build_sun_grid(pk.data(), n, dir, lim, 3, g);
    if (!ok) {
@@ -276,6 +277,22 @@ int main(int argc, char** argv) {
       add_patch(pk, F3{-5, 0, -5}, F3{10, 0, 0}, F3{0, 0, 10}, 20, 20, 0.0f);
       check_scene("edge-on wall, vertical sun", pk, F3{0, 1, 0}, {}, 3000, -6.0f, 11.0f, false);
       check_scene("edge-on wall, grazing sun", pk, F3{1e-3f, 1, 0}, {}, 3000, -6.0f, 11.0f, false);
+   }
+   // 4b. deeper than the rays' tmax along the sun: a floor, a roof 20,000 units above it, a mid-air slab; origins nearer
+   // and farther than tmax = 10000 below each covering patch - the cover shortcut must not call a ray occluded whose occluder lies
+   // beyond tmax (the tree walk and the per-packet test reject t >= 10000)
+   {
+      std::vector<float> pk;
+      add_patch(pk, F3{-4, 0, -4}, F3{8, 0, 0}, F3{0, 0, 8}, 16, 16, 0.0f);
+      add_patch(pk, F3{-40, 20000, -40}, F3{80, 0, 0}, F3{0, 0, 80}, 2, 2, 0.0f);  // big triangles: the margins at |y| = 20000 are ~0.5, and a cover must contain its cell eroded by three of them
+      add_patch(pk, F3{-20, 12000, -20}, F3{40, 0, 0}, F3{0, 0, 40}, 1, 1, 0.0f);
+      std::vector<F3> extra;
+      for (int i = 0; i < 400; i++) {
+         const float x = -3.9f + 7.8f * rnd(), z = -3.9f + 7.8f * rnd();
+         for (float y : {1.0f, 1999.0f, 2001.0f, 9990.0f, 9999.5f, 10000.5f, 10010.0f, 11000.0f, 11999.0f, 19990.0f, 19999.9f}) extra.push_back(F3{x, y, z});
+      }
+      check_scene("deeper than tmax, vertical sun", pk, F3{0, 1, 0}, extra, 500, -4.0f, 4.0f, false);
+      check_scene("deeper than tmax, tilted sun", pk, F3{1e-4f, 1, 2e-4f}, extra, 500, -4.0f, 4.0f, false);
    }
    // 5. refusals: empty scene, degenerate directions
    {

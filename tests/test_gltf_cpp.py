@@ -334,3 +334,18 @@ def test_cpp_loader_rejects_malformed_files_instead_of_reading_out_of_bounds(tmp
     huge["accessors"][0]["byteOffset"] = 1e300
     r = run(huge)
     assert r.returncode == 1, r.stdout + r.stderr
+    # a byteStride whose product with the element count wraps size_t (2^52 x 4097 = 2^64 + 2^52) must not pass the bounds
+    # check; the format allows strides of 4..252 only
+    wrap = doc()
+    wrap["bufferViews"][0]["byteStride"] = 2.0 ** 52
+    wrap["accessors"][0]["count"] = 4097
+    r = run(wrap)
+    assert r.returncode == 1 and "byteStride" in r.stdout, r.stdout + r.stderr
+    wide = doc()
+    wide["bufferViews"][0]["byteStride"] = 16  # a legal stride, but four elements at 16 bytes need 60 of the buffer view's 48 + 36
+    wide["accessors"][0]["count"] = 8
+    r = run(wide)
+    assert r.returncode == 1 and "past its buffer" in r.stdout, r.stdout + r.stderr
+    ok16 = doc()
+    ok16["bufferViews"][0]["byteStride"] = 16  # 3 x 16 + 12 = 60 <= 84 bytes of buffer: strided positions are read
+    assert run(ok16).returncode == 0

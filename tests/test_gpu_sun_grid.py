@@ -270,3 +270,32 @@ def test_tile_partition_and_batches_with_the_grid(atrium):
     rr.FrameLoop(group, atrium.make_view(W, H)).frames(6, rr.PASS_REFERENCE_PT)
     assert np.array_equal(ref.read_accumulation().view(np.uint32), group.read_accumulation().view(np.uint32))
     assert list(ref.get_stats().rays) == list(group.get_stats().rays)
+
+
+def test_scene_deeper_than_tmax_along_the_sun():
+    """the cell's cover depth must respect the rays' tmax = 10000 (rgen:45,66-67). A floor at y = 0 under a roof at
+    y = 20000 with the sun straight up: the roof covers every cell, but a ray from the floor would meet it at t = 19999 > tmax -
+    the tree walk and the oracle leave the floor lit, and so must the grid. A slab at y = 8000 does shade its part of the floor."""
+    from rust_renderer_amd.scenes import Mesh, Model, Scene, quad
+    from rust_renderer_amd.camera import Camera
+
+    meshes = [Mesh(*quad((-4, 0, -4), (0, 0, 8), (8, 0, 0), 8, 8), base_color=(0.8, 0.8, 0.8, 1.0), name="floor"),
+              Mesh(*quad((-40, 20000, -40), (80, 0, 0), (0, 0, 80), 1, 1), base_color=(0.5, 0.5, 0.5, 1.0), name="roof"),
+              Mesh(*quad((-1, 8000, -1), (2, 0, 0), (0, 0, 2), 1, 1), base_color=(0.5, 0.5, 0.5, 1.0), name="slab")]
+    cam = Camera((0.0, 6.0, 7.0), (0.0, 0.0, 0.0), 60.0, 1.0, 0.01, 1000.0)
+    scene = Scene("deep", [(Model(meshes, []), None)], [], cam, dict(sky_enabled=0, sun_shadow_enabled=1, lights_enabled=0, num_bounces=2))
+    W, H = 96, 96
+    grid = scene.upload(rr.Renderer(W, H))
+    grid.set_option("sun_grid_max_mean_list_x10", 10000)  # margins at |y| = 20000 are half a unit wide: long lists, and this test wants the grid
+    grid.set_option("sun_grid_max_fallback_pct", 100)
+    tree = scene.upload(rr.Renderer(W, H))
+    tree.set_option("sun_grid", 0)
+    cpu = scene.upload(oa.OracleRenderer(W, H))
+    for r in (grid, tree, cpu):
+        render(r, scene, W, H, (0.0, 1.0, 0.0), frames=2)
+    assert grid.get_stats().sun_grid_cells > 0, "the grid was refused: the test does not test it"
+    a = grid.read_accumulation()
+    assert np.array_equal(a.view(np.uint32), tree.read_accumulation().view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), cpu.read_accumulation().view(np.uint32))
+    lit = a[..., 0] > 0
+    assert lit.any() and not lit.all()  # the floor is lit except under the slab
