@@ -217,6 +217,28 @@ typedef struct UhStats {
 
 typedef struct uh_ctx uh_ctx;
 
+/* ---- Stream ordering (what a caller may rely on; tests/test_gpu_stream_order.py holds the library to it) ----------------
+ * uh_render_frame / uh_render_frames ENQUEUE and return; up to "frames_in_flight" frames run on streams of their own, the
+ * reservoir passes on another. Every other verb that reads or writes device state WAITS for all frames in flight first and
+ * is COMPLETE when it returns (its own copies and clears are waited for: the next frame may run on any of the library's
+ * streams, none of which is ordered against the null stream):
+ *   waits + complete on return:  uh_reset_stats, uh_get_stats, uh_reset_accumulation, uh_synchronize, every uh_read_*,
+ *        uh_write_reservoirs, uh_build_acceleration, uh_refit_acceleration (also when uh_render_frame calls it for
+ *        view->rebuild_tlas), uh_set_tile_partition, uh_set_restir_partition, uh_rccl_attach / uh_rccl_detach, uh_pack_tiles,
+ *        uh_unpack_tiles, uh_compose_tiles, uh_resolve_output, uh_add_isosurface_mesh, uh_destroy;
+ *        uh_set_option for "frames_in_flight" and for "time_kernels" 1 -> 0 (the others only change what the NEXT enqueued
+ *        frame does: "furnace", "sun_grid*", "overlap_*", "batch_frames", "*_variant", "*_blocks_per_cu", "count_visits",
+ *        "full_frame_restir", "primary_tiles"; "device_build", "spatial_splits", "ploc_*" invalidate the tree: the next frame
+ *        needs uh_build_acceleration, which waits);
+ *   host state only (no device access, nothing to wait for):  uh_add_mesh, uh_add_light, uh_set_instance_transform,
+ *        uh_get_num_lights, uh_mesh_info, uh_read_mesh, uh_get_restir_rows, uh_tile_pack_count, uh_last_error;
+ *   uh_add_texture_rgba8 uploads into a fresh allocation no frame in flight can reference (textures enter a frame's tables at the
+ *        next uh_build_acceleration) and is complete on return;
+ *   uh_trace_closest / uh_trace_any run on the context's first stream, in order with the frames of that stream, read the scene
+ *        only, and are complete on return.
+ * The sun-direction grid is (re)built inside the first frame call that wants it, after a wait for the frames in flight
+ * (option "sun_grid_async": on a host thread, adopted - after such a wait - by the first later frame call that finds it done). */
+
 /* ---- lifetime -------------------------------------------------------------------------- */
 int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out);
 void uh_destroy(uh_ctx* ctx);

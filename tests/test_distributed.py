@@ -208,3 +208,56 @@ def test_reservoir_rows_cover_what_the_passes_read():
             if world == 1:
                 assert (r.band_rows, r.reuse_rows, r.cast_rows) == (H, H, H)
         assert (covered == 1).all(), (H, world)
+
+
+class _MailboxGather:
+    """torch.distributed.gather for ranks that live in ONE process: the non-root ranks' calls leave their device tensor in a
+    shared mailbox, the root's call (made last) copies them into its gather list - device to device, as RCCL would deliver them"""
+
+    def __init__(self, rank, mailbox):
+        self.rank, self.mailbox = rank, mailbox
+
+    def gather(self, tensor, gather_list=None, dst=0):
+        if self.rank != dst:
+            assert gather_list is None
+            self.mailbox[self.rank] = tensor.clone()
+            return
+        for r, slot in enumerate(gather_list):
+            slot.copy_(tensor if r == self.rank else self.mailbox[r])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resolve", [True, False])
+def test_device_branch_of_the_composition_with_three_ranks_in_one_process(resolve):
+    """the HIP branch of distributed.gather_and_compose (uh_pack_tiles -> gather of DEVICE tensors ->
+    uh_compose_tiles / uh_unpack_tiles on the root) had only ever run at world = 1. Three contexts on GPU 0 stand for three
+    ranks; the tensors travel through a mailbox in place of the RCCL gather; the root's image must be the single context's."""
+    torch = pytest.importorskip("torch")
+    import rust_renderer_amd as rr
+
+    W, H, tile, world, frames = 200, 120, 32, 3, 5  # 7 x 4 tiles, the last column and row partial; 28 tiles over 3 ranks: 10 / 9 / 9
+    scene = rr.scenes.cornell_scene(subdivisions=2, tex_size=16)
+    single = scene.upload(rr.Renderer(W, H, device=0))
+    loop = rr.FrameLoop(single, scene.make_view(W, H))
+    loop.frames(frames, rr.PASS_REFERENCE_PT)
+    want_acc, want_out, want_rays = single.read_accumulation(), single.read_output_bgra8(), single.get_stats().path_rays
+    total = loop.view.total_samples
+    ranks, mailbox, rays = [], {}, 0
+    for r in range(world):
+        ctx = scene.upload(rr.Renderer(W, H, device=0))
+        ctx.set_tile_partition(r, world, tile)
+        lp = rr.FrameLoop(ctx, scene.make_view(W, H))
+        lp.frames(frames, rr.PASS_REFERENCE_PT)
+        rays += ctx.get_stats().path_rays
+        ranks.append(ctx)
+    assert rays == want_rays, "the ranks' ray counts add up to the full frame's"
+    for r in (2, 1, 0):  # the root last: its gather finds the others' tiles in the mailbox
+        rr.distributed.gather_and_compose(ranks[r], r, world, tile, _MailboxGather(r, mailbox), torch, "cuda:0",
+                                          resolve=(total, loop.view.accumulation_limit) if resolve else None)
+    got = ranks[0].read_accumulation()
+    assert np.array_equal(got.view(np.uint32), want_acc.view(np.uint32))
+    if resolve:
+        assert np.array_equal(ranks[0].read_output_bgra8(), want_out)  # uh_compose_tiles recomputed pt_output_image for every pixel
+    else:
+        ranks[0].resolve_output(total, loop.view.accumulation_limit)
+        assert np.array_equal(ranks[0].read_output_bgra8(), want_out)
