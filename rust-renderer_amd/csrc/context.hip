@@ -80,7 +80,7 @@ struct Slot {
    hipEvent_t ev_traced = nullptr, ev_missed = nullptr, ev_shaded = nullptr, ev_shadowed = nullptr, ev_side_done = nullptr;
    hipEvent_t ev_acc = nullptr;  // recorded after the frame's accumulate / store tail
    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
-   DevBuf<float4> rec, rad, pixcol;  // rec: the four path-state planes (device_types.h PathState)
+   DevBuf<float4> rec, radf, pixcol;  // rec: two sets of four path-state planes + the hit plane (device_types.h PathState)
    DevBuf<uint32_t> queues[5];
    DevBuf<Control> control;
    PathState ps{};
@@ -108,17 +108,20 @@ struct Slot {
       // (shard segment + position in the shard's queue), which runs to kShards * shard_cap >= n
       const size_t cap_q = (size_t)shard_cap * kShards;
       const size_t plane = (n > cap_q ? n : cap_q) + stagger / sizeof(float4);
-      SLOT_TRY(rec.alloc(plane * kRecQuads, 0 * stagger));
-      SLOT_TRY(rad.alloc(n, 1 * stagger));
+      SLOT_TRY(rec.alloc(plane * (2 * kRecQuads + 1), 0 * stagger));
+      SLOT_TRY(radf.alloc(n, 1 * stagger));
       SLOT_TRY(pixcol.alloc(n, 2 * stagger));
       // sharded queues: capacity per shard = the pixels (64-pixel runs) a shard can own
-      for (auto& q : queues) SLOT_TRY(q.alloc((size_t)shard_cap * kShards));
+      // (the miss queue holds (position, id) pairs: twice the words)
+      for (int qi = 0; qi < 5; qi++) SLOT_TRY(queues[qi].alloc((size_t)shard_cap * kShards * (qi == 4 ? 2 : 1)));
       SLOT_TRY(control.alloc(1));
       SLOT_TRY(hipMemsetAsync(control.p, 0, sizeof(Control), stream));
       SLOT_TRY(hipStreamSynchronize(stream));
 #undef SLOT_TRY
-      ps.rec = PathRecs{rec.p, plane};
-      ps.rad = rad.p;
+      ps.set[0] = PathRecs{rec.p, plane};
+      ps.set[1] = PathRecs{rec.p + plane * kRecQuads, plane};
+      ps.hit = rec.p + plane * 2 * kRecQuads;
+      ps.radf = radf.p;
       ps.pixcol = pixcol.p;
       for (int i = 0; i < 5; i++) ps.queue[i] = queues[i].p;
       ps.shard_cap = shard_cap;
@@ -129,7 +132,7 @@ struct Slot {
       if (stream) (void)hipStreamSynchronize(stream);
       if (side) (void)hipStreamSynchronize(side);
       rec.release();
-      rad.release();
+      radf.release();
       pixcol.release();
       for (auto& q : queues) q.release();
       control.release();
@@ -1207,11 +1210,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       launch_generate(lc, fp, s.ps, ctl, smp);
       for (uint32_t b = 0; b < fp.num_bounces; b++) {
          begin_timed(c, 0, s.stream);
-         const bool tiles = b == 0 && c->primary_tiles && primary_tiles_apply(fp);
-         if (tiles)
-            launch_trace_primary_tiles(lc, fp, c->scene, s.ps, st);  // coherent: one wave per 8 x 8 pixel tile, nodes through the scalar path
-         else
-            launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
+         launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
          end_timed(c, s.stream);
          const bool side_shadow = c->overlap_shadow && (fp.sun_shadow_enabled == 1 || fp.lights_enabled == 1);
          const bool side_used = side_shadow || c->overlap_miss;
@@ -1219,7 +1218,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          // miss queue shade_miss(b-1) reads there
          if (side_used && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_shadowed, 0));
          begin_timed(c, 2, s.stream);
-         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b, tiles);  // also hands the bounce's misses to shade_miss (Q_MISS)
+         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b);  // also hands the bounce's misses to shade_miss (Q_MISS)
          if (!c->overlap_miss) launch_shade_miss(lc, fp, s.ps, ctl, st, b);
          end_timed(c, s.stream);
          // shade_miss(b) and the shadow queries of bounce b are independent of trace_closest(b+1) (they only read what
@@ -1261,6 +1260,9 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          HIP_TRY(c, hipEventRecord(s.ev_side_done, s.side));
          HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_side_done, 0));
       }
+      // the paths still alive after the last bounce: their radiance (with what the last bounce's shadow rays added) goes to the
+      // per-id array the tail reads
+      if (fp.num_bounces > 0) launch_flush_survivors(lc, fp, s.ps, ctl);
       const bool last = smp + 1 == fp.samples_per_frame;
       // the accumulate / store tail (rgen:130-144) is a read-modify-write on the accumulation image:
       // frames must apply it in order, everything before it may overlap with other frames in flight

@@ -121,30 +121,39 @@ struct FrameParams {
    uint32_t n_owned;
 };
 
-// Path state: four 16-byte quads per path (path id == frame-in-batch * W*H + pixel), each quad in a PLANE of its own (SoA over
-// paths), so that a wave working on consecutive ids moves contiguous kilobytes - the CU's vector-memory pipeline, which bounds
-// this path, handles a coalesced wave access several times faster than 64 scattered sectors. (One 64-byte record per path -
-// one sector per path instead of four - was built and measured: 6.4-6.7 against 7.1 Grays/s, profiles/README.md "path records".)
+// Path state: four 16-byte quads per path, each quad in a PLANE of its own (SoA), and - round 4 - indexed by the path's POSITION
+// IN ITS BOUNCE'S RAY QUEUE (shard segment + position), not by path id. Two SETS of planes ping-pong: set b & 1 holds the paths of
+// bounce b's queue; k_shade_hit(b) reads a path's state at its position in queue b and writes the scattered path's new state at
+// the position it gets in queue b + 1 (in set (b + 1) & 1). Why: every kernel of the path walks a queue, so state by position is
+// read and written as contiguous streams (a wave's scattered paths get consecutive positions from one wave-level append), where
+// state by path id was one 64-byte sector per 16-byte record once the first bounce had thinned the ids out (rounds 1-3: the
+// shading and sun-ray kernels ran at the memory system's random-sector rate, profiles/r03_counters.json). The price: the
+// radiance travels with the path (plane 3: k_shade_hit copies it forward, +32 dense bytes per scattered hit) instead of resting
+// in a per-id array, and a path's final radiance is written where the path ends - miss, absorption, or the flush of the paths
+// still alive after the last bounce - into `radf`, by path id, once.
 // The RNG words ride in the w components the constant ray range (rgen:45-47: 0.001, 10000) does not need:
 //   plane 0  ray origin.xyz            | raygen rngState (bits)            reference.rgen:24,31
 //   plane 1  ray direction.xyz         | rayPayload.randomSeed (bits)      un-normalised direction (rgen:61); seed: rgen:30, rchit:91
 //   plane 2  throughput.rgb            | light weight f                    radiance += throughput * f when the light is visible (rgen:121)
-//   plane 3  hit: t, u, v              | triangle packet index (bits), 0xffffffff = miss
-// so a shaded hit reads four planes and writes three (the round-2 layout: five and four, with a separate RNG array).
+//   plane 3  radiance.rgb              | light index (bits)                rgen:69-78, :118-122 add to it; not materialised for bounce 0 (it is zero)
+// The hit record of a bounce's ray (t, u, v | packet index, 0xffffffff = miss) lies in a plane of its own at the same position.
 constexpr uint32_t kRecQuads = 4;
-enum { REC_ORIGIN = 0, REC_DIR = 1, REC_THR = 2, REC_HIT = 3 };
+enum { REC_ORIGIN = 0, REC_DIR = 1, REC_THR = 2, REC_RAD = 3 };
 struct PathRecs {
    float4* base;
-   size_t plane;  // float4 between two planes (the path capacity plus a stagger: the planes must not alias in the caches)
+   size_t plane;  // float4 between two planes (the queue capacity plus a stagger: the planes must not alias in the caches)
 };
 struct PathState {
-   PathRecs rec;
-   float4* rad;     // radiance.rgb, light index (bits): touched only where a path ends or a light / sun sample lands
-   float4* pixcol;  // sum over the frame's samples
-   uint32_t* queue[5];  // 0,1 = ray ping-pong; 2 = light; 3 = sun rays for the tree walk; 4 = misses; each kShards * shard_cap entries
+   PathRecs set[2];  // set b & 1: state of the paths of bounce b's RAY queue, by queue position
+   float4* hit;      // hit record of the bounce being traced, by queue position
+   float4* radf;     // by path id: a finished path's radiance.rgb | its raygen rngState (the frame's next sample starts from it, rgen:28-31)
+   float4* pixcol;   // by path id: sum over the frame's samples
+   // 0,1 = ray ping-pong: path ids; 2 = light, 3 = sun rays for the tree walk: positions in the NEXT bounce's ray queue; 4 = misses:
+   // positions in the CURRENT one; each kShards * shard_cap entries
+   uint32_t* queue[5];
    uint32_t shard_cap;  // entries per shard segment = pixels a shard can own (multiple of 64)
 };
-__host__ __device__ inline float4* rec_quad(const PathRecs& rec, uint32_t id, int quad) { return rec.base + rec.plane * (size_t)quad + id; }
+__host__ __device__ inline float4* rec_quad(const PathRecs& rec, uint32_t pos, int quad) { return rec.base + rec.plane * (size_t)quad + pos; }
 
 // rays of the stand-alone queries (uh_trace_closest, the G-buffer cast): record i = ray i, tmin / tmax in the w components
 struct RawRays {
@@ -186,17 +195,17 @@ struct LaunchCfg {
    // next ray from an LDS pool (kernels.hip "Ray replacement"), the default
    int closest_variant, shadow_variant;
    bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
-   bool primary_tiles = false;     // primary rays and the G-buffer cast: one wave per 8 x 8 pixel tile (k_trace_closest_tiles)
+   bool primary_tiles = false;     // the G-buffer cast: one wave per 8 x 8 pixel tile (k_trace_closest_tiles)
    uint32_t miss_blocks_per_cu = 8; // k_shade_miss (dense miss queue, VALU-bound sky integral): option "miss_blocks_per_cu"
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);
 void launch_trace_closest(const LaunchCfg&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce, uint32_t cursor_slot,
                           int ray_kind);
-bool primary_tiles_apply(const FrameParams&);
-void launch_trace_primary_tiles(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, DeviceStats*);
 void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, DeviceStats*, uint32_t bounce);
-void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce, bool hits_by_path);
+void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
+// the paths still alive after the last bounce hand their radiance to the per-id array k_finish_sample reads
+void launch_flush_survivors(const LaunchCfg&, const FrameParams&, const PathState&, Control*);
 void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
                          uint32_t cursor_slot, bool light, bool sun_leftovers = false);
 // sun shadow rays through the per-direction grid (sun_grid.h) instead of the tree

@@ -465,13 +465,14 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
 // the same queue and reads the records back as one contiguous stream (a record per path id was a 64-byte sector per 16-byte
 // record there).
 // ------------------------------------------------------------------------------------------
-// Path rays (queue_base != null): ray_o / ray_d / hit_out are planes 0 / 1 / 3 of the path state, whose w components carry RNG
-// words: the range is rgen:45-47's constants. Raw rays (queue_base == null, RawRays): the range is in the w components.
+// Path rays (sharded): ray_o / ray_d are the origin / direction planes of the bounce's state set, hit_out the hit plane - all by
+// queue position, so the rays of a 64-entry chunk are two contiguous kilobytes; their w components carry RNG words: the range is
+// rgen:45-47's constants. Raw rays (!sharded, RawRays): record i = ray i, the range is in the w components.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const uint32_t* __restrict__ queue_base, const float4* __restrict__ ray_o,
+__global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, bool sharded, const float4* __restrict__ ray_o,
                                                                const float4* __restrict__ ray_d, float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl,
                                                                DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
-   const bool range_in_w = queue_base == nullptr;
+   const bool range_in_w = !sharded;
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    __shared__ RayPool<2> s_pool[kWavesPerBlock];
    const uint32_t lane = lane_id();
@@ -479,11 +480,11 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
    uint32_t* lds_col = &s_stack[wave][0][lane];
    RayPool<2>& pool = s_pool[wave];
    RaySource src;
-   uint32_t seg = 0;  // first record of this block's results: its shard's segment (path rays) or 0 (raw rays: record i = ray i)
-   if (queue_base) {  // path tracer: this block's shard of the bounce's ray queue, chunks from the shard's cursor
+   uint32_t seg = 0;  // first record of this block's rays and results: its shard's segment (path rays) or 0 (raw rays)
+   if (sharded) {  // path tracer: this block's shard of the bounce's ray queue, chunks from the shard's cursor; ray = record at its position
       const ShardCtx sx = shard_ctx();
       seg = sx.shard * shard_cap;
-      src.queue = queue_base + seg;
+      src.queue = nullptr;
       src.count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
       src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
       src.wave_index = src.num_waves = 0;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, const 
    }
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
-   auto source_of = [&](int a, uint32_t id) { return (a == 0 ? ray_o : ray_d) + id; };
+   auto source_of = [&](int a, uint32_t pos) { return (a == 0 ? ray_o : ray_d) + seg + pos; };
    Feeder<2> f;
    Trav t;
    t.cur = kEmptyRef;
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_tiles(SceneDev sc, Til
 // then the wave takes the next 64. Kept as the baseline the refill kernels are measured against, and for the
 // per-ray visit counts of the diagnostics (DIAG: u,v of the result carry the ray's node / triangle visits).
 template <bool COUNT, bool DIAG>
-__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_batch(SceneDev sc, const uint32_t* __restrict__ queue_base,
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_batch(SceneDev sc, bool sharded,
                                                                                                       const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                                                                       float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl, DeviceStats* stats,
                                                                                                       uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    const uint32_t lane = lane_id();
    uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
    uint32_t n_nodes = 0, n_tris = 0;
-   if (!queue_base) {
+   if (!sharded) {
       for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < raw_count; i += gridDim.x * kBlock) {
          float4 ro = ray_o[i], rd = ray_d[i];
          Hit h;
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
       return;
    }
    const ShardCtx sx = shard_ctx();
-   const uint32_t* __restrict__ queue = queue_base + sx.shard * shard_cap;
+   const uint32_t seg = sx.shard * shard_cap;
    uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
    for (;;) {
@@ -686,11 +687,10 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
       if (base >= count) break;
       uint32_t i = base + lane;
       if (i < count) {
-         const uint32_t id = queue[i];
-         float4 ro = ray_o[id], rd = ray_d[id];  // path state: w = RNG words, range = rgen:45-47's constants
+         float4 ro = ray_o[seg + i], rd = ray_d[seg + i];  // path state by queue position: w = RNG words, range = rgen:45-47's constants
          Hit h;
          traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 0.001f, 10000.0f, 0.0f, h, lds_col, n_nodes, n_tris);
-         hit_out[sx.shard * shard_cap + i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));  // by queue position, as the refill kernel
+         hit_out[seg + i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));  // by queue position, as the refill kernel
       }
    }
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
@@ -746,8 +746,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
    RaySource src;
-   // sun rays leave from every scattered path = the next bounce's ray queue; light rays from the light queue
-   src.queue = (LIGHT ? ps.queue[2] : leftovers ? ps.queue[3] : ps.queue[(bounce + 1) & 1]) + seg;
+   // sun rays leave from every scattered path = every position of the next bounce's ray queue (identity); light rays and the sun
+   // rays the grid handed over from the positions listed in their queues
+   src.queue = LIGHT ? ps.queue[2] + seg : leftovers ? ps.queue[3] + seg : nullptr;
    src.count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : leftovers ? ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    src.wave_index = src.num_waves = 0;
@@ -757,14 +758,14 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    }
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
-   const PathRecs rec = ps.rec;
-   const float4* rad = ps.rad;
-   auto source_of = [&](int a, uint32_t id) { return a == 2 ? rad + id : (const float4*)rec_quad(rec, id, a == 0 ? REC_ORIGIN : REC_THR); };
+   const PathRecs rec = ps.set[(bounce + 1) & 1];  // the state of the scattered paths, at their positions in the next bounce's queue
+   float4* rad = rec_quad(rec, seg, REC_RAD);
+   auto source_of = [&](int a, uint32_t pos) { return (const float4*)rec_quad(rec, seg + pos, a == 0 ? REC_ORIGIN : a == 1 ? REC_THR : REC_RAD); };
    Feeder<3> f;
    Trav t;
    t.cur = kEmptyRef;
    t.sp = 0;
-   uint32_t id = 0, n_nodes = 0, n_tris = 0;
+   uint32_t id = 0, n_nodes = 0, n_tris = 0;  // id: the path's position in the next bounce's queue
    float4 lit = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
    uint32_t spill[kSpillStack];
    auto take = [&](uint32_t slot) {
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    while (refill_lanes<3>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<true, COUNT>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) st_stream(ps.rad + id, lit);
+         if (trav_step<true, COUNT>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) st_stream(rad + id, lit);
       }
    }
    if (COUNT) {
@@ -794,19 +795,20 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
    uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t* __restrict__ queue = (LIGHT ? ps.queue[2] : ps.queue[(bounce + 1) & 1]) + seg;
+   const uint32_t* __restrict__ queue = ps.queue[2] + seg;  // light rays: positions in the next bounce's ray queue; sun rays: every position
    const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
+   const PathRecs rec = ps.set[(bounce + 1) & 1];
    uint32_t n_nodes = 0, n_tris = 0;
    for (;;) {
       uint32_t base = next_batch(cursor);
       if (base >= count) break;
       uint32_t i = base + lane;
       if (i < count) {
-         const uint32_t id = queue[i];
-         const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, *rec_quad(ps.rec, id, REC_ORIGIN), *rec_quad(ps.rec, id, REC_THR), ps.rad[id]);
+         const uint32_t pos = seg + (LIGHT ? queue[i] : i);
+         const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, *rec_quad(rec, pos, REC_ORIGIN), *rec_quad(rec, pos, REC_THR), *rec_quad(rec, pos, REC_RAD));
          Hit h;
-         if (!traverse<true, COUNT>(sc, xyz(s.ro), xyz(s.rd), s.ro.w, s.rd.w, s.tlimit, h, lds_col, n_nodes, n_tris)) ps.rad[id] = s.lit;
+         if (!traverse<true, COUNT>(sc, xyz(s.ro), xyz(s.rd), s.ro.w, s.rd.w, s.tlimit, h, lds_col, n_nodes, n_tris)) *rec_quad(rec, pos, REC_RAD) = s.lit;
       }
    }
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
    const uint32_t lane = lane_id();
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t* __restrict__ queue = ps.queue[(bounce + 1) & 1] + seg;  // a sun ray leaves every scattered path
+   const PathRecs rec = ps.set[(bounce + 1) & 1];  // a sun ray leaves every scattered path: every position of the next bounce's ray queue
    const uint32_t count = ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const float4* __restrict__ tris = sc.tris;
@@ -843,11 +845,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
       if (base >= count) break;
       const uint32_t i = base + lane;
       const bool valid = i < count;
-      uint32_t id = 0;
+      const uint32_t id = i;  // the path's position in the queue: its state lies there, a wave reads and writes contiguous kilobytes
       bool defer = false;
       if (valid) {
-         id = ld_stream(queue + i);
-         const float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN));
+         const float4 ro = ld_rec(rec_quad(rec, seg + id, REC_ORIGIN));
          const V3 o = v3(ro.x, ro.y, ro.z);
          const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o), pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
          // the ray's cell; outside the grid (or NaN) it is a border cell
@@ -895,8 +896,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
                e++;
             }
             if (!occluded) {  // rgen:69-78: radiance += throughput
-               const float4 thr = ld_rec(rec_quad(ps.rec, id, REC_THR)), rad = ld_stream(ps.rad + id);
-               st_stream(ps.rad + id, make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w));
+               const float4 thr = ld_rec(rec_quad(rec, seg + id, REC_THR)), rad = ld_rec(rec_quad(rec, seg + id, REC_RAD));
+               st_rec(rec_quad(rec, seg + id, REC_RAD), make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w));
             }
          }
       }
@@ -932,13 +933,14 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
    const uint32_t n = fp.n_owned * fp.batch_frames;  // owned pixels x frames of the batch
    const uint32_t lane = lane_id();
    const uint32_t groups = (n + 63) / 64;
-   // one wave per 64 owned pixels, streamed in order (plain coalesced 1-KiB stores per array for
-   // whole tile rows); a path's shard (shard_of_run of its 64-path run) decides which queue segment
-   // receives its id
+   // one wave per 64 owned pixels; a path's shard (shard_of_run of its 64-path run) decides which queue segment receives its id,
+   // and its state goes to the position it gets there (set 0: the state of bounce 0's queue) - the 64 paths of a wave are one
+   // run, so one append hands them 64 consecutive positions: plain coalesced 1-KiB stores per plane
    for (uint32_t g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); g < groups; g += gridDim.x * kWavesPerBlock) {
       const uint32_t q = g * 64u + lane;
       bool own = q < n;
       uint32_t id = 0;
+      float4 s_o = make_float4(0, 0, 0, 0), s_d = make_float4(0, 0, 0, 0);
       if (own) {
          // path id = frame of the batch x owned pixels + index into the rank's owned-pixel list: dense, so a rank's wavefront
          // carries as many frames as its share of the frame allows (on one GPU: frame x W x H + pixel)
@@ -946,14 +948,13 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
          const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
          id = q;
          uint32_t px = pix % fp.W, py = pix / fp.W;
-         uint32_t rng = sample == 0 ? init_rng(px, py, fp.W, fp.frame_numbers[f]) : __float_as_uint(rec_quad(ps.rec, id, REC_ORIGIN)->w);  // rgen:24
+         uint32_t rng = sample == 0 ? init_rng(px, py, fp.W, fp.frame_numbers[f]) : __float_as_uint(ps.radf[id].w);  // rgen:24; later samples: where the last one left it
          uint32_t seed = rng;                                                                   // rgen:30
          float jx = random_float(rng), jy = random_float(rng);                                  // rgen:31
          V3 o, d;
          primary_ray(fp, px, py, jx, jy, o, d);
-         st_rec(rec_quad(ps.rec, id, REC_ORIGIN), make_float4(o.x, o.y, o.z, __uint_as_float(rng)));
-         st_rec(rec_quad(ps.rec, id, REC_DIR), make_float4(d.x, d.y, d.z, __uint_as_float(seed)));
-         st_rec(rec_quad(ps.rec, id, REC_THR), make_float4(1.0f, 1.0f, 1.0f, 0.0f));  // throughput = 1 (rgen:39)
+         s_o = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+         s_d = make_float4(d.x, d.y, d.z, __uint_as_float(seed));
          // radiance = 0 / pixelColor = 0 (rgen:26,40) are not materialised: the bounce-0 shading kernels and the first
          // finish_sample use the constants directly
       }
@@ -965,7 +966,13 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
          const uint32_t s = __shfl(shard, leader);
          const bool mine = own && shard == s;
          uint32_t slot = wave_append(&ctl->q_count[qc_index(0, Q_RAY, s)], mine);
-         if (mine) ps.queue[0][s * ps.shard_cap + slot] = id;
+         if (mine) {
+            const uint32_t pos = s * ps.shard_cap + slot;
+            ps.queue[0][pos] = id;
+            st_rec(rec_quad(ps.set[0], pos, REC_ORIGIN), s_o);
+            st_rec(rec_quad(ps.set[0], pos, REC_DIR), s_d);
+            st_rec(rec_quad(ps.set[0], pos, REC_THR), make_float4(1.0f, 1.0f, 1.0f, 0.0f));  // throughput = 1 (rgen:39)
+         }
          todo &= ~__ballot(mine);
       }
    }
@@ -978,20 +985,24 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
 // misses are first compacted inside the wave: ids collect in a per-wave LDS list and the integral
 // runs on 64 of them at a time with every lane live.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const PathState& ps, uint32_t id, uint32_t bounce) {
+// pos: the path's position in the bounce's ray queue (shard segment included), id: its path id. The path ends here: its radiance
+// goes to the per-id array, with the raygen's RNG word (the frame's next sample starts from it, rgen:28-31)
+__device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const PathState& ps, uint32_t pos, uint32_t id, uint32_t bounce) {
+   const PathRecs rec = ps.set[bounce & 1];
+   const float4 ro = ld_rec(rec_quad(rec, pos, REC_ORIGIN));
    V3 sky_color = v3(0.0f, 0.0f, 0.0f);
    if (fp.furnace) {
       sky_color = v3(1.0f, 1.0f, 1.0f);  // rmiss:12 with FURNACE_TEST defined: the #ifndef block (rmiss:14-28) is compiled out
    } else if (fp.sky_enabled == 1) {
-      float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN)), rd = ld_rec(rec_quad(ps.rec, id, REC_DIR));
+      const float4 rd = ld_rec(rec_quad(rec, pos, REC_DIR));
       V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
       sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
    }
-   const float4 thr = ld_rec(rec_quad(ps.rec, id, REC_THR));  // 1 at bounce 0 (k_generate)
+   const float4 thr = ld_rec(rec_quad(rec, pos, REC_THR));  // 1 at bounce 0 (k_generate)
    float4 rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-   if (bounce != 0) rad = ld_stream(ps.rad + id);
+   if (bounce != 0) rad = ld_rec(rec_quad(rec, pos, REC_RAD));
    V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
-   st_stream(ps.rad + id, make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, rad.w));   // rgen:55
+   st_stream(ps.radf + id, make_float4(rad.x + t.x, rad.y + t.y, rad.z + t.z, ro.w));   // rgen:55
 }
 
 // The bounce's misses arrive as a queue of their own (Q_MISS), written by k_shade_hit while it classifies the bounce's RAY
@@ -999,9 +1010,13 @@ __device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const Pat
 // path) and four 16-byte records per path is left in the kernel.
 __global__ __launch_bounds__(kBlock) void k_shade_miss(FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
    const ShardCtx sx = shard_ctx();
-   const uint32_t* __restrict__ queue = ps.queue[4] + sx.shard * ps.shard_cap;
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint2* __restrict__ queue = reinterpret_cast<const uint2*>(ps.queue[4]) + seg;  // (position in the bounce's ray queue, path id)
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   for (uint32_t i = sx.lb * kBlock + threadIdx.x; i < count; i += sx.nb * kBlock) shade_miss_path(fp, ps, ld_stream(queue + i), bounce);
+   for (uint32_t i = sx.lb * kBlock + threadIdx.x; i < count; i += sx.nb * kBlock) {
+      const uint2 e = ld_stream(queue + i);
+      shade_miss_path(fp, ps, seg + e.x, e.y, bounce);
+   }
    if (sx.lb == 0 && threadIdx.x == 0 && count) atomicAdd(&stats->misses, (unsigned long long)count);
 }
 
@@ -1052,8 +1067,7 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
    return I * eta - N * (eta * dn + sqrtf(k));
 }
 
-// hits_by_path: the hit records lie by path id (the wave-per-tile kernel wrote them), not by queue position
-__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce, bool hits_by_path) {
+__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
    // c / 255.0f table in LDS: the 12 per-fetch table gathers were texture-addresser traffic (the
    // kernel ran 86 % TA-busy at 2 % VALU, profiles/r01c_*); LDS serves them at no TA cost
    __shared__ float s_lut[256];
@@ -1066,8 +1080,8 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    const uint32_t n_lds_mesh = sc.num_meshes < kLdsMeshes ? sc.num_meshes : kLdsMeshes;
    const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
    __shared__ uint32_t s_hits;
-   __shared__ uint32_t s_list[kWavesPerBlock][5][128];  // per wave: path ids, and the hit record (t, u, v, packet) the classification read with them
-   __shared__ uint32_t s_miss[kWavesPerBlock][128];     // per wave: ids of the paths that missed, handed to k_shade_miss 64 at a time
+   __shared__ uint32_t s_list[kWavesPerBlock][6][128];  // per wave: path ids, their queue positions, and the hit record (t, u, v, packet) the classification read with them
+   __shared__ uint32_t s_miss[kWavesPerBlock][2][128];  // per wave: (position, id) of the paths that missed, handed to k_shade_miss 64 at a time
    if (threadIdx.x == 0) s_hits = 0;
    if (threadIdx.x < n_lds_mesh) s_mesh[threadIdx.x] = sc.meshes[threadIdx.x];
    if (threadIdx.x < n_lds_tex) s_tex[threadIdx.x] = sc.textures[threadIdx.x];
@@ -1077,27 +1091,32 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    // the bounce's RAY queue: paths whose hit record says "miss" belong to k_shade_miss and are skipped here
    const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
    const uint32_t* __restrict__ queue = ps.queue[bounce & 1] + seg;
+   const PathRecs cur = ps.set[bounce & 1], nxt = ps.set[(bounce + 1) & 1];  // state by position in this bounce's queue / in the next one's
    uint32_t* q_next = ps.queue[(bounce + 1) & 1] + seg;
    uint32_t* n_next = &ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    uint32_t* q_light = ps.queue[2] + seg;
    uint32_t* n_light = &ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)];
-   uint32_t* q_miss = ps.queue[4] + seg;
+   uint2* q_miss = reinterpret_cast<uint2*>(ps.queue[4]) + seg;
    uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
    const uint32_t stride = sx.nb * kBlock;
    const uint32_t rounds = (count + stride - 1) / stride;
    uint32_t n_hits = 0;
-   // one path per lane: `valid` lanes shade their hit; every lane of the wave takes part in the queue appends
-   auto shade = [&](uint32_t id, float4 hr, bool valid) {
+   // one path per lane: `valid` lanes shade their hit; every lane of the wave takes part in the queue appends.
+   // pos: the path's position in this bounce's queue (without the shard segment)
+   auto shade = [&](uint32_t id, uint32_t pos, float4 hr, bool valid) {
       const uint32_t pk = __float_as_uint(hr.w);
       bool scattered = false, want_light = false;
+      float4 n_o = make_float4(0, 0, 0, 0), n_d = make_float4(0, 0, 0, 0), n_t = make_float4(0, 0, 0, 0), n_r = make_float4(0, 0, 0, 0);  // the scattered path's new state
       if (valid) {
          // every record of the path is requested up front, together with the shading packet (whose index the
-         // classification below already read): one round trip for all of them, then one for the texels
-         // the path's state: three more planes (the RNG words ride in the rays' w components); the hit record came with the
-         // classification below
-         float4 ro = ld_rec(rec_quad(ps.rec, id, REC_ORIGIN)), rd = ld_rec(rec_quad(ps.rec, id, REC_DIR));
+         // classification below already read): one round trip for all of them, then one for the texels.
+         // The path's state: four planes at its queue position (the RNG words ride in the rays' w components); the lanes of a wave
+         // hold hits of nearly consecutive positions, so these are nearly contiguous reads
+         float4 ro = ld_rec(rec_quad(cur, seg + pos, REC_ORIGIN)), rd = ld_rec(rec_quad(cur, seg + pos, REC_DIR));
          uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
-         float4 thr4 = ld_rec(rec_quad(ps.rec, id, REC_THR));
+         float4 thr4 = ld_rec(rec_quad(cur, seg + pos, REC_THR));
+         float4 rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // radiance so far: zero before the first bounce (not materialised)
+         if (bounce != 0) rad4 = ld_rec(rec_quad(cur, seg + pos, REC_RAD));
          const V3 ray_dir = v3(rd.x, rd.y, rd.z);
          const float t = hr.x, bu = hr.y, bv = hr.z;
          const float4* sp = sc.shade + 4 * (size_t)pk;  // pk = hr.w, known since the classification: no wait for hr before these
@@ -1112,7 +1131,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          const float bx = 1.0f - bu - bv, by = bu, bz = bv;                            // rchit:30
          V3 normal = (n0 * bx + n1 * by) + n2 * bz;                                    // rchit:31
          // keeps the compiler from sinking the early loads to their first use
-         asm volatile("" : "+v"(rng.x), "+v"(rng.y), "+v"(thr4.x), "+v"(thr4.y), "+v"(thr4.z));
+         asm volatile("" : "+v"(rng.x), "+v"(rng.y), "+v"(thr4.x), "+v"(thr4.y), "+v"(thr4.z), "+v"(rad4.x), "+v"(rad4.y), "+v"(rad4.z));
          V3 wn = v3((normal.x * ms.w2o[0] + normal.y * ms.w2o[3]) + normal.z * ms.w2o[6],
                     (normal.x * ms.w2o[1] + normal.y * ms.w2o[4]) + normal.z * ms.w2o[7],
                     (normal.x * ms.w2o[2] + normal.y * ms.w2o[5]) + normal.z * ms.w2o[8]);  // rchit:32
@@ -1161,19 +1180,13 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          rng.y = seed;                                                                 // rchit:91
 
          V3 thr = v3(thr4.x, thr4.y, thr4.z) * color;                                  // rgen:48
-         // the radiance record is only touched when this path ends here (rgen:53-57) or a light sample
-         // has to be parked in its w component; a scattered path with lights off leaves it alone
-         if (!scattered) {                                                             // rgen:53-57
-            float4 rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (bounce != 0) rad4 = ld_stream(ps.rad + id);
-            st_stream(ps.rad + id, make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, rad4.w));
-            // the RNG words go back into the ray planes: the next sample of the frame starts from them (rgen:28-31)
-            st_rec(rec_quad(ps.rec, id, REC_ORIGIN), make_float4(ro.x, ro.y, ro.z, __uint_as_float(rng.x)));
-            st_rec(rec_quad(ps.rec, id, REC_DIR), make_float4(rd.x, rd.y, rd.z, __uint_as_float(rng.y)));
+         if (!scattered) {                                                             // rgen:53-57: the path ends here
+            // its radiance goes to the per-id array k_finish_sample reads, with the raygen's RNG word: the next sample of the
+            // frame starts from it (rgen:28-31)
+            st_stream(ps.radf + id, make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, __uint_as_float(rng.x)));
          } else {
             V3 origin = v3(ro.x, ro.y, ro.z) + t * ray_dir;                            // rgen:59
             origin = offset_ray(origin, world_normal);                                 // rgen:60
-            // (the path's three planes are written below, once the raygen's RNG word is final)
             float f = 0.0f;
             int light_index = 0;
             if (fp.lights_enabled == 1) {                                              // rgen:81-110
@@ -1196,38 +1209,41 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
                   f = target_function(sc.lights, sc.num_lights, light_index, origin) * light_sample_weight;  // rgen:121
                }
             }
-            st_rec(rec_quad(ps.rec, id, REC_ORIGIN), make_float4(origin.x, origin.y, origin.z, __uint_as_float(rng.x)));
-            st_rec(rec_quad(ps.rec, id, REC_DIR), make_float4(scatter.x, scatter.y, scatter.z, __uint_as_float(rng.y)));  // rgen:61
-            st_rec(rec_quad(ps.rec, id, REC_THR), make_float4(thr.x, thr.y, thr.z, f));
-            if (bounce == 0) {
-               // first write of this path's radiance record (generate does not materialise the zero)
-               st_stream(ps.rad + id, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)light_index)));
-            } else if (fp.lights_enabled == 1) {
-               float4 rad4 = ld_stream(ps.rad + id);
-               st_stream(ps.rad + id, make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index)));
-            }
+            // the path's state for the next bounce; written below at the position the path gets in the next bounce's queue
+            n_o = make_float4(origin.x, origin.y, origin.z, __uint_as_float(rng.x));
+            n_d = make_float4(scatter.x, scatter.y, scatter.z, __uint_as_float(rng.y));  // rgen:61
+            n_t = make_float4(thr.x, thr.y, thr.z, f);
+            n_r = make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index));  // the radiance travels with the path
          }
       }
-      uint32_t slot = wave_append(n_next, scattered);
-      if (scattered) st_stream(q_next + slot, id);
-      slot = wave_append(n_light, want_light);
-      if (want_light) st_stream(q_light + slot, id);
+      // a wave's scattered paths get consecutive positions: their new state leaves as contiguous stores, and the next bounce's
+      // traversal, sun-ray and shading kernels read it back as streams
+      const uint32_t slot = wave_append(n_next, scattered);
+      if (scattered) {
+         st_stream(q_next + slot, id);
+         st_rec(rec_quad(nxt, seg + slot, REC_ORIGIN), n_o);
+         st_rec(rec_quad(nxt, seg + slot, REC_DIR), n_d);
+         st_rec(rec_quad(nxt, seg + slot, REC_THR), n_t);
+         st_rec(rec_quad(nxt, seg + slot, REC_RAD), n_r);
+      }
+      const uint32_t lslot = wave_append(n_light, want_light);
+      if (want_light) st_stream(q_light + lslot, slot);  // the light ray leaves from the path's new position
    };
    // The bounce's RAY queue holds hits and misses (the traversal kernels build no hit / miss queues). Shading a wave of
    // queue entries as they come leaves the lanes of the misses idle through the whole material evaluation, so the hits
    // are first compacted inside the wave: their ids collect in a per-wave LDS list and are shaded 64 at a time.
-   uint32_t(*list)[128] = s_list[threadIdx.x >> 6];  // [0] ids, [1..4] the hit record's four words
-   uint32_t* missed = s_miss[threadIdx.x >> 6];
+   uint32_t(*list)[128] = s_list[threadIdx.x >> 6];  // [0] ids, [1] positions, [2..5] the hit record's four words
+   uint32_t(*missed)[128] = s_miss[threadIdx.x >> 6];  // [0] positions, [1] ids
    const uint32_t lane = lane_id();
    uint32_t n_list = 0, n_missed = 0;  // wave-uniform
-   // `n` ids from the front of the wave's miss list go to the bounce's miss queue (one atomic per call)
+   // `n` entries from the front of the wave's miss list go to the bounce's miss queue (one atomic per call)
    auto flush_misses = [&](uint32_t n) {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(n_miss, n);
       base = __shfl(base, 0);
-      if (lane < n) st_stream(q_miss + base + lane, missed[lane]);
+      if (lane < n) st_stream(q_miss + base + lane, make_uint2(missed[0][lane], missed[1][lane]));
    };
-   auto entry = [&](uint32_t k) { return make_float4(__uint_as_float(list[1][k]), __uint_as_float(list[2][k]), __uint_as_float(list[3][k]), __uint_as_float(list[4][k])); };
+   auto entry = [&](uint32_t k) { return make_float4(__uint_as_float(list[2][k]), __uint_as_float(list[3][k]), __uint_as_float(list[4][k]), __uint_as_float(list[5][k])); };
    for (uint32_t r = 0; r < rounds; r++) {
       const uint32_t i = r * stride + sx.lb * kBlock + threadIdx.x;
       uint32_t id = 0;
@@ -1236,23 +1252,32 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          id = ld_stream(queue + i);
          // the whole record (one 16-byte lane load, as the packet index alone would be): shade() does not read it again. The
          // traversal kernel left it at the ray's queue position: the wave reads 1 KiB in one piece
-         hr = ld_rec(rec_quad(ps.rec, hits_by_path ? id : seg + i, REC_HIT));
+         hr = ld_rec(ps.hit + seg + i);
       }
       const bool is_hit = __float_as_uint(hr.w) != kEmptyRef;
       const unsigned long long mask = __ballot(is_hit);
       const unsigned long long mmask = __ballot(i < count && !is_hit);
       if (mmask) {
          const uint32_t mp = __builtin_amdgcn_mbcnt_hi((uint32_t)(mmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mmask, 0u));
-         if (i < count && !is_hit) missed[n_missed + mp] = id;
+         if (i < count && !is_hit) {
+            missed[0][n_missed + mp] = i;
+            missed[1][n_missed + mp] = id;
+         }
          n_missed += (uint32_t)__popcll(mmask);
          __builtin_amdgcn_wave_barrier();
          if (n_missed >= 64u) {
             flush_misses(64u);
             const uint32_t rest = n_missed - 64u;  // at most 63: to the front (one wave, LDS operations execute in order)
-            uint32_t tmp = 0;
-            if (lane < rest) tmp = missed[64u + lane];
+            uint32_t tmp0 = 0, tmp1 = 0;
+            if (lane < rest) {
+               tmp0 = missed[0][64u + lane];
+               tmp1 = missed[1][64u + lane];
+            }
             __builtin_amdgcn_wave_barrier();
-            if (lane < rest) missed[lane] = tmp;
+            if (lane < rest) {
+               missed[0][lane] = tmp0;
+               missed[1][lane] = tmp1;
+            }
             __builtin_amdgcn_wave_barrier();
             n_missed = rest;
          }
@@ -1261,29 +1286,30 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
       const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
       if (is_hit) {
          list[0][n_list + prefix] = id;
-         list[1][n_list + prefix] = __float_as_uint(hr.x);
-         list[2][n_list + prefix] = __float_as_uint(hr.y);
-         list[3][n_list + prefix] = __float_as_uint(hr.z);
-         list[4][n_list + prefix] = __float_as_uint(hr.w);
+         list[1][n_list + prefix] = i;
+         list[2][n_list + prefix] = __float_as_uint(hr.x);
+         list[3][n_list + prefix] = __float_as_uint(hr.y);
+         list[4][n_list + prefix] = __float_as_uint(hr.z);
+         list[5][n_list + prefix] = __float_as_uint(hr.w);
       }
       n_list += (uint32_t)__popcll(mask);
       __builtin_amdgcn_wave_barrier();
       if (n_list >= 64u) {
-         shade(list[0][lane], entry(lane), true);
+         shade(list[0][lane], list[1][lane], entry(lane), true);
          n_hits += 64u;
          const uint32_t rest = n_list - 64u;  // move the tail (at most 63 entries) to the front: one wave, LDS operations execute in order
-         uint32_t tmp[5] = {0, 0, 0, 0, 0};
+         uint32_t tmp[6] = {0, 0, 0, 0, 0, 0};
          if (lane < rest)
-            for (int k = 0; k < 5; k++) tmp[k] = list[k][64u + lane];
+            for (int k = 0; k < 6; k++) tmp[k] = list[k][64u + lane];
          __builtin_amdgcn_wave_barrier();
          if (lane < rest)
-            for (int k = 0; k < 5; k++) list[k][lane] = tmp[k];
+            for (int k = 0; k < 6; k++) list[k][lane] = tmp[k];
          __builtin_amdgcn_wave_barrier();
          n_list = rest;
       }
    }
    if (n_list) {
-      shade(lane < n_list ? list[0][lane] : 0u, lane < n_list ? entry(lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f), lane < n_list);
+      shade(lane < n_list ? list[0][lane] : 0u, lane < n_list ? list[1][lane] : 0u, lane < n_list ? entry(lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f), lane < n_list);
       n_hits += n_list;
    }
    if (n_missed) flush_misses(n_missed);
@@ -1291,6 +1317,22 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    if (lane_id() == 0 && n_hits) atomicAdd(&s_hits, n_hits);
    __syncthreads();
    if (threadIdx.x == 0 && s_hits) atomicAdd(&stats->closest_hits, (unsigned long long)s_hits);
+}
+
+// The paths still alive after the last bounce (the ray queue shade_hit(num_bounces - 1) built): their radiance - with what the
+// last bounce's shadow rays added - and their raygen RNG word go to the per-id array k_finish_sample and the next sample's
+// k_generate read (rgen:127, :28-31). Dense reads by queue position, one 16-byte store per surviving path.
+__global__ __launch_bounds__(kBlock) void k_flush_survivors(FrameParams fp, PathState ps, Control* ctl) {
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap, b = fp.num_bounces;
+   const uint32_t count = ctl->q_count[qc_index(b, Q_RAY, sx.shard)];
+   const uint32_t* __restrict__ queue = ps.queue[b & 1] + seg;
+   const PathRecs rec = ps.set[b & 1];
+   for (uint32_t i = sx.lb * kBlock + threadIdx.x; i < count; i += sx.nb * kBlock) {
+      const uint32_t id = ld_stream(queue + i);
+      const float4 rad = ld_rec(rec_quad(rec, seg + i, REC_RAD)), ro = ld_rec(rec_quad(rec, seg + i, REC_ORIGIN));
+      st_stream(ps.radf + id, make_float4(rad.x, rad.y, rad.z, ro.w));
+   }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1315,7 +1357,7 @@ __global__ __launch_bounds__(kBlock) void k_finish_sample(FrameParams fp, PathSt
          const uint32_t id = f * fp.n_owned + k;
          float4 pc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
          if (sample != 0) pc = ps.pixcol[id];
-         if (fp.num_bounces != 0) rad = ps.rad[id];  // with zero bounces no kernel ever wrote a radiance
+         if (fp.num_bounces != 0) rad = ps.radf[id];  // where the path ended (miss, absorption, or the flush after the last bounce); with zero bounces no kernel ever wrote one
          pc = make_float4(pc.x + rad.x, pc.y + rad.y, pc.z + rad.z, 0.0f);                  // rgen:127
          if (!last) {
             ps.pixcol[id] = pc;
@@ -1565,10 +1607,10 @@ void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState&
 
 // closest-hit traversal over a sharded queue of path ids (queue != null) or over n raw rays (queue == null).
 // Variant 0 = batch kernel (the baseline), anything else = refill kernel (the default).
-static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, const uint32_t* queue, const float4* ray_o, const float4* ray_d, float4* hit,
+static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, bool sharded, const float4* ray_o, const float4* ray_d, float4* hit,
                            uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag) {
-#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, queue, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
-   const bool count = c.count_visits && queue;
+#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, sharded, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
+   const bool count = c.count_visits && sharded;
    if (diag) {
       UH_CLOSEST((k_trace_closest_batch<false, true>));
       return;
@@ -1585,8 +1627,8 @@ static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, co
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                           uint32_t cursor_slot, int ray_kind) {
-   launch_closest(c, closest_grid(c), sc, ps.queue[bounce & 1], rec_quad(ps.rec, 0, REC_ORIGIN), rec_quad(ps.rec, 0, REC_DIR), rec_quad(ps.rec, 0, REC_HIT), ps.shard_cap, ctl, stats,
-                  bounce, cursor_slot, ray_kind, 0, false);
+   const PathRecs& rec = ps.set[bounce & 1];
+   launch_closest(c, closest_grid(c), sc, true, rec_quad(rec, 0, REC_ORIGIN), rec_quad(rec, 0, REC_DIR), ps.hit, ps.shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, 0, false);
 }
 
 static TileJob tile_job(const FrameParams& fp, uint32_t frames, bool raw) {
@@ -1609,13 +1651,6 @@ static void launch_tiles(const LaunchCfg& c, const SceneDev& sc, const TileJob& 
    else
       k_trace_closest_tiles<false><<<grid, kBlock, 0, c.stream>>>(sc, j, ray_o, ray_d, hit, stats, ray_kind);
 }
-bool primary_tiles_apply(const FrameParams& fp) { return fp.tp_world <= 1; }  // the tile kernel derives path ids from pixel coordinates: whole frames only
-// bounce 0 of the path tracer, wave per 8 x 8 pixel tile (k_trace_closest_tiles): every path of the wavefront is in the bounce's
-// queue, so the tiles are enumerated directly
-void launch_trace_primary_tiles(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, DeviceStats* stats) {
-   launch_tiles(c, sc, tile_job(fp, fp.batch_frames, false), rec_quad(ps.rec, 0, REC_ORIGIN), rec_quad(ps.rec, 0, REC_DIR), rec_quad(ps.rec, 0, REC_HIT), stats, UH_RAY_PRIMARY,
-                c.count_visits);
-}
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
    // the bounce's misses are a dense queue (Q_MISS, written by k_shade_hit): every lane shades one; the count is on the
@@ -1625,8 +1660,11 @@ void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathStat
 }
 
 void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
-                      DeviceStats* stats, uint32_t bounce, bool hits_by_path) {
-   k_shade_hit<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce, hits_by_path);
+                      DeviceStats* stats, uint32_t bounce) {
+   k_shade_hit<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce);
+}
+void launch_flush_survivors(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl) {
+   k_flush_survivors<<<shade_grid(c, fp.n_owned * fp.batch_frames), kBlock, 0, c.stream>>>(fp, ps, ctl);
 }
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
@@ -1683,7 +1721,7 @@ void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& s
       launch_tiles(c, sc, tile_job(fp, 1, true), ps.ray_o, ps.ray_d, ps.hit, stats, -1, false);
    else {
       const uint32_t full = c.num_cus * c.closest_blocks_per_cu, need = (n + kBlock - 1) / kBlock;
-      launch_closest(c, dim3(need < full ? need : full), sc, nullptr, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n, false);
+      launch_closest(c, dim3(need < full ? need : full), sc, false, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n, false);
    }
    k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats, spans, counted);
 }
@@ -1709,7 +1747,7 @@ void launch_spatial_reuse(const LaunchCfg& c, const FrameParams& fp, const Scene
 void launch_trace_closest_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n) {
    // a grid that fills the chip once; smaller queries get one block per 256 rays
    const uint32_t full = c.num_cus * c.closest_blocks_per_cu, need = (n + kBlock - 1) / kBlock;
-   launch_closest(c, dim3(need < full ? (need ? need : 1) : full), sc, nullptr, ray_o, ray_d, hit, 0, nullptr, nullptr, 0, 0, 0, n, c.raw_visit_counts);
+   launch_closest(c, dim3(need < full ? (need ? need : 1) : full), sc, false, ray_o, ray_d, hit, 0, nullptr, nullptr, 0, 0, 0, n, c.raw_visit_counts);
 }
 void launch_trace_any_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n) {
    k_trace_any_raw<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, occluded, n);

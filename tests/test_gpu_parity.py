@@ -729,6 +729,9 @@ def test_isosurface_extraction_is_marching_cubes_and_renders_like_the_oracle():
     W, H = 96, 64
     cell = (hi - lo) / res
     gpu = rr.Renderer(W, H)
+    # this repository's own tables (round 3's form: watertight bit for bit, slivers dropped); the default - the reference's
+    # triangles, cell by cell - is held against the oracle in tests/test_marching_cubes.py and renders below like any mesh
+    gpu.set_option("iso_reference_triangulation", 0)
     mesh, ntri = gpu.add_isosurface_mesh(res, lo, hi)
     assert mesh is not None and ntri > 1000
     v, idx = gpu.read_mesh(mesh)
@@ -773,8 +776,24 @@ def test_isosurface_extraction_is_marching_cubes_and_renders_like_the_oracle():
     assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays)
     # deterministic output order (device scan, not an atomic append): a second extraction gives the same bytes
     again = rr.Renderer(8, 8)
+    again.set_option("iso_reference_triangulation", 0)
     m2, n2 = again.add_isosurface_mesh(res, lo, hi)
     assert n2 == ntri and again.read_mesh(m2)[0].tobytes() == v.tobytes()
+    # the default extraction (the reference's triangles, zero-area ones included) renders against the oracle on the same triangles too
+    ref_gpu = rr.Renderer(W, H)
+    rmesh, rtri = ref_gpu.add_isosurface_mesh(res, lo, hi)
+    assert rtri >= ntri
+    rv, ridx = ref_gpu.read_mesh(rmesh)
+    ref_cpu = oa.OracleRenderer(W, H, threads=3)
+    ref_cpu.add_mesh(rv, ridx, rr.make_material(base_color=(0.8, 0.8, 0.8, 1.0), diffuse_map=ref_cpu.default_diffuse_map()), None)
+    for r in (ref_gpu, ref_cpu):
+        r.initialize_raytracing()
+        loop = rr.FrameLoop(r, rr.default_view(cam, W, H))
+        loop.view.lights_enabled = 0
+        for _ in range(2):
+            loop.frame(rr.PASS_REFERENCE_PT)
+    assert per_pixel_l2(ref_gpu.read_accumulation(), ref_cpu.read_accumulation()) <= L2_TOL
+    assert list(ref_gpu.get_stats().rays) == list(ref_cpu.get_stats().rays)
     # the animated sphere (marching_cubes.comp:90) adds surface; nothing crossing the iso value adds no mesh
     _, with_sphere = rr.Renderer(8, 8).add_isosurface_mesh(res, lo, hi, time=3.0)
     assert with_sphere > ntri
