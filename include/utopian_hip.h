@@ -307,12 +307,21 @@ int uh_reset_stats(uh_ctx* ctx);
  * tree in tens to hundreds: same hits bit for bit, about 10 % (1: clusters under a SAH top) or 30 % (2: radix tree) more
  * traversal work per ray - for geometry that changes every few frames),
  * "sun_grid" (0/1, default 1: sun shadow rays through a per-direction visibility grid once the direction has settled; same
- * images), "sun_grid_async" (0/1: that grid is built on a host thread and no frame call waits for it - for interactive
- * callers), "sun_grid_density", "sun_grid_max_mb", "sun_grid_max_walk",
+ * images), "sun_grid_build" (0/1, default 1: that grid is built on the device in a few milliseconds; 0: by the host builder, the
+ * reference implementation, in 130-550 ms), "sun_grid_async" (0/1, host builder only: the grid is built on a host thread and no frame
+ * call waits for it), "sun_grid_density", "sun_grid_max_mb", "sun_grid_max_walk",
  * tuning knobs documented in DESIGN.md section 7 ("frames_in_flight", "batch_frames", "closest_variant", "shadow_variant",
  * "*_blocks_per_cu", "overlap_miss", "overlap_shadow", "spatial_splits", "primary_tiles", "ploc_radius", "ploc_sah_top").
  * Unknown names return UH_ERR_INVALID_ARGUMENT. */
 int uh_set_option(uh_ctx* ctx, const char* name, int value);
+
+/* diagnostics: the sun-direction grid in use (built on the device, option "sun_grid_build" = 1) read back and held against the host
+ * builder - the reference implementation whose margins tests/cpp/sun_grid_check.cpp checks against brute force - run on the same
+ * packets and the same raster. out[0] cells, out[1] / out[2] entries of the device / host grid, out[3] cells whose list length
+ * differs, out[4] cells whose list differs (element by element where a ray may walk it - interior cells of at most
+ * "sun_grid_max_walk" entries -, as a set elsewhere), out[5] cells whose cover depth differs in any bit, out[6] walkable cells
+ * compared, out[7] the host builder's time in microseconds. UH_ERR_INVALID_ARGUMENT when no grid is in use. */
+int uh_sun_grid_compare_builders(uh_ctx* ctx, uint64_t out[8]);
 
 /* ---- multi-GPU framebuffer tile partition (one process per GPU) ------------------------ */
 /* After this call uh_render_frame path-traces only pixels of tiles t with t % world == rank

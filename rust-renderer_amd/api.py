@@ -446,6 +446,14 @@ class Renderer:
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self._check(self._lib.uh_rccl_attach(self._ctx, rank, world, buf))
 
+    def sun_grid_compare_builders(self):
+        """uh_sun_grid_compare_builders: the device-built grid in use against the host builder on the same raster"""
+        out = (C.c_uint64 * 8)()
+        self._lib.uh_sun_grid_compare_builders.argtypes, self._lib.uh_sun_grid_compare_builders.restype = [C.c_void_p, C.POINTER(C.c_uint64)], C.c_int
+        self._check(self._lib.uh_sun_grid_compare_builders(self._ctx, out))
+        keys = ("cells", "entries_device", "entries_host", "cells_length_differs", "cells_list_differs", "cells_cover_differs", "walkable_cells", "host_build_us")
+        return dict(zip(keys, (int(x) for x in out)))
+
     def rccl_comm_count(self):
         """ranks of the attached RCCL communicator as ncclCommCount reports them (0: none attached)"""
         n = C.c_uint32(0)

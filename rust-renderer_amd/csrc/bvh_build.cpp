@@ -42,6 +42,22 @@ struct Box {
    }
 };
 
+// build knobs of the study in tools/bvh_visits.py (UH_BVH_* environment variables; the defaults are what ships)
+struct Knobs {
+   int collapse = 1;        // 0 = greedy by area (rounds 1-3), 1 = SAH-optimal collapse by dynamic programming (Ylitie et al. 2017)
+   int sweep_below = 0;     // ranges of at most this many triangles are split by an exact sweep over the sorted centroids instead of 16 bins
+   int bins = 16;
+   float c_tri = 1.0f;      // cost of a triangle slot relative to a node visit, per unit of area (collapse = 1)
+};
+static Knobs knobs_from_env() {
+   Knobs k;
+   if (const char* e = std::getenv("UH_BVH_COLLAPSE")) k.collapse = std::atoi(e);
+   if (const char* e = std::getenv("UH_BVH_SWEEP")) k.sweep_below = std::atoi(e);
+   if (const char* e = std::getenv("UH_BVH_BINS")) k.bins = std::max(4, std::min(64, std::atoi(e)));
+   if (const char* e = std::getenv("UH_BVH_CTRI")) k.c_tri = (float)std::atof(e);
+   return k;
+}
+
 struct Node2 {
    Box box;
    int32_t left, right;    // children (interior) or -1
@@ -55,6 +71,7 @@ struct Builder {
    std::vector<Node2> nodes;
    uint32_t max_depth = 0;
    bool balanced = false;  // median splits only: depth ceil(log2 n), for geometry whose SAH tree would be too deep for the traversal stack
+   Knobs kn;
 
    Builder(const std::vector<Box>& tb_, const std::vector<float>& cen_, std::vector<uint32_t>& idx_) : tb(tb_), cen(cen_), idx(idx_) {}
 
@@ -78,14 +95,64 @@ struct Builder {
          return me;
       };
       if (count == 1) return make_leaf();
-      constexpr int NB = 16;
+      if (count == 2) {  // nothing to choose
+         int32_t l = build(first, 1, depth + 1), r = build(first + 1, 1, depth + 1);
+         nodes[me].left = l;
+         nodes[me].right = r;
+         nodes[me].first = first;
+         nodes[me].count = count;
+         return me;
+      }
+      if ((int)count <= kn.sweep_below && !balanced && depth <= 48) {
+         // exact sweep: every split position of the range sorted by centroid, on each axis
+         float best = INFINITY;
+         int axis = -1;
+         uint32_t at = 0;
+         std::vector<uint32_t> order(idx.begin() + first, idx.begin() + first + count), best_order;
+         std::vector<float> right(count);
+         for (int a = 0; a < 3; a++) {
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+               const float cx = cen[3 * (size_t)x + a], cy = cen[3 * (size_t)y + a];
+               return cx < cy || (cx == cy && x < y);
+            });
+            Box acc;
+            acc.reset();
+            for (uint32_t k = count - 1; k > 0; k--) {
+               acc.grow(tb[order[k]]);
+               right[k] = acc.half_area();
+            }
+            acc.reset();
+            for (uint32_t k = 0; k + 1 < count; k++) {
+               acc.grow(tb[order[k]]);
+               const float cost = acc.half_area() * (float)(k + 1) + right[k + 1] * (float)(count - k - 1);
+               if (cost < best) {
+                  best = cost;
+                  axis = a;
+                  at = k + 1;
+               }
+            }
+            if (axis == a) best_order = order;
+         }
+         if (axis >= 0) {
+            std::copy(best_order.begin(), best_order.end(), idx.begin() + first);
+            int32_t l = build(first, at, depth + 1);
+            int32_t r = build(first + at, count - at, depth + 1);
+            nodes[me].left = l;
+            nodes[me].right = r;
+            nodes[me].first = first;
+            nodes[me].count = count;
+            return me;
+         }
+      }
+      constexpr int NBMAX = 64;
+      const int NB = kn.bins;
       float best_cost = INFINITY;
       int best_axis = -1, best_split = -1;
       for (int a = 0; a < 3; a++) {
          float lo = cb.lo[a], ext = cb.hi[a] - cb.lo[a];
          if (!(ext > 0) || !std::isfinite(ext)) continue;
-         Box bb[NB];
-         uint32_t bc[NB];
+         Box bb[NBMAX];
+         uint32_t bc[NBMAX];
          for (int b = 0; b < NB; b++) {
             bb[b].reset();
             bc[b] = 0;
@@ -98,8 +165,8 @@ struct Builder {
             bb[b].grow(tb[t]);
             bc[b]++;
          }
-         float right_area[NB];
-         uint32_t right_cnt[NB];
+         float right_area[NBMAX];
+         uint32_t right_cnt[NBMAX];
          Box acc;
          acc.reset();
          uint32_t c = 0;
@@ -419,6 +486,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    {
       Builder top(tb, cen, out.tri_order);
       top.balanced = balanced;
+      top.kn = knobs_from_env();
       if (num_threads <= 1 || n < 65536) {
          top.build(0, n, 0);
          n2.swap(top.nodes);
@@ -545,6 +613,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
                if (j >= jobs.size()) break;
                Builder b(tb, cen, out.tri_order);
                b.balanced = balanced;
+               b.kn = top.kn;
                b.build(jobs[j].first, jobs[j].count, jobs[j].depth);
                sub[j].swap(b.nodes);
                sub_depth[j] = b.max_depth;
@@ -573,19 +642,118 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    // ---- collapse to BVH4, breadth-first emission. Slot order inside a node: its triangle children first (their
    // packets are consecutive: the packet order is DEFINED here, node by node), then its node children (consecutive
    // node indices), then empty slots.
+   // SAH-optimal collapse (Ylitie, Karras, Laine 2017, section 3.1, for single-triangle leaves): T[n][i] = the least cost of
+   // representing BVH2 subtree n by at most i + 1 slots of a wide node - a slot being one triangle (cost c_tri x its area) or one
+   // wide node (its area, plus the best distribution of its two children over W slots). Replaces the greedy "open the child
+   // with the largest area" of rounds 1-3, which fills nodes to 3.0 of 4 children on the config-1 scene.
+   const Knobs kn = knobs_from_env();
+   const int W = (int)width;
+   std::vector<float> T;      // [n * W + i]
+   std::vector<uint8_t> split;  // [n * W + i]: how many of the i + 1 slots the left child gets (0 = n itself is one slot)
+   if (kn.collapse == 1) {
+      T.assign(n2.size() * (size_t)W, 0.0f);
+      split.assign(n2.size() * (size_t)W, 0);
+      // children carry larger indices than their parents in both build orders (a node is pushed before its subtrees; stitched
+      // subtrees are appended): one backwards pass sees every child before its parent
+      for (size_t k = n2.size(); k-- > 0;) {
+         const Node2& nd = n2[k];
+         const float area = nd.box.half_area();
+         float* t = &T[k * (size_t)W];
+         uint8_t* sp = &split[k * (size_t)W];
+         if (nd.left < 0) {
+            for (int i = 0; i < W; i++) t[i] = kn.c_tri * area;
+            continue;
+         }
+         const float* tl = &T[(size_t)nd.left * W];
+         const float* tr = &T[(size_t)nd.right * W];
+         // D[j]: the two children over j + 1 slots (j >= 1)
+         float D[kMaxWidth];
+         uint8_t Dk[kMaxWidth];
+         D[0] = INFINITY;
+         Dk[0] = 0;
+         for (int j = 1; j < W; j++) {
+            D[j] = INFINITY;
+            Dk[j] = 1;
+            for (int a = 1; a <= j; a++) {  // left gets a slots, right gets j + 1 - a
+               const float c = tl[a - 1] + tr[j - a];
+               if (c < D[j]) {
+                  D[j] = c;
+                  Dk[j] = (uint8_t)a;
+               }
+            }
+         }
+         t[0] = area + D[W - 1];
+         sp[0] = 0;
+         for (int i = 1; i < W; i++) {
+            if (D[i] < t[0] && D[i] <= t[i - 1]) {
+               t[i] = D[i];
+               sp[i] = Dk[i];
+            } else if (t[i - 1] < t[0]) {
+               t[i] = t[i - 1];
+               sp[i] = sp[i - 1];
+            } else {
+               t[i] = t[0];
+               sp[i] = 0;
+            }
+         }
+      }
+   }
+   // slots of the wide node made from BVH2 node `root`: its two children over W slots by the table
+   auto dp_children = [&](int32_t root, int32_t* ch) {
+      int nc = 0;
+      struct It {
+         int32_t n;
+         int slots;
+      };
+      It st[2 * kMaxWidth];
+      int sp_ = 0;
+      const Node2& r = n2[root];
+      // the root's own distribution: best a for D[W - 1]
+      {
+         const float* tl = &T[(size_t)r.left * W];
+         const float* tr = &T[(size_t)r.right * W];
+         int best_a = 1;
+         float best = INFINITY;
+         for (int a = 1; a <= W - 1; a++) {
+            const float c = tl[a - 1] + tr[W - 1 - a];
+            if (c < best) {
+               best = c;
+               best_a = a;
+            }
+         }
+         st[sp_++] = It{r.right, W - best_a};
+         st[sp_++] = It{r.left, best_a};
+      }
+      while (sp_) {
+         const It it = st[--sp_];
+         const Node2& nd = n2[it.n];
+         const uint8_t a = nd.left < 0 ? 0 : split[(size_t)it.n * W + (it.slots - 1)];
+         if (a == 0 || it.slots == 1) {
+            ch[nc++] = it.n;
+            continue;
+         }
+         // how many slots the stored decision really uses: t[i] may have been inherited from a smaller i
+         int use = it.slots;
+         while (use > 1 && T[(size_t)it.n * W + (use - 2)] == T[(size_t)it.n * W + (use - 1)] && split[(size_t)it.n * W + (use - 2)] == a) use--;
+         st[sp_++] = It{nd.right, use - a};
+         st[sp_++] = It{nd.left, a};
+      }
+      return nc;
+   };
    std::vector<int32_t> queue;  // BVH2 node index of each emitted BVH4 node
    std::vector<uint32_t> packet_order;  // packet p holds input triangle packet_order[p]
    packet_order.reserve(n);
    queue.push_back(0);
    out.nodes.reserve(n2.size() / 2 + 1);
    out.nodes.push_back(NodeW());
-   const int W = (int)width;
    for (size_t qi = 0; qi < queue.size(); qi++) {
       const Node2& src = n2[queue[qi]];
       int32_t ch[kMaxWidth];
       int nc = 0;
       if (src.left < 0) {
          ch[nc++] = queue[qi];  // a single triangle at the root: wrap it
+      } else if (kn.collapse == 1) {
+         nc = dp_children(queue[qi], ch);
       } else {
          ch[nc++] = src.left;
          ch[nc++] = src.right;

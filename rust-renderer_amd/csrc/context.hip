@@ -266,7 +266,8 @@ struct uh_ctx {
    float sun_build_ms = 0.0f, sun_mean_list = 0.0f;
    uint32_t sun_cells = 0, sun_entries = 0, sun_max_list = 0;
    bool sun_this_frame = false;     // set by render_batch for the frame being enqueued
-   bool sun_async = false;          // option "sun_grid_async": build on a host thread, walk the tree until it is done
+   bool sun_async = false;          // option "sun_grid_async": build on a host thread, walk the tree until it is done (host builder only)
+   bool sun_device_build = true;    // option "sun_grid_build": 1 = on the device (sun_grid_build.hip: a few ms), 0 = the host builder (sun_grid.cpp)
    struct SunJob* sun_job = nullptr;
 
    // tile partition
@@ -1110,6 +1111,49 @@ static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float 
    return UH_OK;
 }
 
+// the device builder's result becomes the context's grid (its buffers change owner)
+static int adopt_sun_grid_device(uh_ctx* c, SunGridDevice& g, bool ok, const float dir[3], uint64_t geom) {
+   c->sun_attempted = true;
+   c->sun_have_pending = false;
+   c->sun_geom = geom;
+   std::memcpy(c->sun_dir_built, dir, sizeof(float) * 3);
+   c->sun_valid = false;
+   c->sun_why = g.why_not;
+   c->sun_mean_list = (float)g.mean_list;
+   c->sun_max_list = g.max_list;
+   c->sun_cells = c->sun_entries = 0;
+   c->d_sun_cells.release();
+   c->d_sun_entries.release();
+   if (ok) {
+      const size_t ncell = (size_t)g.params.nx * g.params.ny;
+      c->d_sun_cells.p = g.cells;
+      c->d_sun_cells.base = g.cells;
+      c->d_sun_cells.n = 2 * (ncell + 1);
+      c->d_sun_entries.p = g.entries;
+      c->d_sun_entries.base = g.entries;
+      c->d_sun_entries.n = (size_t)g.num_entries;
+      g.cells = nullptr;
+      g.entries = nullptr;
+      SunGridDev& d = c->sun_dev;
+      std::memcpy(d.U, g.params.U, sizeof(d.U));
+      std::memcpy(d.V, g.params.V, sizeof(d.V));
+      std::memcpy(d.W, g.params.W, sizeof(d.W));
+      d.u0 = g.params.u0;
+      d.v0 = g.params.v0;
+      d.inv_cell = g.params.inv_cell;
+      d.nx = g.params.nx;
+      d.ny = g.params.ny;
+      d.max_walk = c->sun_limits.max_walk;
+      d.cell_start = c->d_sun_cells.p;
+      d.entries = c->d_sun_entries.p;
+      c->sun_cells = g.params.nx * g.params.ny;
+      c->sun_entries = (uint32_t)g.num_entries;
+      c->sun_valid = true;
+   }
+   g.release();
+   return UH_OK;
+}
+
 static void drop_sun_job(uh_ctx* c) {
    if (!c->sun_job) return;
    if (c->sun_job->worker.joinable()) c->sun_job->worker.join();
@@ -1160,6 +1204,19 @@ static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
    }
    // build: the packets as the device holds them (leaf order; host build, device build and refit all end there)
    const uint32_t n = c->scene.num_tris;
+   if (c->sun_device_build) {
+      // on the device, from the packets where they lie: a few milliseconds, inside this frame call; the frames in flight may still
+      // read the grid this one replaces
+      if (int st = sync_all(c)) return st;
+      const auto t0 = std::chrono::steady_clock::now();
+      SunGridDevice g;
+      const bool ok = build_sun_grid_device((void*)c->stream, c->d_tris.p, n, dir, c->sun_limits, nullptr, g);
+      if (!ok && g.why_not.rfind("device build:", 0) == 0) return fail(c, UH_ERR_HIP, "sun grid: " + g.why_not);
+      if (int st = adopt_sun_grid_device(c, g, ok, dir, c->geom_version)) return st;
+      c->sun_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      c->sun_this_frame = c->sun_valid;
+      return UH_OK;
+   }
    int threads = (int)std::thread::hardware_concurrency();
    threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
    if (c->sun_async) {
@@ -1781,6 +1838,10 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 0 || value > 100) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_fallback_pct must be 0..100");
       c->sun_limits.max_fallback_area = value / 100.0;  // share of the scene's surface whose sun rays may go on to the tree before the grid is refused
       c->sun_attempted = false;
+   } else if (n == "sun_grid_build") {
+      // 1 (default): the grid is built on the device (sun_grid_build.hip); 0: by the host builder (sun_grid.cpp, the reference implementation)
+      c->sun_device_build = value != 0;
+      c->sun_attempted = false;
    } else if (n == "sun_grid_async") {
       // 1: a grid is built on a host thread while frames go on with the tree walk (no 130 ms stall when the sun or the geometry
       // comes to rest; images are the same either way); 0 (default): built inside the frame call that asks for it
@@ -2014,6 +2075,75 @@ int uh_rccl_comm_count(uh_ctx* c, uint32_t* out_ranks) {
    int n = 0;
    if (!rccl_api()->CommCount || rccl_api()->CommCount(l->comm, &n) != ncclSuccess) return fail(c, UH_ERR_HIP, "ncclCommCount failed");
    *out_ranks = (uint32_t)n;
+   return UH_OK;
+}
+
+// diagnostics: the grid in use (built on the device) against the host builder on the same raster - see utopian_hip.h
+int uh_sun_grid_compare_builders(uh_ctx* c, uint64_t out[8]) {
+   if (!c || !out) return UH_ERR_INVALID_ARGUMENT;
+   for (int k = 0; k < 8; k++) out[k] = 0;
+   HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
+   if (!c->sun_valid) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_sun_grid_compare_builders: no sun grid in use (" + c->sun_why + ")");
+   const uint32_t n = c->scene.num_tris;
+   const size_t ncell = (size_t)c->sun_dev.nx * c->sun_dev.ny;
+   std::vector<float> packets(12 * (size_t)n);
+   HIP_TRY(c, hipMemcpy2D(packets.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), n, hipMemcpyDeviceToHost));
+   std::vector<uint32_t> cells(2 * (ncell + 1));
+   std::vector<SunGridEntry> entries(c->sun_entries);
+   HIP_TRY(c, hipMemcpy(cells.data(), c->d_sun_cells.p, cells.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+   if (!entries.empty()) HIP_TRY(c, hipMemcpy(entries.data(), c->d_sun_entries.p, entries.size() * sizeof(SunGridEntry), hipMemcpyDeviceToHost));
+   SunGridParams prm;
+   std::memcpy(prm.U, c->sun_dev.U, sizeof(prm.U));
+   std::memcpy(prm.V, c->sun_dev.V, sizeof(prm.V));
+   std::memcpy(prm.W, c->sun_dev.W, sizeof(prm.W));
+   prm.u0 = c->sun_dev.u0;
+   prm.v0 = c->sun_dev.v0;
+   prm.inv_cell = c->sun_dev.inv_cell;
+   prm.nx = c->sun_dev.nx;
+   prm.ny = c->sun_dev.ny;
+   SunGridLimits lim = c->sun_limits;
+   lim.max_mean_list = 1e30;  // the comparison wants the host grid whatever the host builder thinks of its worth
+   lim.max_fallback_area = 2.0;
+   SunGridHost h;
+   int threads = (int)std::thread::hardware_concurrency();
+   threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+   if (!build_sun_grid(packets.data(), n, c->sun_dir_built, lim, threads, h, &prm)) return fail(c, UH_ERR_INVALID_ARGUMENT, "host builder refused: " + h.why_not);
+   out[0] = ncell;
+   out[1] = entries.size();
+   out[2] = h.entries.size();
+   if (h.cell_start.size() != ncell + 1) return fail(c, UH_ERR_INVALID_ARGUMENT, "host grid has another raster");
+   std::vector<uint32_t> a, b;
+   for (size_t k = 0; k < ncell; k++) {
+      const uint32_t d0 = cells[2 * k], d1 = cells[2 * (k + 1)], h0 = h.cell_start[k], h1 = h.cell_start[k + 1];
+      uint32_t hc;
+      std::memcpy(&hc, &h.cell_cover[k], 4);
+      if (cells[2 * k + 1] != hc) out[5]++;  // cover depth: bit for bit
+      if (d1 - d0 != h1 - h0 || d0 != h0) {
+         out[3]++;  // another list length (or offset)
+         continue;
+      }
+      const uint32_t ix = (uint32_t)(k % prm.nx), iy = (uint32_t)(k / prm.nx), len = d1 - d0;
+      const bool walkable = !(ix == 0 || iy == 0 || ix == prm.nx - 1 || iy == prm.ny - 1) && len <= lim.max_walk;
+      bool same = true;
+      if (walkable) {
+         out[6]++;
+         for (uint32_t e = 0; e < len && same; e++) same = entries[d0 + e].packet == h.entries[h0 + e].packet && std::memcmp(&entries[d0 + e].wmax, &h.entries[h0 + e].wmax, 4) == 0;
+      } else {
+         // lists no ray walks are left in arrival order on the device: the same packets, as a set
+         a.clear();
+         b.clear();
+         for (uint32_t e = 0; e < len; e++) {
+            a.push_back(entries[d0 + e].packet);
+            b.push_back(h.entries[h0 + e].packet);
+         }
+         std::sort(a.begin(), a.end());
+         std::sort(b.begin(), b.end());
+         same = a == b;
+      }
+      if (!same) out[4]++;
+   }
+   out[7] = (uint64_t)(h.build_ms * 1000.0);  // the host builder's time on this box, microseconds
    return UH_OK;
 }
 

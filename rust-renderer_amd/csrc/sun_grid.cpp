@@ -123,7 +123,29 @@ inline void for_cells(const Proj& p, double u0, double v0, double inv, uint32_t 
 
 }  // namespace
 
-bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, int num_threads, SunGridHost& out) {
+void sun_grid_frame(const float sun_dir[3], SunGridParams& out) {
+   int a = 0;
+   for (int k = 1; k < 3; k++)
+      if (std::fabs(sun_dir[k]) < std::fabs(sun_dir[a])) a = k;
+   double ax[3] = {0, 0, 0}, W[3] = {sun_dir[0], sun_dir[1], sun_dir[2]}, U[3], V[3];
+   ax[a] = 1.0;
+   U[0] = ax[1] * W[2] - ax[2] * W[1];
+   U[1] = ax[2] * W[0] - ax[0] * W[2];
+   U[2] = ax[0] * W[1] - ax[1] * W[0];
+   const double ul = std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+   for (int k = 0; k < 3; k++) U[k] /= ul;
+   V[0] = W[1] * U[2] - W[2] * U[1];
+   V[1] = W[2] * U[0] - W[0] * U[2];
+   V[2] = W[0] * U[1] - W[1] * U[0];
+   const double vl = std::sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+   for (int k = 0; k < 3; k++) {
+      out.U[k] = (float)U[k];
+      out.V[k] = (float)(V[k] / vl);
+      out.W[k] = sun_dir[k];
+   }
+}
+
+bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, int num_threads, SunGridHost& out, const SunGridParams* forced) {
    const auto t_start = std::chrono::steady_clock::now();
    out = SunGridHost();
    auto refuse = [&](const std::string& why) {
@@ -140,25 +162,11 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
 
    // ---- frame: W = the direction as given; U, V complete it (rounded to float: the device uses these very numbers)
    {
-      int a = 0;
-      for (int k = 1; k < 3; k++)
-         if (std::fabs(sun_dir[k]) < std::fabs(sun_dir[a])) a = k;
-      double ax[3] = {0, 0, 0}, W[3] = {sun_dir[0], sun_dir[1], sun_dir[2]}, U[3], V[3];
-      ax[a] = 1.0;
-      U[0] = ax[1] * W[2] - ax[2] * W[1];
-      U[1] = ax[2] * W[0] - ax[0] * W[2];
-      U[2] = ax[0] * W[1] - ax[1] * W[0];
-      const double ul = std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
-      for (int k = 0; k < 3; k++) U[k] /= ul;
-      V[0] = W[1] * U[2] - W[2] * U[1];
-      V[1] = W[2] * U[0] - W[0] * U[2];
-      V[2] = W[0] * U[1] - W[1] * U[0];
-      const double vl = std::sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
-      for (int k = 0; k < 3; k++) {
-         out.U[k] = (float)U[k];
-         out.V[k] = (float)(V[k] / vl);
-         out.W[k] = sun_dir[k];
-      }
+      SunGridParams fr;
+      sun_grid_frame(sun_dir, fr);
+      std::memcpy(out.U, fr.U, sizeof(out.U));
+      std::memcpy(out.V, fr.V, sizeof(out.V));
+      std::memcpy(out.W, fr.W, sizeof(out.W));
    }
    const double U[3] = {out.U[0], out.U[1], out.U[2]}, V[3] = {out.V[0], out.V[1], out.V[2]}, W[3] = {out.W[0], out.W[1], out.W[2]};
 
@@ -309,9 +317,17 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
       out.nx = (uint32_t)std::ceil(ext_x / cell) + 2;  // + the two border columns
       out.ny = (uint32_t)std::ceil(ext_y / cell) + 2;
       out.inv_cell = (float)(1.0 / cell);
-      const double inv = out.inv_cell;  // the device's number
+      double inv = out.inv_cell;  // the device's number
       out.u0 = (float)(ex0 - 1.0 / inv);
       out.v0 = (float)(ey0 - 1.0 / inv);
+      if (forced) {
+         out.nx = forced->nx;
+         out.ny = forced->ny;
+         out.inv_cell = forced->inv_cell;
+         out.u0 = forced->u0;
+         out.v0 = forced->v0;
+         inv = out.inv_cell;
+      }
       const size_t ncell = (size_t)out.nx * out.ny;
       counts.assign(ncell + 1, 0u);
       parallel_for(n, num_threads, [&](size_t a, size_t b) {
@@ -321,7 +337,7 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
       total = 0;
       for (size_t c = 0; c < ncell; c++) total += counts[c];
       if (total <= lim.max_entries) break;
-      if (attempt >= 10) return refuse("entry budget exceeded");
+      if (attempt >= 10 || forced) return refuse("entry budget exceeded");
       cell *= 1.3;
    }
 

@@ -71,9 +71,37 @@ struct SunGridLimits {
    double max_fallback_area = 0.2;      // share of the scene's surface area that may lie in such cells; above it the grid is refused as a whole
 };
 
+// the grid's frame and raster: what a builder chooses and the kernel is told
+struct SunGridParams {
+   float U[3] = {0, 0, 0}, V[3] = {0, 0, 0}, W[3] = {0, 0, 0};
+   float u0 = 0, v0 = 0, inv_cell = 0;
+   uint32_t nx = 0, ny = 0;
+};
+// the orthonormal frame both builders use: W = the direction as given, U and V complete it (rounded to float)
+void sun_grid_frame(const float sun_dir[3], SunGridParams& out);
+
 // packets: n x 12 floats in TriPacket layout (v0.xyz e1.x | e1.yz e2.xy | e2.z key pad pad). sun_dir: the frame's
 // normalised direction (the floats the kernels use). Returns false (and says why in out.why_not) when the direction is not
 // finite, the scene is empty or a limit is exceeded; the caller then keeps the tree walk.
-bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, int num_threads, SunGridHost& out);
+// forced: the raster (u0, v0, inv_cell, nx, ny) to bin into instead of the builder's own choice (tests hold the two builders against
+// each other on the same raster)
+bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, int num_threads, SunGridHost& out, const SunGridParams* forced = nullptr);
+
+// The same grid built on the device (sun_grid_build.hip) from the packets where they lie (d_packets: n records of kTriStride16 x 16
+// bytes): a few milliseconds instead of the host builder's 130-550, nothing but a few dozen numbers over PCIe. `cells` (two words
+// per cell, nx * ny + 1 of them: offset | cover depth) and `entries` are hipMalloc'ed and owned by the result. The lists of the
+// cells a ray may walk (interior, at most lim.max_walk entries) are sorted as the host builder sorts them; the others - whose rays
+// k_trace_sun_grid hands to the tree - are left in arrival order. Runs on `hip_stream` and waits for it.
+struct SunGridDevice {
+   uint32_t* cells = nullptr;
+   SunGridEntry* entries = nullptr;
+   SunGridParams params;
+   uint64_t num_entries = 0;
+   double mean_list = 0.0, fallback_area = 0.0, build_ms = 0.0;
+   uint32_t max_list = 0;
+   std::string why_not;  // non-empty: refused, as the host builder refuses
+   void release();
+};
+bool build_sun_grid_device(void* hip_stream, const void* d_packets, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, const SunGridParams* forced, SunGridDevice& out);
 
 }  // namespace uh

@@ -299,3 +299,36 @@ def test_scene_deeper_than_tmax_along_the_sun():
     assert np.array_equal(a.view(np.uint32), cpu.read_accumulation().view(np.uint32))
     lit = a[..., 0] > 0
     assert lit.any() and not lit.all()  # the floor is lit except under the slab
+
+
+@pytest.mark.parametrize("sun", [SUNS[0], SUNS[2], SUNS[8], SUNS[3]])
+def test_device_built_grid_equals_the_host_built_one(atrium, sun):
+    """round 4: the grid is built on the device (sun_grid_build.hip) by default. The host builder stays the reference
+    implementation (its margins are held against brute force on the CPU); run on the same packets and the same raster, the two
+    must bin every packet into the same cells, find the same cover depth in every cell, bit for bit, and sort the lists a ray may
+    walk into the same order."""
+    W, H = 96, 54
+    r = atrium.upload(rr.Renderer(W, H))
+    r.set_option("sun_grid_max_fallback_pct", 100)
+    r.set_option("sun_grid_max_mean_list_x10", 10000)
+    render(r, atrium, W, H, sun, frames=1, sky_enabled=0, lights_enabled=0)
+    s = r.get_stats()
+    assert s.sun_grid_cells > 0 and s.sun_grid_entries > 0, "no grid was built"
+    d = r.sun_grid_compare_builders()
+    assert d["entries_device"] == d["entries_host"] == s.sun_grid_entries
+    assert d["cells_length_differs"] == 0 and d["cells_list_differs"] == 0 and d["cells_cover_differs"] == 0, d
+    assert d["walkable_cells"] > 1000
+    assert s.sun_grid_build_ms < d["host_build_us"] / 1000.0, (s.sun_grid_build_ms, d["host_build_us"])
+
+
+def test_host_builder_is_still_selectable(atrium):
+    W, H = 96, 54
+    dev, host, tree = (atrium.upload(rr.Renderer(W, H)) for _ in range(3))
+    host.set_option("sun_grid_build", 0)
+    tree.set_option("sun_grid", 0)
+    for r in (dev, host, tree):
+        render(r, atrium, W, H, SUNS[1], frames=2, sky_enabled=1, lights_enabled=0)
+    assert dev.get_stats().sun_grid_cells > 0 and host.get_stats().sun_grid_cells > 0
+    a = dev.read_accumulation().view(np.uint32)
+    assert np.array_equal(a, host.read_accumulation().view(np.uint32)) and np.array_equal(a, tree.read_accumulation().view(np.uint32))
+    assert list(dev.get_stats().rays) == list(host.get_stats().rays) == list(tree.get_stats().rays)
