@@ -360,8 +360,9 @@ void SunGridDevice::release() {
    entries = nullptr;
 }
 
-bool build_sun_grid_device(void* stream_v, const float4* d_tris, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, const SunGridParams* forced, SunGridDevice& out) {
+bool build_sun_grid_device(void* stream_v, const void* d_packets, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, const SunGridParams* forced, SunGridDevice& out) {
    hipStream_t stream = (hipStream_t)stream_v;
+   const float4* d_tris = (const float4*)d_packets;
    const auto t_start = std::chrono::steady_clock::now();
    out.release();
    out = SunGridDevice();
