@@ -1204,7 +1204,7 @@ static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
    }
    // build: the packets as the device holds them (leaf order; host build, device build and refit all end there)
    const uint32_t n = c->scene.num_tris;
-   if (c->sun_device_build) {
+   if (c->sun_device_build && !c->sun_async) {  // ("sun_grid_async" asks for the host builder on a host thread)
       // on the device, from the packets where they lie: a few milliseconds, inside this frame call; the frames in flight may still
       // read the grid this one replaces
       if (int st = sync_all(c)) return st;
