@@ -213,6 +213,11 @@ typedef struct UhStats {
    float sun_grid_build_ms;     /* host time of its last build (once per sun direction and geometry) */
    float sun_grid_mean_list;    /* entries per occupied cell */
    uint64_t sun_tree_rays;      /* sun shadow rays the grid handed to the tree walk (border cells, long lists); part of rays[UH_RAY_SUN_SHADOW] */
+   uint32_t camera_grid_cells;  /* the per-camera grid the primary rays go through (pixels; 0 = none: they walk the tree) */
+   uint32_t camera_grid_entries;
+   float camera_grid_build_ms;  /* host wall time of its last build (on the device; once per camera at rest and geometry) */
+   float camera_grid_mean_list; /* entries per occupied pixel */
+   uint64_t camera_tree_rays;   /* primary rays the grid handed to the tree walk (pixels with long lists); part of rays[UH_RAY_PRIMARY] */
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;
@@ -306,6 +311,9 @@ int uh_reset_stats(uh_ctx* ctx);
  * "device_build" (0/1/2; 1 or 2 = uh_build_acceleration builds the tree ON THE DEVICE in a few ms instead of the host SAH
  * tree in tens to hundreds: same hits bit for bit, about 10 % (1: clusters under a SAH top) or 30 % (2: radix tree) more
  * traversal work per ray - for geometry that changes every few frames),
+ * "camera_grid" (0/1, default 1: the primary rays of a camera that has been the same for two consecutive frame calls - or for a
+ * call of 8 or more frames - go through a per-camera grid of packet lists, one cell per pixel, instead of the tree; same hit records
+ * bit for bit), "camera_grid_max_walk", "camera_grid_max_mean_list_x10",
  * "sun_grid" (0/1, default 1: sun shadow rays through a per-direction visibility grid once the direction has settled; same
  * images), "sun_grid_build" (0/1, default 1: that grid is built on the device in a few milliseconds; 0: by the host builder, the
  * reference implementation, in 130-550 ms), "sun_grid_async" (0/1, host builder only: the grid is built on a host thread and no frame

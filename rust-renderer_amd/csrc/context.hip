@@ -270,6 +270,23 @@ struct uh_ctx {
    bool sun_device_build = true;    // option "sun_grid_build": 1 = on the device (sun_grid_build.hip: a few ms), 0 = the host builder (sun_grid.cpp)
    struct SunJob* sun_job = nullptr;
 
+   // the primary rays through a per-camera grid instead of the tree (sun_grid.h "camera grid"; option "camera_grid"). The grid belongs
+   // to one (geometry, inverse_view, inverse_projection, frame size): it is built - on the device, a few milliseconds - when the
+   // same camera has been asked for in two consecutive frame calls, or at once by a call that carries several frames of it; a
+   // camera that moves every frame keeps the tree walk.
+   bool cam_grid_enabled = true;
+   bool cam_valid = false, cam_attempted = false, cam_have_pending = false;
+   uint64_t cam_geom = 0, cam_geom_pending = 0;
+   float cam_mats[32] = {0}, cam_mats_pending[32] = {0};  // inverse_view, inverse_projection of the grid / of the last request
+   DevBuf<uint32_t> d_cam_cells;
+   DevBuf<SunGridEntry> d_cam_entries;
+   SunGridDev cam_dev{};
+   SunGridLimits cam_limits;
+   std::string cam_why;
+   float cam_build_ms = 0.0f, cam_mean_list = 0.0f;
+   uint32_t cam_cells = 0, cam_entries = 0, cam_max_list = 0;
+   bool cam_this_frame = false;
+
    // tile partition
    uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
    DevBuf<uint32_t> owned_pixels;  // ascending pixel ids this rank owns (empty = the whole frame)
@@ -428,6 +445,9 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    c->im.prev_spatial = c->reservoirs[2].p;
    c->res_stride = n;
    c->rp_band_rows = height;
+   c->cam_limits.max_walk = 48;          // a pixel listing more packets than this hands its ray to the tree walk
+   c->cam_limits.max_mean_list = 24.0;   // entries per occupied pixel beyond which the grid is refused (the tree walk costs about 20 records per ray)
+   c->cam_limits.max_fallback_area = 2.0;
    *out = c;
    return UH_OK;
 }
@@ -484,6 +504,8 @@ void uh_destroy(uh_ctx* c) {
    c->d_lut.release();
    c->d_sun_cells.release();
    c->d_sun_entries.release();
+   c->d_cam_cells.release();
+   c->d_cam_entries.release();
    c->accumulation.release();
    c->gbuffer.release();
    c->output.release();
@@ -1254,6 +1276,69 @@ static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
    return UH_OK;
 }
 
+// the camera grid for this call's camera, if there is (or now should be) one: see uh_ctx::cam_*
+static int ensure_camera_grid(uh_ctx* c, const FrameParams& fp, uint32_t batch) {
+   c->cam_this_frame = false;
+   if (!c->cam_grid_enabled || c->scene.num_tris == 0) return UH_OK;
+   float mats[32];
+   std::memcpy(mats, fp.inv_view, sizeof(float) * 16);
+   std::memcpy(mats + 16, fp.inv_proj, sizeof(float) * 16);
+   const bool same = c->cam_attempted && c->cam_geom == c->geom_version && std::memcmp(mats, c->cam_mats, sizeof(mats)) == 0;
+   if (same) {
+      c->cam_have_pending = false;
+      c->cam_this_frame = c->cam_valid;
+      return UH_OK;
+   }
+   // another camera or other geometry than the grid's: build once the same pair has been asked for twice in a row - or at once
+   // when this call alone carries enough frames of it to repay the build
+   const bool settled = c->cam_have_pending && c->cam_geom_pending == c->geom_version && std::memcmp(mats, c->cam_mats_pending, sizeof(mats)) == 0;
+   std::memcpy(c->cam_mats_pending, mats, sizeof(mats));
+   c->cam_geom_pending = c->geom_version;
+   c->cam_have_pending = true;
+   if (!settled && batch < 8) return UH_OK;
+   if (int st = sync_all(c)) return st;
+   const auto t0 = std::chrono::steady_clock::now();
+   SunGridDevice g;
+   const bool ok = build_camera_grid_device((void*)c->stream, c->d_tris.p, c->scene.num_tris, fp.inv_view, fp.inv_proj, c->W, c->H, c->cam_limits, g);
+   if (!ok && g.why_not.rfind("device build:", 0) == 0) return fail(c, UH_ERR_HIP, "camera grid: " + g.why_not);
+   c->cam_attempted = true;
+   c->cam_have_pending = false;
+   c->cam_geom = c->geom_version;
+   std::memcpy(c->cam_mats, mats, sizeof(mats));
+   c->cam_valid = false;
+   c->cam_why = g.why_not;
+   c->cam_mean_list = (float)g.mean_list;
+   c->cam_max_list = g.max_list;
+   c->cam_cells = c->cam_entries = 0;
+   c->d_cam_cells.release();
+   c->d_cam_entries.release();
+   if (ok) {
+      const size_t ncell = (size_t)g.params.nx * g.params.ny;
+      c->d_cam_cells.p = g.cells;
+      c->d_cam_cells.base = g.cells;
+      c->d_cam_cells.n = 2 * (ncell + 1);
+      c->d_cam_entries.p = g.entries;
+      c->d_cam_entries.base = g.entries;
+      c->d_cam_entries.n = (size_t)g.num_entries;
+      g.cells = nullptr;
+      g.entries = nullptr;
+      SunGridDev& d = c->cam_dev;
+      d = SunGridDev{};
+      d.nx = g.params.nx;
+      d.ny = g.params.ny;
+      d.max_walk = c->cam_limits.max_walk;
+      d.cell_start = c->d_cam_cells.p;
+      d.entries = c->d_cam_entries.p;
+      c->cam_cells = c->W * c->H;
+      c->cam_entries = (uint32_t)g.num_entries;
+      c->cam_valid = true;
+   }
+   g.release();
+   c->cam_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+   c->cam_this_frame = c->cam_valid;
+   return UH_OK;
+}
+
 // reference_pt_pass of one frame on one slot (reference.rgen:22-145 as a kernel chain)
 static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
    LaunchCfg lc = cfg(c);
@@ -1267,7 +1352,11 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       launch_generate(lc, fp, s.ps, ctl, smp);
       for (uint32_t b = 0; b < fp.num_bounces; b++) {
          begin_timed(c, 0, s.stream);
-         launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
+         if (b == 0 && c->cam_this_frame) {
+            launch_trace_camera_grid(lc, fp, c->scene, s.ps, ctl, st, slot, slot + 1, c->cam_dev);  // no tree walk for the primary rays of a camera at rest
+            slot += 2;
+         } else
+            launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
          end_timed(c, s.stream);
          const bool side_shadow = c->overlap_shadow && (fp.sun_shadow_enabled == 1 || fp.lights_enabled == 1);
          const bool side_used = side_shadow || c->overlap_miss;
@@ -1401,6 +1490,11 @@ static int batch_begin(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_m
       fp.total_samples_of[f] = total;
       fp.frame_numbers[f] = (uint32_t)(int32_t)((float)total + view->time * 10000.0f);
    }
+   // the per-camera grid serves the primary rays of the path tracer and the G-buffer cast of this call
+   c->cam_this_frame = false;
+   const bool primary_rays = ((pass_mask & UH_PASS_REFERENCE_PT) && fp.num_bounces > 0 && fp.samples_per_frame > 0) || (pass_mask & UH_PASS_GBUFFER);
+   if (primary_rays)
+      if (int st = ensure_camera_grid(c, fp, batch)) return st;
    bs.pass_mask = pass_mask;
    bs.batch = batch;
    bs.restir_frame = (pass_mask & UH_PASS_RESTIR) != 0;
@@ -1459,7 +1553,7 @@ static int batch_restir_frame(uh_ctx* c, uh_batch& bs, uint32_t f) {
          HIP_TRY(c, c->gb_hit.alloc(npix));
       }
       const RawRays gps{c->gb_ray_o.p, c->gb_ray_d.p, c->gb_hit.p};
-      launch_gbuffer(bs.rc, ff, c->scene, gps, im, c->dstats.p, cast, band.total());
+      launch_gbuffer(bs.rc, ff, c->scene, gps, im, c->dstats.p, cast, band.total(), c->cam_this_frame ? &c->cam_dev : nullptr);
    }
    if (pass_mask & UH_PASS_RESET_RESERVOIRS) launch_reset_reservoirs(bs.rc, ff, im, reuse);
    if (pass_mask & UH_PASS_INITIAL_RIS) launch_initial_ris(bs.rc, ff, c->scene, im, reuse);
@@ -1783,6 +1877,11 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->sun_grid_build_ms = c->sun_build_ms;
    out->sun_grid_mean_list = c->sun_mean_list;
    out->sun_tree_rays = ds.sun_tree_rays;
+   out->camera_grid_cells = c->cam_valid ? c->cam_cells : 0;
+   out->camera_grid_entries = c->cam_valid ? c->cam_entries : 0;
+   out->camera_grid_build_ms = c->cam_build_ms;
+   out->camera_grid_mean_list = c->cam_mean_list;
+   out->camera_tree_rays = ds.cam_tree_rays;
    return UH_OK;
 }
 
@@ -1838,6 +1937,17 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 0 || value > 100) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_fallback_pct must be 0..100");
       c->sun_limits.max_fallback_area = value / 100.0;  // share of the scene's surface whose sun rays may go on to the tree before the grid is refused
       c->sun_attempted = false;
+   } else if (n == "camera_grid") {
+      // 1 (default): the primary rays of a camera at rest go through the per-camera grid; 0: always the tree
+      c->cam_grid_enabled = value != 0;
+   } else if (n == "camera_grid_max_walk") {
+      if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "camera_grid_max_walk must be 1..4096");
+      c->cam_limits.max_walk = (uint32_t)value;
+      c->cam_attempted = false;
+   } else if (n == "camera_grid_max_mean_list_x10") {
+      if (value < 1 || value > 100000) return fail(c, UH_ERR_INVALID_ARGUMENT, "camera_grid_max_mean_list_x10 must be 1..100000");
+      c->cam_limits.max_mean_list = value / 10.0;
+      c->cam_attempted = false;
    } else if (n == "sun_grid_build") {
       // 1 (default): the grid is built on the device (sun_grid_build.hip); 0: by the host builder (sun_grid.cpp, the reference implementation)
       c->sun_device_build = value != 0;

@@ -15,11 +15,13 @@ namespace uh {
 constexpr uint32_t kMaxBounces = 64;
 // per bounce: RAY (paths whose ray the bounce traces; the shading kernels tell hits from misses by the hit
 // record, so no hit / miss queues exist) and LIGHT (scattered paths that carry a light sample)
-constexpr uint32_t kQueueKinds = 4;
+constexpr uint32_t kQueueKinds = 5;
 // Q_SUN_TREE: sun rays the grid kernel hands to the tree walk (border cells, long lists). Q_MISS: the paths of a bounce whose ray
 // left the scene - k_shade_hit meets them while it classifies the bounce's RAY queue and hands their ids to k_shade_miss
-enum { Q_RAY = 0, Q_LIGHT = 1, Q_SUN_TREE = 2, Q_MISS = 3 };
-constexpr uint32_t kLaunchSlots = kMaxBounces * 4 + 4;  // per bounce: closest, sun (grid), sun leftovers (tree), light
+// Q_CAM_TREE (bounce 0 only): primary rays the camera grid hands to the tree walk (pixels with long lists); shares queue 3 with
+// Q_SUN_TREE, which the same bounce's sun rays fill only after the shading kernel
+enum { Q_RAY = 0, Q_LIGHT = 1, Q_SUN_TREE = 2, Q_MISS = 3, Q_CAM_TREE = 4 };
+constexpr uint32_t kLaunchSlots = kMaxBounces * 4 + 8;  // per bounce: closest, sun (grid), sun leftovers (tree), light; bounce 0: + camera grid, its leftovers
 
 // Queues are sharded: path p lives in shard shard_of_run(p / 64) for its whole life, every queue
 // has one segment (capacity PathState::shard_cap) and one counter per shard, and the blocks of a
@@ -57,6 +59,7 @@ struct DeviceStats {
    unsigned long long nodes_visited, tris_tested, shadow_nodes_visited, shadow_tris_tested;
    unsigned long long closest_hits, misses;
    unsigned long long sun_tree_rays;  // sun rays k_trace_sun_grid handed to the tree walk
+   unsigned long long cam_tree_rays;  // primary rays k_trace_camera_grid handed to the tree walk
 };
 
 // per-mesh shading record (80 B): inverse instance rotation/scale + the material fields the
@@ -202,6 +205,8 @@ struct LaunchCfg {
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);
 void launch_trace_closest(const LaunchCfg&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce, uint32_t cursor_slot,
                           int ray_kind);
+void launch_trace_camera_grid(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t cursor_slot_grid, uint32_t cursor_slot_tree,
+                              const SunGridDev&);
 void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, DeviceStats*, uint32_t bounce);
 void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
 // the paths still alive after the last bounce hand their radiance to the per-id array k_finish_sample reads
@@ -216,7 +221,8 @@ void launch_resolve(const LaunchCfg&, const Images&, uint32_t W, uint32_t H, uin
 // G-buffer + ReSTIR
 // the reservoir passes and the G-buffer cast over the rows of `spans`; `counted` = the G-buffer rays this launch adds to the
 // statistics (a rank counts its own band, not the halo it casts again)
-void launch_gbuffer(const LaunchCfg&, const FrameParams&, const SceneDev&, const RawRays&, const Images&, DeviceStats*, const RowSpans& spans, uint32_t counted);
+void launch_gbuffer(const LaunchCfg&, const FrameParams&, const SceneDev&, const RawRays&, const Images&, DeviceStats*, const RowSpans& spans, uint32_t counted,
+                    const SunGridDev* camera_grid = nullptr);  // camera_grid: the cast walks the per-camera grid instead of the tree
 void launch_reset_reservoirs(const LaunchCfg&, const FrameParams&, const Images&, const RowSpans& spans);
 void launch_initial_ris(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&, const RowSpans& spans);
 void launch_temporal_reuse(const LaunchCfg&, const FrameParams&, const SceneDev&, const Images&, const RowSpans& spans);

@@ -468,10 +468,13 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
 // Path rays (sharded): ray_o / ray_d are the origin / direction planes of the bounce's state set, hit_out the hit plane - all by
 // queue position, so the rays of a 64-entry chunk are two contiguous kilobytes; their w components carry RNG words: the range is
 // rgen:45-47's constants. Raw rays (!sharded, RawRays): record i = ray i, the range is in the w components.
+// listed != null (sharded only): the rays are the queue positions listed there (count: Control q_count of kind Q_CAM_TREE) - the
+// primary rays k_trace_camera_grid handed over -, already counted.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, bool sharded, const float4* __restrict__ ray_o,
                                                                const float4* __restrict__ ray_d, float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl,
-                                                               DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
+                                                               DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count,
+                                                               const uint32_t* __restrict__ listed) {
    const bool range_in_w = !sharded;
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    __shared__ RayPool<2> s_pool[kWavesPerBlock];
@@ -484,11 +487,14 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, bool s
    if (sharded) {  // path tracer: this block's shard of the bounce's ray queue, chunks from the shard's cursor; ray = record at its position
       const ShardCtx sx = shard_ctx();
       seg = sx.shard * shard_cap;
-      src.queue = nullptr;
-      src.count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
+      src.queue = listed ? listed + seg : nullptr;
+      src.count = ctl->q_count[qc_index(bounce, listed ? Q_CAM_TREE : Q_RAY, sx.shard)];
       src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
       src.wave_index = src.num_waves = 0;
-      if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)src.count);
+      if (sx.lb == 0 && threadIdx.x == 0) {
+         if (!listed) atomicAdd(&stats->rays[ray_kind], (unsigned long long)src.count);
+         else if (src.count) atomicAdd(&stats->cam_tree_rays, (unsigned long long)src.count);  // counted as primary rays by the grid kernel already
+      }
    } else {
       // stand-alone query over raw_count rays (uh_trace_closest, the G-buffer cast): ray i = record i
       src.queue = nullptr;
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, bool s
    uint32_t where = 0, n_nodes = 0, n_tris = 0;
    uint32_t spill[kSpillStack];
    auto take = [&](uint32_t slot) {
-      where = seg + f.pool_base + slot;  // the ray's position in the queue (the pool holds one chunk: positions pool_base ..)
+      where = seg + (listed ? pool.id[slot] : f.pool_base + slot);  // the ray's position in the queue (the pool holds one chunk: positions pool_base ..)
       const float4 ro = pool.v[0][slot], rd = pool.v[1][slot];
       trav_init(t, ro, rd, range_in_w ? ro.w : 0.001f, range_in_w ? rd.w : 10000.0f, INFINITY);
    };
@@ -910,6 +916,108 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
    if (COUNT) {
       atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_cells);
       atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// trace_camera_grid - the primary rays of reference.rgen:31-47 (bounce 0 of the path tracer) through the per-camera grid of
+// sun_grid.h "camera grid" instead of the tree: the ray's cell is its own pixel, the cell's packets are tested front to back
+// with the closest-hit test of the tree walk (tri_compute<false>: the same t, u, v and the same tie-break by key) until the next
+// packet's distance bound exceeds the best hit. Same hit record as k_trace_closest, bit for bit: the grid only prunes
+// (conservatively) which triangles are asked. A pixel whose list is longer than max_walk hands its ray to the tree walk
+// (queue 3, Q_CAM_TREE: k_trace_closest over the listed positions, right after this kernel).
+// The 64 rays of a wave are 64 neighbouring pixels: cell records, entries and packets are shared or adjacent - this kernel runs
+// out of the caches where the tree walk of the same rays fetched ~20 records per ray.
+// ------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_camera_grid(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t cursor_slot, SunGridDev g) {
+   const uint32_t lane = lane_id();
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const uint32_t* __restrict__ queue = ps.queue[0] + seg;
+   const uint32_t count = ctl->q_count[qc_index(0, Q_RAY, sx.shard)];
+   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
+   const PathRecs rec = ps.set[0];
+   const float4* __restrict__ tris = sc.tris;
+   uint32_t* q_tree = ps.queue[3] + seg;
+   uint32_t* n_tree = &ctl->q_count[qc_index(0, Q_CAM_TREE, sx.shard)];
+   uint32_t n_tris = 0;
+   for (;;) {
+      const uint32_t base = next_batch(cursor);
+      if (base >= count) break;
+      const uint32_t i = base + lane;
+      const bool valid = i < count;
+      bool defer = false;
+      if (valid) {
+         const uint32_t id = ld_stream(queue + i);
+         const uint32_t k = id % fp.n_owned;
+         const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
+         const uint32_t px = pix % fp.W, py = pix / fp.W;
+         const uint32_t cell = (py + 1) * g.nx + (px + 1);
+         uint32_t e = g.cell_start[2 * (size_t)cell];
+         const uint32_t end = g.cell_start[2 * (size_t)cell + 2];
+         defer = end - e > g.max_walk;
+         if (!defer) {
+            const float4 ro = ld_rec(rec_quad(rec, seg + i, REC_ORIGIN)), rd = ld_rec(rec_quad(rec, seg + i, REC_DIR));
+            const V3 o = v3(ro.x, ro.y, ro.z), d = v3(rd.x, rd.y, rd.z);
+            Hit best;
+            best.t = 10000.0f;  // rgen:45: tmax
+            best.u = best.v = 0.0f;
+            best.idx = kEmptyRef;
+            best.key = 0xffffffffu;
+            uint2 en = make_uint2(0u, 0u);
+            if (e < end) en = reinterpret_cast<const uint2*>(g.entries)[e];
+            while (e < end) {
+               // sorted by the bound, ascending: from here on no packet can be hit nearer than the best hit (nor tie with it)
+               if (-__uint_as_float(en.y) > best.t) break;
+               const uint32_t pk = en.x;
+               uint2 nxt = make_uint2(0u, 0u);
+               if (e + 1 < end) nxt = reinterpret_cast<const uint2*>(g.entries)[e + 1];  // in flight with the packet
+               const float4 a = tris[kTriStride16 * (size_t)pk + 0], b = tris[kTriStride16 * (size_t)pk + 1], c = tris[kTriStride16 * (size_t)pk + 2];
+               if (COUNT) n_tris++;
+               tri_compute<false>(a, b, c, pk, o, d, 0.001f, INFINITY, best);
+               en = nxt;
+               e++;
+            }
+            st_rec(ps.hit + seg + i, make_float4(best.t, best.u, best.v, __uint_as_float(best.idx)));
+         }
+      }
+      if (__ballot(defer) != 0ull) {  // wave-uniform: every lane of the wave takes part in the append
+         const uint32_t slot = wave_append(n_tree, defer);
+         if (defer) st_stream(q_tree + slot, i);
+      }
+   }
+   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[UH_RAY_PRIMARY], (unsigned long long)count);
+   if (COUNT) atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+}
+
+// the G-buffer cast (gbuffer.rs:11-52 as a primary-ray cast: k_gbuffer_generate) through the camera grid: ray j of the cast is the ray
+// through the centre of pixel spans.pixel_of(j). A pixel whose list is too long to have been sorted is walked whole (no early exit).
+__global__ __launch_bounds__(kBlock) void k_gbuffer_camera_grid(SceneDev sc, RawRays ps, RowSpans spans, uint32_t W, SunGridDev g) {
+   const uint32_t n = spans.total();
+   const float4* __restrict__ tris = sc.tris;
+   for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+      const uint32_t pix = spans.pixel_of(j);
+      const uint32_t px = pix % W, py = pix / W;
+      const uint32_t cell = (py + 1) * g.nx + (px + 1);
+      uint32_t e = g.cell_start[2 * (size_t)cell];
+      const uint32_t end = g.cell_start[2 * (size_t)cell + 2];
+      const bool sorted = end - e <= g.max_walk;
+      const float4 ro = ps.ray_o[j], rd = ps.ray_d[j];
+      const V3 o = v3(ro.x, ro.y, ro.z), d = v3(rd.x, rd.y, rd.z);
+      Hit best;
+      best.t = rd.w;
+      best.u = best.v = 0.0f;
+      best.idx = kEmptyRef;
+      best.key = 0xffffffffu;
+      for (; e < end; e++) {
+         const uint2 en = reinterpret_cast<const uint2*>(g.entries)[e];
+         if (sorted && -__uint_as_float(en.y) > best.t) break;
+         const uint32_t pk = en.x;
+         const float4 a = tris[kTriStride16 * (size_t)pk + 0], b = tris[kTriStride16 * (size_t)pk + 1], c = tris[kTriStride16 * (size_t)pk + 2];
+         tri_compute<false>(a, b, c, pk, o, d, ro.w, INFINITY, best);
+      }
+      ps.hit[j] = make_float4(best.t, best.u, best.v, __uint_as_float(best.idx));
    }
 }
 
@@ -1608,21 +1716,24 @@ void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState&
 // closest-hit traversal over a sharded queue of path ids (queue != null) or over n raw rays (queue == null).
 // Variant 0 = batch kernel (the baseline), anything else = refill kernel (the default).
 static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, bool sharded, const float4* ray_o, const float4* ray_d, float4* hit,
-                           uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag) {
-#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, sharded, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
+                           uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag,
+                           const uint32_t* listed = nullptr) {
+#define UH_BATCH(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, sharded, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
+#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, sharded, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n, listed)
    const bool count = c.count_visits && sharded;
    if (diag) {
-      UH_CLOSEST((k_trace_closest_batch<false, true>));
+      UH_BATCH((k_trace_closest_batch<false, true>));
       return;
    }
-   if (c.closest_variant == 0) {
-      if (count) UH_CLOSEST((k_trace_closest_batch<true, false>));
-      else UH_CLOSEST((k_trace_closest_batch<false, false>));
+   if (c.closest_variant == 0 && !listed) {
+      if (count) UH_BATCH((k_trace_closest_batch<true, false>));
+      else UH_BATCH((k_trace_closest_batch<false, false>));
    } else {
       if (count) UH_CLOSEST((k_trace_closest<true>));
       else UH_CLOSEST((k_trace_closest<false>));
    }
 #undef UH_CLOSEST
+#undef UH_BATCH
 }
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
@@ -1650,6 +1761,19 @@ static void launch_tiles(const LaunchCfg& c, const SceneDev& sc, const TileJob& 
       k_trace_closest_tiles<true><<<grid, kBlock, 0, c.stream>>>(sc, j, ray_o, ray_d, hit, stats, ray_kind);
    else
       k_trace_closest_tiles<false><<<grid, kBlock, 0, c.stream>>>(sc, j, ray_o, ray_d, hit, stats, ray_kind);
+}
+
+// bounce 0 of the path tracer through the camera grid, then the tree walk for the rays of the pixels with long lists
+void launch_trace_camera_grid(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t cursor_slot_grid,
+                              uint32_t cursor_slot_tree, const SunGridDev& g) {
+   const dim3 grid = sharded_grid(c.num_cus * 8);
+   if (c.count_visits)
+      k_trace_camera_grid<true><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, cursor_slot_grid, g);
+   else
+      k_trace_camera_grid<false><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, cursor_slot_grid, g);
+   const PathRecs& rec = ps.set[0];
+   launch_closest(c, closest_grid(c), sc, true, rec_quad(rec, 0, REC_ORIGIN), rec_quad(rec, 0, REC_DIR), ps.hit, ps.shard_cap, ctl, stats, 0, cursor_slot_tree, UH_RAY_PRIMARY, 0, false,
+                  ps.queue[3]);
 }
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
@@ -1712,12 +1836,15 @@ void launch_resolve(const LaunchCfg& c, const Images& im, uint32_t W, uint32_t H
    k_resolve<<<stream_grid(c, W * H), kBlock, 0, c.stream>>>(im, W * H, total_samples, limit);
 }
 
-void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const RawRays& ps, const Images& im, DeviceStats* stats, const RowSpans& spans, uint32_t counted) {
+void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const RawRays& ps, const Images& im, DeviceStats* stats, const RowSpans& spans, uint32_t counted,
+                    const SunGridDev* camera_grid) {
    const uint32_t n = spans.total();
    if (n == 0) return;
    const bool whole = n == fp.W * fp.H;
    k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, spans);
-   if (c.primary_tiles && whole)  // the tile kernel addresses rays by pixel: whole frames only
+   if (camera_grid)
+      k_gbuffer_camera_grid<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ps, spans, fp.W, *camera_grid);
+   else if (c.primary_tiles && whole)  // the tile kernel addresses rays by pixel: whole frames only
       launch_tiles(c, sc, tile_job(fp, 1, true), ps.ray_o, ps.ray_d, ps.hit, stats, -1, false);
    else {
       const uint32_t full = c.num_cus * c.closest_blocks_per_cu, need = (n + kBlock - 1) / kBlock;

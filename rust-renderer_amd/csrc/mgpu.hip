@@ -358,6 +358,7 @@ int uh_mgpu_get_stats(uh_mgpu* m, UhStats* out) {
       out->closest_hits += s.closest_hits;
       out->misses += s.misses;
       out->sun_tree_rays += s.sun_tree_rays;
+      out->camera_tree_rays += s.camera_tree_rays;
       out->frames = s.frames;
       out->bvh_nodes = s.bvh_nodes;
       out->bvh_triangles = s.bvh_triangles;

@@ -104,4 +104,15 @@ struct SunGridDevice {
 };
 bool build_sun_grid_device(void* hip_stream, const void* d_packets, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, const SunGridParams* forced, SunGridDevice& out);
 
+// The camera grid: the same structure for the rays that leave ONE POINT - the primary rays of reference.rgen:31-47 and the
+// G-buffer cast (renderers/gbuffer.rs:11-52) of a camera at rest. The raster is the frame: one cell per pixel, cell (px + 1, py + 1)
+// of a (W + 2) x (H + 2) grid (the border ring takes what projects outside the frame); a cell lists every packet some ray through
+// the pixel's square can be accepted by (margins: sun_grid_build.hip k_pg_project), sorted by a LOWER BOUND of the hit distance,
+// ascending - stored as SunGridEntry::wmax = -bound, so the shared sort (descending) serves. k_trace_camera_grid walks a pixel's
+// list front to back with the closest-hit test of the tree walk (tri_compute<false>: same t, same tie-break) and stops when the
+// next bound exceeds the best hit: the same hit record, bit for bit, without a tree walk. inverse_view / inverse_projection:
+// the 16 floats of UhViewUniformData (column-major), the very numbers primary_ray reads.
+bool build_camera_grid_device(void* hip_stream, const void* d_packets, uint32_t n, const float inverse_view[16], const float inverse_projection[16], uint32_t W, uint32_t H,
+                              const SunGridLimits& lim, SunGridDevice& out);
+
 }  // namespace uh

@@ -128,6 +128,11 @@ class Stats(C.Structure):
         ("sun_grid_build_ms", C.c_float),
         ("sun_grid_mean_list", C.c_float),
         ("sun_tree_rays", C.c_uint64),
+        ("camera_grid_cells", C.c_uint32),
+        ("camera_grid_entries", C.c_uint32),
+        ("camera_grid_build_ms", C.c_float),
+        ("camera_grid_mean_list", C.c_float),
+        ("camera_tree_rays", C.c_uint64),
     ]
 
     @property

@@ -62,13 +62,19 @@ int main(int argc, char** argv) {
       double fill = 0;
       for (const NodeW& n : bo.nodes) fill += n.count;
       std::printf("width %u: %zu nodes, %zu levels, %.2f children per node\n", width, bo.nodes.size(), bo.level_start.size() - 1, fill / bo.nodes.size());
-      for (int policy = 0; policy < 3; policy++) {
+      std::vector<float> hint_t(nr, INFINITY);
+      for (int policy = 0; policy < 4; policy++) {
+         // policy 3 = policy 1 with every ray's search interval cut to its own hit distance beforehand (UH_HINT_SLACK: relative slack,
+         // a neighbouring sample's hit instead of the ray's own): what testing a cached triangle first buys a primary ray
+         const bool hint_pass = policy == 3;
+         const int pol = policy == 3 ? 1 : policy;
          double nodes = 0, tris = 0, pushes = 0, maxsp = 0;
          std::vector<uint32_t> iters(nr);
          for (uint32_t ri = 0; ri < nr; ri++) {
             const Ray& r = rays[ri];
             const float idir[3] = {1.0f / r.d[0], 1.0f / r.d[1], 1.0f / r.d[2]};
             float best = r.tmax;
+            if (hint_pass && hint_t[ri] < r.tmax) best = hint_t[ri];  // the closest hit of an earlier frame's ray through the same pixel, tested first
             std::vector<uint32_t> st;
             uint32_t cur = 0, it = 0;
             bool done = false;
@@ -79,7 +85,7 @@ int main(int argc, char** argv) {
                   float t;
                   if (tri_hit(&corners[9 * (size_t)bo.tri_order[cur & ~kLeafBit]], r, t) && t < best) {
                      best = t;
-                     if (policy == 2) done = true;
+                     if (pol == 2) done = true;
                   }
                   if (st.empty()) break;
                   cur = st.back();
@@ -110,7 +116,7 @@ int main(int argc, char** argv) {
                   st.pop_back();
                   continue;
                }
-               if (policy == 0) {
+               if (pol == 0) {
                   // full sort: nearest next, the others pushed far to near
                   int idx[kMaxWidth];
                   for (int k = 0; k < nh; k++) idx[k] = k;
@@ -129,6 +135,7 @@ int main(int argc, char** argv) {
                maxsp = std::fmax(maxsp, (double)st.size());
             }
             iters[ri] = it;
+            if (policy == 1) hint_t[ri] = best < r.tmax ? best * (1.0f + (std::getenv("UH_HINT_SLACK") ? (float)std::atof(std::getenv("UH_HINT_SLACK")) : 0.0f)) + 1e-6f : INFINITY;
          }
          double wave_iters = 0, lane_iters = 0;
          for (uint32_t w = 0; w + 64 <= nr; w += 64) {
