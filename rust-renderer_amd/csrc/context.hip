@@ -1877,8 +1877,8 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->sun_grid_build_ms = c->sun_build_ms;
    out->sun_grid_mean_list = c->sun_mean_list;
    out->sun_tree_rays = ds.sun_tree_rays;
-   out->camera_grid_cells = c->cam_valid ? c->cam_cells : 0;
-   out->camera_grid_entries = c->cam_valid ? c->cam_entries : 0;
+   out->camera_grid_cells = c->cam_valid && c->cam_this_frame ? c->cam_cells : 0;  // in use by the last frame call
+   out->camera_grid_entries = c->cam_valid && c->cam_this_frame ? c->cam_entries : 0;
    out->camera_grid_build_ms = c->cam_build_ms;
    out->camera_grid_mean_list = c->cam_mean_list;
    out->camera_tree_rays = ds.cam_tree_rays;
