@@ -139,14 +139,18 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    # ---- untimed: one counted frame gives nodes / triangles visited per ray (deterministic)
+    # ---- untimed: one counted frame gives nodes / triangles visited per ray of the dominant kernel (deterministic). A wavefront of
+    # frames first: the sun grid and the camera grid exist from then on, as in the timed region - the primary rays then go through
+    # k_trace_camera_grid, and k_trace_closest traces the bounce rays (and the primary rays of pixels with long lists)
+    loop.frames(16, pass_mask)
     renderer.set_option("count_visits", 1)
     renderer.reset_stats()
     loop.frame(pass_mask)
     cs = renderer.get_stats()
-    closest_rays = cs.rays[rr.RAY_PRIMARY] + cs.rays[rr.RAY_BOUNCE]
+    closest_rays = cs.rays[rr.RAY_BOUNCE] + (cs.camera_tree_rays if cs.camera_grid_cells else cs.rays[rr.RAY_PRIMARY])
     nodes_per_ray = cs.nodes_visited / max(closest_rays, 1)
     tris_per_ray = cs.tris_tested / max(closest_rays, 1)
+    camera_tests_per_ray = cs.camera_grid_tris_tested / max(cs.rays[rr.RAY_PRIMARY] - cs.camera_tree_rays, 1) if cs.camera_grid_cells else None
     sun_rays_counted = max(cs.rays[rr.RAY_SUN_SHADOW], 1)
     sun_grid = {
         "in_use": bool(cs.sun_grid_cells),
@@ -158,6 +162,7 @@ def main():
         "handed_to_tree": cs.sun_tree_rays / sun_rays_counted,       # share of the sun rays the grid gives back to the tree (border cells, long lists)
     }
     renderer.set_option("count_visits", 0)
+    camera_grid = None  # filled after the timed region (the grid is built by the first multi-frame call)
 
     # ---- untimed: the dominant kernel alone on the GPU (no frame overlap, no second stream), in launches of the SAME size as
     # the timed ones (one wavefront of the library's default batch): its serialised launch duration, without co-scheduled kernels
@@ -174,8 +179,9 @@ def main():
         loop.frames(16, pass_mask)
         alone = renderer.get_stats()
         alone_ms = alone.trace_closest_ms / max(alone.trace_closest_launches, 1)
-        alone_rays = float(alone.rays[rr.RAY_PRIMARY] + alone.rays[rr.RAY_BOUNCE]) / max(alone.trace_closest_launches, 1)
-        serial_ms_per_frame = {"trace_closest": alone.trace_closest_ms / 16, "trace_shadow": alone.trace_shadow_ms / 16, "shade_hit_and_miss": alone.shade_ms / 16}
+        alone_rays = float(alone.rays[rr.RAY_BOUNCE] + (alone.camera_tree_rays if alone.camera_grid_cells else alone.rays[rr.RAY_PRIMARY])) / max(alone.trace_closest_launches, 1)
+        serial_ms_per_frame = {"trace_closest": alone.trace_closest_ms / 16, "camera_grid": alone.camera_grid_ms / 16, "trace_shadow": alone.trace_shadow_ms / 16,
+                               "shade_hit_and_miss": alone.shade_ms / 16}
         # what a caller of uh_render_frame sees with nothing overlapped: one frame per call, one stream, no batching
         # (per-kernel event timing is on in these frames: a few percent of launch overhead included)
         renderer.set_option("batch_frames", 1)
@@ -248,12 +254,22 @@ def main():
 
     st = renderer.get_stats()
     my_rays = float(st.path_rays)
-    my_closest = float(st.rays[rr.RAY_PRIMARY] + st.rays[rr.RAY_BOUNCE])
+    my_closest = float(st.rays[rr.RAY_BOUNCE] + (st.camera_tree_rays if st.camera_grid_cells else st.rays[rr.RAY_PRIMARY]))  # the rays k_trace_closest traced
 
-    # ---- the same K steps once more with the sun grid off (every sun shadow ray walks the tree): the figure that owes nothing
-    # to a structure built outside the timed region. Same protocol: priming wavefront, barrier, K frames (+ composition), barrier.
+    # ---- the same K steps once more with the sun grid and the camera grid off (every ray walks the tree): the figure that owes
+    # nothing to a structure built outside the timed region. Same protocol: priming wavefront, barrier, K frames (+ composition), barrier.
     renderer.set_option("time_kernels", 0)
+    camera_grid = {
+        "in_use": bool(st.camera_grid_cells),
+        "build_ms": st.camera_grid_build_ms,       # once per camera at rest (and geometry), on the device, OUTSIDE the timed region
+        "pixels": st.camera_grid_cells,
+        "entries": st.camera_grid_entries,
+        "mean_list": st.camera_grid_mean_list,
+        "handed_to_tree": st.camera_tree_rays / max(st.rays[rr.RAY_PRIMARY], 1),  # share of the primary rays whose pixel lists too many packets
+        "tests_per_ray": camera_tests_per_ray,     # triangle tests per primary ray served by the grid (no node visit)
+    }
     renderer.set_option("sun_grid", 0)
+    renderer.set_option("camera_grid", 0)
     loop.frames(16, pass_mask)
     loop.reset()
     renderer.reset_stats()
@@ -266,6 +282,7 @@ def main():
     elapsed_tree = time.perf_counter() - t1
     tree_rays = float(renderer.get_stats().path_rays)
     renderer.set_option("sun_grid", 1)
+    renderer.set_option("camera_grid", 1)
     if use_dist:
         t = torch.tensor([elapsed, my_rays, my_closest, st.trace_closest_ms, elapsed_tree, tree_rays], dtype=torch.float64, device=f"cuda:{local_rank}")
         tmax = t.clone()
@@ -292,12 +309,14 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            # the same steps with option sun_grid = 0 (tree walk for the sun shadow rays), and with the grid's one-off build charged
-            # to THIS run's K frames: the grid is built once per (geometry, sun direction), before the timed region
+            # the same steps with options sun_grid = 0 and camera_grid = 0 (every ray walks the tree), and with the two grids' one-off
+            # builds charged to THIS run's K frames: they are built once per (geometry, sun direction) / (geometry, camera), on the
+            # device, before the timed region
             "value_tree_walk": tree_rays / elapsed_tree / 1e6,
             "ms_per_step_tree_walk": elapsed_tree / args.steps * 1e3,
-            "value_with_sun_grid_build": total_rays / (elapsed + sun_grid["build_ms"] * 1e-3) / 1e6 if sun_grid["in_use"] else None,
+            "value_with_grid_builds": total_rays / (elapsed + ((sun_grid["build_ms"] if sun_grid["in_use"] else 0.0) + (camera_grid["build_ms"] if camera_grid["in_use"] else 0.0)) * 1e-3) / 1e6,
             "sun_grid": sun_grid,
+            "camera_grid": camera_grid,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
@@ -417,8 +436,8 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     uncorrected = (k.get("hbm_bytes_per_launch_uncorrected") or 0.0) / k["hbm_bytes_per_launch"] if traffic else None  # share of `traffic` the raw counters report
     # vector-memory issue: every per-lane load or store of <= 16 B takes one slot of the CU's texture addresser / data path, and
     # that path retires about one lane per clock (profiles/r02_microbench_rates.txt). Lane operations of one closest-hit ray: 3
-    # per node visit (48-B node), 3 per triangle tested (48-B packet), 4 for queue id + ray (2 LDS-DMA) + hit.
-    lane_ops = 3.0 * nodes_per_ray + 3.0 * tris_per_ray + 4.0
+    # per node visit (48-B node), 3 per triangle tested (48-B packet), 3 for the ray (2 LDS-DMA, by queue position) + hit.
+    lane_ops = 3.0 * nodes_per_ray + 3.0 * tris_per_ray + 3.0
     peak_lane_rate = 256 * 2.4e9  # CUs x max clock (MI355X_MICROARCH.md); the clock under load is lower
     alone_rate = alone_rays * lane_ops / (alone_ms * 1e-3) if alone_ms > 0 else 0.0
     ref = serial_ms or avg_ms

@@ -218,6 +218,9 @@ typedef struct UhStats {
    float camera_grid_build_ms;  /* host wall time of its last build (on the device; once per camera at rest and geometry) */
    float camera_grid_mean_list; /* entries per occupied pixel */
    uint64_t camera_tree_rays;   /* primary rays the grid handed to the tree walk (pixels with long lists); part of rays[UH_RAY_PRIMARY] */
+   uint64_t camera_grid_tris_tested; /* triangle packets tested by the grid walk of the primary rays (option "count_visits") */
+   float camera_grid_ms;        /* summed hipEvent time of the primary rays' launches when they go through the grid (option "time_kernels") */
+   uint32_t reserved0;
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;

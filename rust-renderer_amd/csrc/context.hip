@@ -240,7 +240,7 @@ struct uh_ctx {
    int closest_variant = 1, shadow_variant = 1;  // refill kernels (0 = batch kernels)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
-   float ms_by_kind[3] = {0, 0, 0};
+   float ms_by_kind[4] = {0, 0, 0, 0};  // trace_closest, trace_shadow, shade, camera grid (bounce 0 through the grid + its leftovers)
    uint32_t trace_closest_launches = 0;
    bool frame_timed = false;
    std::vector<EventPair> pending, free_events;
@@ -1351,7 +1351,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       uint32_t slot = 0;
       launch_generate(lc, fp, s.ps, ctl, smp);
       for (uint32_t b = 0; b < fp.num_bounces; b++) {
-         begin_timed(c, 0, s.stream);
+         begin_timed(c, (b == 0 && c->cam_this_frame) ? 3 : 0, s.stream);
          if (b == 0 && c->cam_this_frame) {
             launch_trace_camera_grid(lc, fp, c->scene, s.ps, ctl, st, slot, slot + 1, c->cam_dev);  // no tree walk for the primary rays of a camera at rest
             slot += 2;
@@ -1871,6 +1871,7 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->trace_closest_ms = c->ms_by_kind[0];
    out->trace_shadow_ms = c->ms_by_kind[1];
    out->shade_ms = c->ms_by_kind[2];
+   out->camera_grid_ms = c->ms_by_kind[3];
    out->trace_closest_launches = c->trace_closest_launches;
    out->sun_grid_cells = c->sun_valid ? c->sun_cells : 0;
    out->sun_grid_entries = c->sun_valid ? c->sun_entries : 0;
@@ -1882,6 +1883,7 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->camera_grid_build_ms = c->cam_build_ms;
    out->camera_grid_mean_list = c->cam_mean_list;
    out->camera_tree_rays = ds.cam_tree_rays;
+   out->camera_grid_tris_tested = ds.cam_tris_tested;
    return UH_OK;
 }
 
@@ -1895,7 +1897,7 @@ int uh_reset_stats(uh_ctx* c) {
    HIP_TRY(c, hipMemsetAsync(c->dstats.p, 0, sizeof(DeviceStats), c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    c->frames = 0;
-   c->ms_by_kind[0] = c->ms_by_kind[1] = c->ms_by_kind[2] = 0.0f;
+   c->ms_by_kind[0] = c->ms_by_kind[1] = c->ms_by_kind[2] = c->ms_by_kind[3] = 0.0f;
    c->trace_closest_launches = 0;
    return UH_OK;
 }

@@ -60,6 +60,7 @@ struct DeviceStats {
    unsigned long long closest_hits, misses;
    unsigned long long sun_tree_rays;  // sun rays k_trace_sun_grid handed to the tree walk
    unsigned long long cam_tree_rays;  // primary rays k_trace_camera_grid handed to the tree walk
+   unsigned long long cam_tris_tested;  // triangle packets k_trace_camera_grid tested (count_visits)
 };
 
 // per-mesh shading record (80 B): inverse instance rotation/scale + the material fields the

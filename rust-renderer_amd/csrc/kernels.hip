@@ -988,7 +988,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_camera_grid(SceneDev sc, Frame
       }
    }
    if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[UH_RAY_PRIMARY], (unsigned long long)count);
-   if (COUNT) atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+   if (COUNT) atomicAdd(&stats->cam_tris_tested, (unsigned long long)n_tris);
 }
 
 // the G-buffer cast (gbuffer.rs:11-52 as a primary-ray cast: k_gbuffer_generate) through the camera grid: ray j of the cast is the ray

@@ -133,6 +133,9 @@ class Stats(C.Structure):
         ("camera_grid_build_ms", C.c_float),
         ("camera_grid_mean_list", C.c_float),
         ("camera_tree_rays", C.c_uint64),
+        ("camera_grid_tris_tested", C.c_uint64),
+        ("camera_grid_ms", C.c_float),
+        ("reserved0", C.c_uint32),
     ]
 
     @property

@@ -91,5 +91,5 @@ def test_metric_names_the_real_step_count():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "64 frames x 1 spp" not in src
     assert "{args.steps} frames x {args.spp} spp" in src
-    for key in ('"value_tree_walk"', '"sun_grid"', '"value_with_sun_grid_build"', '"rccl_ranks"'):
+    for key in ('"value_tree_walk"', '"sun_grid"', '"camera_grid"', '"value_with_grid_builds"', '"rccl_ranks"'):
         assert key in src, key
