@@ -182,6 +182,7 @@ struct PgCam {
    double Kinv[9];               // row-major inverse of [Dx Dy D0]: Kinv r = lambda (dx, dy, 1) for a point O + r in front of the camera
    double Dmax;                  // largest |D0 + dx Dx + dy Dy| over the frame
    double smax;                  // largest stretch of a unit vector by the upper 3x3 of inverse_view (1 for a rigid camera): t >= distance / smax
+   double lam_clip;              // points of the frame with lambda below this are nearer than tmin / 2 (0: unknown - a packet that crosses the camera plane takes the whole frame as its box)
    double W, H;
 };
 
@@ -316,8 +317,53 @@ __global__ __launch_bounds__(kBlock) void k_pg_project(const float4* __restrict_
                p.px[k] = sx[k];
                p.py[k] = sy[k];
             }
+         } else if (cam.lam_clip > 0) {
+            // crosses the camera plane: the box of the part with lambda >= lam_clip (the rest is behind the camera or nearer than the
+            // rays' tmin: no ray can be accepted there) - Sutherland-Hodgman against that one plane, then the projection
+            double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
+            int kept = 0;
+            for (int k = 0; k < 3; k++) {
+               const int j = (k + 1) % 3;
+               const bool ik = lam[k] >= cam.lam_clip, ij = lam[j] >= cam.lam_clip;
+               double pts[2][3];
+               int np = 0;
+               if (ik) {
+                  for (int a = 0; a < 3; a++) pts[np][a] = r[k][a];
+                  np++;
+               }
+               if (ik != ij) {
+                  const double t = (cam.lam_clip - lam[k]) / (lam[j] - lam[k]);
+                  for (int a = 0; a < 3; a++) pts[np][a] = r[k][a] + t * (r[j][a] - r[k][a]);
+                  np++;
+               }
+               for (int m = 0; m < np; m++) {
+                  const double hx = cam.Kinv[0] * pts[m][0] + cam.Kinv[1] * pts[m][1] + cam.Kinv[2] * pts[m][2];
+                  const double hy = cam.Kinv[3] * pts[m][0] + cam.Kinv[4] * pts[m][1] + cam.Kinv[5] * pts[m][2];
+                  double lm = cam.Kinv[6] * pts[m][0] + cam.Kinv[7] * pts[m][1] + cam.Kinv[8] * pts[m][2];
+                  lm = fmax(lm, 0.5 * cam.lam_clip);  // (an intersection point: lambda = lam_clip up to rounding)
+                  const double u = (hx / lm + 1.0) * 0.5 * cam.W, v = (1.0 - hy / lm) * 0.5 * cam.H;
+                  // a coordinate beyond the frame by more than this is as good as infinite (and keeps the arithmetic finite)
+                  const double big = 16.0 * (cam.W + cam.H);
+                  bx0 = fmin(bx0, fmax(u, -big));
+                  bx1 = fmax(bx1, fmin(u, big));
+                  by0 = fmin(by0, fmax(v, -big));
+                  by1 = fmax(by1, fmin(v, big));
+                  kept++;
+               }
+            }
+            if (kept == 0) {
+               front = false;  // nothing of it at lambda >= lam_clip: marked unused below
+               p.x0 = NAN;
+            } else {
+               const double slack = 1.0 + padmax;  // the clipped outline is a chord of the true one: a pixel of room
+               p.x0 = bx0 - slack;
+               p.x1 = bx1 + slack;
+               p.y0 = by0 - slack;
+               p.y1 = by1 + slack;
+            }
+            if (edge_on) ne = 0;
          } else {
-            // crosses the camera plane: its projection is unbounded - the whole frame is its box, the edge planes (which need no
+            // crosses the camera plane and the camera is not rigid: the whole frame is its box, the edge planes (which need no
             // projection) cut it down to the pixels it can be seen from
             p.x0 = -1.0;
             p.x1 = cam.W + 1.0;
@@ -863,6 +909,9 @@ bool build_camera_grid_device(void* stream_v, const void* d_packets, uint32_t n,
             if (a == b) fro += g;
          }
       cam.smax = dev < 1e-5 ? 1.0 + 1e-5 : std::sqrt(fro);
+      // a point of the frame at lambda is O + lambda (D0 + dx Dx + dy Dy): at most lambda Dmax away, i.e. at t <= lambda Dmax / smin. With
+      // a rigid camera (smin = 1) everything below lam_clip is nearer than half the rays' tmin = 0.001 (rgen:44)
+      cam.lam_clip = dev < 1e-5 && cam.Dmax > 0 ? 2.5e-4 / cam.Dmax : 0.0;
    }
    cam.W = (double)W;
    cam.H = (double)H;
