@@ -88,9 +88,17 @@ __global__ __launch_bounds__(kBlock) void k_sg_bounds(const float4* __restrict__
                m[4 + ax] = fmax(m[4 + ax], c[k][ax]);
             }
    }
+   // one atomic per block and value (thousands of waves on seven words serialise in the L2)
+   __shared__ double s_m[kBlock / 64][7];
    for (int k = 0; k < 7; k++) {
       const double w = wave_max(m[k]);
-      if ((threadIdx.x & 63) == 0 && w > -INFINITY) atomicMax(&keys[k], key_of(w));
+      if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][k] = w;
+   }
+   __syncthreads();
+   if (threadIdx.x < 7) {
+      double w = s_m[0][threadIdx.x];
+      for (int v = 1; v < kBlock / 64; v++) w = fmax(w, s_m[v][threadIdx.x]);
+      if (w > -INFINITY) atomicMax(&keys[threadIdx.x], key_of(w));
    }
 }
 
@@ -512,7 +520,17 @@ __global__ __launch_bounds__(kBlock) void k_sg_occupancy(const uint32_t* __restr
       const uint32_t other = __shfl_xor(mx, o);
       mx = other > mx ? other : mx;
    }
+   __shared__ uint32_t s_occ[kBlock / 64], s_mx[kBlock / 64];
    if ((threadIdx.x & 63) == 0) {
+      s_occ[threadIdx.x >> 6] = occ;
+      s_mx[threadIdx.x >> 6] = mx;
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {  // one atomic per block
+      for (int v = 1; v < kBlock / 64; v++) {
+         occ += s_occ[v];
+         mx = s_mx[v] > mx ? s_mx[v] : mx;
+      }
       if (occ) atomicAdd(occupied, (unsigned long long)occ);
       if (mx) atomicMax(longest, mx);
    }
@@ -651,7 +669,7 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
    Scratch d_keys;
    SG_TRY(d_keys.alloc(7 * sizeof(unsigned long long)));
    SG_TRY(hipMemsetAsync(d_keys.p, 0, 7 * sizeof(unsigned long long), stream));
-   k_sg_bounds<<<std::min<uint32_t>(blocks_n, 2048), kBlock, 0, stream>>>(d_tris, n, (unsigned long long*)d_keys.p);
+   k_sg_bounds<<<std::min<uint32_t>(blocks_n, 512), kBlock, 0, stream>>>(d_tris, n, (unsigned long long*)d_keys.p);
    unsigned long long keys[7];
    SG_TRY(hipMemcpyAsync(keys, d_keys.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
    SG_TRY(hipStreamSynchronize(stream));
@@ -780,7 +798,7 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       SG_TRY(hipMemsetAsync(d_tot.p, 0, 2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t), stream));
       const uint32_t bin_blocks = std::min<uint32_t>((n + (kBlock / 64) - 1) / (kBlock / 64), 1u << 16);
       k_sg_bin<false><<<bin_blocks, kBlock, 0, stream>>>(pr, n, g, counts, nullptr, nullptr);
-      k_sg_occupancy<<<std::min<uint32_t>((uint32_t)((ncell + kBlock - 1) / kBlock), 4096), kBlock, 0, stream>>>(counts, (uint32_t)ncell, d_occupied, d_longest);
+      k_sg_occupancy<<<std::min<uint32_t>((uint32_t)((ncell + kBlock - 1) / kBlock), 1024), kBlock, 0, stream>>>(counts, (uint32_t)ncell, d_occupied, d_longest);
       device_exclusive_scan_u32(counts, (uint32_t)ncell + 1, (uint32_t*)d_chunks.p, d_total, stream);
       struct {
          unsigned long long total, occupied;
