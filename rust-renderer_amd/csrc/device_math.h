@@ -170,16 +170,20 @@ __device__ __noinline__ V3 integrate_scattering(V3 start, V3 dir, float ray_leng
    float phaseM = (1.0f - k * k) / ((4.0f * PI) * (1.0f - kcosth) * (1.0f - kcosth));
    V3 od = v3(0, 0, 0), rayleigh = v3(0, 0, 0), mie = v3(0, 0, 0);
    float prev = 0.0f;
+   // log2(i / 16), i = 1..15: pow(i / 16, exponent) = exp2(exponent * log2(i / 16)) - one transcendental instead of two (i = 0: 0)
+   const float kLog2[16] = {0.0f,          -4.0f,         -3.0f,          -2.4150374993f, -2.0f,          -1.6780719051f, -1.4150374993f, -1.1926450779f,
+                            -1.0f,         -0.8300749986f, -0.6780719051f, -0.5405683814f, -0.4150374993f, -0.2995602819f, -0.1926450779f, -0.0931094044f};
    for (int i = 0; i < 16; i++) {
-      float ray_time = __powf((float)i / 16.0f, exponent) * ray_length;
+      float ray_time = i == 0 ? 0.0f : __builtin_amdgcn_exp2f(exponent * kLog2[i]) * ray_length;
       float step = ray_time - prev;
       V3 p = start + dir * ray_time;
       V3 dens = atmosphere_density(atmosphere_height(p));
       od = od + dens * step;
-      V3 view_t = absorb(od);
-      V3 light_t = absorb(integrate_optical_depth(p, light_dir));
-      rayleigh = rayleigh + view_t * light_t * phaseR * dens.x * step;
-      mie = mie + view_t * light_t * phaseM * dens.y * step;
+      // viewTransmittance * lightTransmittance (atmosphere.glsl:203-206) = absorb(od_view) * absorb(od_light) = absorb(od_view + od_light):
+      // absorb is exp of a linear form - three exponentials per step instead of six (the sky is compared with a tolerance, see above)
+      V3 both_t = absorb(od + integrate_optical_depth(p, light_dir));
+      rayleigh = rayleigh + both_t * phaseR * dens.x * step;
+      mie = mie + both_t * phaseM * dens.y * step;
       prev = ray_time;
    }
    return (rayleigh * C_RAYLEIGH() + mie * C_MIE()) * v3(1, 1, 1) * 20.0f;
