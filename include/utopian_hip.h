@@ -231,7 +231,7 @@ typedef struct uh_ctx uh_ctx;
  * is COMPLETE when it returns (its own copies and clears are waited for: the next frame may run on any of the library's
  * streams, none of which is ordered against the null stream):
  *   waits + complete on return:  uh_reset_stats, uh_get_stats, uh_reset_accumulation, uh_synchronize, every uh_read_*,
- *        uh_write_reservoirs, uh_build_acceleration, uh_refit_acceleration (also when uh_render_frame calls it for
+ *        uh_write_reservoirs, uh_write_gbuffer_position, uh_build_acceleration, uh_refit_acceleration (also when uh_render_frame calls it for
  *        view->rebuild_tlas), uh_set_tile_partition, uh_set_restir_partition, uh_rccl_attach / uh_rccl_detach, uh_pack_tiles,
  *        uh_unpack_tiles, uh_compose_tiles, uh_resolve_output, uh_add_isosurface_mesh, uh_destroy;
  *        uh_set_option for "frames_in_flight" and for "time_kernels" 1 -> 0 (the others only change what the NEXT enqueued
@@ -294,6 +294,8 @@ int uh_read_reservoirs(uh_ctx* ctx, int which /* 0 initial, 1 temporal, 2 spatia
 int uh_read_gbuffer_position(uh_ctx* ctx, float* rgba32f /* W*H*4, un-filtered texels */);
 /* upload a reservoir buffer (tests seed the temporal history with it) */
 int uh_write_reservoirs(uh_ctx* ctx, int which, const UhReservoir* in /* W*H */);
+/* upload gbuffer_position (tests run the reservoir passes on given positions: frames without UH_PASS_GBUFFER read what is there) */
+int uh_write_gbuffer_position(uh_ctx* ctx, const float* rgba32f /* W*H*4 */);
 
 /* ---- stand-alone ray queries through the same traversal kernels (parity tests) ---------- */
 /* rays: n * 8 floats (ox,oy,oz,tmin,dx,dy,dz,tmax); hits: n * 4 words (t,u,v as f32, then

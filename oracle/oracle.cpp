@@ -1318,6 +1318,13 @@ int orc_write_reservoirs(orc_ctx* c, int which, const UhReservoir* in) {
    std::memcpy(c->o.reservoirs[which].data(), in, (size_t)c->o.W * c->o.H * sizeof(UhReservoir));
    return UH_OK;
 }
+// test hook (the twin of uh_write_gbuffer_position): the G-buffer the reservoir passes read, set from outside - the known-answer
+// chains of tests/golden/shading_kat.npz run the passes on synthetic positions, without a cast
+int orc_write_gbuffer_position(orc_ctx* c, const float* in) {
+   if (!c || !in) return UH_ERR_INVALID_ARGUMENT;
+   std::memcpy(c->o.gbuffer_pos.data(), in, c->o.gbuffer_pos.size() * sizeof(float));
+   return UH_OK;
+}
 int orc_read_gbuffer_position(orc_ctx* c, float* out) {
    std::memcpy(out, c->o.gbuffer_pos.data(), c->o.gbuffer_pos.size() * 4);
    return UH_OK;

@@ -57,6 +57,7 @@ class CApi:
             "read_output_bgra8": [vp, vp],
             "read_reservoirs": [vp, C.c_int, vp],
             "write_reservoirs": [vp, C.c_int, vp],
+            "write_gbuffer_position": [vp, vp],
             "read_gbuffer_position": [vp, vp],
             "trace_closest": [vp, vp, u32, vp, vp, vp],
             "trace_any": [vp, vp, u32, vp],
@@ -372,6 +373,12 @@ class Renderer:
         data = np.ascontiguousarray(data, dtype=RESERVOIR_DTYPE)
         assert data.size == self.width * self.height
         self._check(self._api.write_reservoirs(self._ctx, which, data.ctypes.data))
+
+    def write_gbuffer_position(self, rgba32f):
+        """uh_write_gbuffer_position: frames rendered without PASS_GBUFFER read these positions (known-answer tests)"""
+        data = np.ascontiguousarray(rgba32f, dtype=np.float32)
+        assert data.size == self.width * self.height * 4
+        self._check(self._api.write_gbuffer_position(self._ctx, data.ctypes.data))
 
     def read_gbuffer_position(self):
         out = np.empty((self.height, self.width, 4), dtype=np.float32)

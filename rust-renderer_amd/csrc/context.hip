@@ -1707,8 +1707,10 @@ int uh_render_frames(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_mas
    UhViewUniformData v = *view;
    uint32_t done = 0, batch = 1;
    if (int st = plan_batch(c, pass_mask, &batch)) return st;
+   // wavefronts of equal size: 20 frames at 16 per wavefront go as 10 + 10, not 16 + 4 (a short wavefront's launches are mostly tail)
+   const uint32_t n_batches = (count + batch - 1) / batch, even = (count + n_batches - 1) / n_batches;
    while (done < count) {
-      uint32_t b = count - done < batch ? count - done : batch;
+      uint32_t b = count - done < even ? count - done : even;
       int st = render_batch(c, &v, pass_mask, b);
       if (st != UH_OK) return st;
       done += b;
@@ -1760,6 +1762,16 @@ int uh_write_reservoirs(uh_ctx* c, int which, const UhReservoir* in) {
    if (int st = sync_all(c)) return st;
    UhReservoir* dst = which == 2 ? c->im.reservoirs[2] : c->reservoirs[which].p;
    HIP_TRY(c, hipMemcpyAsync(dst, in, (size_t)c->W * c->H * sizeof(UhReservoir), hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   return UH_OK;
+}
+
+int uh_write_gbuffer_position(uh_ctx* c, const float* in) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   if (!in) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_write_gbuffer_position: null source");
+   HIP_TRY(c, hipSetDevice(c->device));
+   if (int st = sync_all(c)) return st;
+   HIP_TRY(c, hipMemcpyAsync(c->gbuffer.p, in, c->gbuffer.n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    return UH_OK;
 }
