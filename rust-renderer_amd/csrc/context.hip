@@ -259,7 +259,6 @@ struct uh_ctx {
    uint64_t geom_version = 1, sun_geom = 0, sun_geom_pending = 0;
    float sun_dir_built[3] = {0, 0, 0}, sun_dir_pending[3] = {0, 0, 0};
    DevBuf<uint32_t> d_sun_cells;
-   DevBuf<uint16_t> d_sun_cover;
    DevBuf<SunGridEntry> d_sun_entries;
    SunGridDev sun_dev{};
    SunGridLimits sun_limits;
@@ -504,7 +503,6 @@ void uh_destroy(uh_ctx* c) {
    c->d_tex.release();
    c->d_lut.release();
    c->d_sun_cells.release();
-   c->d_sun_cover.release();
    c->d_sun_entries.release();
    c->d_cam_cells.release();
    c->d_cam_entries.release();
@@ -1101,13 +1099,16 @@ static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float 
    c->sun_max_list = g.max_list;
    c->sun_cells = c->sun_entries = 0;
    if (ok) {
-      // per cell: its offset into the entries, and - in an array of its own - its cover code (sun_grid.h SunCoverCode)
-      const std::vector<uint32_t>& cells = g.cell_start;
+      // per cell two words: offset into the entries | cover depth (sun_grid.h)
+      std::vector<uint32_t> cells(2 * g.cell_start.size());
+      for (size_t k = 0; k < g.cell_start.size(); k++) {
+         const float cover = k < g.cell_cover.size() ? g.cell_cover[k] : -INFINITY;
+         cells[2 * k] = g.cell_start[k];
+         std::memcpy(&cells[2 * k + 1], &cover, 4);
+      }
       HIP_TRY(c, c->d_sun_cells.alloc(cells.size()));
-      HIP_TRY(c, c->d_sun_cover.alloc(g.cell_cover16.size() ? g.cell_cover16.size() : 1));
       HIP_TRY(c, c->d_sun_entries.alloc(g.entries.size() ? g.entries.size() : 1));
       HIP_TRY(c, hipMemcpy(c->d_sun_cells.p, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      if (!g.cell_cover16.empty()) HIP_TRY(c, hipMemcpy(c->d_sun_cover.p, g.cell_cover16.data(), g.cell_cover16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       if (!g.entries.empty()) HIP_TRY(c, hipMemcpy(c->d_sun_entries.p, g.entries.data(), g.entries.size() * sizeof(SunGridEntry), hipMemcpyHostToDevice));
       SunGridDev& d = c->sun_dev;
       std::memcpy(d.U, g.U, sizeof(d.U));
@@ -1120,16 +1121,12 @@ static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float 
       d.ny = g.ny;
       d.max_walk = c->sun_limits.max_walk;
       d.cell_start = c->d_sun_cells.p;
-      d.cover16 = c->d_sun_cover.p;
-      d.cover_w0 = (float)g.cover_code.w0;
-      d.cover_step = (float)g.cover_code.step;
       d.entries = c->d_sun_entries.p;
       c->sun_cells = g.nx * g.ny;
       c->sun_entries = (uint32_t)g.entries.size();
       c->sun_valid = true;
    } else {
       c->d_sun_cells.release();
-      c->d_sun_cover.release();
       c->d_sun_entries.release();
    }
    c->sun_build_ms = build_ms;
@@ -1148,17 +1145,12 @@ static int adopt_sun_grid_device(uh_ctx* c, SunGridDevice& g, bool ok, const flo
    c->sun_max_list = g.max_list;
    c->sun_cells = c->sun_entries = 0;
    c->d_sun_cells.release();
-   c->d_sun_cover.release();
    c->d_sun_entries.release();
    if (ok) {
       const size_t ncell = (size_t)g.params.nx * g.params.ny;
       c->d_sun_cells.p = g.cells;
       c->d_sun_cells.base = g.cells;
-      c->d_sun_cells.n = ncell + 1;
-      c->d_sun_cover.p = g.cover16;
-      c->d_sun_cover.base = g.cover16;
-      c->d_sun_cover.n = ncell;
-      g.cover16 = nullptr;
+      c->d_sun_cells.n = 2 * (ncell + 1);
       c->d_sun_entries.p = g.entries;
       c->d_sun_entries.base = g.entries;
       c->d_sun_entries.n = (size_t)g.num_entries;
@@ -1175,9 +1167,6 @@ static int adopt_sun_grid_device(uh_ctx* c, SunGridDevice& g, bool ok, const flo
       d.ny = g.params.ny;
       d.max_walk = c->sun_limits.max_walk;
       d.cell_start = c->d_sun_cells.p;
-      d.cover16 = c->d_sun_cover.p;
-      d.cover_w0 = (float)g.cover_code.w0;
-      d.cover_step = (float)g.cover_code.step;
       d.entries = c->d_sun_entries.p;
       c->sun_cells = g.params.nx * g.params.ny;
       c->sun_entries = (uint32_t)g.num_entries;
@@ -1327,7 +1316,7 @@ static int ensure_camera_grid(uh_ctx* c, const FrameParams& fp, uint32_t batch) 
       const size_t ncell = (size_t)g.params.nx * g.params.ny;
       c->d_cam_cells.p = g.cells;
       c->d_cam_cells.base = g.cells;
-      c->d_cam_cells.n = ncell + 1;
+      c->d_cam_cells.n = 2 * (ncell + 1);
       c->d_cam_entries.p = g.entries;
       c->d_cam_entries.base = g.entries;
       c->d_cam_entries.n = (size_t)g.num_entries;
@@ -1907,7 +1896,6 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->camera_grid_mean_list = c->cam_mean_list;
    out->camera_tree_rays = ds.cam_tree_rays;
    out->camera_grid_tris_tested = ds.cam_tris_tested;
-   out->sun_covered_rays = ds.sun_covered_rays;
    return UH_OK;
 }
 
@@ -2225,11 +2213,9 @@ int uh_sun_grid_compare_builders(uh_ctx* c, uint64_t out[8]) {
    const size_t ncell = (size_t)c->sun_dev.nx * c->sun_dev.ny;
    std::vector<float> packets(12 * (size_t)n);
    HIP_TRY(c, hipMemcpy2D(packets.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), n, hipMemcpyDeviceToHost));
-   std::vector<uint32_t> cells(ncell + 1);
-   std::vector<uint16_t> covers(ncell);
+   std::vector<uint32_t> cells(2 * (ncell + 1));
    std::vector<SunGridEntry> entries(c->sun_entries);
    HIP_TRY(c, hipMemcpy(cells.data(), c->d_sun_cells.p, cells.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-   HIP_TRY(c, hipMemcpy(covers.data(), c->d_sun_cover.p, covers.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
    if (!entries.empty()) HIP_TRY(c, hipMemcpy(entries.data(), c->d_sun_entries.p, entries.size() * sizeof(SunGridEntry), hipMemcpyDeviceToHost));
    SunGridParams prm;
    std::memcpy(prm.U, c->sun_dev.U, sizeof(prm.U));
@@ -2253,8 +2239,10 @@ int uh_sun_grid_compare_builders(uh_ctx* c, uint64_t out[8]) {
    if (h.cell_start.size() != ncell + 1) return fail(c, UH_ERR_INVALID_ARGUMENT, "host grid has another raster");
    std::vector<uint32_t> a, b;
    for (size_t k = 0; k < ncell; k++) {
-      const uint32_t d0 = cells[k], d1 = cells[k + 1], h0 = h.cell_start[k], h1 = h.cell_start[k + 1];
-      if (covers[k] != h.cell_cover16[k]) out[5]++;  // cover depth: the same code
+      const uint32_t d0 = cells[2 * k], d1 = cells[2 * (k + 1)], h0 = h.cell_start[k], h1 = h.cell_start[k + 1];
+      uint32_t hc;
+      std::memcpy(&hc, &h.cell_cover[k], 4);
+      if (cells[2 * k + 1] != hc) out[5]++;  // cover depth: bit for bit
       if (d1 - d0 != h1 - h0 || d0 != h0) {
          out[3]++;  // another list length (or offset)
          continue;

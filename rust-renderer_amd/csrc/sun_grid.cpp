@@ -418,9 +418,6 @@ bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], 
       out.cell_cover[c] = f;
    }
    out.covered_cells = covered;
-   out.cover_code = SunCoverCode::for_scene(maxabs);
-   out.cell_cover16.resize(ncell);
-   for (size_t c = 0; c < ncell; c++) out.cell_cover16[c] = out.cover_code.encode(out.cell_cover[c]);
    // Where do sun rays start? On surfaces - so weigh every triangle by its area and ask whether the cell under its centre would
    // serve a ray well (an interior cell with a short list) or hand it to the tree (a border cell: everything beyond the dense
    // part of the scene, e.g. a ground plane around a detailed object; or a long list: walls seen edge-on). A grid that sends a

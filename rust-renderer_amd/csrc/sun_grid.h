@@ -11,7 +11,6 @@
 // Replaces, for this ray class, the any-hit tree walk of k_trace_shadow<sun> (12.6 steps per ray) by about one cell
 // look-up and a few triangle tests.
 #pragma once
-#include <cmath>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -27,31 +26,6 @@ namespace uh {
 constexpr float kSunCoverReach = 9000.0f;
 constexpr double kSunCoverSlack = 900.0;
 
-// The cover depths live in an array of their own, 16 bits per cell: a ray that starts below its cell's cover reads nothing else of
-// the grid, and at two bytes per cell the array (6 MB for three million cells) stays in the caches where the 8-byte records of
-// rounds 3 did not. Quantised DOWNWARDS (a lower cover only sends a few more rays to the lists): code 0 = no cover, code k >= 1 =
-// w0 + (k - 1) * step with w0 = -sqrt(3) max|coordinate| (every depth lies above it), step = 2 sqrt(3) max|coordinate| / 65533 -
-// a twentieth of a millimetre per metre of scene. One step of slack absorbs the kernel's float evaluation of that expression.
-struct SunCoverCode {
-   double w0 = 0.0, step = 0.0;
-   // the code of a cover depth (float, already rounded down by the builders); 0 when there is none or the scale is degenerate
-   uint16_t encode(float cover) const {
-      if (!(step > 0.0) || !(cover > -1e37f)) return 0;
-      const double k = std::floor(((double)cover - w0) / step) - 1.0;  // one step of slack
-      if (!(k >= 0.0)) return 0;
-      return (uint16_t)(k >= 65534.0 ? 65535 : (uint32_t)k + 1);
-   }
-   static SunCoverCode for_scene(double max_abs_coordinate) {
-      SunCoverCode c;
-      const double bound = 1.7320508075688772 * max_abs_coordinate * 1.0001 + 1e-3;
-      c.w0 = -bound;
-      c.step = 2.0 * bound / 65533.0;
-      // the kernel evaluates w0 + (k - 1) step in float: the step must dwarf a float ulp of the depths
-      if (!(c.step > 64.0 * 1.1920929e-7 * bound)) c.step = 0.0;
-      return c;
-   }
-};
-
 struct SunGridEntry {
    uint32_t packet;  // triangle packet index (TriPacket array, leaf order)
    float wmax;       // far end of the packet's depth range along the sun direction, padded
@@ -63,10 +37,8 @@ struct SunGridDev {
    float u0, v0, inv_cell;  // cell (ix, iy) covers u0 + [ix, ix+1) / inv_cell, v0 + [iy, iy+1) / inv_cell
    uint32_t nx, ny;
    uint32_t max_walk;            // cells with a longer list, and the border cells, hand their rays to the tree walk
-   const uint32_t* cell_start;   // nx * ny + 1 offsets into entries
-   const uint16_t* cover16;      // nx * ny cover codes (SunCoverCode; null for the camera grid): a ray of the cell that starts below the
-                                 // cover depth is occluded - some packet spans the whole cell in front of it
-   float cover_w0, cover_step;
+   const uint32_t* cell_start;   // nx * ny + 1 records of two words: offset into entries | cover depth (float bits): a ray of the
+                                 // cell that starts below the cover depth is occluded - some packet spans the whole cell in front of it
    const SunGridEntry* entries;
 };
 
@@ -78,8 +50,6 @@ struct SunGridHost {
    // per cell: the depth below which every ray of the cell is occluded (some packet whose projection, eroded by twice the
    // margins, contains the whole cell lies in front of it by more than the rays' tmin); -inf: no such packet
    std::vector<float> cell_cover;
-   std::vector<uint16_t> cell_cover16;  // what the kernel reads: cell_cover through `cover_code`
-   SunCoverCode cover_code;
    uint64_t covered_cells = 0;
    std::vector<SunGridEntry> entries;
    // quality figures (what a ray can expect): entries per non-empty cell, the longest list, cells
@@ -118,14 +88,12 @@ void sun_grid_frame(const float sun_dir[3], SunGridParams& out);
 bool build_sun_grid(const float* packets12, uint32_t n, const float sun_dir[3], const SunGridLimits& lim, int num_threads, SunGridHost& out, const SunGridParams* forced = nullptr);
 
 // The same grid built on the device (sun_grid_build.hip) from the packets where they lie (d_packets: n records of kTriStride16 x 16
-// bytes): a few milliseconds instead of the host builder's 130-550, nothing but a few dozen numbers over PCIe. `cells` (nx * ny + 1
-// offsets), `cover16` (nx * ny cover codes) and `entries` are hipMalloc'ed and owned by the result. The lists of the
+// bytes): a few milliseconds instead of the host builder's 130-550, nothing but a few dozen numbers over PCIe. `cells` (two words
+// per cell, nx * ny + 1 of them: offset | cover depth) and `entries` are hipMalloc'ed and owned by the result. The lists of the
 // cells a ray may walk (interior, at most lim.max_walk entries) are sorted as the host builder sorts them; the others - whose rays
 // k_trace_sun_grid hands to the tree - are left in arrival order. Runs on `hip_stream` and waits for it.
 struct SunGridDevice {
-   uint32_t* cells = nullptr;      // nx * ny + 1 offsets
-   uint16_t* cover16 = nullptr;    // nx * ny cover codes (sun grid only)
-   SunCoverCode cover_code;
+   uint32_t* cells = nullptr;
    SunGridEntry* entries = nullptr;
    SunGridParams params;
    uint64_t num_entries = 0;

@@ -557,19 +557,16 @@ __global__ __launch_bounds__(kBlock) void k_sg_sort(const uint32_t* __restrict__
    }
 }
 
-// what k_trace_sun_grid reads of a cell: its cover code (SunCoverCode::encode, restated: same double arithmetic)
-__global__ __launch_bounds__(kBlock) void k_sg_covers(const uint32_t* __restrict__ cover_key, uint32_t ncell, double w0, double step, uint16_t* __restrict__ cover16) {
-   for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < ncell; c += gridDim.x * kBlock) {
-      uint16_t code = 0;
-      if (cover_key[c] && step > 0.0) {
+// the records k_trace_sun_grid reads: offset | cover depth (float bits), ncell + 1 of them
+__global__ __launch_bounds__(kBlock) void k_sg_cells(const uint32_t* __restrict__ start, const uint32_t* __restrict__ cover_key, uint32_t ncell, uint32_t* __restrict__ cells) {
+   for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c <= ncell; c += gridDim.x * kBlock) {
+      uint32_t bits = 0xff800000u;  // -inf: no cover
+      if (c < ncell && cover_key[c]) {
          const uint32_t key = cover_key[c];
-         const float cover = __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
-         if (cover > -1e37f) {
-            const double k = floor(((double)cover - w0) / step) - 1.0;
-            if (k >= 0.0) code = (uint16_t)(k >= 65534.0 ? 65535u : (uint32_t)k + 1u);
-         }
+         bits = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
       }
-      cover16[c] = code;
+      cells[2 * (size_t)c] = start[c];
+      cells[2 * (size_t)c + 1] = bits;
    }
 }
 
@@ -616,10 +613,8 @@ struct Scratch {
 
 void SunGridDevice::release() {
    if (cells) (void)hipFree(cells);
-   if (cover16) (void)hipFree(cover16);
    if (entries) (void)hipFree(entries);
    cells = nullptr;
-   cover16 = nullptr;
    entries = nullptr;
 }
 
@@ -687,7 +682,6 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       }
    S = std::sqrt(S);
    fr.S = S;
-   out.cover_code = SunCoverCode::for_scene(maxabs);
    fr.base = 2e-4 + 2e-5 * maxabs + 2e-6 * S;
    base = fr.base;
 
@@ -833,14 +827,14 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
    SG_TRY(hipMemcpyAsync(d_cursor.p, start, ncell * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
    SG_TRY(hipMemsetAsync(d_cover.p, 0, ncell * sizeof(uint32_t), stream));
    SG_TRY(hipMalloc((void**)&out.entries, (total ? total : 1) * sizeof(SunGridEntry)));
-   if (!cam) SG_TRY(hipMalloc((void**)&out.cover16, ncell * sizeof(uint16_t)));
+   SG_TRY(hipMalloc((void**)&out.cells, 2 * (ncell + 1) * sizeof(uint32_t)));
    {
       const uint32_t bin_blocks = std::min<uint32_t>((n + (kBlock / 64) - 1) / (kBlock / 64), 1u << 16);
       k_sg_bin<true><<<bin_blocks, kBlock, 0, stream>>>(pr, n, g, (uint32_t*)d_cursor.p, out.entries, (uint32_t*)d_cover.p);
    }
    const uint32_t cell_blocks = std::min<uint32_t>((uint32_t)((ncell + kBlock) / kBlock), 1u << 15);
    k_sg_sort<<<cell_blocks, kBlock, 0, stream>>>(start, out.entries, prm.nx, prm.ny, lim.max_walk);
-   if (!cam) k_sg_covers<<<cell_blocks, kBlock, 0, stream>>>((const uint32_t*)d_cover.p, (uint32_t)ncell, out.cover_code.w0, out.cover_code.step, out.cover16);
+   k_sg_cells<<<cell_blocks, kBlock, 0, stream>>>(start, (const uint32_t*)d_cover.p, (uint32_t)ncell, out.cells);
    SG_TRY(d_area.alloc(2 * sizeof(double)));
    SG_TRY(hipMemsetAsync(d_area.p, 0, 2 * sizeof(double), stream));
    if (!cam) k_sg_area<<<std::min<uint32_t>(blocks_n, 2048), kBlock, 0, stream>>>(d_tris, pr, n, g, start, lim.max_walk, (double*)d_area.p);
@@ -850,8 +844,6 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
    SG_TRY(hipGetLastError());
    out.fallback_area = area[0] > 0 ? area[1] / area[0] : 0.0;
    out.num_entries = total;
-   out.cells = (uint32_t*)d_counts.p;  // the scanned counts ARE the offsets (ncell + 1 of them): they change owner
-   d_counts.p = nullptr;
    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
    if (out.fallback_area > lim.max_fallback_area)
       return refuse("too much of the scene's surface (" + std::to_string(out.fallback_area) + ") lies beyond the dense extent or in cells with long lists: its rays would walk the tree anyway");

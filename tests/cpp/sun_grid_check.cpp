@@ -87,11 +87,7 @@ static bool grid_occluded(const SunGridHost& g, const std::vector<float>& pk, F3
    fx = fx > max_x ? max_x : fx;
    fy = fy > max_y ? max_y : fy;
    const uint32_t cell = (uint32_t)fy * g.nx + (uint32_t)fx;
-   {  // the cell's cover (its 16-bit code, as k_trace_sun_grid evaluates it): no packet is asked
-      const uint32_t code = g.cell_cover16[cell];
-      const float cover = std::fmaf((float)code - 1.0f, (float)g.cover_code.step, (float)g.cover_code.w0);
-      if (code != 0u && pw < cover && cover - pw < uh::kSunCoverReach) return true;
-   }
+   if (pw < g.cell_cover[cell] && g.cell_cover[cell] - pw < uh::kSunCoverReach) return true;  // the cell's cover: no packet is asked (k_trace_sun_grid does the same)
    for (uint32_t e = g.cell_start[cell]; e < g.cell_start[cell + 1]; e++) {
       if (g.entries[e].wmax < pw) break;
       (*tests)++;
