@@ -160,6 +160,7 @@ def main():
         "mean_list": cs.sun_grid_mean_list,
         "tests_per_ray": cs.shadow_tris_tested / sun_rays_counted,   # triangle tests per sun shadow ray (grid walk + the tree walk of the handed-over rays)
         "handed_to_tree": cs.sun_tree_rays / sun_rays_counted,       # share of the sun rays the grid gives back to the tree (border cells, long lists)
+        "answered_by_cover": cs.sun_covered_rays / sun_rays_counted,  # share answered by the cell's cover depth alone
     }
     renderer.set_option("count_visits", 0)
     camera_grid = None  # filled after the timed region (the grid is built by the first multi-frame call)

@@ -221,6 +221,7 @@ typedef struct UhStats {
    uint64_t camera_grid_tris_tested; /* triangle packets tested by the grid walk of the primary rays (option "count_visits") */
    float camera_grid_ms;        /* summed hipEvent time of the primary rays' launches when they go through the grid (option "time_kernels") */
    uint32_t reserved0;
+   uint64_t sun_covered_rays;   /* sun shadow rays answered by their cell's cover depth alone (option "count_visits") */
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;

@@ -1316,7 +1316,7 @@ static int ensure_camera_grid(uh_ctx* c, const FrameParams& fp, uint32_t batch) 
       const size_t ncell = (size_t)g.params.nx * g.params.ny;
       c->d_cam_cells.p = g.cells;
       c->d_cam_cells.base = g.cells;
-      c->d_cam_cells.n = 2 * (ncell + 1);
+      c->d_cam_cells.n = ncell + 1;
       c->d_cam_entries.p = g.entries;
       c->d_cam_entries.base = g.entries;
       c->d_cam_entries.n = (size_t)g.num_entries;
@@ -1896,6 +1896,7 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->camera_grid_mean_list = c->cam_mean_list;
    out->camera_tree_rays = ds.cam_tree_rays;
    out->camera_grid_tris_tested = ds.cam_tris_tested;
+   out->sun_covered_rays = ds.sun_covered_rays;
    return UH_OK;
 }
 

@@ -843,7 +843,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
    const float4* __restrict__ tris = sc.tris;
    const V3 d = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);  // rgen:64
    const float max_x = (float)(g.nx - 1), max_y = (float)(g.ny - 1);
-   uint32_t n_cells = 0, n_tris = 0;
+   uint32_t n_cells = 0, n_tris = 0, n_covered = 0;
    uint32_t* q_tree = ps.queue[3] + seg;
    uint32_t* n_tree = &ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)];
    for (;;) {
@@ -876,7 +876,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
          // a border cell stands for everything beyond the dense part of the scene, and some interior cells list a great many
          // packets (walls edge-on to the sun): such a ray is cheaper in the tree - k_trace_shadow takes it from queue 3
          defer = !covered && (cx == 0 || cy == 0 || cx + 1 == g.nx || cy + 1 == g.ny || end - e > g.max_walk);
-         if (COUNT) n_cells++;
+         if (COUNT) {
+            n_cells++;
+            n_covered += covered ? 1u : 0u;
+         }
          if (!defer && !covered) {
             bool occluded = false;
             Hit best;
@@ -916,6 +919,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
    if (COUNT) {
       atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_cells);
       atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
+      atomicAdd(&stats->sun_covered_rays, (unsigned long long)n_covered);
    }
 }
 
@@ -954,8 +958,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_camera_grid(SceneDev sc, Frame
          const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
          const uint32_t px = pix % fp.W, py = pix / fp.W;
          const uint32_t cell = (py + 1) * g.nx + (px + 1);
-         uint32_t e = g.cell_start[2 * (size_t)cell];
-         const uint32_t end = g.cell_start[2 * (size_t)cell + 2];
+         uint32_t e = g.cell_start[cell];  // the camera grid's cell records are plain offsets (no cover depths)
+         const uint32_t end = g.cell_start[cell + 1];
          defer = end - e > g.max_walk;
          if (!defer) {
             const float4 ro = ld_rec(rec_quad(rec, seg + i, REC_ORIGIN)), rd = ld_rec(rec_quad(rec, seg + i, REC_DIR));
@@ -1000,8 +1004,8 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_camera_grid(SceneDev sc, Raw
       const uint32_t pix = spans.pixel_of(j);
       const uint32_t px = pix % W, py = pix / W;
       const uint32_t cell = (py + 1) * g.nx + (px + 1);
-      uint32_t e = g.cell_start[2 * (size_t)cell];
-      const uint32_t end = g.cell_start[2 * (size_t)cell + 2];
+      uint32_t e = g.cell_start[cell];
+      const uint32_t end = g.cell_start[cell + 1];
       const bool sorted = end - e <= g.max_walk;
       const float4 ro = ps.ray_o[j], rd = ps.ray_d[j];
       const V3 o = v3(ro.x, ro.y, ro.z), d = v3(rd.x, rd.y, rd.z);

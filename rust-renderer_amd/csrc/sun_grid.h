@@ -112,6 +112,7 @@ bool build_sun_grid_device(void* hip_stream, const void* d_packets, uint32_t n, 
 // list front to back with the closest-hit test of the tree walk (tri_compute<false>: same t, same tie-break) and stops when the
 // next bound exceeds the best hit: the same hit record, bit for bit, without a tree walk. inverse_view / inverse_projection:
 // the 16 floats of UhViewUniformData (column-major), the very numbers primary_ray reads.
+// (The camera grid's `cells` are nx * ny + 1 plain offsets - it has no cover depths -, the sun grid's are (offset, cover) pairs.)
 bool build_camera_grid_device(void* hip_stream, const void* d_packets, uint32_t n, const float inverse_view[16], const float inverse_projection[16], uint32_t W, uint32_t H,
                               const SunGridLimits& lim, SunGridDevice& out);
 

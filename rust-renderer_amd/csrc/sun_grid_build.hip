@@ -827,14 +827,14 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
    SG_TRY(hipMemcpyAsync(d_cursor.p, start, ncell * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
    SG_TRY(hipMemsetAsync(d_cover.p, 0, ncell * sizeof(uint32_t), stream));
    SG_TRY(hipMalloc((void**)&out.entries, (total ? total : 1) * sizeof(SunGridEntry)));
-   SG_TRY(hipMalloc((void**)&out.cells, 2 * (ncell + 1) * sizeof(uint32_t)));
+   if (!cam) SG_TRY(hipMalloc((void**)&out.cells, 2 * (ncell + 1) * sizeof(uint32_t)));
    {
       const uint32_t bin_blocks = std::min<uint32_t>((n + (kBlock / 64) - 1) / (kBlock / 64), 1u << 16);
       k_sg_bin<true><<<bin_blocks, kBlock, 0, stream>>>(pr, n, g, (uint32_t*)d_cursor.p, out.entries, (uint32_t*)d_cover.p);
    }
    const uint32_t cell_blocks = std::min<uint32_t>((uint32_t)((ncell + kBlock) / kBlock), 1u << 15);
    k_sg_sort<<<cell_blocks, kBlock, 0, stream>>>(start, out.entries, prm.nx, prm.ny, lim.max_walk);
-   k_sg_cells<<<cell_blocks, kBlock, 0, stream>>>(start, (const uint32_t*)d_cover.p, (uint32_t)ncell, out.cells);
+   if (!cam) k_sg_cells<<<cell_blocks, kBlock, 0, stream>>>(start, (const uint32_t*)d_cover.p, (uint32_t)ncell, out.cells);
    SG_TRY(d_area.alloc(2 * sizeof(double)));
    SG_TRY(hipMemsetAsync(d_area.p, 0, 2 * sizeof(double), stream));
    if (!cam) k_sg_area<<<std::min<uint32_t>(blocks_n, 2048), kBlock, 0, stream>>>(d_tris, pr, n, g, start, lim.max_walk, (double*)d_area.p);
@@ -844,6 +844,10 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
    SG_TRY(hipGetLastError());
    out.fallback_area = area[0] > 0 ? area[1] / area[0] : 0.0;
    out.num_entries = total;
+   if (cam) {  // the camera grid has no cover depths: the scanned counts ARE its cell records (ncell + 1 offsets) - they change owner
+      out.cells = (uint32_t*)d_counts.p;
+      d_counts.p = nullptr;
+   }
    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
    if (out.fallback_area > lim.max_fallback_area)
       return refuse("too much of the scene's surface (" + std::to_string(out.fallback_area) + ") lies beyond the dense extent or in cells with long lists: its rays would walk the tree anyway");
