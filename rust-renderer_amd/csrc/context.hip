@@ -287,6 +287,15 @@ struct uh_ctx {
    uint32_t cam_cells = 0, cam_entries = 0, cam_max_list = 0;
    bool cam_this_frame = false;
 
+   // One frame per call (a moving camera: uh_render_frame) spread over several slots: the frame's pixels are split, by tiles, into
+   // `interleave` parts, each a wavefront of its own on its own stream pair. A lone 2 M-path wavefront leaves the chip idle in the
+   // tail of every one of its ~30 launches; four half-million-path wavefronts at different stages of their chains fill each
+   // other's tails (the same effect as four frames in flight, inside one frame). Pixels are independent (RNG keyed on absolute
+   // pixel coordinates): the image is bit-identical. Option "interleave" (0 / 1 = off); batches of frames are not split.
+   uint32_t interleave = 4, il_parts = 0, il_tile = 32;
+   DevBuf<uint32_t> il_pixels[kMaxSlots];
+   uint32_t il_count[kMaxSlots] = {0};
+
    // tile partition
    uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
    DevBuf<uint32_t> owned_pixels;  // ascending pixel ids this rank owns (empty = the whole frame)
@@ -506,6 +515,7 @@ void uh_destroy(uh_ctx* c) {
    c->d_sun_entries.release();
    c->d_cam_cells.release();
    c->d_cam_entries.release();
+   for (auto& b : c->il_pixels) b.release();
    c->accumulation.release();
    c->gbuffer.release();
    c->output.release();
@@ -1586,6 +1596,23 @@ static int batch_exchange(uh_ctx* c, uh_batch& bs, uint32_t f) {
    return UH_OK;
 }
 
+// the ascending pixel lists of the `parts` tile classes of a frame (tile t belongs to part t % parts)
+static int ensure_interleave_lists(uh_ctx* c, uint32_t parts) {
+   if (c->il_parts == parts) return UH_OK;
+   if (int st = sync_all(c)) return st;
+   const uint32_t tile = c->il_tile, tiles_x = (c->W + tile - 1) / tile;
+   std::vector<std::vector<uint32_t>> own(parts);
+   for (uint32_t y = 0; y < c->H; y++)
+      for (uint32_t x = 0; x < c->W; x++) own[((y / tile) * tiles_x + x / tile) % parts].push_back(y * c->W + x);
+   for (uint32_t k = 0; k < parts; k++) {
+      c->il_count[k] = (uint32_t)own[k].size();
+      HIP_TRY(c, c->il_pixels[k].alloc(own[k].empty() ? 1 : own[k].size()));
+      if (!own[k].empty()) HIP_TRY(c, hipMemcpy(c->il_pixels[k].p, own[k].data(), own[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   }
+   c->il_parts = parts;
+   return UH_OK;
+}
+
 static int batch_end(uh_ctx* c, uh_batch& bs) {
    HIP_TRY(c, hipSetDevice(c->device));
    FrameParams& fp = bs.fp;
@@ -1602,22 +1629,40 @@ static int batch_end(uh_ctx* c, uh_batch& bs) {
       c->sun_this_frame = false;
       if (fp.sun_shadow_enabled == 1 && fp.num_bounces > 0 && fp.samples_per_frame > 0)
          if (int st = ensure_sun_grid(c, fp.sun_dir)) return st;
-      const uint32_t si = c->next_slot;
-      c->next_slot = (c->next_slot + 1) % (c->frames_in_flight ? c->frames_in_flight : 1);
-      int st = ensure_slot(c, si, batch);
-      if (st != UH_OK) return st;
-      Slot& s = c->slots[si];
-      // rgen:98 reads this frame's spatial_reuse_reservoirs
-      if (bs.reads_reservoirs && c->restir_recorded) HIP_TRY(c, hipStreamWaitEvent(s.stream, c->ev_restir, 0));
-      HIP_TRY(c, hipEventRecord(s.frame_start, s.stream));
-      if (!c->t_start) c->t_start = s.frame_start;
-      st = enqueue_path_trace(c, s, fp);
-      if (st != UH_OK) return st;
-      if (bs.reads_reservoirs)
-         for (uint32_t f = 0; f < batch; f++) c->spatial_reader[bs.read_slot[f]] = s.ev_acc;
-      HIP_TRY(c, hipEventRecord(s.frame_stop, s.stream));
-      c->t_stop = s.frame_stop;
-      c->last_slot = &s;
+      // a single frame is split over the slots (uh_ctx::interleave); a batch, or a rank's share of a partitioned frame, goes whole
+      const uint32_t in_flight = c->frames_in_flight ? c->frames_in_flight : 1;
+      uint32_t parts = 1;
+      if (batch == 1 && c->tp_world <= 1 && c->interleave > 1 && (uint64_t)c->W * c->H >= 4096) parts = c->interleave < in_flight ? c->interleave : in_flight;
+      if (parts > 1)
+         if (int st = ensure_interleave_lists(c, parts)) return st;
+      for (uint32_t part = 0; part < parts; part++) {
+         const uint32_t si = c->next_slot;
+         c->next_slot = (c->next_slot + 1) % in_flight;
+         int st = ensure_slot(c, si, batch);
+         if (st != UH_OK) return st;
+         Slot& s = c->slots[si];
+         FrameParams fk = fp;
+         if (parts > 1) {
+            fk.tp_world = parts;
+            fk.tp_rank = part;
+            fk.tp_tile = c->il_tile;
+            fk.tiles_x = (c->W + c->il_tile - 1) / c->il_tile;
+            fk.owned_pixels = c->il_pixels[part].p;
+            fk.n_owned = c->il_count[part];
+         }
+         // rgen:98 reads this frame's spatial_reuse_reservoirs
+         if (bs.reads_reservoirs && c->restir_recorded) HIP_TRY(c, hipStreamWaitEvent(s.stream, c->ev_restir, 0));
+         HIP_TRY(c, hipEventRecord(s.frame_start, s.stream));
+         if (!c->t_start) c->t_start = s.frame_start;
+         st = enqueue_path_trace(c, s, fk);
+         if (st != UH_OK) return st;
+         // (the parts' accumulate tails are chained through last_acc: the last part's event stands for all of them)
+         if (bs.reads_reservoirs)
+            for (uint32_t f = 0; f < batch; f++) c->spatial_reader[bs.read_slot[f]] = s.ev_acc;
+         HIP_TRY(c, hipEventRecord(s.frame_stop, s.stream));
+         c->t_stop = s.frame_stop;
+         c->last_slot = &s;
+      }
    }
    c->frame_timed = true;
    c->frames += batch;
@@ -1952,6 +1997,9 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 0 || value > 100) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_fallback_pct must be 0..100");
       c->sun_limits.max_fallback_area = value / 100.0;  // share of the scene's surface whose sun rays may go on to the tree before the grid is refused
       c->sun_attempted = false;
+   } else if (n == "interleave") {
+      if (value < 0 || value > (int)kMaxSlots) return fail(c, UH_ERR_INVALID_ARGUMENT, "interleave must be 0..8");
+      c->interleave = (uint32_t)value;
    } else if (n == "camera_grid") {
       // 1 (default): the primary rays of a camera at rest go through the per-camera grid; 0: always the tree
       c->cam_grid_enabled = value != 0;

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -720,7 +721,9 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
          std::nth_element(v.begin(), v.begin() + k, v.end());
          return v[k];
       };
-      ex0 = quantile(cx, 0.005), ex1 = quantile(cx, 0.995), ey0 = quantile(cy, 0.005), ey1 = quantile(cy, 0.995);
+      double qq = 0.005;
+      if (const char* e = std::getenv("UH_SG_QUANTILE")) qq = std::atof(e);  // experiment: how much of the centres' range the dense extent takes
+      ex0 = quantile(cx, qq), ex1 = quantile(cx, 1.0 - qq), ey0 = quantile(cy, qq), ey1 = quantile(cy, 1.0 - qq);
       const double mx = 0.05 * (ex1 - ex0) + 4 * base, my = 0.05 * (ey1 - ey0) + 4 * base;
       ex0 -= mx;
       ex1 += mx;
