@@ -317,8 +317,8 @@ int uh_reset_stats(uh_ctx* ctx);
  * "device_build" (0/1/2; 1 or 2 = uh_build_acceleration builds the tree ON THE DEVICE in a few ms instead of the host SAH
  * tree in tens to hundreds: same hits bit for bit, about 10 % (1: clusters under a SAH top) or 30 % (2: radix tree) more
  * traversal work per ray - for geometry that changes every few frames),
- * "interleave" (0..8, default 4: a uh_render_frame call - one frame - is split by tiles into this many wavefronts on as many of the
- * "frames_in_flight" slots, so that a lone frame's launches fill each other's tails; same image bit for bit; 0 / 1 = off),
+ * "interleave" (0..8, default 0 = off: a uh_render_frame call - one frame - is split by tiles into this many wavefronts on as many of
+ * the "frames_in_flight" slots; same image bit for bit; measured slower than the whole wavefront on MI355X, kept for experiments),
  * "camera_grid" (0/1, default 1: the primary rays of a camera that has been the same for two consecutive frame calls - or for a
  * call of 8 or more frames - go through a per-camera grid of packet lists, one cell per pixel, instead of the tree; same hit records
  * bit for bit), "camera_grid_max_walk", "camera_grid_max_mean_list_x10",

@@ -292,7 +292,11 @@ struct uh_ctx {
    // tail of every one of its ~30 launches; four half-million-path wavefronts at different stages of their chains fill each
    // other's tails (the same effect as four frames in flight, inside one frame). Pixels are independent (RNG keyed on absolute
    // pixel coordinates): the image is bit-identical. Option "interleave" (0 / 1 = off); batches of frames are not split.
-   uint32_t interleave = 4, il_parts = 0, il_tile = 32;
+   // MEASURED AND OFF BY DEFAULT (round 4, config 1, profiles/README.md): one frame per call with a wait after it 2.96 ms whole,
+   // 2.98 in two parts, 4.06 in four, 4.84 in six; four frames in flight 2.22 / 2.74 / 3.82 / 4.70 - the parts' launches are four
+   // times as many and each still pays its fixed cost (a persistent grid over the whole chip for a queue of a few thousand rays):
+   // a lone frame is bound by launch count x fixed cost per launch, not by idle tails that more streams could fill.
+   uint32_t interleave = 0, il_parts = 0, il_tile = 32;
    DevBuf<uint32_t> il_pixels[kMaxSlots];
    uint32_t il_count[kMaxSlots] = {0};
 
