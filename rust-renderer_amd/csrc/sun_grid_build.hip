@@ -702,7 +702,8 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
          std::memcpy(prm.W, frame.W, sizeof(prm.W));
       }
    } else {
-      const uint32_t stride = n > 32768 ? (n + 32767) / 32768 : 1, n_samples = (n + stride - 1) / stride;
+      // (8 Ki boxes, 32 bisection steps: the host's share of the build stays under a millisecond; 32 Ki x 48 cost more than the kernels)
+      const uint32_t stride = n > 8192 ? (n + 8191) / 8192 : 1, n_samples = (n + stride - 1) / stride;
       Scratch d_sample;
       SG_TRY(d_sample.alloc((size_t)n_samples * 4 * sizeof(double)));
       k_sg_sample<<<(n_samples + kBlock - 1) / kBlock, kBlock, 0, stream>>>(pr, n, stride, n_samples, (double*)d_sample.p);
@@ -750,7 +751,7 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       };
       double s_lo = std::sqrt(ext_x * ext_y / (double)lim.max_cells) * 1.001, s_hi = std::max(ext_x, ext_y);
       if (estimate(s_lo) > target) {
-         for (int it = 0; it < 48; it++) {
+         for (int it = 0; it < 32; it++) {
             const double mid = std::sqrt(s_lo * s_hi);
             (estimate(mid) > target ? s_lo : s_hi) = mid;
          }
