@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tree-walk", action="store_true", help="skip the second timed run with both grids off (profiling runs: every frame in the counters is then a frame of the timed kind)")
     ap.add_argument("--no-alone", action="store_true", help="skip the untimed standalone-kernel calibration frames (profiling runs: every launch in the trace is then in the timed regime)")
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only one rank's tiles of an N-rank partition (what one rank sees at --gpus N)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="the rank --emulate-world stands in for")
@@ -167,7 +168,7 @@ def main():
 
     # ---- untimed: the dominant kernel alone on the GPU (no frame overlap, no second stream), in launches of the SAME size as
     # the timed ones (one wavefront of the library's default batch): its serialised launch duration, without co-scheduled kernels
-    frames_rendered = 1
+    frames_rendered = 17  # the wavefront that builds the grids + the counted frame
     renderer.set_option("time_kernels", 1)
     serial = (("frames_in_flight", 1), ("overlap_miss", 0), ("overlap_shadow", 0))
     for k, v in serial:
@@ -269,28 +270,31 @@ def main():
         "handed_to_tree": st.camera_tree_rays / max(st.rays[rr.RAY_PRIMARY], 1),  # share of the primary rays whose pixel lists too many packets
         "tests_per_ray": camera_tests_per_ray,     # triangle tests per primary ray served by the grid (no node visit)
     }
-    renderer.set_option("sun_grid", 0)
-    renderer.set_option("camera_grid", 0)
-    loop.frames(16, pass_mask)
-    loop.reset()
-    renderer.reset_stats()
-    sync_all()
-    t1 = time.perf_counter()
-    loop.frames(args.steps, pass_mask)
+    elapsed_tree, tree_rays = None, 0.0
+    if not args.no_tree_walk:
+        renderer.set_option("sun_grid", 0)
+        renderer.set_option("camera_grid", 0)
+        loop.frames(16, pass_mask)
+        loop.reset()
+        renderer.reset_stats()
+        sync_all()
+        t1 = time.perf_counter()
+        loop.frames(args.steps, pass_mask)
+        if use_dist:
+            rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}", resolve=(view.total_samples, view.accumulation_limit))
+        sync_all()
+        elapsed_tree = time.perf_counter() - t1
+        tree_rays = float(renderer.get_stats().path_rays)
+        renderer.set_option("sun_grid", 1)
+        renderer.set_option("camera_grid", 1)
+        frames_rendered += 16 + args.steps
     if use_dist:
-        rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}", resolve=(view.total_samples, view.accumulation_limit))
-    sync_all()
-    elapsed_tree = time.perf_counter() - t1
-    tree_rays = float(renderer.get_stats().path_rays)
-    renderer.set_option("sun_grid", 1)
-    renderer.set_option("camera_grid", 1)
-    if use_dist:
-        t = torch.tensor([elapsed, my_rays, my_closest, st.trace_closest_ms, elapsed_tree, tree_rays], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, my_rays, my_closest, st.trace_closest_ms, elapsed_tree or 0.0, tree_rays], dtype=torch.float64, device=f"cuda:{local_rank}")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, total_rays = float(tmax[0]), float(t[1])
-        elapsed_tree, tree_rays = float(tmax[4]), float(t[5])
+        elapsed_tree, tree_rays = (float(tmax[4]) if elapsed_tree is not None else None), float(t[5])
     else:
         total_rays = my_rays
 
@@ -313,8 +317,8 @@ def main():
             # the same steps with options sun_grid = 0 and camera_grid = 0 (every ray walks the tree), and with the two grids' one-off
             # builds charged to THIS run's K frames: they are built once per (geometry, sun direction) / (geometry, camera), on the
             # device, before the timed region
-            "value_tree_walk": tree_rays / elapsed_tree / 1e6,
-            "ms_per_step_tree_walk": elapsed_tree / args.steps * 1e3,
+            "value_tree_walk": tree_rays / elapsed_tree / 1e6 if elapsed_tree else None,
+            "ms_per_step_tree_walk": elapsed_tree / args.steps * 1e3 if elapsed_tree else None,
             "value_with_grid_builds": total_rays / (elapsed + ((sun_grid["build_ms"] if sun_grid["in_use"] else 0.0) + (camera_grid["build_ms"] if camera_grid["in_use"] else 0.0)) * 1e-3) / 1e6,
             "sun_grid": sun_grid,
             "camera_grid": camera_grid,

@@ -10,5 +10,5 @@ export TMPDIR=/tmp
 export UH_BENCH_SIGNATURE=$root/gpurun_out/bench_signature.json
 cd $root
 rm -rf $root/gpurun_out/${tag}_kt
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/${tag}_kt --output-format csv -- python3 bench.py --steps 64 --warmup 16 --no-cpu-baseline --no-alone "$@" > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_kt.log || { echo "kernel trace failed"; tail -5 gpurun_out/${tag}_kt.log; }
-tools/pmc_passes.sh $tag python3 bench.py --steps 48 --warmup 16 --no-cpu-baseline --no-alone "$@"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/${tag}_kt --output-format csv -- python3 bench.py --steps 64 --warmup 16 --no-cpu-baseline --no-alone --no-tree-walk "$@" > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_kt.log || { echo "kernel trace failed"; tail -5 gpurun_out/${tag}_kt.log; }
+tools/pmc_passes.sh $tag python3 bench.py --steps 48 --warmup 16 --no-cpu-baseline --no-alone --no-tree-walk "$@"
