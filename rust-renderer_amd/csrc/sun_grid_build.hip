@@ -656,47 +656,46 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       cam_raster.ny = (uint32_t)cam->H + 2;
       forced = &cam_raster;
    } else {
-   const double wl = std::sqrt((double)sun_dir[0] * sun_dir[0] + (double)sun_dir[1] * sun_dir[1] + (double)sun_dir[2] * sun_dir[2]);
-   if (!std::isfinite(wl) || !(wl > 0.99 && wl < 1.01)) return refuse("sun direction is not a finite unit vector");
-   sun_grid_frame(sun_dir, prm);  // U, V, W: the host builder's frame (sun_grid.cpp)
-   for (int k = 0; k < 3; k++) {
-      fr.U[k] = prm.U[k];
-      fr.V[k] = prm.V[k];
-      fr.W[k] = prm.W[k];
-      fr.sun[k] = sun_dir[k];
-   }
-
-   // ---- scene scale
-   Scratch d_keys;
-   SG_TRY(d_keys.alloc(7 * sizeof(unsigned long long)));
-   SG_TRY(hipMemsetAsync(d_keys.p, 0, 7 * sizeof(unsigned long long), stream));
-   k_sg_bounds<<<std::min<uint32_t>(blocks_n, 512), kBlock, 0, stream>>>(d_tris, n, (unsigned long long*)d_keys.p);
-   unsigned long long keys[7];
-   SG_TRY(hipMemcpyAsync(keys, d_keys.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
-   SG_TRY(hipStreamSynchronize(stream));
-   const double maxabs = keys[0] ? double_of(keys[0]) : 0.0;
-   double S = 0.0;
-   for (int a = 0; a < 3; a++)
-      if (keys[1 + a] && keys[4 + a]) {
-         const double lo = -double_of(keys[1 + a]), hi = double_of(keys[4 + a]);
-         if (hi >= lo) S += (hi - lo) * (hi - lo);
+      const double wl = std::sqrt((double)sun_dir[0] * sun_dir[0] + (double)sun_dir[1] * sun_dir[1] + (double)sun_dir[2] * sun_dir[2]);
+      if (!std::isfinite(wl) || !(wl > 0.99 && wl < 1.01)) return refuse("sun direction is not a finite unit vector");
+      sun_grid_frame(sun_dir, prm);  // U, V, W: the host builder's frame (sun_grid.cpp)
+      for (int k = 0; k < 3; k++) {
+         fr.U[k] = prm.U[k];
+         fr.V[k] = prm.V[k];
+         fr.W[k] = prm.W[k];
+         fr.sun[k] = sun_dir[k];
       }
-   S = std::sqrt(S);
-   fr.S = S;
-   fr.base = 2e-4 + 2e-5 * maxabs + 2e-6 * S;
-   base = fr.base;
 
-   // ---- projection
-   k_sg_project<<<blocks_n, kBlock, 0, stream>>>(d_tris, n, fr, pr);
+      // ---- scene scale
+      Scratch d_keys;
+      SG_TRY(d_keys.alloc(7 * sizeof(unsigned long long)));
+      SG_TRY(hipMemsetAsync(d_keys.p, 0, 7 * sizeof(unsigned long long), stream));
+      k_sg_bounds<<<std::min<uint32_t>(blocks_n, 512), kBlock, 0, stream>>>(d_tris, n, (unsigned long long*)d_keys.p);
+      unsigned long long keys[7];
+      SG_TRY(hipMemcpyAsync(keys, d_keys.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
+      SG_TRY(hipStreamSynchronize(stream));
+      const double maxabs = keys[0] ? double_of(keys[0]) : 0.0;
+      double S = 0.0;
+      for (int a = 0; a < 3; a++)
+         if (keys[1 + a] && keys[4 + a]) {
+            const double lo = -double_of(keys[1 + a]), hi = double_of(keys[4 + a]);
+            if (hi >= lo) S += (hi - lo) * (hi - lo);
+         }
+      S = std::sqrt(S);
+      fr.S = S;
+      fr.base = 2e-4 + 2e-5 * maxabs + 2e-6 * S;
+      base = fr.base;
+
+      // ---- projection
+      k_sg_project<<<blocks_n, kBlock, 0, stream>>>(d_tris, n, fr, pr);
    }
 
-   // ---- extent and cell size from a sample of the boxes (at most 32 Ki of them)
+   // ---- extent and cell size from a sample of the boxes (at most 8 Ki of them)
    double ex0, ex1, ey0, ey1, cell;
    if (forced) {
       const SunGridParams frame = prm;
       prm = *forced;
-      if (cam) {  // (the camera grid has no frame of its own; a forced sun raster keeps the direction's)
-      } else {
+      if (!cam) {  // a forced sun raster keeps the direction's frame (the camera grid has none)
          std::memcpy(prm.U, frame.U, sizeof(prm.U));
          std::memcpy(prm.V, frame.V, sizeof(prm.V));
          std::memcpy(prm.W, frame.W, sizeof(prm.W));
