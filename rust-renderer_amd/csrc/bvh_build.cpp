@@ -649,10 +649,12 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    const Knobs kn = knobs_from_env();
    const int W = (int)width;
    std::vector<float> T;      // [n * W + i]
-   std::vector<uint8_t> split;  // [n * W + i]: how many of the i + 1 slots the left child gets (0 = n itself is one slot)
+   std::vector<uint8_t> split;  // [n * W + i]: how many of the slots the left child gets (0 = n itself is one slot) ...
+   std::vector<uint8_t> used;   // ... and how many slots the two children take together (<= i + 1: a smaller budget's plan may be the best)
    if (kn.collapse == 1) {
       T.assign(n2.size() * (size_t)W, 0.0f);
       split.assign(n2.size() * (size_t)W, 0);
+      used.assign(n2.size() * (size_t)W, 0);
       // children carry larger indices than their parents in both build orders (a node is pushed before its subtrees; stitched
       // subtrees are appended): one backwards pass sees every child before its parent
       for (size_t k = n2.size(); k-- > 0;) {
@@ -660,6 +662,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
          const float area = nd.box.half_area();
          float* t = &T[k * (size_t)W];
          uint8_t* sp = &split[k * (size_t)W];
+         uint8_t* us = &used[k * (size_t)W];
          if (nd.left < 0) {
             for (int i = 0; i < W; i++) t[i] = kn.c_tri * area;
             continue;
@@ -684,16 +687,20 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
          }
          t[0] = area + D[W - 1];
          sp[0] = 0;
+         us[0] = 1;
          for (int i = 1; i < W; i++) {
             if (D[i] < t[0] && D[i] <= t[i - 1]) {
                t[i] = D[i];
-               sp[i] = Dk[i];
+               sp[i] = Dk[i];           // left: Dk[i] in [1, i] slots, right: i + 1 - Dk[i] >= 1
+               us[i] = (uint8_t)(i + 1);
             } else if (t[i - 1] < t[0]) {
-               t[i] = t[i - 1];
+               t[i] = t[i - 1];        // the smaller budget's plan, as it was made
                sp[i] = sp[i - 1];
+               us[i] = us[i - 1];
             } else {
                t[i] = t[0];
                sp[i] = 0;
+               us[i] = 1;
             }
          }
       }
@@ -727,14 +734,12 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
       while (sp_) {
          const It it = st[--sp_];
          const Node2& nd = n2[it.n];
-         const uint8_t a = nd.left < 0 ? 0 : split[(size_t)it.n * W + (it.slots - 1)];
-         if (a == 0 || it.slots == 1) {
-            ch[nc++] = it.n;
+         const uint8_t a = (nd.left < 0 || it.slots < 2) ? 0 : split[(size_t)it.n * W + (it.slots - 1)];
+         const int use = a ? used[(size_t)it.n * W + (it.slots - 1)] : 1;  // slots the stored plan takes: a for the left child, use - a >= 1 for the right
+         if (a == 0 || use - (int)a < 1 || nc >= W || sp_ + 2 > 2 * kMaxWidth) {
+            if (nc < W) ch[nc++] = it.n;
             continue;
          }
-         // how many slots the stored decision really uses: t[i] may have been inherited from a smaller i
-         int use = it.slots;
-         while (use > 1 && T[(size_t)it.n * W + (use - 2)] == T[(size_t)it.n * W + (use - 1)] && split[(size_t)it.n * W + (use - 2)] == a) use--;
          st[sp_++] = It{nd.right, use - a};
          st[sp_++] = It{nd.left, a};
       }
