@@ -317,6 +317,8 @@ int uh_reset_stats(uh_ctx* ctx);
  * "device_build" (0/1/2; 1 or 2 = uh_build_acceleration builds the tree ON THE DEVICE in a few ms instead of the host SAH
  * tree in tens to hundreds: same hits bit for bit, about 10 % (1: clusters under a SAH top) or 30 % (2: radix tree) more
  * traversal work per ray - for geometry that changes every few frames),
+ * "bvh_optimise" (0..16, default 0: passes of insertion-based optimisation of the host-built tree, about a second each for 262 k
+ * triangles; hits unchanged),
  * "interleave" (0..8, default 0 = off: a uh_render_frame call - one frame - is split by tiles into this many wavefronts on as many of
  * the "frames_in_flight" slots; same image bit for bit; measured slower than the whole wavefront on MI355X, kept for experiments),
  * "camera_grid" (0/1, default 1: the primary rays of a camera that has been the same for two consecutive frame calls - or for a

@@ -87,6 +87,10 @@ struct BuildInput {
    // optional: the boxes to build over (6 floats each: lo xyz, hi xyz), `count` of them, instead of the corners' own boxes -
    // the references of split_references() below. Leaves then refer to REFERENCES (tri_order holds reference indices).
    const float* boxes6 = nullptr;
+   // passes of insertion-based optimisation over the binary tree before the collapse (Bittner, Hapala, Havran 2013; 0 = none).
+   // About a second per pass and 262 k triangles; worth 1 % of the bounce rays' steps on the regularly tessellated config scenes
+   // (profiles/README.md round 4), more on irregular ones. Hits do not depend on it.
+   int optimise_passes = 0;
 };
 
 // Spatial splits ("early split clipping", Ernst & Greiner 2007; the reference-duplication idea of SBVH, Stich et al. 2009):

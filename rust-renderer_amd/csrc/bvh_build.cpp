@@ -48,6 +48,8 @@ struct Knobs {
    int sweep_below = 0;     // ranges of at most this many triangles are split by an exact sweep over the sorted centroids instead of 16 bins
    int bins = 16;
    float c_tri = 1.0f;      // cost of a triangle slot relative to a node visit, per unit of area (collapse = 1)
+   int optimise = 0;        // passes of insertion-based optimisation over the binary tree before the collapse (Bittner, Hapala, Havran 2013)
+   float optimise_frac = 1.0f;  // share of the inner nodes (the most inefficient first) a pass takes out and reinserts
 };
 static Knobs knobs_from_env() {
    Knobs k;
@@ -55,6 +57,8 @@ static Knobs knobs_from_env() {
    if (const char* e = std::getenv("UH_BVH_SWEEP")) k.sweep_below = std::atoi(e);
    if (const char* e = std::getenv("UH_BVH_BINS")) k.bins = std::max(4, std::min(64, std::atoi(e)));
    if (const char* e = std::getenv("UH_BVH_CTRI")) k.c_tri = (float)std::atof(e);
+   if (const char* e = std::getenv("UH_BVH_OPT")) k.optimise = std::atoi(e);
+   if (const char* e = std::getenv("UH_BVH_OPT_FRAC")) k.optimise_frac = (float)std::atof(e);
    return k;
 }
 
@@ -218,6 +222,135 @@ struct Builder {
       nodes[me].first = first;
       nodes[me].count = count;
       return me;
+   }
+};
+
+// Insertion-based optimisation of the binary tree (Bittner, Hapala, Havran: "Fast Insertion-Based Optimization of Bounding
+// Volume Hierarchies", CGF 2013): an inner node N (and its parent P) is taken out - N's sibling moves up into P's place - and
+// N's two children are reinserted, one after the other, wherever they add the least surface area to the tree (branch and bound
+// from the root on the area the insertion adds to the ancestors; N and P are reused as the new parents). Boxes only: the leaf
+// ranges (one triangle each) never move, so the packet order the collapse defines afterwards is unaffected.
+struct TreeOptimiser {
+   std::vector<Node2>& nd;
+   std::vector<int32_t> parent;
+   int32_t root = 0;
+   explicit TreeOptimiser(std::vector<Node2>& nodes) : nd(nodes), parent(nodes.size(), -1) {
+      for (size_t i = 0; i < nd.size(); i++)
+         if (nd[i].left >= 0) {
+            parent[nd[i].left] = (int32_t)i;
+            parent[nd[i].right] = (int32_t)i;
+         }
+   }
+   static Box unite(const Box& a, const Box& b) {
+      Box r = a;
+      r.grow(b);
+      return r;
+   }
+   void refit_up(int32_t n) {
+      while (n >= 0) {
+         const Box b = unite(nd[nd[n].left].box, nd[nd[n].right].box);
+         if (std::memcmp(&b, &nd[n].box, sizeof(Box)) == 0) break;
+         nd[n].box = b;
+         n = parent[n];
+      }
+   }
+   // the subtree `sub` goes where it adds the least area; `free_node` becomes its new parent
+   void insert(int32_t sub, int32_t free_node) {
+      struct Cand {
+         float induced;
+         int32_t node;
+         bool operator<(const Cand& o) const { return induced > o.induced; }  // min-heap
+      };
+      const Box sb = nd[sub].box;
+      const float sub_area = sb.half_area();
+      std::vector<Cand> heap;
+      heap.push_back(Cand{0.0f, root});
+      float best = INFINITY;
+      int32_t best_node = root;
+      while (!heap.empty()) {
+         std::pop_heap(heap.begin(), heap.end());
+         const Cand c = heap.back();
+         heap.pop_back();
+         if (c.induced + sub_area >= best) break;  // every position below costs at least this
+         const float direct = unite(nd[c.node].box, sb).half_area();
+         const float total = c.induced + direct;
+         if (total < best) {
+            best = total;
+            best_node = c.node;
+         }
+         const float child_induced = total - nd[c.node].box.half_area();
+         if (nd[c.node].left >= 0 && child_induced + sub_area < best) {
+            heap.push_back(Cand{child_induced, nd[c.node].left});
+            std::push_heap(heap.begin(), heap.end());
+            heap.push_back(Cand{child_induced, nd[c.node].right});
+            std::push_heap(heap.begin(), heap.end());
+         }
+      }
+      const int32_t q = parent[best_node];
+      nd[free_node].left = best_node;
+      nd[free_node].right = sub;
+      nd[free_node].box = unite(nd[best_node].box, sb);
+      parent[best_node] = free_node;
+      parent[sub] = free_node;
+      parent[free_node] = q;
+      if (q < 0)
+         root = free_node;
+      else {
+         (nd[q].left == best_node ? nd[q].left : nd[q].right) = free_node;
+         refit_up(q);
+      }
+   }
+   void reinsert_children_of(int32_t n) {
+      const int32_t p = parent[n];
+      if (p < 0 || nd[n].left < 0) return;
+      const int32_t g = parent[p];
+      if (g < 0) return;  // (children of the root stay: the root keeps its index)
+      const int32_t s = nd[p].left == n ? nd[p].right : nd[p].left;
+      (nd[g].left == p ? nd[g].left : nd[g].right) = s;
+      parent[s] = g;
+      refit_up(g);
+      const int32_t l = nd[n].left, r = nd[n].right;
+      // the larger subtree first (it has the fewer good places)
+      const bool l_first = nd[l].box.half_area() >= nd[r].box.half_area();
+      insert(l_first ? l : r, n);
+      insert(l_first ? r : l, p);
+   }
+   void pass(float frac) {
+      std::vector<std::pair<float, int32_t>> order;
+      for (size_t i = 0; i < nd.size(); i++) {
+         if (nd[i].left < 0 || parent[i] < 0 || parent[parent[i]] < 0) continue;
+         const float a = nd[i].box.half_area(), al = nd[nd[i].left].box.half_area(), ar = nd[nd[i].right].box.half_area();
+         const float m = std::fmin(al, ar);
+         // the paper's combined inefficiency: area x (area / mean child area) x (area / smaller child's area)
+         const float ineff = a * (a / (0.5f * (al + ar) + 1e-30f)) * (a / (m + 1e-30f));
+         order.emplace_back(ineff, (int32_t)i);
+      }
+      std::sort(order.begin(), order.end(), [](const std::pair<float, int32_t>& x, const std::pair<float, int32_t>& y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
+      const size_t take = (size_t)((double)order.size() * (double)frac);
+      for (size_t k = 0; k < take && k < order.size(); k++) reinsert_children_of(order[k].second);
+   }
+   // the root may have moved: bring it back to index 0 (the collapse starts there) by swapping the two nodes' contents
+   void root_to_zero() {
+      if (root == 0) return;
+      const int32_t r = root, pz = parent[0];
+      std::swap(nd[0], nd[r]);
+      // node contents swapped: fix the links that named either index
+      auto relink_children = [&](int32_t i) {
+         if (nd[i].left >= 0) {
+            parent[nd[i].left] = i;
+            parent[nd[i].right] = i;
+         }
+      };
+      // who pointed at old 0 now must point at r (unless it is the node that moved to 0 itself)
+      if (pz >= 0) {
+         const int32_t holder = pz == r ? 0 : pz;
+         (nd[holder].left == 0 ? nd[holder].left : nd[holder].right) = r;
+      }
+      parent[r] = pz == r ? 0 : pz;
+      parent[0] = -1;
+      relink_children(0);
+      relink_children(r);
+      root = 0;
    }
 };
 
@@ -642,6 +775,30 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    // ---- collapse to BVH4, breadth-first emission. Slot order inside a node: its triangle children first (their
    // packets are consecutive: the packet order is DEFINED here, node by node), then its node children (consecutive
    // node indices), then empty slots.
+   {
+      Knobs ko = knobs_from_env();
+      if (in.optimise_passes > ko.optimise) ko.optimise = in.optimise_passes;
+      if (ko.optimise > 0 && n2.size() > 8 && !balanced) {
+         TreeOptimiser opt(n2);
+         for (int it = 0; it < ko.optimise; it++) opt.pass(ko.optimise_frac);
+         opt.root_to_zero();
+         // depth of the optimised tree (the collapse and the traversal stack care)
+         std::vector<uint32_t> depth(n2.size(), 0);
+         std::vector<int32_t> stack{0};
+         uint32_t md = 0;
+         while (!stack.empty()) {
+            const int32_t k = stack.back();
+            stack.pop_back();
+            md = std::max(md, depth[k]);
+            if (n2[k].left >= 0) {
+               depth[n2[k].left] = depth[n2[k].right] = depth[k] + 1;
+               stack.push_back(n2[k].left);
+               stack.push_back(n2[k].right);
+            }
+         }
+         out.max_depth = md;
+      }
+   }
    // SAH-optimal collapse (Ylitie, Karras, Laine 2017, section 3.1, for single-triangle leaves): T[n][i] = the least cost of
    // representing BVH2 subtree n by at most i + 1 slots of a wide node - a slot being one triangle (cost c_tri x its area) or one
    // wide node (its area, plus the best distribution of its two children over W slots). Replaces the greedy "open the child
@@ -655,9 +812,24 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
       T.assign(n2.size() * (size_t)W, 0.0f);
       split.assign(n2.size() * (size_t)W, 0);
       used.assign(n2.size() * (size_t)W, 0);
-      // children carry larger indices than their parents in both build orders (a node is pushed before its subtrees; stitched
-      // subtrees are appended): one backwards pass sees every child before its parent
-      for (size_t k = n2.size(); k-- > 0;) {
+      // every child before its parent: the reverse of a pre-order walk from the root (the index order of the builders has that
+      // property too, but not once the optimiser has moved nodes around)
+      std::vector<int32_t> pre;
+      pre.reserve(n2.size());
+      {
+         std::vector<int32_t> stack{0};
+         while (!stack.empty()) {
+            const int32_t k = stack.back();
+            stack.pop_back();
+            pre.push_back(k);
+            if (n2[k].left >= 0) {
+               stack.push_back(n2[k].left);
+               stack.push_back(n2[k].right);
+            }
+         }
+      }
+      for (size_t pi = pre.size(); pi-- > 0;) {
+         const size_t k = (size_t)pre[pi];
          const Node2& nd = n2[k];
          const float area = nd.box.half_area();
          float* t = &T[k * (size_t)W];

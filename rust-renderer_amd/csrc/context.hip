@@ -237,6 +237,7 @@ struct uh_ctx {
    bool iso_reference = true;  // option "iso_reference_triangulation": uh_add_isosurface_mesh emits the reference's triangles (isosurface.hip)
    bool furnace = false;  // option "furnace": reference.rmiss compiled with FURNACE_TEST (a miss returns white whatever view.sky_enabled says)
    int spatial_split_factor = 0;  // option "spatial_splits": 0 = off, k = split triangles whose box diagonal exceeds k x the median
+   int bvh_optimise = 0;          // option "bvh_optimise": passes of insertion-based optimisation in the host builder (bvh.h BuildInput)
    int closest_variant = 1, shadow_variant = 1;  // refill kernels (0 = batch kernels)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
@@ -735,6 +736,7 @@ int uh_build_acceleration(uh_ctx* c) {
       total = ref_tri.size();
    }
    BuildInput in{corners.data(), keys.data(), (uint32_t)total};
+   in.optimise_passes = c->bvh_optimise;
    if (split) in.boxes6 = ref_boxes.data();
    BuildOutput bo;
    int threads = (int)std::thread::hardware_concurrency();
@@ -1983,6 +1985,11 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 0 || value > 1000) return fail(c, UH_ERR_INVALID_ARGUMENT, "spatial_splits must be 0 (off) or a factor of the median triangle box diagonal, 2..1000");
       if (c->spatial_split_factor != value) c->built = c->topology_valid = false;
       c->spatial_split_factor = value;
+   }
+   else if (n == "bvh_optimise") {
+      if (value < 0 || value > 16) return fail(c, UH_ERR_INVALID_ARGUMENT, "bvh_optimise must be 0..16 passes");
+      if (c->bvh_optimise != value) c->built = c->topology_valid = false;
+      c->bvh_optimise = value;
    }
    else if (n == "primary_tiles")
       c->primary_tiles = value != 0;

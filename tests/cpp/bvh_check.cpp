@@ -23,11 +23,15 @@ static float rnd() {
    return (float)w / 4294967296.0f;
 }
 
-static int check(const std::vector<float>& corners, int threads, const char* name, bool geometry = true) {
+static int check(const std::vector<float>& corners, int threads, const char* name, bool geometry = true, int optimise_passes = -1);
+static int check(const std::vector<float>& corners, int threads, const char* name, bool geometry, int optimise_passes) {
+   if (optimise_passes < 0)  // every scene of this check: as built, and after two passes of the insertion-based optimiser
+      return check(corners, threads, name, geometry, 0) + check(corners, threads, name, geometry, 2);
    const uint32_t n = (uint32_t)(corners.size() / 9);
    std::vector<uint32_t> keys(n);
    for (uint32_t i = 0; i < n; i++) keys[i] = i;
    BuildInput in{corners.data(), keys.data(), n};
+   in.optimise_passes = optimise_passes;
    BuildOutput out;
    build_bvh4(in, out, threads);
    int errors = 0;

@@ -901,3 +901,22 @@ def test_wave_per_tile_traversal_is_bit_identical(atrium, size, world):
     (a0, g0, r0, c0), (a1, g1, r1, c1) = out
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and np.array_equal(g0.view(np.uint32), g1.view(np.uint32))
     assert all(x.tobytes() == y.tobytes() for x, y in zip(r0, r1)) and c0 == c1
+
+
+def test_insertion_optimised_tree_gives_the_same_hits(atrium):
+    """option bvh_optimise (Bittner et al. 2013: subtrees taken out and reinserted where they add the least surface area, before the
+    collapse to 4-wide nodes): another tree over the same triangles - hits, images and ray counts do not change (the closest
+    hit does not depend on the tree, DESIGN.md "Arithmetic contract")"""
+    W, H = 96, 54
+    plain, opt = atrium.upload(rr.Renderer(W, H)), rr.Renderer(W, H)
+    opt.set_option("bvh_optimise", 3)
+    atrium.upload(opt)
+    rays = random_rays(((-14, 0, -7), (14, 11, 7)), 4000, seed=11)
+    for a, b in zip(plain.trace_closest(rays), opt.trace_closest(rays)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(plain.trace_any(rays), opt.trace_any(rays))
+    for r in (plain, opt):
+        run_frames(r, atrium, W, H, 3, rr.PASS_ALL)
+    assert np.array_equal(plain.read_accumulation().view(np.uint32), opt.read_accumulation().view(np.uint32))
+    assert list(plain.get_stats().rays) == list(opt.get_stats().rays)
+    assert plain.get_stats().bvh_triangles == opt.get_stats().bvh_triangles
