@@ -81,15 +81,16 @@ struct Slot {
    hipEvent_t ev_acc = nullptr;  // recorded after the frame's accumulate / store tail
    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
    DevBuf<float4> rec, radf, pixcol;  // rec: two sets of four path-state planes + the hit plane (device_types.h PathState)
-   DevBuf<uint32_t> queues[5];
+   DevBuf<uint32_t> queues[6];
    DevBuf<Control> control;
    PathState ps{};
    bool ready = false;
    size_t capacity = 0;  // path ids this slot can hold (pixels x frames per batch)
 
-   hipError_t create(size_t n, uint32_t shard_cap) {
+   hipError_t create(size_t n) {
       capacity = n;
-      if (shard_cap == 0) {  // exact: the largest number of 64-path runs one shard receives (shard_of_run)
+      uint32_t shard_cap = 0;
+      {  // exact: the largest number of 64-path runs one shard receives (shard_of_run)
          const uint32_t runs = (uint32_t)((n + 63) / 64);
          uint32_t per_shard[kShards] = {0};
          for (uint32_t r = 0; r < runs; r++) per_shard[shard_of_run(r)]++;
@@ -113,7 +114,7 @@ struct Slot {
       SLOT_TRY(pixcol.alloc(n, 2 * stagger));
       // sharded queues: capacity per shard = the pixels (64-pixel runs) a shard can own
       // (the miss queue holds (position, id) pairs: twice the words)
-      for (int qi = 0; qi < 5; qi++) SLOT_TRY(queues[qi].alloc((size_t)shard_cap * kShards * (qi == 4 ? 2 : 1)));
+      for (int qi = 0; qi < 6; qi++) SLOT_TRY(queues[qi].alloc((size_t)shard_cap * kShards * (qi == 4 ? 2 : 1)));
       SLOT_TRY(control.alloc(1));
       SLOT_TRY(hipMemsetAsync(control.p, 0, sizeof(Control), stream));
       SLOT_TRY(hipStreamSynchronize(stream));
@@ -123,7 +124,7 @@ struct Slot {
       ps.hit = rec.p + plane * 2 * kRecQuads;
       ps.radf = radf.p;
       ps.pixcol = pixcol.p;
-      for (int i = 0; i < 5; i++) ps.queue[i] = queues[i].p;
+      for (int i = 0; i < 6; i++) ps.queue[i] = queues[i].p;
       ps.shard_cap = shard_cap;
       ready = true;
       return hipSuccess;
@@ -261,6 +262,11 @@ struct uh_ctx {
    float sun_dir_built[3] = {0, 0, 0}, sun_dir_pending[3] = {0, 0, 0};
    DevBuf<uint32_t> d_sun_cells;
    DevBuf<SunGridEntry> d_sun_entries;
+   DevBuf<float4> d_sun_recs;       // the entries with their packets inline (SunGridDev::recs; option "sun_grid_inline")
+   DevBuf<float> d_sun_coarse;      // the coarse cover (SunGridDev::coarse; option "sun_grid_coarse")
+   uint32_t sun_coarse_shift = 2;   // blocks of 4 x 4 cells; 0: no coarse cover
+   bool sun_inline = true;
+   uint64_t sun_inline_max_bytes = 8ull << 30;
    SunGridDev sun_dev{};
    SunGridLimits sun_limits;
    std::string sun_why;
@@ -268,6 +274,7 @@ struct uh_ctx {
    uint32_t sun_cells = 0, sun_entries = 0, sun_max_list = 0;
    bool sun_this_frame = false;     // set by render_batch for the frame being enqueued
    bool sun_async = false;          // option "sun_grid_async": build on a host thread, walk the tree until it is done (host builder only)
+   bool sun_grid_fused = false;     // option "sun_grid_fused": k_shade_hit looks the sun rays' cells up itself (kernels.hip k_shade_hit<true>); 0: k_trace_sun_grid does
    bool sun_device_build = true;    // option "sun_grid_build": 1 = on the device (sun_grid_build.hip: a few ms), 0 = the host builder (sun_grid.cpp)
    struct SunJob* sun_job = nullptr;
 
@@ -434,7 +441,7 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
       if (c->shadow_blocks_per_cu > occ) c->shadow_blocks_per_cu = occ;
    }
    const size_t n = (size_t)width * height;
-   CREATE_TRY(c->slots[0].create(n, 0));
+   CREATE_TRY(c->slots[0].create(n));
    CREATE_TRY(c->accumulation.alloc(n));
    CREATE_TRY(c->gbuffer.alloc(n));
    CREATE_TRY(c->output.alloc(n));
@@ -518,6 +525,8 @@ void uh_destroy(uh_ctx* c) {
    c->d_lut.release();
    c->d_sun_cells.release();
    c->d_sun_entries.release();
+   c->d_sun_recs.release();
+   c->d_sun_coarse.release();
    c->d_cam_cells.release();
    c->d_cam_entries.release();
    for (auto& b : c->il_pixels) b.release();
@@ -1086,7 +1095,7 @@ static int ensure_slot(uh_ctx* c, uint32_t i, uint32_t batch = 1) {
       if (c->last_slot == &s) c->last_slot = nullptr;
       s.destroy();
    }
-   HIP_TRY(c, s.create(need, 0));
+   HIP_TRY(c, s.create(need));
    return UH_OK;
 }
 
@@ -1102,6 +1111,7 @@ struct SunJob {
    double ms = 0.0;
 };
 
+static int attach_sun_inline_records(uh_ctx* c);
 // the grid `g` (or its refusal) becomes the context's grid for (geom, dir). Frames in flight may still read the old buffers.
 static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float dir[3], uint64_t geom, float build_ms) {
    if (int st = sync_all(c)) return st;
@@ -1146,7 +1156,7 @@ static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float 
       c->d_sun_entries.release();
    }
    c->sun_build_ms = build_ms;
-   return UH_OK;
+   return attach_sun_inline_records(c);
 }
 
 // the device builder's result becomes the context's grid (its buffers change owner)
@@ -1189,6 +1199,34 @@ static int adopt_sun_grid_device(uh_ctx* c, SunGridDevice& g, bool ok, const flo
       c->sun_valid = true;
    }
    g.release();
+   return attach_sun_inline_records(c);
+}
+
+// the adopted grid's lists once more with the packets inline (sun_grid.h SunGridDev::recs): 64 bytes per entry
+static int attach_sun_inline_records(uh_ctx* c) {
+   c->d_sun_recs.release();
+   c->sun_dev.recs = nullptr;
+   c->d_sun_coarse.release();
+   c->sun_dev.coarse = nullptr;
+   c->sun_dev.coarse_shift = c->sun_dev.coarse_nx = 0;
+   if (c->sun_valid && c->sun_coarse_shift) {  // the coarse cover (sun_grid.h)
+      const uint32_t sh = c->sun_coarse_shift, b = 1u << sh, cnx = (c->sun_dev.nx + b - 1) / b, cny = (c->sun_dev.ny + b - 1) / b;
+      HIP_TRY(c, c->d_sun_coarse.alloc((size_t)cnx * cny));
+      HIP_TRY(c, (hipError_t)build_sun_coarse_cover((void*)c->stream, c->d_sun_cells.p, c->sun_dev.nx, c->sun_dev.ny, sh, c->d_sun_coarse.p));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      c->sun_dev.coarse = c->d_sun_coarse.p;
+      c->sun_dev.coarse_shift = sh;
+      c->sun_dev.coarse_nx = cnx;
+   }
+   const uint64_t n = c->sun_entries;
+   if (!c->sun_valid || !c->sun_inline || n == 0 || n * 64ull > c->sun_inline_max_bytes) return UH_OK;
+   if (c->d_sun_recs.alloc((size_t)n * 4) != hipSuccess) {  // no room: the plain lists serve
+      (void)hipGetLastError();
+      return UH_OK;
+   }
+   HIP_TRY(c, (hipError_t)build_sun_inline_records((void*)c->stream, c->d_tris.p, c->d_sun_entries.p, n, c->d_sun_recs.p));
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   c->sun_dev.recs = reinterpret_cast<const float*>(c->d_sun_recs.p);
    return UH_OK;
 }
 
@@ -1380,7 +1418,9 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          // miss queue shade_miss(b-1) reads there
          if (side_used && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_shadowed, 0));
          begin_timed(c, 2, s.stream);
-         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b);  // also hands the bounce's misses to shade_miss (Q_MISS)
+         // also hands the bounce's misses to shade_miss (Q_MISS) and, fused, asks the sun grid's coarse cover for the scattered paths' sun rays
+         const bool sun_fused = fp.sun_shadow_enabled == 1 && c->sun_this_frame && c->sun_grid_fused && c->sun_dev.coarse != nullptr;
+         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b, sun_fused ? &c->sun_dev : nullptr);
          if (!c->overlap_miss) launch_shade_miss(lc, fp, s.ps, ctl, st, b);
          end_timed(c, s.stream);
          // shade_miss(b) and the shadow queries of bounce b are independent of trace_closest(b+1) (they only read what
@@ -1405,7 +1445,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          if (fp.sun_shadow_enabled == 1) {
             begin_timed(c, 1, sh_stream);
             if (c->sun_this_frame) {
-               launch_trace_sun_grid(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, c->sun_dev);
+               launch_trace_sun_grid(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, c->sun_dev, sun_fused);
                launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, false, true);  // the rays the grid handed over (border cells, long lists)
             } else
                launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, false);
@@ -2026,6 +2066,24 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       // 1 (default): the grid is built on the device (sun_grid_build.hip); 0: by the host builder (sun_grid.cpp, the reference implementation)
       c->sun_device_build = value != 0;
       c->sun_attempted = false;
+   } else if (n == "sun_grid_coarse") {
+      // the coarse cover (sun_grid.h): one depth per block of 2^value x 2^value cells, asked before the cell's own record; 0: none
+      if (value < 0 || value > 6) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_coarse (log2 of the block edge in cells) must be 0..6");
+      c->sun_coarse_shift = (uint32_t)value;
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_inline") {
+      // 1 (default): the grid's lists are kept a second time as 64-byte records that carry their packet (one sector and one round trip
+      // per triangle test instead of two); 0: entries and packets apart (round 3). Takes effect with the next grid that is built.
+      c->sun_inline = value != 0;
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_inline_max_mb") {
+      if (value < 1 || value > (1 << 20)) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_inline_max_mb must be 1..1048576");
+      c->sun_inline_max_bytes = (uint64_t)value << 20;
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_fused") {
+      // 1: the shading kernel asks the grid's coarse cover for each scattered path's sun ray while it waits for its texels, and the
+      // grid kernel serves the rays that are left; 0: the grid kernel does both. Same images.
+      c->sun_grid_fused = value != 0;
    } else if (n == "sun_grid_async") {
       // 1: a grid is built on a host thread while frames go on with the tree walk (no 130 ms stall when the sun or the geometry
       // comes to rest; images are the same either way); 0 (default): built inside the frame call that asks for it

@@ -231,9 +231,16 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
    return m < n ? m : period - 1 - m;
 }
 // lds_tex (may be null): the first n_lds_tex texture descriptors staged in LDS by the caller
+// RIDER: one more dword (from `rider_at`, into `rider`) is fetched IN THE SAME BLOCK as the four texels - one round trip for
+// both. k_shade_hit's sun-grid look-up rides here: requested any earlier, the wait for a texture descriptor from global
+// memory (vmcnt counts in order) made the texel fetch wait for it - three round trips in a row instead of two.
+template <bool RIDER = false>
 __device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __restrict__ lut, uint32_t index, float u, float v, const TexInfo* lds_tex = nullptr,
-                                             uint32_t n_lds_tex = 0) {
-   if (index >= sc.num_textures) return v3(1, 1, 1);
+                                             uint32_t n_lds_tex = 0, const uint32_t* rider_at = nullptr, uint32_t* rider = nullptr) {
+   if (index >= sc.num_textures) {
+      if (RIDER) *rider = *rider_at;
+      return v3(1, 1, 1);
+   }
    TexInfo t;
    if (lds_tex) {
       // unconditional LDS read + one-armed replacement: see the mesh record in k_shade_hit (no flat loads)
@@ -243,7 +250,10 @@ __device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __
       t = sc.textures[index];
    }
    float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
-   if (!(fabsf(x) < 1e9f) || !(fabsf(y) < 1e9f)) return v3(0, 0, 0);
+   if (!(fabsf(x) < 1e9f) || !(fabsf(y) < 1e9f)) {
+      if (RIDER) *rider = *rider_at;
+      return v3(0, 0, 0);
+   }
    float fx = floorf(x), fy = floorf(y);
    float ax = x - fx, ay = y - fy;
    int x0 = mirror_index((int)fx, (int)t.w), x1 = mirror_index((int)fx + 1, (int)t.w);
@@ -263,6 +273,17 @@ __device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __
    // one block: as four C++ loads the compiler still made the third wait for the first (register reuse), and as loads
    // through the descriptor's generic pointer they were flat loads
    uint32_t w00, w10, w01, w11;
+   if (RIDER) {
+      uint32_t r;
+      asm volatile(
+         "global_load_dword %4, %9, off\n\t"
+         "global_load_dword %0, %5, off\n\tglobal_load_dword %1, %6, off\n\tglobal_load_dword %2, %7, off\n\tglobal_load_dword %3, %8, off\n\t"
+         "s_waitcnt vmcnt(0)"
+         : "=&v"(w00), "=&v"(w10), "=&v"(w01), "=&v"(w11), "=&v"(r)
+         : "v"(q00), "v"(q10), "v"(q01), "v"(q11), "v"(rider_at)
+         : "memory");
+      *rider = r;
+   } else
    asm volatile(
       "global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off\n\t"
       "s_waitcnt vmcnt(0)"
@@ -392,6 +413,30 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
    }
    uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
    return base + prefix;
+}
+
+// N wave-aggregated appends in ONE round trip: lane k (k < N) adds the k-th count to the k-th counter, so the wave waits for one
+// returning atomic instead of N in a row (k_shade_hit appends to up to five queues per 64 hits). Same contract as wave_append.
+template <int N>
+__device__ __forceinline__ void wave_append_multi(uint32_t* const (&counter)[N], const bool (&pred)[N], uint32_t (&slot)[N]) {
+   static_assert(N >= 1 && N <= 8, "a handful of queues");
+   const uint32_t lane = lane_id();
+   unsigned long long mask[N];
+   uint32_t* mine = counter[0];
+   uint32_t n_mine = 0;
+#pragma unroll
+   for (int k = 0; k < N; k++) {
+      mask[k] = __ballot(pred[k]);
+      if (lane == (uint32_t)k) {
+         mine = counter[k];
+         n_mine = (uint32_t)__popcll(mask[k]);
+      }
+   }
+   uint32_t base = 0;
+   if (lane < (uint32_t)N && n_mine) base = atomicAdd(mine, n_mine);
+#pragma unroll
+   for (int k = 0; k < N; k++)
+      slot[k] = (uint32_t)__builtin_amdgcn_readlane((int)base, k) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[k], 0u));
 }
 
 }  // namespace uh

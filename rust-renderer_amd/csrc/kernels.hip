@@ -11,6 +11,8 @@
 // device-side cursor until the queue (whose length only the device knows) is drained.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_math.h"
 #include "device_types.h"
 
@@ -18,6 +20,9 @@ namespace uh {
 
 constexpr int kBlock = 256;                 // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
+#ifndef UH_SUN_RAYS_PER_LANE
+#define UH_SUN_RAYS_PER_LANE 2  // k_trace_sun_grid (inline records): chains of dependent loads a lane keeps in flight
+#endif
 #ifndef UH_SHADE_HIT_BLOCKS
 #define UH_SHADE_HIT_BLOCKS 4  // blocks per CU the register budget of k_shade_hit is sized for
 #endif
@@ -831,93 +836,274 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 // triangle accepts the ray with 0.001 < t < 10000 - bit for bit, the grid only prunes (conservatively) which triangles are asked.
 // Batch form: rays do a handful of steps, and their lengths (0..a few tests) differ little inside a wave.
 // ------------------------------------------------------------------------------------------
-template <bool COUNT>
+// The walk down a cell's list, entries [e, end), not empty: true = some packet occludes the ray.
+// INLINE (option sun_grid_inline, the default): the list is an array of 64-byte records that CARRY their packet (SunGridDev::recs:
+// v0 e1 e2 key | this entry's far depth | the next entry's) - one sector and one round trip per test where the entry (packet
+// index, far depth) and then the packet were two of each; the next record is only asked for when the ray has to go on.
+template <bool COUNT, bool INLINE>
+__device__ __forceinline__ bool sun_walk(const SunGridDev& g, const float4* __restrict__ tris, uint32_t e, uint32_t end, V3 o, V3 d, float pw, uint32_t& n_tris) {
+   Hit best;
+   best.t = 10000.0f;  // tmax (rgen:66)
+   best.u = best.v = 0.0f;
+   best.idx = kEmptyRef;
+   best.key = 0xffffffffu;
+   if (INLINE) {
+      const float4* r = reinterpret_cast<const float4*>(g.recs) + 4 * (size_t)e;
+      for (;;) {
+         const float4 a = r[0], b = r[1], c = r[2];
+         // sorted by far depth, descending: from here on every packet ends behind the origin (t < 0 for all of them)
+         if (c.z < pw) return false;
+         if (COUNT) n_tris++;
+         if (tri_compute<true>(a, b, c, 0u, o, d, 0.001f, INFINITY, best)) return true;
+         e++;
+         if (e >= end || c.w < pw) return false;
+         r += 4;
+      }
+   }
+   uint2 en = reinterpret_cast<const uint2*>(g.entries)[e];
+   while (e < end) {
+      if (__uint_as_float(en.y) < pw) break;
+      const uint32_t pk = en.x;
+      uint2 nxt = make_uint2(0u, 0u);
+      if (e + 1 < end) nxt = reinterpret_cast<const uint2*>(g.entries)[e + 1];  // in flight with the packet
+      const float4 a = tris[kTriStride16 * (size_t)pk + 0], b = tris[kTriStride16 * (size_t)pk + 1], c = tris[kTriStride16 * (size_t)pk + 2];
+      if (COUNT) n_tris++;
+      if (tri_compute<true>(a, b, c, pk, o, d, 0.001f, INFINITY, best)) return true;
+      en = nxt;
+      e++;
+   }
+   return false;
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop the compiler cannot leave rolled (arrays indexed by its
+// counter stay in registers whatever the body holds)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+   if constexpr (I < N) {
+      f(std::integral_constant<int, I>{});
+      static_for<N, I + 1>(f);
+   }
+}
+
+// The ray's cell: (pu, pv) = its origin in the grid's frame; outside the grid (or NaN) it is a border cell.
+__device__ __forceinline__ void sun_cell_of(const SunGridDev& g, float pu, float pv, uint32_t& cx, uint32_t& cy) {
+   float fx = (pu - g.u0) * g.inv_cell, fy = (pv - g.v0) * g.inv_cell;
+   fx = !(fx >= 0.0f) ? 0.0f : fx;
+   fy = !(fy >= 0.0f) ? 0.0f : fy;
+   const float max_x = (float)(g.nx - 1), max_y = (float)(g.ny - 1);
+   fx = fx > max_x ? max_x : fx;
+   fy = fy > max_y ? max_y : fy;
+   cx = (uint32_t)fx;
+   cy = (uint32_t)fy;
+}
+// The coarse cover (SunGridDev::coarse, sun_grid.h): one depth per block of cells, below every cell's own cover depth - a ray that
+// starts below it is below its own cell's cover too. 0.7 MB on the config-1 scene: it stays in an XCD's L2, where the cell
+// records (23 MB) are a request to the memory side per ray.
+__device__ __forceinline__ bool sun_coarse_covered(float coarse, float pw) { return pw < coarse && coarse - pw < kSunCoarseReach; }
+
+// LISTED (option sun_grid_fused): k_shade_hit<true> has asked the coarse cover already and listed the rays it did not answer in
+// Q_SUN_GRID (positions in the next bounce's ray queue); otherwise every position of that queue is a ray, and the coarse cover -
+// when the grid has one - is asked here first.
+template <bool COUNT, bool LISTED, bool INLINE>
 __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                                                             uint32_t cursor_slot, SunGridDev g) {
    const uint32_t lane = lane_id();
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
    const PathRecs rec = ps.set[(bounce + 1) & 1];  // a sun ray leaves every scattered path: every position of the next bounce's ray queue
-   const uint32_t count = ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   const uint32_t all = ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   const uint32_t count = LISTED ? ctl->q_count[qc_index(bounce, Q_SUN_GRID, sx.shard)] : all;
+   const uint32_t* __restrict__ q_listed = ps.queue[5] + seg;
    uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const float4* __restrict__ tris = sc.tris;
    const V3 d = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);  // rgen:64
-   const float max_x = (float)(g.nx - 1), max_y = (float)(g.ny - 1);
-   uint32_t n_cells = 0, n_tris = 0, n_covered = 0;
+   uint32_t n_tris = 0, n_covered = 0;
    uint32_t* q_tree = ps.queue[3] + seg;
    uint32_t* n_tree = &ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)];
+   if (INLINE) {
+      // K rays per lane, each step of the chain (origin -> cell record -> first list record -> throughput / radiance) requested for
+      // all K before the first is used: the kernel is a chain of dependent round trips with a few instructions between them, and
+      // a wave that keeps K chains in flight hides K times the latency (registers are no constraint here: 40 at K = 1)
+      constexpr int K = UH_SUN_RAYS_PER_LANE;
+      const float4* __restrict__ recs = reinterpret_cast<const float4*>(g.recs);
+      const uint2* __restrict__ cells = reinterpret_cast<const uint2*>(g.cell_start);
+      for (;;) {
+         uint32_t base = 0;
+         if (lane == 0) base = atomicAdd(cursor, 64u * K);
+         base = __builtin_amdgcn_readfirstlane(base);
+         if (base >= count) break;
+         uint32_t id[K];
+         bool valid[K];
+         static_for<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const uint32_t i = base + 64u * k + lane;
+            valid[k] = i < count;
+            id[k] = i;
+            if (LISTED && valid[k]) id[k] = ld_stream(q_listed + i);
+         });
+         float4 ro[K];
+         static_for<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            ro[k] = valid[k] ? ld_rec(rec_quad(rec, seg + id[k], REC_ORIGIN)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+         });
+         float pw[K];
+         uint32_t cx[K], cy[K];
+         bool covered[K], ask[K];
+         static_for<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const V3 o = v3(ro[k].x, ro[k].y, ro[k].z);
+            const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o);
+            pw[k] = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
+            sun_cell_of(g, pu, pv, cx[k], cy[k]);
+            covered[k] = false;
+         });
+         if (!LISTED && g.coarse) {
+            float cw[K];
+            static_for<K>([&](auto kc) {
+               constexpr int k = decltype(kc)::value;
+               cw[k] = valid[k] ? g.coarse[(cy[k] >> g.coarse_shift) * g.coarse_nx + (cx[k] >> g.coarse_shift)] : -INFINITY;
+            });
+            static_for<K>([&](auto kc) {
+               constexpr int k = decltype(kc)::value;
+               covered[k] = valid[k] && sun_coarse_covered(cw[k], pw[k]);
+            });
+         }
+         uint2 cs[K];
+         uint32_t end[K];
+         static_for<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            ask[k] = valid[k] && !covered[k];
+            cs[k] = make_uint2(0u, 0u);
+            end[k] = 0u;
+            if (ask[k]) {
+               const uint32_t cell = cy[k] * g.nx + cx[k];
+               cs[k] = cells[cell];
+               end[k] = cells[cell + 1].x;
+            }
+         });
+         bool defer[K], walk[K], lit[K];
+         typedef float f4_t __attribute__((ext_vector_type(4)));  // (arrays of HIP's float4 struct assigned under a condition end up in scratch)
+         f4_t ra[K], rb[K], rc[K];
+         static_for<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const float cover = __uint_as_float(cs[k].y);
+            const bool cov = ask[k] && pw[k] < cover && cover - pw[k] < kSunCoverReach;  // as below
+            covered[k] = covered[k] || cov;
+            defer[k] = ask[k] && !cov && (cx[k] == 0 || cy[k] == 0 || cx[k] + 1 == g.nx || cy[k] + 1 == g.ny || end[k] - cs[k].x > g.max_walk);
+            walk[k] = ask[k] && !cov && !defer[k] && cs[k].x < end[k];
+            lit[k] = ask[k] && !cov && !defer[k] && !walk[k];  // nothing projects into the cell
+            if (walk[k]) {
+               const f4_t* r = reinterpret_cast<const f4_t*>(recs + 4 * (size_t)cs[k].x);
+               ra[k] = r[0];
+               rb[k] = r[1];
+               rc[k] = r[2];
+            }
+            if (COUNT) n_covered += covered[k] ? 1u : 0u;
+         });
+         static_for<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (walk[k]) {
+               const V3 o = v3(ro[k].x, ro[k].y, ro[k].z);
+               Hit best;
+               best.t = 10000.0f;  // tmax (rgen:66)
+               best.u = best.v = 0.0f;
+               best.idx = kEmptyRef;
+               best.key = 0xffffffffu;
+               uint32_t e = cs[k].x;
+               const float4* r = recs + 4 * (size_t)e;
+               float4 a = make_float4(ra[k].x, ra[k].y, ra[k].z, ra[k].w), b = make_float4(rb[k].x, rb[k].y, rb[k].z, rb[k].w), c = make_float4(rc[k].x, rc[k].y, rc[k].z, rc[k].w);
+               bool occluded = false;
+               for (;;) {  // sun_walk<.., true>, its first record already here
+                  if (c.z < pw[k]) break;
+                  if (COUNT) n_tris++;
+                  if (tri_compute<true>(a, b, c, 0u, o, d, 0.001f, INFINITY, best)) {
+                     occluded = true;
+                     break;
+                  }
+                  e++;
+                  if (e >= end[k] || c.w < pw[k]) break;
+                  r += 4;
+                  a = r[0];
+                  b = r[1];
+                  c = r[2];
+               }
+               lit[k] = !occluded;
+            }
+         });
+         float4 thr[K], rad[K];
+         static_for<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (lit[k]) {  // rgen:69-78: radiance += throughput
+               thr[k] = ld_rec(rec_quad(rec, seg + id[k], REC_THR));
+               rad[k] = ld_rec(rec_quad(rec, seg + id[k], REC_RAD));
+            }
+         });
+         static_for<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (lit[k]) st_rec(rec_quad(rec, seg + id[k], REC_RAD), make_float4(rad[k].x + thr[k].x, rad[k].y + thr[k].y, rad[k].z + thr[k].z, rad[k].w));
+         });
+         static_for<K>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (__ballot(defer[k]) != 0ull) {  // wave-uniform: every lane of the wave takes part in the append
+               const uint32_t slot = wave_append(n_tree, defer[k]);
+               if (defer[k]) st_stream(q_tree + slot, id[k]);
+            }
+         });
+      }
+   } else
    for (;;) {
       const uint32_t base = next_batch(cursor);
       if (base >= count) break;
       const uint32_t i = base + lane;
       const bool valid = i < count;
-      const uint32_t id = i;  // the path's position in the queue: its state lies there, a wave reads and writes contiguous kilobytes
+      // the path's position in the next bounce's queue: its state lies there (unlisted: a wave reads and writes contiguous kilobytes)
+      uint32_t id = i;
+      if (LISTED && valid) id = ld_stream(q_listed + i);
       bool defer = false;
       if (valid) {
          const float4 ro = ld_rec(rec_quad(rec, seg + id, REC_ORIGIN));
          const V3 o = v3(ro.x, ro.y, ro.z);
          const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o), pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
-         // the ray's cell; outside the grid (or NaN) it is a border cell
-         float fx = (pu - g.u0) * g.inv_cell, fy = (pv - g.v0) * g.inv_cell;
-         fx = !(fx >= 0.0f) ? 0.0f : fx;
-         fy = !(fy >= 0.0f) ? 0.0f : fy;
-         fx = fx > max_x ? max_x : fx;
-         fy = fy > max_y ? max_y : fy;
-         const uint32_t cx = (uint32_t)fx, cy = (uint32_t)fy;
-         const uint32_t cell = cy * g.nx + cx;
-         const uint2 cs = reinterpret_cast<const uint2*>(g.cell_start)[cell];  // offset into the entries | cover depth
-         uint32_t e = cs.x;
-         const uint32_t end = reinterpret_cast<const uint2*>(g.cell_start)[cell + 1].x;
-         // the cell's cover: some packet spans the whole cell (with the margins to spare) and every ray that starts below this
-         // depth has it in front, further than tmin away - occluded, and the tree walk would have said so too
-         // (... and nearer than tmax: sun_grid.h kSunCoverReach)
-         const float cover = __uint_as_float(cs.y);
-         const bool covered = pw < cover && cover - pw < kSunCoverReach;
-         // a border cell stands for everything beyond the dense part of the scene, and some interior cells list a great many
-         // packets (walls edge-on to the sun): such a ray is cheaper in the tree - k_trace_shadow takes it from queue 3
-         defer = !covered && (cx == 0 || cy == 0 || cx + 1 == g.nx || cy + 1 == g.ny || end - e > g.max_walk);
-         if (COUNT) {
-            n_cells++;
-            n_covered += covered ? 1u : 0u;
-         }
-         if (!defer && !covered) {
-            bool occluded = false;
-            Hit best;
-            best.t = 10000.0f;  // tmax (rgen:66)
-            best.u = best.v = 0.0f;
-            best.idx = kEmptyRef;
-            best.key = 0xffffffffu;
-            uint2 en = make_uint2(0u, 0u);
-            if (e < end) en = reinterpret_cast<const uint2*>(g.entries)[e];
-            while (e < end) {
-               // sorted by far depth, descending: from here on every packet ends behind the origin (t < 0 for all of them)
-               if (__uint_as_float(en.y) < pw) break;
-               const uint32_t pk = en.x;
-               uint2 nxt = make_uint2(0u, 0u);
-               if (e + 1 < end) nxt = reinterpret_cast<const uint2*>(g.entries)[e + 1];  // in flight with the packet
-               const float4 a = tris[kTriStride16 * (size_t)pk + 0], b = tris[kTriStride16 * (size_t)pk + 1], c = tris[kTriStride16 * (size_t)pk + 2];
-               if (COUNT) n_tris++;
-               if (tri_compute<true>(a, b, c, pk, o, d, 0.001f, INFINITY, best)) {
-                  occluded = true;
-                  break;
+         uint32_t cx, cy;
+         sun_cell_of(g, pu, pv, cx, cy);
+         bool covered = false;
+         if (!LISTED && g.coarse) covered = sun_coarse_covered(g.coarse[(cy >> g.coarse_shift) * g.coarse_nx + (cx >> g.coarse_shift)], pw);
+         if (!covered) {
+            const uint32_t cell = cy * g.nx + cx;
+            const uint2 cs = reinterpret_cast<const uint2*>(g.cell_start)[cell];  // offset into the entries | cover depth
+            const uint32_t e = cs.x;
+            const uint32_t end = reinterpret_cast<const uint2*>(g.cell_start)[cell + 1].x;
+            // the cell's cover: some packet spans the whole cell (with the margins to spare) and every ray that starts below this
+            // depth has it in front, further than tmin away - occluded, and the tree walk would have said so too
+            // (... and nearer than tmax: sun_grid.h kSunCoverReach)
+            const float cover = __uint_as_float(cs.y);
+            covered = pw < cover && cover - pw < kSunCoverReach;
+            // a border cell stands for everything beyond the dense part of the scene, and some interior cells list a great many
+            // packets (walls edge-on to the sun): such a ray is cheaper in the tree - k_trace_shadow takes it from queue 3
+            defer = !covered && (cx == 0 || cy == 0 || cx + 1 == g.nx || cy + 1 == g.ny || end - e > g.max_walk);
+            if (!defer && !covered) {
+               const bool occluded = e < end && sun_walk<COUNT, INLINE>(g, tris, e, end, o, d, pw, n_tris);
+               if (!occluded) {  // rgen:69-78: radiance += throughput
+                  const float4 thr = ld_rec(rec_quad(rec, seg + id, REC_THR)), rad = ld_rec(rec_quad(rec, seg + id, REC_RAD));
+                  st_rec(rec_quad(rec, seg + id, REC_RAD), make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w));
                }
-               en = nxt;
-               e++;
-            }
-            if (!occluded) {  // rgen:69-78: radiance += throughput
-               const float4 thr = ld_rec(rec_quad(rec, seg + id, REC_THR)), rad = ld_rec(rec_quad(rec, seg + id, REC_RAD));
-               st_rec(rec_quad(rec, seg + id, REC_RAD), make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w));
             }
          }
+         if (COUNT) n_covered += covered ? 1u : 0u;
       }
       if (__ballot(defer) != 0ull) {  // wave-uniform: every lane of the wave takes part in the append
          const uint32_t slot = wave_append(n_tree, defer);
          if (defer) st_stream(q_tree + slot, id);
       }
    }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[UH_RAY_SUN_SHADOW], (unsigned long long)count);
+   if (sx.lb == 0 && threadIdx.x == 0) {
+      atomicAdd(&stats->rays[UH_RAY_SUN_SHADOW], (unsigned long long)all);
+      if (COUNT) {  // every sun ray looked one cell up (here, or its block's coarse cover in k_shade_hit: those it did not list were covered)
+         atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)all);
+         atomicAdd(&stats->sun_covered_rays, (unsigned long long)(all - count));
+      }
+   }
    if (COUNT) {
-      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_cells);
       atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
       atomicAdd(&stats->sun_covered_rays, (unsigned long long)n_covered);
    }
@@ -1179,7 +1365,14 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
    return I * eta - N * (eta * dn + sqrtf(k));
 }
 
-__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
+// SUN (option sun_grid_fused): the sun rays of the scattered paths (rgen:63-79) ask the grid's COARSE COVER here (sun_grid.h: one
+// depth per block of cells, 0.7 MB: L2-resident) - the word rides with the texels, the ray's origin is known before them, so the
+// look-up costs the kernel no round trip of its own. A ray that starts below it is occluded: no queue entry, nothing to do. The
+// others are listed in Q_SUN_GRID (positions in the next bounce's ray queue) for k_trace_sun_grid<.., true, ..>, whose waves then
+// hold only rays that have a cell to look up. Same verdicts: the coarse cover lies below every cell's own cover depth.
+template <bool SUN>
+__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
+                                                                           SunGridDev g) {
    // c / 255.0f table in LDS: the 12 per-fetch table gathers were texture-addresser traffic (the
    // kernel ran 86 % TA-busy at 2 % VALU, profiles/r01c_*); LDS serves them at no TA cost
    __shared__ float s_lut[256];
@@ -1210,6 +1403,8 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    uint32_t* n_light = &ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)];
    uint2* q_miss = reinterpret_cast<uint2*>(ps.queue[4]) + seg;
    uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
+   uint32_t* q_sun_grid = ps.queue[5] + seg;
+   uint32_t* n_sun_grid = &ctl->q_count[qc_index(bounce, Q_SUN_GRID, sx.shard)];
    const uint32_t stride = sx.nb * kBlock;
    const uint32_t rounds = (count + stride - 1) / stride;
    uint32_t n_hits = 0;
@@ -1218,6 +1413,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    auto shade = [&](uint32_t id, uint32_t pos, float4 hr, bool valid) {
       const uint32_t pk = __float_as_uint(hr.w);
       bool scattered = false, want_light = false;
+      bool sun_listed = false;  // SUN: the scattered path's sun ray is not below its block's coarse cover: k_trace_sun_grid takes it
       float4 n_o = make_float4(0, 0, 0, 0), n_d = make_float4(0, 0, 0, 0), n_t = make_float4(0, 0, 0, 0), n_r = make_float4(0, 0, 0, 0);  // the scattered path's new state
       if (valid) {
          // every record of the path is requested up front, together with the shading packet (whose index the
@@ -1227,8 +1423,16 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          float4 ro = ld_rec(rec_quad(cur, seg + pos, REC_ORIGIN)), rd = ld_rec(rec_quad(cur, seg + pos, REC_DIR));
          uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
          float4 thr4 = ld_rec(rec_quad(cur, seg + pos, REC_THR));
-         float4 rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // radiance so far: zero before the first bounce (not materialised)
-         if (bounce != 0) rad4 = ld_rec(rec_quad(cur, seg + pos, REC_RAD));
+         // radiance so far: zero before the first bounce, where the plane is not materialised - it is read all the same and the words
+         // discarded: as `if (bounce != 0) load` the compiler put the load in a branch of its own with a wait for ALL outstanding
+         // loads at its end, and the shading packet below was requested a whole round trip later
+         float4 rad4 = ld_rec(rec_quad(cur, seg + pos, REC_RAD));
+         {
+            const bool first = bounce == 0;
+            rad4.x = first ? 0.0f : rad4.x;
+            rad4.y = first ? 0.0f : rad4.y;
+            rad4.z = first ? 0.0f : rad4.z;
+         }
          const V3 ray_dir = v3(rd.x, rd.y, rd.z);
          const float t = hr.x, bu = hr.y, bv = hr.z;
          const float4* sp = sc.shade + 4 * (size_t)pk;  // pk = hr.w, known since the classification: no wait for hr before these
@@ -1249,9 +1453,24 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
                     (normal.x * ms.w2o[2] + normal.y * ms.w2o[5]) + normal.z * ms.w2o[8]);  // rchit:32
          V3 world_normal = normalize3(wn);
          if (dot3(world_normal, ray_dir) > 0.0f) world_normal = vneg(world_normal);   // rchit:35-37
+         // where the path goes on from (and its sun ray starts): needs nothing the texels bring
+         V3 origin = v3(ro.x, ro.y, ro.z) + t * ray_dir;                               // rgen:59
+         origin = offset_ray(origin, world_normal);                                    // rgen:60
+         float sun_pw = 0.0f, sun_coarse = 0.0f;
          float uu = (uv0x * bx + uv1x * by) + uv2x * bz;                               // rchit:39
          float vv = (uv0y * bx + uv1y * by) + uv2y * bz;
-         V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);       // rchit:40
+         V3 color;
+         if (SUN) {  // k_trace_sun_grid's cell arithmetic, word for word; the coarse cover rides with the texels: one round trip for both
+            const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), origin), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), origin);
+            sun_pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), origin);
+            uint32_t cx, cy;
+            sun_cell_of(g, pu, pv, cx, cy);
+            uint32_t word;
+            color = sample_texture<true>(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex,
+                                         reinterpret_cast<const uint32_t*>(g.coarse) + ((cy >> g.coarse_shift) * g.coarse_nx + (cx >> g.coarse_shift)), &word);  // rchit:40
+            sun_coarse = __uint_as_float(word);
+         } else
+            color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);       // rchit:40
          color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
 
          uint32_t seed = rng.y;
@@ -1297,8 +1516,6 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
             // frame starts from it (rgen:28-31)
             st_stream(ps.radf + id, make_float4(rad4.x + thr.x, rad4.y + thr.y, rad4.z + thr.z, __uint_as_float(rng.x)));
          } else {
-            V3 origin = v3(ro.x, ro.y, ro.z) + t * ray_dir;                            // rgen:59
-            origin = offset_ray(origin, world_normal);                                 // rgen:60
             float f = 0.0f;
             int light_index = 0;
             if (fp.lights_enabled == 1) {                                              // rgen:81-110
@@ -1326,11 +1543,29 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
             n_d = make_float4(scatter.x, scatter.y, scatter.z, __uint_as_float(rng.y));  // rgen:61
             n_t = make_float4(thr.x, thr.y, thr.z, f);
             n_r = make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index));  // the radiance travels with the path
+            if (SUN) sun_listed = !sun_coarse_covered(sun_coarse, sun_pw);  // rgen:63-79; covered: occluded, nothing to add
          }
       }
       // a wave's scattered paths get consecutive positions: their new state leaves as contiguous stores, and the next bounce's
       // traversal, sun-ray and shading kernels read it back as streams
-      const uint32_t slot = wave_append(n_next, scattered);
+      // every queue of the call in one round trip
+      uint32_t slot, lslot;
+      if (SUN) {
+         uint32_t* const counters[3] = {n_next, n_light, n_sun_grid};
+         const bool preds[3] = {scattered, want_light, sun_listed};
+         uint32_t slots[3];
+         wave_append_multi<3>(counters, preds, slots);
+         slot = slots[0];
+         lslot = slots[1];
+         if (sun_listed) st_stream(q_sun_grid + slots[2], slot);
+      } else {
+         uint32_t* const counters[2] = {n_next, n_light};
+         const bool preds[2] = {scattered, want_light};
+         uint32_t slots[2];
+         wave_append_multi<2>(counters, preds, slots);
+         slot = slots[0];
+         lslot = slots[1];
+      }
       if (scattered) {
          st_stream(q_next + slot, id);
          st_rec(rec_quad(nxt, seg + slot, REC_ORIGIN), n_o);
@@ -1338,7 +1573,6 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          st_rec(rec_quad(nxt, seg + slot, REC_THR), n_t);
          st_rec(rec_quad(nxt, seg + slot, REC_RAD), n_r);
       }
-      const uint32_t lslot = wave_append(n_light, want_light);
       if (want_light) st_stream(q_light + lslot, slot);  // the light ray leaves from the path's new position
    };
    // The bounce's RAY queue holds hits and misses (the traversal kernels build no hit / miss queues). Shading a wave of
@@ -1788,8 +2022,11 @@ void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathStat
 }
 
 void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
-                      DeviceStats* stats, uint32_t bounce) {
-   k_shade_hit<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce);
+                      DeviceStats* stats, uint32_t bounce, const SunGridDev* sun_grid) {
+   if (sun_grid)
+      k_shade_hit<true><<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce, *sun_grid);
+   else
+      k_shade_hit<false><<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce, SunGridDev{});
 }
 void launch_flush_survivors(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl) {
    k_flush_survivors<<<shade_grid(c, fp.n_owned * fp.batch_frames), kBlock, 0, c.stream>>>(fp, ps, ctl);
@@ -1824,12 +2061,23 @@ void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneD
 }
 
 void launch_trace_sun_grid(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
-                           uint32_t cursor_slot, const SunGridDev& g) {
+                           uint32_t cursor_slot, const SunGridDev& g, bool fused) {
    const dim3 grid = sharded_grid(c.num_cus * 8);
-   if (c.count_visits)
-      k_trace_sun_grid<true><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, g);
-   else
-      k_trace_sun_grid<false><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, g);
+#define UH_SUN_GRID(COUNT, FUSED, INLINE) k_trace_sun_grid<COUNT, FUSED, INLINE><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, g)
+#define UH_SUN_GRID2(COUNT, FUSED)            \
+   do {                                       \
+      if (g.recs) UH_SUN_GRID(COUNT, FUSED, true); \
+      else UH_SUN_GRID(COUNT, FUSED, false);  \
+   } while (0)
+   if (fused) {
+      if (c.count_visits) UH_SUN_GRID2(true, true);
+      else UH_SUN_GRID2(false, true);
+   } else {
+      if (c.count_visits) UH_SUN_GRID2(true, false);
+      else UH_SUN_GRID2(false, false);
+   }
+#undef UH_SUN_GRID2
+#undef UH_SUN_GRID
 }
 
 void launch_finish_sample(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, const Images& im, uint32_t sample, bool last) {

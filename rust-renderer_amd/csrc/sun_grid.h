@@ -25,6 +25,14 @@ namespace uh {
 // tree like any other ray.
 constexpr float kSunCoverReach = 9000.0f;
 constexpr double kSunCoverSlack = 900.0;
+// The coarse cover: one depth per block of 2^shift x 2^shift cells = the LOWEST cover depth of the block's cells (-inf when a cell of
+// the block has none, or when the cells' cover depths lie more than kSunCoarseSpread apart). A ray below it is below its own cell's
+// cover depth c as well, and c - w0 <= coarse + kSunCoarseSpread - w0 < kSunCoarseReach + kSunCoarseSpread = kSunCoverReach: the
+// cell's own shortcut would have answered the same. It only exists to be SMALL: 4 x 4 cells per word are 0.7 MB for the 2.9 M
+// cells of the config-1 scene - resident in each XCD's 4 MiB L2, where the 23 MB of cell records are not -, and about 85 % of the
+// rays a cell's cover depth answers start below their block's coarse cover too.
+constexpr float kSunCoarseSpread = 100.0f;
+constexpr float kSunCoarseReach = kSunCoverReach - kSunCoarseSpread;
 
 struct SunGridEntry {
    uint32_t packet;  // triangle packet index (TriPacket array, leaf order)
@@ -40,7 +48,22 @@ struct SunGridDev {
    const uint32_t* cell_start;   // nx * ny + 1 records of two words: offset into entries | cover depth (float bits): a ray of the
                                  // cell that starts below the cover depth is occluded - some packet spans the whole cell in front of it
    const SunGridEntry* entries;
+   // the lists once more, as 64-byte records that carry their packet (null: not built): sixteen floats per entry, in the entries'
+   // order - v0.xyz e1.x | e1.yz e2.xy | e2.z key, this entry's wmax, the next entry's wmax | unused. One sector and one round
+   // trip per triangle test instead of two of each (entry, then packet). Built by build_sun_inline_records.
+   const float* recs;
+   // the coarse cover (null: none): coarse_nx x ceil(ny >> coarse_shift) depths, block (cx >> coarse_shift, cy >> coarse_shift)
+   const float* coarse;
+   uint32_t coarse_shift, coarse_nx;
 };
+
+// 64 bytes per entry (SunGridDev::recs) from the entries and the packets where they lie; `out` holds 64 * num_entries bytes.
+// Enqueued on `hip_stream`, not waited for. Returns a hipError_t as int.
+int build_sun_inline_records(void* hip_stream, const void* d_packets, const SunGridEntry* d_entries, uint64_t num_entries, void* out);
+
+// the coarse cover of a grid's cell records (two words per cell: offset | cover depth), `out`: ((nx + b - 1) / b) x ((ny + b - 1) / b)
+// floats with b = 1 << shift. Enqueued on `hip_stream`, not waited for. Returns a hipError_t as int.
+int build_sun_coarse_cover(void* hip_stream, const uint32_t* d_cells, uint32_t nx, uint32_t ny, uint32_t shift, float* out);
 
 struct SunGridHost {
    float U[3], V[3], W[3];

@@ -602,6 +602,34 @@ __global__ __launch_bounds__(kBlock) void k_sg_area(const float4* __restrict__ t
    }
 }
 
+// SunGridDev::recs: every entry with its packet in one 64-byte record
+__global__ __launch_bounds__(kBlock) void k_sg_inline(const float4* __restrict__ tris, const SunGridEntry* __restrict__ entries, uint64_t n, float4* __restrict__ out) {
+   for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (uint64_t)gridDim.x * kBlock) {
+      const SunGridEntry en = entries[e];
+      const float next = e + 1 < n ? entries[e + 1].wmax : -INFINITY;  // of the next cell's first entry at a list's end: the walk knows where its list ends
+      const float4 a = tris[kTriStride16 * (size_t)en.packet], b = tris[kTriStride16 * (size_t)en.packet + 1], c = tris[kTriStride16 * (size_t)en.packet + 2];
+      out[4 * e] = a;
+      out[4 * e + 1] = b;
+      out[4 * e + 2] = make_float4(c.x, c.y, en.wmax, next);
+   }
+}
+
+// SunGridDev::coarse: the lowest cover depth of each block of cells (sun_grid.h kSunCoarseSpread)
+__global__ __launch_bounds__(kBlock) void k_sg_coarse(const uint32_t* __restrict__ cells, uint32_t nx, uint32_t ny, uint32_t shift, uint32_t cnx, uint32_t cny, float* __restrict__ out) {
+   const uint32_t b = 1u << shift;
+   for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < cnx * cny; k += gridDim.x * kBlock) {
+      const uint32_t bx = (k % cnx) << shift, by = (k / cnx) << shift;
+      float lo = INFINITY, hi = -INFINITY;
+      for (uint32_t y = by; y < by + b && y < ny; y++)
+         for (uint32_t x = bx; x < bx + b && x < nx; x++) {
+            const float c = __uint_as_float(cells[2 * ((size_t)y * nx + x) + 1]);
+            lo = c < lo ? c : lo;  // a NaN never gets in: the builders write depths or -inf
+            hi = c > hi ? c : hi;
+         }
+      out[k] = (lo > -INFINITY && hi - lo <= kSunCoarseSpread) ? lo : -INFINITY;
+   }
+}
+
 struct Scratch {
    void* p = nullptr;
    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
@@ -611,6 +639,20 @@ struct Scratch {
 };
 
 }  // namespace
+
+int build_sun_inline_records(void* stream_v, const void* d_packets, const SunGridEntry* d_entries, uint64_t num_entries, void* out) {
+   if (num_entries == 0) return (int)hipSuccess;
+   const uint32_t blocks = (uint32_t)std::min<uint64_t>((num_entries + kBlock - 1) / kBlock, 1u << 16);
+   k_sg_inline<<<blocks, kBlock, 0, (hipStream_t)stream_v>>>((const float4*)d_packets, d_entries, num_entries, (float4*)out);
+   return (int)hipGetLastError();
+}
+
+int build_sun_coarse_cover(void* stream_v, const uint32_t* d_cells, uint32_t nx, uint32_t ny, uint32_t shift, float* out) {
+   const uint32_t b = 1u << shift, cnx = (nx + b - 1) / b, cny = (ny + b - 1) / b;
+   if (cnx * cny == 0) return (int)hipSuccess;
+   k_sg_coarse<<<std::min<uint32_t>((cnx * cny + kBlock - 1) / kBlock, 4096u), kBlock, 0, (hipStream_t)stream_v>>>(d_cells, nx, ny, shift, cnx, cny, out);
+   return (int)hipGetLastError();
+}
 
 void SunGridDevice::release() {
    if (cells) (void)hipFree(cells);

@@ -332,3 +332,44 @@ def test_host_builder_is_still_selectable(atrium):
     a = dev.read_accumulation().view(np.uint32)
     assert np.array_equal(a, host.read_accumulation().view(np.uint32)) and np.array_equal(a, tree.read_accumulation().view(np.uint32))
     assert list(dev.get_stats().rays) == list(host.get_stats().rays) == list(tree.get_stats().rays)
+
+
+@pytest.mark.parametrize("options", [{"sun_grid_inline": 0}, {"sun_grid_fused": 1}, {"sun_grid_fused": 1, "sun_grid_inline": 0}])
+@pytest.mark.parametrize("sun", [SUNS[0], SUNS[2], SUNS[8]])
+def test_round4_variants_of_the_grid_walk_change_nothing(atrium, sun, options):
+    """options sun_grid_inline (the lists as 64-byte records that carry their packet), sun_grid_fused (k_shade_hit looks the cell and
+    its cover depth up itself and sorts the sun rays into covered / lit at once / list walk / tree walk): same images, ray counts and counted visits as the default path and as the tree walk"""
+    W, H = 160, 90
+    out = []
+    for opts in ({}, options, {"sun_grid": 0}):
+        r = atrium.upload(rr.Renderer(W, H))
+        r.set_option("count_visits", 1)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        render(r, atrium, W, H, sun, frames=3, sky_enabled=1, lights_enabled=0)
+        out.append((r.read_accumulation().view(np.uint32), r.get_stats()))
+    (a0, s0), (a1, s1), (a2, s2) = out
+    assert s0.sun_grid_cells > 0 and s1.sun_grid_cells > 0 and s2.sun_grid_cells == 0
+    assert np.array_equal(a0, a1) and np.array_equal(a0, a2)
+    assert list(s0.rays) == list(s1.rays) == list(s2.rays)
+    # the same cells looked up, the same packets tested, the same rays handed to the tree, the same rays answered by the cover depth
+    assert (s0.shadow_nodes_visited, s0.shadow_tris_tested, s0.sun_tree_rays, s0.sun_covered_rays) == (s1.shadow_nodes_visited, s1.shadow_tris_tested, s1.sun_tree_rays, s1.sun_covered_rays)
+
+
+def test_round4_variants_with_lights_and_batches(atrium):
+    """the fused look-up appends to five queues in one round trip (ray, light, grid walk, tree walk, lit at once): config-2 style
+    frames (lights on, reservoir passes, batches of frames) against the default path"""
+    scene = rr.scenes.sponza_class_scene(detail=0.12, tex_size=32, with_spheres=True, num_lights=48, sphere_subdivisions=2)
+    W, H = 128, 72
+    images = []
+    for opts in ({}, {"sun_grid_fused": 1}):
+        r = scene.upload(rr.Renderer(W, H))
+        for k, v in opts.items():
+            r.set_option(k, v)
+        loop = rr.FrameLoop(r, scene.make_view(W, H, sun_shadow_enabled=1, sky_enabled=1, lights_enabled=1))
+        loop.frame(rr.PASS_ALL)
+        loop.frame(rr.PASS_ALL)
+        loop.frames(6, rr.PASS_ALL)
+        images.append((r.read_accumulation().view(np.uint32), list(r.get_stats().rays), r.get_stats().sun_grid_cells))
+    assert images[0][2] > 0 and images[1][2] > 0
+    assert np.array_equal(images[0][0], images[1][0]) and images[0][1] == images[1][1]
