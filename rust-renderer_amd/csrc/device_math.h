@@ -231,14 +231,15 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
    return m < n ? m : period - 1 - m;
 }
 // lds_tex (may be null): the first n_lds_tex texture descriptors staged in LDS by the caller
-// RIDER: one more dword (from `rider_at`, into `rider`) is fetched IN THE SAME BLOCK as the four texels - one round trip for
-// both. k_shade_hit's sun-grid look-up rides here: requested any earlier, the wait for a texture descriptor from global
-// memory (vmcnt counts in order) made the texel fetch wait for it - three round trips in a row instead of two.
-template <bool RIDER = false>
-__device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __restrict__ lut, uint32_t index, float u, float v, const TexInfo* lds_tex = nullptr,
-                                             uint32_t n_lds_tex = 0, const uint32_t* rider_at = nullptr, uint32_t* rider = nullptr) {
+// `pre` is called exactly once, right before the four texels are requested (or before an early return): what it requests
+// is in flight TOGETHER with the texels. k_shade_hit asks for its scattered paths' queue positions there (a returning atomic) and,
+// fused, for the sun grid's coarse cover: requested any earlier, the wait for a texture descriptor from global memory (vmcnt
+// counts in order) made everything wait for them first - three round trips in a row instead of two.
+template <typename Pre>
+__device__ __forceinline__ V3 sample_texture_pre(const SceneDev& sc, const float* __restrict__ lut, uint32_t index, float u, float v, const TexInfo* lds_tex, uint32_t n_lds_tex,
+                                                 Pre&& pre) {
    if (index >= sc.num_textures) {
-      if (RIDER) *rider = *rider_at;
+      pre();
       return v3(1, 1, 1);
    }
    TexInfo t;
@@ -251,7 +252,7 @@ __device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __
    }
    float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
    if (!(fabsf(x) < 1e9f) || !(fabsf(y) < 1e9f)) {
-      if (RIDER) *rider = *rider_at;
+      pre();
       return v3(0, 0, 0);
    }
    float fx = floorf(x), fy = floorf(y);
@@ -273,17 +274,7 @@ __device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __
    // one block: as four C++ loads the compiler still made the third wait for the first (register reuse), and as loads
    // through the descriptor's generic pointer they were flat loads
    uint32_t w00, w10, w01, w11;
-   if (RIDER) {
-      uint32_t r;
-      asm volatile(
-         "global_load_dword %4, %9, off\n\t"
-         "global_load_dword %0, %5, off\n\tglobal_load_dword %1, %6, off\n\tglobal_load_dword %2, %7, off\n\tglobal_load_dword %3, %8, off\n\t"
-         "s_waitcnt vmcnt(0)"
-         : "=&v"(w00), "=&v"(w10), "=&v"(w01), "=&v"(w11), "=&v"(r)
-         : "v"(q00), "v"(q10), "v"(q01), "v"(q11), "v"(rider_at)
-         : "memory");
-      *rider = r;
-   } else
+   pre();
    asm volatile(
       "global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off\n\t"
       "s_waitcnt vmcnt(0)"
@@ -297,6 +288,10 @@ __device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __
    V3 a = t00 * (1.0f - ax) + t10 * ax;
    V3 b = t01 * (1.0f - ax) + t11 * ax;
    return a * (1.0f - ay) + b * ay;
+}
+__device__ __forceinline__ V3 sample_texture(const SceneDev& sc, const float* __restrict__ lut, uint32_t index, float u, float v, const TexInfo* lds_tex = nullptr,
+                                             uint32_t n_lds_tex = 0) {
+   return sample_texture_pre(sc, lut, index, u, v, lds_tex, n_lds_tex, [] {});
 }
 
 // ---- include/restir_sampling.glsl ------------------------------------------------------------

@@ -1414,6 +1414,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
       const uint32_t pk = __float_as_uint(hr.w);
       bool scattered = false, want_light = false;
       bool sun_listed = false;  // SUN: the scattered path's sun ray is not below its block's coarse cover: k_trace_sun_grid takes it
+      uint32_t slot = 0;        // the scattered path's position in the next bounce's queue
       float4 n_o = make_float4(0, 0, 0, 0), n_d = make_float4(0, 0, 0, 0), n_t = make_float4(0, 0, 0, 0), n_r = make_float4(0, 0, 0, 0);  // the scattered path's new state
       if (valid) {
          // every record of the path is requested up front, together with the shading packet (whose index the
@@ -1456,32 +1457,43 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          // where the path goes on from (and its sun ray starts): needs nothing the texels bring
          V3 origin = v3(ro.x, ro.y, ro.z) + t * ray_dir;                               // rgen:59
          origin = offset_ray(origin, world_normal);                                    // rgen:60
+         // Does the path go on? Decided by the material type and the side the ray came from (rchit:47-89) - nothing the texels
+         // bring -, so the scattered paths' places in the next bounce's queue are asked for together with the texels: the returning
+         // atomic is in flight with them instead of a round trip of its own after the material evaluation. (Inside the divergent
+         // block: the ballot sees the valid lanes, which are the only ones that can scatter.)
+         scattered = (ms.type == 0.0f || ms.type == 4.0f) ? dot3(ray_dir, world_normal) < 0.0f : (ms.type == 1.0f || ms.type == 2.0f);
+         const unsigned long long scat_mask = __ballot(scattered);
+         const int scat_leader = __ffsll((long long)scat_mask) - 1;
+         uint32_t scat_base = 0;
          float sun_pw = 0.0f, sun_coarse = 0.0f;
-         float uu = (uv0x * bx + uv1x * by) + uv2x * bz;                               // rchit:39
-         float vv = (uv0y * bx + uv1y * by) + uv2y * bz;
-         V3 color;
-         if (SUN) {  // k_trace_sun_grid's cell arithmetic, word for word; the coarse cover rides with the texels: one round trip for both
+         const float* sun_coarse_at = g.coarse;
+         if (SUN) {  // k_trace_sun_grid's cell arithmetic, word for word
             const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), origin), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), origin);
             sun_pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), origin);
             uint32_t cx, cy;
             sun_cell_of(g, pu, pv, cx, cy);
-            uint32_t word;
-            color = sample_texture<true>(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex,
-                                         reinterpret_cast<const uint32_t*>(g.coarse) + ((cy >> g.coarse_shift) * g.coarse_nx + (cx >> g.coarse_shift)), &word);  // rchit:40
-            sun_coarse = __uint_as_float(word);
-         } else
-            color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);       // rchit:40
+            sun_coarse_at = g.coarse + ((cy >> g.coarse_shift) * g.coarse_nx + (cx >> g.coarse_shift));
+         }
+         float uu = (uv0x * bx + uv1x * by) + uv2x * bz;                               // rchit:39
+         float vv = (uv0y * bx + uv1y * by) + uv2y * bz;
+         V3 color = sample_texture_pre(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex, [&] {  // rchit:40
+            // (the counter's address goes through a register the compiler cannot see into: for a wave-uniform address its atomic
+            // optimiser rewrites the add as a wave reduction with a readfirstlane of the result - and a wait for it - on the spot)
+            typedef __attribute__((address_space(1))) uint32_t* global_u32_t;  // (a pointer of unknown address space would make it a flat atomic, which LDS waits wait for)
+            global_u32_t counter = (global_u32_t)n_next;
+            asm volatile("" : "+v"(counter));
+            if (scattered && (int)lane_id() == scat_leader) scat_base = __hip_atomic_fetch_add(counter, (uint32_t)__popcll(scat_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (SUN) sun_coarse = *sun_coarse_at;
+         });
          color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
 
          uint32_t seed = rng.y;
          V3 scatter = v3(0, 0, 0);
          if (ms.type == 0.0f) {                                                        // rchit:47-50
-            scatter = world_normal + random_point_in_unit_sphere(seed);
-            scattered = dot3(ray_dir, world_normal) < 0.0f;
+            scatter = world_normal + random_point_in_unit_sphere(seed);            // scattered = dot(ray, normal) < 0: above
          } else if (ms.type == 1.0f) {                                                 // rchit:52-59
             scatter = reflect3(normalize3(ray_dir), world_normal);
             scatter = scatter + ms.property * random_point_in_unit_sphere(seed);
-            scattered = true;
             color = v3(1, 1, 1);
          } else if (ms.type == 2.0f) {                                                 // rchit:61-83
             V3 nd = normalize3(ray_dir);
@@ -1497,18 +1509,16 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
                scatter = reflect3(nd, outward);
             else
                scatter = refract3(nd, outward, ratio);
-            scattered = true;
             color = v3(1, 1, 1);
          } else if (ms.type == 4.0f) {
             // EXTENSION (never produced by the reference's scenes): Cook-Torrance, see pbr_weight()
             scatter = world_normal + random_point_in_unit_sphere(seed);
-            scattered = dot3(ray_dir, world_normal) < 0.0f;
             color = pbr_weight(world_normal, -1.0f * normalize3(ray_dir), normalize3(scatter), color, ms.metallic, ms.roughness);
-         } else {                                                                      // rchit:85-89
-            scattered = false;
+         } else {                                                                      // rchit:85-89: the path ends
             color = v3(1, 1, 1);
          }
          rng.y = seed;                                                                 // rchit:91
+         if (scat_leader >= 0) slot = (uint32_t)__builtin_amdgcn_readlane((int)scat_base, scat_leader) + __builtin_amdgcn_mbcnt_hi((uint32_t)(scat_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)scat_mask, 0u));
 
          V3 thr = v3(thr4.x, thr4.y, thr4.z) * color;                                  // rgen:48
          if (!scattered) {                                                             // rgen:53-57: the path ends here
@@ -1548,23 +1558,15 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
       }
       // a wave's scattered paths get consecutive positions: their new state leaves as contiguous stores, and the next bounce's
       // traversal, sun-ray and shading kernels read it back as streams
-      // every queue of the call in one round trip
-      uint32_t slot, lslot;
-      if (SUN) {
-         uint32_t* const counters[3] = {n_next, n_light, n_sun_grid};
-         const bool preds[3] = {scattered, want_light, sun_listed};
-         uint32_t slots[3];
-         wave_append_multi<3>(counters, preds, slots);
-         slot = slots[0];
-         lslot = slots[1];
-         if (sun_listed) st_stream(q_sun_grid + slots[2], slot);
-      } else {
-         uint32_t* const counters[2] = {n_next, n_light};
-         const bool preds[2] = {scattered, want_light};
+      // the light queue (and, fused, the sun-grid queue): one round trip for both - none at all when neither has an entry
+      uint32_t lslot;
+      {
+         uint32_t* const counters[2] = {n_light, n_sun_grid};
+         const bool preds[2] = {want_light, SUN && sun_listed};
          uint32_t slots[2];
          wave_append_multi<2>(counters, preds, slots);
-         slot = slots[0];
-         lslot = slots[1];
+         lslot = slots[0];
+         if (SUN && sun_listed) st_stream(q_sun_grid + slots[1], slot);
       }
       if (scattered) {
          st_stream(q_next + slot, id);

@@ -86,11 +86,15 @@ struct SunGridHost {
 struct SunGridLimits {
    uint64_t max_entries = 96ull << 20;  // 8 bytes each
    uint64_t max_cells = 24ull << 20;
-   double entries_per_triangle = 48.0;  // target density: the cell size is the finest that keeps the estimate under it (MI355X, config 1: 24 / 48 / 96 / 200 = 0.590 / 0.515 / 0.490 / 0.479 ms of sun rays per frame, tree walk 0.632)
-   // beyond this the grid does not beat the tree walk. With the cover depth: Sponza-class atrium 4.5 entries per occupied cell,
-   // sun rays -37 %; Bistro-class street 7.4, -9 % (555 ms of build, 340 MB); without the cover depth that street gained 2 %
-   double max_mean_list = 8.0;
-   uint32_t max_walk = 32;              // a ray whose cell lists more than this (or is a border cell) walks the tree instead (k_trace_sun_grid's fallback queue)
+   double entries_per_triangle = 96.0;  // target density: the cell size is the finest that keeps the estimate under it (MI355X, config 1, round 4: 24 / 48 / 96 / 200 = 0.347 / 0.315 / 0.291 / 0.285 ms of sun rays per frame at 2.9 / 3.4 / 4.5 / 6.8 ms of build; round 3, lists and packets apart: 0.590 / 0.515 / 0.490 / 0.479, tree walk 0.632)
+   // beyond this the grid does not beat the tree walk. Round 4 (lists with their packets inline, two rays per lane): Sponza-class
+   // atrium 4.1 entries per occupied cell, sun rays -50 % against the tree walk; Bistro-class street (config 3) 8.2 entries per
+   // occupied cell: the frame +5 % (7,080 -> 7,430-7,480 Mrays/s at 4K) with lists of up to 48 / 64 / 96 walked.
+   // (Round 3, entries and packets apart: 4.5 -> -37 %; 7.4 -> -9 % at 555 ms of host build, +2 % without the cover depth: limit 8.)
+   double max_mean_list = 12.0;
+   // a ray whose cell lists more than this (or is a border cell) walks the tree instead (k_trace_sun_grid's fallback queue).
+   // Config 1: 32 / 48 / 64 = 9,905-9,941 / 9,932-9,984 / 9,868-9,870 Mrays/s
+   uint32_t max_walk = 48;
    double max_fallback_area = 0.2;      // share of the scene's surface area that may lie in such cells; above it the grid is refused as a whole
 };
 

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void k_sg_area(const float4* __restrict__ t
       const size_t c = (size_t)iy * g.nx + ix;
       const bool border = ix == 0 || iy == 0 || ix == g.nx - 1 || iy == g.ny - 1;
       all += area;
-      if (border || start[c + 1] - start[c] > max_walk) bad += area;
+      if (border || (start && start[c + 1] - start[c] > max_walk)) bad += area;  // start == null: the border's share alone (known before the count pass)
    }
    for (int o = 32; o > 0; o >>= 1) {
       all += __shfl_xor(all, o);
@@ -839,6 +839,19 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       SG_TRY(d_counts.alloc((ncell + 1) * sizeof(uint32_t)));
       SG_TRY(d_chunks.alloc((size_t)scan_chunk_count((uint32_t)ncell + 1) * sizeof(uint32_t)));
       uint32_t* counts = (uint32_t*)d_counts.p;
+      if (!cam && attempt == 0) {
+         // the share of the surface that lies in the border ring is known from the raster alone: a scene whose ground plane reaches far
+         // beyond the dense extent (configs 0 and 4) is refused here, before the count pass
+         if (!d_area.p) SG_TRY(d_area.alloc(2 * sizeof(double)));
+         SG_TRY(hipMemsetAsync(d_area.p, 0, 2 * sizeof(double), stream));
+         k_sg_area<<<std::min<uint32_t>(blocks_n, 2048), kBlock, 0, stream>>>(d_tris, pr, n, g, nullptr, lim.max_walk, (double*)d_area.p);
+         double area[2] = {0, 0};
+         SG_TRY(hipMemcpyAsync(area, d_area.p, sizeof(area), hipMemcpyDeviceToHost, stream));
+         SG_TRY(hipStreamSynchronize(stream));
+         out.fallback_area = area[0] > 0 ? area[1] / area[0] : 0.0;
+         if (out.fallback_area > lim.max_fallback_area)
+            return refuse("too much of the scene's surface (" + std::to_string(out.fallback_area) + ") lies beyond the dense extent: its rays would walk the tree anyway");
+      }
       SG_TRY(hipMemsetAsync(counts, 0, (ncell + 1) * sizeof(uint32_t), stream));
       SG_TRY(hipMemsetAsync(d_tot.p, 0, 2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t), stream));
       const uint32_t bin_blocks = std::min<uint32_t>((n + (kBlock / 64) - 1) / (kBlock / 64), 1u << 16);
@@ -864,8 +877,23 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
    out.max_list = longest;
    if (out.mean_list > lim.max_mean_list) return refuse("lists too long for this direction (mean " + std::to_string(out.mean_list) + " entries per occupied cell)");
 
-   // ---- fill, sort, cell records
    uint32_t* start = (uint32_t*)d_counts.p;  // the scan turned the counts into offsets, start[ncell] = total
+   // ---- the last reason to refuse needs the offsets only: before the fill, so that a refused grid costs the count pass and no more
+   // (the 512^3 iso-surface of config 4 - a ground plane beyond the dense extent - cost 23-38 ms to refuse after the fill)
+   if (!cam) {
+      if (!d_area.p) SG_TRY(d_area.alloc(2 * sizeof(double)));
+      SG_TRY(hipMemsetAsync(d_area.p, 0, 2 * sizeof(double), stream));
+      k_sg_area<<<std::min<uint32_t>(blocks_n, 2048), kBlock, 0, stream>>>(d_tris, pr, n, g, start, lim.max_walk, (double*)d_area.p);
+      double area[2] = {0, 0};
+      SG_TRY(hipMemcpyAsync(area, d_area.p, sizeof(area), hipMemcpyDeviceToHost, stream));
+      SG_TRY(hipStreamSynchronize(stream));
+      SG_TRY(hipGetLastError());
+      out.fallback_area = area[0] > 0 ? area[1] / area[0] : 0.0;
+      if (out.fallback_area > lim.max_fallback_area)
+         return refuse("too much of the scene's surface (" + std::to_string(out.fallback_area) + ") lies beyond the dense extent or in cells with long lists: its rays would walk the tree anyway");
+   }
+
+   // ---- fill, sort, cell records
    Scratch d_cursor;
    SG_TRY(d_cursor.alloc(ncell * sizeof(uint32_t)));
    SG_TRY(d_cover.alloc(ncell * sizeof(uint32_t)));
@@ -880,22 +908,14 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
    const uint32_t cell_blocks = std::min<uint32_t>((uint32_t)((ncell + kBlock) / kBlock), 1u << 15);
    k_sg_sort<<<cell_blocks, kBlock, 0, stream>>>(start, out.entries, prm.nx, prm.ny, lim.max_walk);
    if (!cam) k_sg_cells<<<cell_blocks, kBlock, 0, stream>>>(start, (const uint32_t*)d_cover.p, (uint32_t)ncell, out.cells);
-   SG_TRY(d_area.alloc(2 * sizeof(double)));
-   SG_TRY(hipMemsetAsync(d_area.p, 0, 2 * sizeof(double), stream));
-   if (!cam) k_sg_area<<<std::min<uint32_t>(blocks_n, 2048), kBlock, 0, stream>>>(d_tris, pr, n, g, start, lim.max_walk, (double*)d_area.p);
-   double area[2] = {0, 0};
-   SG_TRY(hipMemcpyAsync(area, d_area.p, sizeof(area), hipMemcpyDeviceToHost, stream));
    SG_TRY(hipStreamSynchronize(stream));
    SG_TRY(hipGetLastError());
-   out.fallback_area = area[0] > 0 ? area[1] / area[0] : 0.0;
    out.num_entries = total;
    if (cam) {  // the camera grid has no cover depths: the scanned counts ARE its cell records (ncell + 1 offsets) - they change owner
       out.cells = (uint32_t*)d_counts.p;
       d_counts.p = nullptr;
    }
    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-   if (out.fallback_area > lim.max_fallback_area)
-      return refuse("too much of the scene's surface (" + std::to_string(out.fallback_area) + ") lies beyond the dense extent or in cells with long lists: its rays would walk the tree anyway");
    return true;
 #undef SG_TRY
 }

@@ -13,6 +13,6 @@ for spec in "${opts[@]}"; do
   printf "%-44s" "$spec"
   UTOPIAN_HIP_LIB=$root/rust-renderer_amd/$lib timeout -k 10 200 python bench.py --warmup 8 --steps 64 --no-cpu-baseline --no-tree-walk --opt $o "$@" 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d['config']['serial_kernel_ms_per_frame']
-print('%.1f Mrays/s %.3f ms | ' % (d['value'], d['ms_per_step']) + ' '.join('%s %.4f' % (a, b) for a, b in k.items()) + ' | pipelined %.3f interactive %.3f' % (d['config']['pipelined_frame_ms'], d['config']['interactive_frame_ms']))"
+print('%.1f Mrays/s %.3f ms | ' % (d['value'], d['ms_per_step']) + ' '.join('%s %.4f' % (a, b) for a, b in k.items()) + ' | pipelined %.3f interactive %.3f | sun grid build %.2f ms, %d entries; with builds %.0f' % (d['config']['pipelined_frame_ms'], d['config']['interactive_frame_ms'], d['sun_grid']['build_ms'], d['sun_grid']['entries'], d['value_with_grid_builds']))"
 done
 done

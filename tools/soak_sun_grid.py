@@ -1,6 +1,6 @@
 """Soak for the sun grid (cover depth, margins, fall-back): random sun directions over several scenes, the grid against the tree
 walk it replaces - accumulation bit for bit and ray counts - on the GPU. Not part of the test suite.
-usage (GPU box): python tools/soak_sun_grid.py [first_seed] [count]"""
+usage (GPU box): [UH_SOAK_OPTS=name=value,...] python tools/soak_sun_grid.py [first_seed] [count]   (the options go to the grid's renderer)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -19,6 +19,8 @@ pairs = []
 for sc in scenes:
     g, t = sc.upload(rr.Renderer(W, H)), sc.upload(rr.Renderer(W, H))
     t.set_option("sun_grid", 0)
+    for kv in filter(None, os.environ.get("UH_SOAK_OPTS", "").split(",")):
+        g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     pairs.append((sc, g, t))
 for k in range(count):
     rng = np.random.default_rng(first + k)
