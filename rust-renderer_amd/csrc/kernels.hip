@@ -1424,16 +1424,8 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          float4 ro = ld_rec(rec_quad(cur, seg + pos, REC_ORIGIN)), rd = ld_rec(rec_quad(cur, seg + pos, REC_DIR));
          uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
          float4 thr4 = ld_rec(rec_quad(cur, seg + pos, REC_THR));
-         // radiance so far: zero before the first bounce, where the plane is not materialised - it is read all the same and the words
-         // discarded: as `if (bounce != 0) load` the compiler put the load in a branch of its own with a wait for ALL outstanding
-         // loads at its end, and the shading packet below was requested a whole round trip later
-         float4 rad4 = ld_rec(rec_quad(cur, seg + pos, REC_RAD));
-         {
-            const bool first = bounce == 0;
-            rad4.x = first ? 0.0f : rad4.x;
-            rad4.y = first ? 0.0f : rad4.y;
-            rad4.z = first ? 0.0f : rad4.z;
-         }
+         float4 rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // radiance so far: zero before the first bounce (not materialised)
+         if (bounce != 0) rad4 = ld_rec(rec_quad(cur, seg + pos, REC_RAD));  // (the compiler waits for it on the spot: measured level with an unconditional read, which costs 16 bytes per hit at bounce 0)
          const V3 ray_dir = v3(rd.x, rd.y, rd.z);
          const float t = hr.x, bu = hr.y, bv = hr.z;
          const float4* sp = sc.shade + 4 * (size_t)pk;  // pk = hr.w, known since the classification: no wait for hr before these
