@@ -327,7 +327,12 @@ int uh_reset_stats(uh_ctx* ctx);
  * "sun_grid" (0/1, default 1: sun shadow rays through a per-direction visibility grid once the direction has settled; same
  * images), "sun_grid_build" (0/1, default 1: that grid is built on the device in a few milliseconds; 0: by the host builder, the
  * reference implementation, in 130-550 ms), "sun_grid_async" (0/1, host builder only: the grid is built on a host thread and no frame
- * call waits for it), "sun_grid_density", "sun_grid_max_mb", "sun_grid_max_walk",
+ * call waits for it), "sun_grid_density", "sun_grid_max_mb", "sun_grid_max_walk", "sun_grid_max_mean_list_x10",
+ * "sun_grid_inline" (0/1, default 1: the grid's lists are kept a second time as 64-byte records that carry their triangle packet - one
+ * round trip per triangle test instead of two), "sun_grid_inline_max_mb" (default 8192: beyond it the plain lists serve),
+ * "sun_grid_coarse" (0..6, default 2: a cover depth per block of 4 x 4 cells, small enough to stay in the L2, asked before the cell's own
+ * record; 0: none), "sun_grid_fused" (0/1, default 0: the shading kernel asks that coarse cover itself and the grid kernel serves the
+ * rays it could not answer; same images, measured level),
  * tuning knobs documented in DESIGN.md section 7 ("frames_in_flight", "batch_frames", "closest_variant", "shadow_variant",
  * "*_blocks_per_cu", "overlap_miss", "overlap_shadow", "spatial_splits", "primary_tiles", "ploc_radius", "ploc_sah_top").
  * Unknown names return UH_ERR_INVALID_ARGUMENT. */
