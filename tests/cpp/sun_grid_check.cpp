@@ -77,6 +77,28 @@ static bool meets_box(const float* q, F3 o, F3 d) {
    return tn <= tf * 1.0000005f + 1e-30f;
 }
 
+// build_sun_coarse_cover (sun_grid_build.hip k_sg_coarse) on the host: the lowest cover depth of each block of cells, none where a
+// cell of the block has none or where the block's cover depths lie more than kSunCoarseSpread apart
+static std::vector<float> coarse_cover;
+static uint32_t coarse_shift = 2, coarse_nx = 0;
+static uint64_t coarse_answers = 0;
+static void build_coarse(const SunGridHost& g) {
+   const uint32_t b = 1u << coarse_shift, cnx = (g.nx + b - 1) / b, cny = (g.ny + b - 1) / b;
+   coarse_nx = cnx;
+   coarse_cover.assign((size_t)cnx * cny, -INFINITY);
+   for (uint32_t by = 0; by < cny; by++)
+      for (uint32_t bx = 0; bx < cnx; bx++) {
+         float lo = INFINITY, hi = -INFINITY;
+         for (uint32_t y = by << coarse_shift; y < ((by + 1) << coarse_shift) && y < g.ny; y++)
+            for (uint32_t x = bx << coarse_shift; x < ((bx + 1) << coarse_shift) && x < g.nx; x++) {
+               const float c = g.cell_cover[(size_t)y * g.nx + x];
+               lo = c < lo ? c : lo;
+               hi = c > hi ? c : hi;
+            }
+         coarse_cover[(size_t)by * cnx + bx] = (lo > -INFINITY && hi - lo <= uh::kSunCoarseSpread) ? lo : -INFINITY;
+      }
+}
+
 // k_trace_sun_grid for one ray, on the host
 static bool grid_occluded(const SunGridHost& g, const std::vector<float>& pk, F3 o, F3 d, uint32_t* tests, bool solid = false) {
    const float pu = dot_fma(F3{g.U[0], g.U[1], g.U[2]}, o), pv = dot_fma(F3{g.V[0], g.V[1], g.V[2]}, o), pw = dot_fma(F3{g.W[0], g.W[1], g.W[2]}, o);
@@ -87,6 +109,13 @@ static bool grid_occluded(const SunGridHost& g, const std::vector<float>& pk, F3
    fx = fx > max_x ? max_x : fx;
    fy = fy > max_y ? max_y : fy;
    const uint32_t cell = (uint32_t)fy * g.nx + (uint32_t)fx;
+   {  // the coarse cover first, as the kernel asks it (sun_grid.h kSunCoarseReach)
+      const float c = coarse_cover[(size_t)((uint32_t)fy >> coarse_shift) * coarse_nx + ((uint32_t)fx >> coarse_shift)];
+      if (pw < c && c - pw < uh::kSunCoarseReach) {
+         coarse_answers++;
+         return true;
+      }
+   }
    if (pw < g.cell_cover[cell] && g.cell_cover[cell] - pw < uh::kSunCoverReach) return true;  // the cell's cover: no packet is asked (k_trace_sun_grid does the same)
    for (uint32_t e = g.cell_start[cell]; e < g.cell_start[cell + 1]; e++) {
       if (g.entries[e].wmax < pw) break;
@@ -137,6 +166,7 @@ static void check_scene(const char* name, const std::vector<float>& pk, F3 sun, 
       failures++;
       return;
    }
+   build_coarse(g);
    for (size_t c = 0; c + 1 < g.cell_start.size(); c++)
       for (uint32_t e = g.cell_start[c]; e + 1 < g.cell_start[c + 1]; e++)
          if (g.entries[e].wmax < g.entries[e + 1].wmax || g.entries[e].packet >= n) {
@@ -341,8 +371,8 @@ int main(int argc, char** argv) {
       }
    }
    std::printf("%llu rays checked (%llu occluded; %llu more 'accepted' only by packets whose box they never meet; %llu rays lying in the plane of an edge-on packet scored on the "
-               "solid packets), %.2f grid tests per ray\n", (unsigned long long)rays_checked, (unsigned long long)occluded_rays, (unsigned long long)noise_accepts,
-               (unsigned long long)in_plane_noise, (double)grid_tests / (double)(rays_checked ? rays_checked : 1));
+               "solid packets), %.2f grid tests per ray, %llu rays answered by the coarse cover\n", (unsigned long long)rays_checked, (unsigned long long)occluded_rays, (unsigned long long)noise_accepts,
+               (unsigned long long)in_plane_noise, (double)grid_tests / (double)(rays_checked ? rays_checked : 1), (unsigned long long)coarse_answers);
    if (failures) {
       std::printf("SUN GRID CHECK FAILED (%d)\n", failures);
       return 1;
