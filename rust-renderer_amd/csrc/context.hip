@@ -274,6 +274,7 @@ struct uh_ctx {
    uint32_t sun_cells = 0, sun_entries = 0, sun_max_list = 0;
    bool sun_this_frame = false;     // set by render_batch for the frame being enqueued
    bool sun_async = false;          // option "sun_grid_async": build on a host thread, walk the tree until it is done (host builder only)
+   bool primary_implicit = true;    // option "primary_implicit" (FrameParams::primary_implicit)
    bool sun_grid_fused = false;     // option "sun_grid_fused": k_shade_hit looks the sun rays' cells up itself (kernels.hip k_shade_hit<true>); 0: k_trace_sun_grid does
    bool sun_device_build = true;    // option "sun_grid_build": 1 = on the device (sun_grid_build.hip: a few ms), 0 = the host builder (sun_grid.cpp)
    struct SunJob* sun_job = nullptr;
@@ -1551,6 +1552,8 @@ static int batch_begin(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_m
    const bool primary_rays = ((pass_mask & UH_PASS_REFERENCE_PT) && fp.num_bounces > 0 && fp.samples_per_frame > 0) || (pass_mask & UH_PASS_GBUFFER);
    if (primary_rays)
       if (int st = ensure_camera_grid(c, fp, batch)) return st;
+   // with the camera grid nothing but bounce 0's own kernels reads a primary ray's origin and throughput: they are not stored
+   fp.primary_implicit = (c->primary_implicit && c->cam_this_frame && fp.samples_per_frame == 1) ? 1u : 0u;
    bs.pass_mask = pass_mask;
    bs.batch = batch;
    bs.restir_frame = (pass_mask & UH_PASS_RESTIR) != 0;
@@ -2066,6 +2069,10 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       // 1 (default): the grid is built on the device (sun_grid_build.hip); 0: by the host builder (sun_grid.cpp, the reference implementation)
       c->sun_device_build = value != 0;
       c->sun_attempted = false;
+   } else if (n == "primary_implicit") {
+      // 1 (default): with the camera grid in use and one sample per frame, the origin and throughput planes of bounce 0 are neither
+      // written nor read (every primary ray leaves the camera with throughput 1); 0: as stored by k_generate. Same images.
+      c->primary_implicit = value != 0;
    } else if (n == "sun_grid_coarse") {
       // the coarse cover (sun_grid.h): one depth per block of 2^value x 2^value cells, asked before the cell's own record; 0: none
       if (value < 0 || value > 6) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_coarse (log2 of the block edge in cells) must be 0..6");

@@ -332,6 +332,18 @@ __device__ __forceinline__ void primary_ray(const FrameParams& fp, uint32_t px, 
    dir = v3(d4.x, d4.y, d4.z);
 }
 
+// FrameParams::primary_implicit: what k_generate would have stored for a path of bounce 0
+__device__ __forceinline__ V3 primary_origin(const FrameParams& fp) {  // primary_ray's `org`, the same expression
+   float4 o4 = mat4_mul(fp.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
+   return v3(o4.x, o4.y, o4.z);
+}
+__device__ __forceinline__ uint32_t primary_rng(uint32_t seed) {  // rgen:30-31: the raygen RNG word after the two jitter draws
+   uint32_t r = seed;
+   (void)random_float(r);
+   (void)random_float(r);
+   return r;
+}
+
 __device__ __forceinline__ bool owns_pixel(const FrameParams& fp, uint32_t x, uint32_t y) {
    if (fp.tp_world <= 1) return true;
    uint32_t tile = (y / fp.tp_tile) * fp.tiles_x + (x / fp.tp_tile);

@@ -1147,9 +1147,19 @@ __global__ __launch_bounds__(kBlock) void k_trace_camera_grid(SceneDev sc, Frame
          uint32_t e = g.cell_start[cell];  // the camera grid's cell records are plain offsets (no cover depths)
          const uint32_t end = g.cell_start[cell + 1];
          defer = end - e > g.max_walk;
+         if (defer && fp.primary_implicit) {  // the tree walk reads its rays' origins from the plane: this one's is written after all
+            const float4 rd = ld_rec(rec_quad(rec, seg + i, REC_DIR));
+            const V3 o = primary_origin(fp);
+            st_rec(rec_quad(rec, seg + i, REC_ORIGIN), make_float4(o.x, o.y, o.z, __uint_as_float(primary_rng(__float_as_uint(rd.w)))));
+         }
          if (!defer) {
-            const float4 ro = ld_rec(rec_quad(rec, seg + i, REC_ORIGIN)), rd = ld_rec(rec_quad(rec, seg + i, REC_DIR));
-            const V3 o = v3(ro.x, ro.y, ro.z), d = v3(rd.x, rd.y, rd.z);
+            const float4 rd = ld_rec(rec_quad(rec, seg + i, REC_DIR));
+            V3 o = primary_origin(fp);
+            if (!fp.primary_implicit) {
+               const float4 ro = ld_rec(rec_quad(rec, seg + i, REC_ORIGIN));
+               o = v3(ro.x, ro.y, ro.z);
+            }
+            const V3 d = v3(rd.x, rd.y, rd.z);
             Hit best;
             best.t = 10000.0f;  // rgen:45: tmax
             best.u = best.v = 0.0f;
@@ -1267,9 +1277,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
          if (mine) {
             const uint32_t pos = s * ps.shard_cap + slot;
             ps.queue[0][pos] = id;
-            st_rec(rec_quad(ps.set[0], pos, REC_ORIGIN), s_o);
+            if (!fp.primary_implicit) st_rec(rec_quad(ps.set[0], pos, REC_ORIGIN), s_o);
             st_rec(rec_quad(ps.set[0], pos, REC_DIR), s_d);
-            st_rec(rec_quad(ps.set[0], pos, REC_THR), make_float4(1.0f, 1.0f, 1.0f, 0.0f));  // throughput = 1 (rgen:39)
+            if (!fp.primary_implicit) st_rec(rec_quad(ps.set[0], pos, REC_THR), make_float4(1.0f, 1.0f, 1.0f, 0.0f));  // throughput = 1 (rgen:39)
          }
          todo &= ~__ballot(mine);
       }
@@ -1287,7 +1297,14 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
 // goes to the per-id array, with the raygen's RNG word (the frame's next sample starts from it, rgen:28-31)
 __device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const PathState& ps, uint32_t pos, uint32_t id, uint32_t bounce) {
    const PathRecs rec = ps.set[bounce & 1];
-   const float4 ro = ld_rec(rec_quad(rec, pos, REC_ORIGIN));
+   const bool implicit = bounce == 0 && fp.primary_implicit;  // origin and throughput of a primary ray: not stored (FrameParams)
+   float4 ro;
+   if (implicit) {
+      const float4 rd0 = ld_rec(rec_quad(rec, pos, REC_DIR));
+      const V3 o = primary_origin(fp);
+      ro = make_float4(o.x, o.y, o.z, __uint_as_float(primary_rng(__float_as_uint(rd0.w))));
+   } else
+      ro = ld_rec(rec_quad(rec, pos, REC_ORIGIN));
    V3 sky_color = v3(0.0f, 0.0f, 0.0f);
    if (fp.furnace) {
       sky_color = v3(1.0f, 1.0f, 1.0f);  // rmiss:12 with FURNACE_TEST defined: the #ifndef block (rmiss:14-28) is compiled out
@@ -1296,7 +1313,8 @@ __device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const Pat
       V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
       sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
    }
-   const float4 thr = ld_rec(rec_quad(rec, pos, REC_THR));  // 1 at bounce 0 (k_generate)
+   float4 thr = make_float4(1.0f, 1.0f, 1.0f, 0.0f);  // rgen:39
+   if (!implicit) thr = ld_rec(rec_quad(rec, pos, REC_THR));
    float4 rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
    if (bounce != 0) rad = ld_rec(rec_quad(rec, pos, REC_RAD));
    V3 t = v3(thr.x, thr.y, thr.z) * sky_color;                               // rgen:48
@@ -1421,9 +1439,17 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          // classification below already read): one round trip for all of them, then one for the texels.
          // The path's state: four planes at its queue position (the RNG words ride in the rays' w components); the lanes of a wave
          // hold hits of nearly consecutive positions, so these are nearly contiguous reads
-         float4 ro = ld_rec(rec_quad(cur, seg + pos, REC_ORIGIN)), rd = ld_rec(rec_quad(cur, seg + pos, REC_DIR));
+         float4 rd = ld_rec(rec_quad(cur, seg + pos, REC_DIR));
+         float4 ro, thr4;
+         if (bounce == 0 && fp.primary_implicit) {  // a primary ray's origin and throughput are not stored (FrameParams::primary_implicit)
+            const V3 o = primary_origin(fp);
+            ro = make_float4(o.x, o.y, o.z, __uint_as_float(primary_rng(__float_as_uint(rd.w))));
+            thr4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+         } else {
+            ro = ld_rec(rec_quad(cur, seg + pos, REC_ORIGIN));
+            thr4 = ld_rec(rec_quad(cur, seg + pos, REC_THR));
+         }
          uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
-         float4 thr4 = ld_rec(rec_quad(cur, seg + pos, REC_THR));
          float4 rad4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // radiance so far: zero before the first bounce (not materialised)
          if (bounce != 0) rad4 = ld_rec(rec_quad(cur, seg + pos, REC_RAD));  // (the compiler waits for it on the spot: measured level with an unconditional read, which costs 16 bytes per hit at bounce 0)
          const V3 ray_dir = v3(rd.x, rd.y, rd.z);
@@ -1563,7 +1589,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
       if (scattered) {
          st_stream(q_next + slot, id);
          st_rec(rec_quad(nxt, seg + slot, REC_ORIGIN), n_o);
-         st_rec(rec_quad(nxt, seg + slot, REC_DIR), n_d);
+         if (bounce + 1 < fp.num_bounces) st_rec(rec_quad(nxt, seg + slot, REC_DIR), n_d);  // (after the last bounce no ray is traced: k_flush_survivors reads radiance and the raygen RNG word)
          st_rec(rec_quad(nxt, seg + slot, REC_THR), n_t);
          st_rec(rec_quad(nxt, seg + slot, REC_RAD), n_r);
       }

@@ -161,3 +161,25 @@ def test_refused_when_the_lists_are_too_long(atrium):
         loop.frames(9, rr.PASS_ALL)
     assert grid.get_stats().camera_grid_cells == 0
     same(grid, tree, "refused grid")
+
+
+@pytest.mark.parametrize("max_walk", [48, 2])
+def test_primary_rays_without_stored_origin_and_throughput(atrium, max_walk):
+    """option primary_implicit (default 1: with the camera grid and one sample per frame the origin and throughput planes of bounce 0
+    are neither written nor read - the camera position, 1.0 and the RNG word recomputed from the payload seed stand in) against the
+    stored form and against the tree walk, also with most rays handed to the tree (their origins are written after all)"""
+    W, H = 160, 90
+    out = []
+    atrium.camera = Camera(CAMERAS[1][0], CAMERAS[1][1], 60.0, W / H, 0.01, 1000.0)  # (the fixture is shared: the test before leaves a camera whose grid is refused)
+    for opts in ({}, {"primary_implicit": 0}, {"camera_grid": 0}):
+        r = atrium.upload(rr.Renderer(W, H))
+        r.set_option("camera_grid_max_walk", max_walk)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        loop = rr.FrameLoop(r, atrium.make_view(W, H, sky_enabled=1, sun_shadow_enabled=1, lights_enabled=1))
+        loop.frames(9, rr.PASS_ALL)
+        loop.frame(rr.PASS_ALL)
+        out.append((r.read_accumulation().view(np.uint32), list(r.get_stats().rays), r.get_stats().camera_grid_cells))
+    assert out[0][2] == W * H and out[1][2] == W * H and out[2][2] == 0
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0])
+    assert out[0][1] == out[1][1] == out[2][1]
