@@ -324,8 +324,8 @@ int uh_reset_stats(uh_ctx* ctx);
  * "camera_grid" (0/1, default 1: the primary rays of a camera that has been the same for two consecutive frame calls - or for a
  * call of 8 or more frames - go through a per-camera grid of packet lists, one cell per pixel, instead of the tree; same hit records
  * bit for bit), "camera_grid_max_walk", "camera_grid_max_mean_list_x10",
- * "primary_implicit" (0/1, default 1: with that grid in use and one sample per frame, the origin and throughput of the primary rays are
- * not stored - every one of them leaves the camera position with throughput 1; same images),
+ * "primary_implicit" (0/1, default 1: with that grid in use and one sample per frame, the primary rays' state is not stored - the
+ * kernels of the first bounce compute it from the path id; same images),
  * "sun_grid" (0/1, default 1: sun shadow rays through a per-direction visibility grid once the direction has settled; same
  * images), "sun_grid_build" (0/1, default 1: that grid is built on the device in a few milliseconds; 0: by the host builder, the
  * reference implementation, in 130-550 ms), "sun_grid_async" (0/1, host builder only: the grid is built on a host thread and no frame

@@ -1552,7 +1552,7 @@ static int batch_begin(uh_ctx* c, const UhViewUniformData* view, uint32_t pass_m
    const bool primary_rays = ((pass_mask & UH_PASS_REFERENCE_PT) && fp.num_bounces > 0 && fp.samples_per_frame > 0) || (pass_mask & UH_PASS_GBUFFER);
    if (primary_rays)
       if (int st = ensure_camera_grid(c, fp, batch)) return st;
-   // with the camera grid nothing but bounce 0's own kernels reads a primary ray's origin and throughput: they are not stored
+   // with the camera grid nothing but bounce 0's own kernels reads a primary ray's state: it is not stored
    fp.primary_implicit = (c->primary_implicit && c->cam_this_frame && fp.samples_per_frame == 1) ? 1u : 0u;
    bs.pass_mask = pass_mask;
    bs.batch = batch;
@@ -2070,8 +2070,8 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->sun_device_build = value != 0;
       c->sun_attempted = false;
    } else if (n == "primary_implicit") {
-      // 1 (default): with the camera grid in use and one sample per frame, the origin and throughput planes of bounce 0 are neither
-      // written nor read (every primary ray leaves the camera with throughput 1); 0: as stored by k_generate. Same images.
+      // 1 (default): with the camera grid in use and one sample per frame, the state planes of bounce 0 are neither written nor
+      // read (the kernels of bounce 0 compute a primary ray from its path id); 0: as stored by k_generate. Same images.
       c->primary_implicit = value != 0;
    } else if (n == "sun_grid_coarse") {
       // the coarse cover (sun_grid.h): one depth per block of 2^value x 2^value cells, asked before the cell's own record; 0: none

@@ -332,16 +332,19 @@ __device__ __forceinline__ void primary_ray(const FrameParams& fp, uint32_t px, 
    dir = v3(d4.x, d4.y, d4.z);
 }
 
-// FrameParams::primary_implicit: what k_generate would have stored for a path of bounce 0
-__device__ __forceinline__ V3 primary_origin(const FrameParams& fp) {  // primary_ray's `org`, the same expression
-   float4 o4 = mat4_mul(fp.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
-   return v3(o4.x, o4.y, o4.z);
-}
-__device__ __forceinline__ uint32_t primary_rng(uint32_t seed) {  // rgen:30-31: the raygen RNG word after the two jitter draws
-   uint32_t r = seed;
-   (void)random_float(r);
-   (void)random_float(r);
-   return r;
+// the whole state k_generate gives a path of a frame's first sample, from its id (rgen:24-38): origin | raygen RNG word, direction |
+// payload seed - the same functions on the same inputs, so the words are those k_generate would have stored
+__device__ __forceinline__ void primary_state(const FrameParams& fp, uint32_t id, float4& ro, float4& rd) {
+   const uint32_t f = id / fp.n_owned, k = id - f * fp.n_owned;
+   const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
+   const uint32_t px = pix % fp.W, py = pix / fp.W;
+   uint32_t rng = init_rng(px, py, fp.W, fp.frame_numbers[f]);                                 // rgen:24
+   const uint32_t seed = rng;                                                                  // rgen:30
+   const float jx = random_float(rng), jy = random_float(rng);                                 // rgen:31
+   V3 o, d;
+   primary_ray(fp, px, py, jx, jy, o, d);
+   ro = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+   rd = make_float4(d.x, d.y, d.z, __uint_as_float(seed));
 }
 
 __device__ __forceinline__ bool owns_pixel(const FrameParams& fp, uint32_t x, uint32_t y) {

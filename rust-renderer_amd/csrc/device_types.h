@@ -118,9 +118,9 @@ struct FrameParams {
    uint32_t W, H, frame_number;
    uint32_t samples_per_frame, total_samples, num_bounces, accumulation_limit;
    uint32_t sky_enabled, sun_shadow_enabled, lights_enabled, use_ris, full_frame_restir;
-   // option "primary_implicit" (camera grid in use, one sample per frame): the origin and throughput planes of bounce 0 are not
-   // materialised - every primary ray leaves the camera position (primary_origin) with throughput 1, and the raygen RNG word is
-   // the payload seed advanced by the two jitter draws (primary_rng): 32 bytes less written and 48 less read per path
+   // option "primary_implicit" (camera grid in use, one sample per frame): the state planes of bounce 0 are not materialised -
+   // k_generate only fills the ray queue with path ids, and every kernel of bounce 0 computes a path's origin, direction,
+   // throughput (1) and RNG words from its id (device_math.h primary_state): 48 bytes less written and 96 less read per path
    uint32_t primary_implicit;
    uint32_t furnace;  // option "furnace": the reference's FURNACE_TEST build of the miss shader (reference.rmiss:14-28): a miss returns white
    uint32_t num_lights_used;  // min(view.num_lights, view.max_num_lights_used)

@@ -1147,19 +1147,21 @@ __global__ __launch_bounds__(kBlock) void k_trace_camera_grid(SceneDev sc, Frame
          uint32_t e = g.cell_start[cell];  // the camera grid's cell records are plain offsets (no cover depths)
          const uint32_t end = g.cell_start[cell + 1];
          defer = end - e > g.max_walk;
-         if (defer && fp.primary_implicit) {  // the tree walk reads its rays' origins from the plane: this one's is written after all
-            const float4 rd = ld_rec(rec_quad(rec, seg + i, REC_DIR));
-            const V3 o = primary_origin(fp);
-            st_rec(rec_quad(rec, seg + i, REC_ORIGIN), make_float4(o.x, o.y, o.z, __uint_as_float(primary_rng(__float_as_uint(rd.w)))));
+         if (defer && fp.primary_implicit) {  // the tree walk reads its rays from the planes: this one's is written after all
+            float4 ro, rd;
+            primary_state(fp, id, ro, rd);
+            st_rec(rec_quad(rec, seg + i, REC_ORIGIN), ro);
+            st_rec(rec_quad(rec, seg + i, REC_DIR), rd);
          }
          if (!defer) {
-            const float4 rd = ld_rec(rec_quad(rec, seg + i, REC_DIR));
-            V3 o = primary_origin(fp);
-            if (!fp.primary_implicit) {
-               const float4 ro = ld_rec(rec_quad(rec, seg + i, REC_ORIGIN));
-               o = v3(ro.x, ro.y, ro.z);
+            float4 ro, rd;
+            if (fp.primary_implicit)
+               primary_state(fp, id, ro, rd);
+            else {
+               ro = ld_rec(rec_quad(rec, seg + i, REC_ORIGIN));
+               rd = ld_rec(rec_quad(rec, seg + i, REC_DIR));
             }
-            const V3 d = v3(rd.x, rd.y, rd.z);
+            const V3 o = v3(ro.x, ro.y, ro.z), d = v3(rd.x, rd.y, rd.z);
             Hit best;
             best.t = 10000.0f;  // rgen:45: tmax
             best.u = best.v = 0.0f;
@@ -1249,12 +1251,12 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
       bool own = q < n;
       uint32_t id = 0;
       float4 s_o = make_float4(0, 0, 0, 0), s_d = make_float4(0, 0, 0, 0);
-      if (own) {
+      if (own) id = q;
+      if (own && !fp.primary_implicit) {  // (primary_implicit: the kernels of bounce 0 compute the state from the id)
          // path id = frame of the batch x owned pixels + index into the rank's owned-pixel list: dense, so a rank's wavefront
          // carries as many frames as its share of the frame allows (on one GPU: frame x W x H + pixel)
          const uint32_t f = q / fp.n_owned, k = q - f * fp.n_owned;
          const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
-         id = q;
          uint32_t px = pix % fp.W, py = pix / fp.W;
          uint32_t rng = sample == 0 ? init_rng(px, py, fp.W, fp.frame_numbers[f]) : __float_as_uint(ps.radf[id].w);  // rgen:24; later samples: where the last one left it
          uint32_t seed = rng;                                                                   // rgen:30
@@ -1277,9 +1279,11 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
          if (mine) {
             const uint32_t pos = s * ps.shard_cap + slot;
             ps.queue[0][pos] = id;
-            if (!fp.primary_implicit) st_rec(rec_quad(ps.set[0], pos, REC_ORIGIN), s_o);
-            st_rec(rec_quad(ps.set[0], pos, REC_DIR), s_d);
-            if (!fp.primary_implicit) st_rec(rec_quad(ps.set[0], pos, REC_THR), make_float4(1.0f, 1.0f, 1.0f, 0.0f));  // throughput = 1 (rgen:39)
+            if (!fp.primary_implicit) {
+               st_rec(rec_quad(ps.set[0], pos, REC_ORIGIN), s_o);
+               st_rec(rec_quad(ps.set[0], pos, REC_DIR), s_d);
+               st_rec(rec_quad(ps.set[0], pos, REC_THR), make_float4(1.0f, 1.0f, 1.0f, 0.0f));  // throughput = 1 (rgen:39)
+            }
          }
          todo &= ~__ballot(mine);
       }
@@ -1298,18 +1302,16 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, PathState p
 __device__ __forceinline__ void shade_miss_path(const FrameParams& fp, const PathState& ps, uint32_t pos, uint32_t id, uint32_t bounce) {
    const PathRecs rec = ps.set[bounce & 1];
    const bool implicit = bounce == 0 && fp.primary_implicit;  // origin and throughput of a primary ray: not stored (FrameParams)
-   float4 ro;
-   if (implicit) {
-      const float4 rd0 = ld_rec(rec_quad(rec, pos, REC_DIR));
-      const V3 o = primary_origin(fp);
-      ro = make_float4(o.x, o.y, o.z, __uint_as_float(primary_rng(__float_as_uint(rd0.w))));
-   } else
+   float4 ro, rd_implicit = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+   if (implicit)
+      primary_state(fp, id, ro, rd_implicit);
+   else
       ro = ld_rec(rec_quad(rec, pos, REC_ORIGIN));
    V3 sky_color = v3(0.0f, 0.0f, 0.0f);
    if (fp.furnace) {
       sky_color = v3(1.0f, 1.0f, 1.0f);  // rmiss:12 with FURNACE_TEST defined: the #ifndef block (rmiss:14-28) is compiled out
    } else if (fp.sky_enabled == 1) {
-      const float4 rd = ld_rec(rec_quad(rec, pos, REC_DIR));
+      const float4 rd = implicit ? rd_implicit : ld_rec(rec_quad(rec, pos, REC_DIR));
       V3 c = sky::integrate_scattering(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 999999999.0f, v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]));
       sky_color = v3(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f));  // rmiss:22
    }
@@ -1439,14 +1441,13 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          // classification below already read): one round trip for all of them, then one for the texels.
          // The path's state: four planes at its queue position (the RNG words ride in the rays' w components); the lanes of a wave
          // hold hits of nearly consecutive positions, so these are nearly contiguous reads
-         float4 rd = ld_rec(rec_quad(cur, seg + pos, REC_DIR));
-         float4 ro, thr4;
-         if (bounce == 0 && fp.primary_implicit) {  // a primary ray's origin and throughput are not stored (FrameParams::primary_implicit)
-            const V3 o = primary_origin(fp);
-            ro = make_float4(o.x, o.y, o.z, __uint_as_float(primary_rng(__float_as_uint(rd.w))));
+         float4 ro, rd, thr4;
+         if (bounce == 0 && fp.primary_implicit) {  // a primary ray's state is not stored (FrameParams::primary_implicit): from its id
+            primary_state(fp, id, ro, rd);
             thr4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
          } else {
             ro = ld_rec(rec_quad(cur, seg + pos, REC_ORIGIN));
+            rd = ld_rec(rec_quad(cur, seg + pos, REC_DIR));
             thr4 = ld_rec(rec_quad(cur, seg + pos, REC_THR));
          }
          uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
