@@ -334,7 +334,8 @@ def test_host_builder_is_still_selectable(atrium):
     assert list(dev.get_stats().rays) == list(host.get_stats().rays) == list(tree.get_stats().rays)
 
 
-@pytest.mark.parametrize("options", [{"sun_grid_inline": 0}, {"sun_grid_fused": 1}, {"sun_grid_fused": 1, "sun_grid_inline": 0}])
+@pytest.mark.parametrize("options", [{"sun_grid_inline": 0}, {"sun_grid_fused": 1}, {"sun_grid_fused": 1, "sun_grid_inline": 0}, {"sun_grid_coarse": 0}, {"sun_grid_coarse": 4, "sun_grid_fused": 1},
+                                     {"sun_grid_inline_max_mb": 1}, {"sun_grid_density": 24, "sun_grid_max_walk": 8}])
 @pytest.mark.parametrize("sun", [SUNS[0], SUNS[2], SUNS[8]])
 def test_round4_variants_of_the_grid_walk_change_nothing(atrium, sun, options):
     """options sun_grid_inline (the lists as 64-byte records that carry their packet), sun_grid_fused (k_shade_hit looks the cell and
@@ -352,8 +353,9 @@ def test_round4_variants_of_the_grid_walk_change_nothing(atrium, sun, options):
     assert s0.sun_grid_cells > 0 and s1.sun_grid_cells > 0 and s2.sun_grid_cells == 0
     assert np.array_equal(a0, a1) and np.array_equal(a0, a2)
     assert list(s0.rays) == list(s1.rays) == list(s2.rays)
-    # the same cells looked up, the same packets tested, the same rays handed to the tree, the same rays answered by the cover depth
-    assert (s0.shadow_nodes_visited, s0.shadow_tris_tested, s0.sun_tree_rays, s0.sun_covered_rays) == (s1.shadow_nodes_visited, s1.shadow_tris_tested, s1.sun_tree_rays, s1.sun_covered_rays)
+    if "sun_grid_density" not in options:  # (another raster: other lists)
+        # the same cells looked up, the same packets tested, the same rays handed to the tree, the same rays answered by a cover depth
+        assert (s0.shadow_nodes_visited, s0.shadow_tris_tested, s0.sun_tree_rays, s0.sun_covered_rays) == (s1.shadow_nodes_visited, s1.shadow_tris_tested, s1.sun_tree_rays, s1.sun_covered_rays)
 
 
 def test_round4_variants_with_lights_and_batches(atrium):
