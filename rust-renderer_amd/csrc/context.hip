@@ -186,6 +186,7 @@ struct uh_ctx {
    uint32_t W = 0, H = 0;
    uint32_t num_cus = 256;
    uint32_t closest_blocks_per_cu = 6, shadow_blocks_per_cu = 5;  // what the refill kernels' LDS (stacks + ray pool) admits
+   bool sun_leftover_batch = false;  // option "sun_leftover_batch"
    uint32_t miss_blocks_per_cu = 8;  // 2 / 4 / 6 / 8: 7,599 / 7,613-7,656 / 7,699 / 7,676-7,678 Mrays/s
    std::string err;
 
@@ -366,7 +367,7 @@ void set_transform(HostMesh& m, const float* w) {
 
 LaunchCfg cfg(uh_ctx* c) {
    return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->closest_variant, c->shadow_variant, c->raw_visit_counts,
-                    c->primary_tiles, c->miss_blocks_per_cu};
+                    c->primary_tiles, c->miss_blocks_per_cu, c->sun_leftover_batch};
 }
 
 void begin_timed(uh_ctx* c, int kind, hipStream_t stream = nullptr) {
@@ -2141,6 +2142,8 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 0 || value > 1) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0 (batch kernels) or 1 (refill kernels)");
       if (n != "shadow_variant") c->closest_variant = value;
       if (n != "closest_variant") c->shadow_variant = value;
+   } else if (n == "sun_leftover_batch") {
+      c->sun_leftover_batch = value != 0;  // the sun rays the grid hands to the tree walk the tree in the batch kernel (1) or the refill kernel (0)
    } else if (n == "miss_blocks_per_cu") {
       if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, "miss_blocks_per_cu must be 1..8");
       c->miss_blocks_per_cu = (uint32_t)value;

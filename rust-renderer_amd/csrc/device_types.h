@@ -209,6 +209,7 @@ struct LaunchCfg {
    bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
    bool primary_tiles = false;     // the G-buffer cast: one wave per 8 x 8 pixel tile (k_trace_closest_tiles)
    uint32_t miss_blocks_per_cu = 8; // k_shade_miss (dense miss queue, VALU-bound sky integral): option "miss_blocks_per_cu"
+   bool sun_leftover_batch = false; // the sun rays the grid hands to the tree: batch kernel instead of the refill kernel (option "sun_leftover_batch")
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);

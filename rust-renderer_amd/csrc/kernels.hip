@@ -800,14 +800,15 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
 // batch form (option shadow_variant = 0), the baseline of the refill kernel
 template <bool COUNT, bool LIGHT>
 __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_shadow_batch(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats,
-                                                                                                     uint32_t bounce, uint32_t cursor_slot) {
+                                                                                                     uint32_t bounce, uint32_t cursor_slot, bool leftovers = false) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    const uint32_t lane = lane_id();
    uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
-   const uint32_t* __restrict__ queue = ps.queue[2] + seg;  // light rays: positions in the next bounce's ray queue; sun rays: every position
-   const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   // light rays: positions in the next bounce's ray queue; sun rays: every position - or, leftovers, the positions the grid kernel listed
+   const uint32_t* __restrict__ queue = ps.queue[leftovers ? 3 : 2] + seg;
+   const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : leftovers ? ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    const PathRecs rec = ps.set[(bounce + 1) & 1];
    uint32_t n_nodes = 0, n_tris = 0;
@@ -816,13 +817,16 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
       if (base >= count) break;
       uint32_t i = base + lane;
       if (i < count) {
-         const uint32_t pos = seg + (LIGHT ? queue[i] : i);
+         const uint32_t pos = seg + ((LIGHT || leftovers) ? queue[i] : i);
          const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, *rec_quad(rec, pos, REC_ORIGIN), *rec_quad(rec, pos, REC_THR), *rec_quad(rec, pos, REC_RAD));
          Hit h;
          if (!traverse<true, COUNT>(sc, xyz(s.ro), xyz(s.rd), s.ro.w, s.rd.w, s.tlimit, h, lds_col, n_nodes, n_tris)) *rec_quad(rec, pos, REC_RAD) = s.lit;
       }
    }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
+   if (sx.lb == 0 && threadIdx.x == 0) {
+      if (!leftovers) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
+      else if (count) atomicAdd(&stats->sun_tree_rays, (unsigned long long)count);  // counted as sun rays by the grid kernel already
+   }
    if (COUNT) {
       atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
       atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
@@ -2055,7 +2059,14 @@ void launch_flush_survivors(const LaunchCfg& c, const FrameParams& fp, const Pat
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
                          uint32_t bounce, uint32_t cursor_slot, bool light, bool sun_leftovers) {
-   if (sun_leftovers) {  // what the sun grid handed to the tree (queue 3): always the refill kernel
+   if (sun_leftovers && c.sun_leftover_batch) {  // what the sun grid handed to the tree (queue 3), through the batch kernel
+      if (c.count_visits)
+         k_trace_shadow_batch<true, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, true);
+      else
+         k_trace_shadow_batch<false, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, true);
+      return;
+   }
+   if (sun_leftovers) {  // ... or the refill kernel
       if (c.count_visits)
          k_trace_shadow<true, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, true);
       else
