@@ -185,7 +185,11 @@ struct uh_ctx {
    bool overlap_miss = true, overlap_shadow = true;
    uint32_t W = 0, H = 0;
    uint32_t num_cus = 256;
-   uint32_t closest_blocks_per_cu = 6, shadow_blocks_per_cu = 5;  // what the refill kernels' LDS (stacks + ray pool) admits
+   // persistent grids of the traversal kernels, blocks per CU (the refill kernels' LDS - stacks + ray pool - admits 6 / 5). Round 4,
+   // closest / shadow = 6/5, 5/5, 5/4, 4/4, 4/3, 3/4: a 16-frame wavefront 1.774 / 1.777 / 1.764 / 1.780 / 1.773 / 1.799 ms per frame,
+   // one frame per call with a wait after it 2.95 / 2.88 / 2.88 / 2.84 / 2.85 / 2.89 ms: fewer waves finish a small launch's tail sooner
+   uint32_t closest_blocks_per_cu = 5, shadow_blocks_per_cu = 5;  // (config 2, whose light shadow rays are a third of the frame: 6/5, 5/5, 5/4, 6/4 = 8,230 / 8,266 / 7,997 / 7,950 Mrays/s)
+   uint32_t single_frame_blocks_per_cu = 4;  // option "single_frame_blocks_per_cu": the cap on both for a wavefront of one frame
    bool sun_leftover_batch = false;  // option "sun_leftover_batch"
    uint32_t miss_blocks_per_cu = 8;  // 2 / 4 / 6 / 8: 7,599 / 7,613-7,656 / 7,699 / 7,676-7,678 Mrays/s
    std::string err;
@@ -1399,6 +1403,10 @@ static int ensure_camera_grid(uh_ctx* c, const FrameParams& fp, uint32_t batch) 
 static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
    LaunchCfg lc = cfg(c);
    lc.stream = s.stream;
+   if (fp.batch_frames == 1) {  // a lone frame's launches are small: fewer persistent waves reach the end of their tails sooner
+      lc.closest_blocks_per_cu = std::min(lc.closest_blocks_per_cu, c->single_frame_blocks_per_cu);
+      lc.shadow_blocks_per_cu = std::min(lc.shadow_blocks_per_cu, c->single_frame_blocks_per_cu);
+   }
    Control* ctl = s.control.p;
    DeviceStats* st = c->dstats.p;
    // reference.rgen:28: samples of one frame run back to back (the raygen RNG state carries over)
@@ -2142,6 +2150,9 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 0 || value > 1) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0 (batch kernels) or 1 (refill kernels)");
       if (n != "shadow_variant") c->closest_variant = value;
       if (n != "closest_variant") c->shadow_variant = value;
+   } else if (n == "single_frame_blocks_per_cu") {
+      if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, "single_frame_blocks_per_cu must be 1..8");
+      c->single_frame_blocks_per_cu = (uint32_t)value;
    } else if (n == "sun_leftover_batch") {
       c->sun_leftover_batch = value != 0;  // the sun rays the grid hands to the tree walk the tree in the batch kernel (1) or the refill kernel (0)
    } else if (n == "miss_blocks_per_cu") {
