@@ -276,6 +276,7 @@ struct uh_ctx {
    SunGridLimits sun_limits;
    std::string sun_why;
    float sun_build_ms = 0.0f, sun_mean_list = 0.0f;
+   float sun_fallback_area = 1.0f;  // share of the scene's surface whose cell hands its sun rays to the tree (the builders' figure)
    uint32_t sun_cells = 0, sun_entries = 0, sun_max_list = 0;
    bool sun_this_frame = false;     // set by render_batch for the frame being enqueued
    bool sun_async = false;          // option "sun_grid_async": build on a host thread, walk the tree until it is done (host builder only)
@@ -1129,6 +1130,7 @@ static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float 
    c->sun_why = g.why_not;
    c->sun_mean_list = (float)g.mean_list;
    c->sun_max_list = g.max_list;
+   c->sun_fallback_area = (float)g.fallback_area;
    c->sun_cells = c->sun_entries = 0;
    if (ok) {
       // per cell two words: offset into the entries | cover depth (sun_grid.h)
@@ -1175,6 +1177,7 @@ static int adopt_sun_grid_device(uh_ctx* c, SunGridDevice& g, bool ok, const flo
    c->sun_why = g.why_not;
    c->sun_mean_list = (float)g.mean_list;
    c->sun_max_list = g.max_list;
+   c->sun_fallback_area = (float)g.fallback_area;
    c->sun_cells = c->sun_entries = 0;
    c->d_sun_cells.release();
    c->d_sun_entries.release();
@@ -1406,6 +1409,9 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
    if (fp.batch_frames == 1) {  // a lone frame's launches are small: fewer persistent waves reach the end of their tails sooner
       lc.closest_blocks_per_cu = std::min(lc.closest_blocks_per_cu, c->single_frame_blocks_per_cu);
       lc.shadow_blocks_per_cu = std::min(lc.shadow_blocks_per_cu, c->single_frame_blocks_per_cu);
+      // ... and a handful of sun rays handed to the tree are cheaper without the refill kernel's pool (many are not: config 3's grid
+      // hands 17 % of the surface over, config 1's 4 %)
+      if (c->sun_fallback_area < 0.08f) lc.sun_leftover_batch = true;
    }
    Control* ctl = s.control.p;
    DeviceStats* st = c->dstats.p;
