@@ -323,7 +323,7 @@ int uh_reset_stats(uh_ctx* ctx);
  * the "frames_in_flight" slots; same image bit for bit; measured slower than the whole wavefront on MI355X, kept for experiments),
  * "camera_grid" (0/1, default 1: the primary rays of a camera that has been the same for two consecutive frame calls - or for a
  * call of 8 or more frames - go through a per-camera grid of packet lists, one cell per pixel, instead of the tree; same hit records
- * bit for bit), "camera_grid_max_walk", "camera_grid_max_mean_list_x10",
+ * bit for bit), "camera_grid_max_walk", "camera_grid_walk_whole", "camera_grid_max_mean_list_x10",
  * "primary_implicit" (0/1, default 1: with that grid in use and one sample per frame, the primary rays' state is not stored - the
  * kernels of the first bounce compute it from the path id; same images),
  * "sun_grid" (0/1, default 1: sun shadow rays through a per-direction visibility grid once the direction has settled; same

@@ -189,6 +189,7 @@ struct uh_ctx {
    // closest / shadow = 6/5, 5/5, 5/4, 4/4, 4/3, 3/4: a 16-frame wavefront 1.774 / 1.777 / 1.764 / 1.780 / 1.773 / 1.799 ms per frame,
    // one frame per call with a wait after it 2.95 / 2.88 / 2.88 / 2.84 / 2.85 / 2.89 ms: fewer waves finish a small launch's tail sooner
    uint32_t closest_blocks_per_cu = 5, shadow_blocks_per_cu = 5;  // (config 2, whose light shadow rays are a third of the frame: 6/5, 5/5, 5/4, 6/4 = 8,230 / 8,266 / 7,997 / 7,950 Mrays/s)
+   uint32_t cam_walk_whole = 512;     // option "camera_grid_walk_whole" (sun_grid.h SunGridDev::walk_whole)
    uint32_t single_frame_blocks_per_cu = 4;  // option "single_frame_blocks_per_cu": the cap on both for a wavefront of one frame
    bool sun_leftover_batch = false;  // option "sun_leftover_batch"
    uint32_t miss_blocks_per_cu = 8;  // 2 / 4 / 6 / 8: 7,599 / 7,613-7,656 / 7,699 / 7,676-7,678 Mrays/s
@@ -299,7 +300,7 @@ struct uh_ctx {
    SunGridLimits cam_limits;
    std::string cam_why;
    float cam_build_ms = 0.0f, cam_mean_list = 0.0f;
-   uint32_t cam_cells = 0, cam_entries = 0, cam_max_list = 0;
+   uint32_t cam_cells = 0, cam_entries = 0, cam_max_list = 0, cam_max_list_interior = 0;
    bool cam_this_frame = false;
 
    // One frame per call (a moving camera: uh_render_frame) spread over several slots: the frame's pixels are split, by tiles, into
@@ -1372,6 +1373,7 @@ static int ensure_camera_grid(uh_ctx* c, const FrameParams& fp, uint32_t batch) 
    c->cam_why = g.why_not;
    c->cam_mean_list = (float)g.mean_list;
    c->cam_max_list = g.max_list;
+   c->cam_max_list_interior = g.max_list_interior;
    c->cam_cells = c->cam_entries = 0;
    c->d_cam_cells.release();
    c->d_cam_entries.release();
@@ -1390,6 +1392,7 @@ static int ensure_camera_grid(uh_ctx* c, const FrameParams& fp, uint32_t batch) 
       d.nx = g.params.nx;
       d.ny = g.params.ny;
       d.max_walk = c->cam_limits.max_walk;
+      d.walk_whole = c->cam_walk_whole;
       d.cell_start = c->d_cam_cells.p;
       d.entries = c->d_cam_entries.p;
       c->cam_cells = c->W * c->H;
@@ -1423,7 +1426,8 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       for (uint32_t b = 0; b < fp.num_bounces; b++) {
          begin_timed(c, (b == 0 && c->cam_this_frame) ? 3 : 0, s.stream);
          if (b == 0 && c->cam_this_frame) {
-            launch_trace_camera_grid(lc, fp, c->scene, s.ps, ctl, st, slot, slot + 1, c->cam_dev);  // no tree walk for the primary rays of a camera at rest
+            // no tree walk for the primary rays of a camera at rest (and no launch for one when no pixel's list is too long for the grid kernel)
+            launch_trace_camera_grid(lc, fp, c->scene, s.ps, ctl, st, slot, slot + 1, c->cam_dev, c->cam_max_list_interior > std::max(c->cam_dev.walk_whole, c->cam_dev.max_walk));
             slot += 2;
          } else
             launch_trace_closest(lc, c->scene, s.ps, ctl, st, b, slot++, b == 0 ? UH_RAY_PRIMARY : UH_RAY_BOUNCE);
@@ -2156,6 +2160,12 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       if (value < 0 || value > 1) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0 (batch kernels) or 1 (refill kernels)");
       if (n != "shadow_variant") c->closest_variant = value;
       if (n != "closest_variant") c->shadow_variant = value;
+   } else if (n == "camera_grid_walk_whole") {
+      // the camera grid's kernel walks lists of up to this many packets whole (those beyond camera_grid_max_walk are not sorted: no early
+      // exit) instead of handing the ray to the tree; 0: every list beyond camera_grid_max_walk goes to the tree (round 4's first form)
+      if (value < 0 || value > 65536) return fail(c, UH_ERR_INVALID_ARGUMENT, "camera_grid_walk_whole must be 0..65536");
+      c->cam_walk_whole = (uint32_t)value;
+      c->cam_attempted = false;
    } else if (n == "single_frame_blocks_per_cu") {
       if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, "single_frame_blocks_per_cu must be 1..8");
       c->single_frame_blocks_per_cu = (uint32_t)value;

@@ -216,7 +216,7 @@ void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Con
 void launch_trace_closest(const LaunchCfg&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce, uint32_t cursor_slot,
                           int ray_kind);
 void launch_trace_camera_grid(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t cursor_slot_grid, uint32_t cursor_slot_tree,
-                              const SunGridDev&);
+                              const SunGridDev&, bool leftovers_possible = true);  // false: the grid's longest list is one its kernel walks itself - no tree-walk launch behind it
 void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, DeviceStats*, uint32_t bounce);
 // sun_grid != null (it must have a coarse cover): the kernel also asks the coarse cover for the scattered paths' sun rays and lists
 // those it does not answer in Q_SUN_GRID; launch_trace_sun_grid(.., fused = true) then serves that queue only

@@ -1150,7 +1150,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_camera_grid(SceneDev sc, Frame
          const uint32_t cell = (py + 1) * g.nx + (px + 1);
          uint32_t e = g.cell_start[cell];  // the camera grid's cell records are plain offsets (no cover depths)
          const uint32_t end = g.cell_start[cell + 1];
-         defer = end - e > g.max_walk;
+         const bool sorted = end - e <= g.max_walk;  // the builder sorts the lists a ray may walk with the early exit
+         defer = end - e > (g.walk_whole > g.max_walk ? g.walk_whole : g.max_walk);
          if (defer && fp.primary_implicit) {  // the tree walk reads its rays from the planes: this one's is written after all
             float4 ro, rd;
             primary_state(fp, id, ro, rd);
@@ -1175,7 +1176,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_camera_grid(SceneDev sc, Frame
             if (e < end) en = reinterpret_cast<const uint2*>(g.entries)[e];
             while (e < end) {
                // sorted by the bound, ascending: from here on no packet can be hit nearer than the best hit (nor tie with it)
-               if (-__uint_as_float(en.y) > best.t) break;
+               if (sorted && -__uint_as_float(en.y) > best.t) break;
                const uint32_t pk = en.x;
                uint2 nxt = make_uint2(0u, 0u);
                if (e + 1 < end) nxt = reinterpret_cast<const uint2*>(g.entries)[e + 1];  // in flight with the packet
@@ -2028,12 +2029,13 @@ static void launch_tiles(const LaunchCfg& c, const SceneDev& sc, const TileJob& 
 
 // bounce 0 of the path tracer through the camera grid, then the tree walk for the rays of the pixels with long lists
 void launch_trace_camera_grid(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t cursor_slot_grid,
-                              uint32_t cursor_slot_tree, const SunGridDev& g) {
+                              uint32_t cursor_slot_tree, const SunGridDev& g, bool leftovers_possible) {
    const dim3 grid = sharded_grid(c.num_cus * 8);
    if (c.count_visits)
       k_trace_camera_grid<true><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, cursor_slot_grid, g);
    else
       k_trace_camera_grid<false><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, cursor_slot_grid, g);
+   if (!leftovers_possible) return;  // no pixel lists more than the grid kernel walks itself
    const PathRecs& rec = ps.set[0];
    launch_closest(c, closest_grid(c), sc, true, rec_quad(rec, 0, REC_ORIGIN), rec_quad(rec, 0, REC_DIR), ps.hit, ps.shard_cap, ctl, stats, 0, cursor_slot_tree, UH_RAY_PRIMARY, 0, false,
                   ps.queue[3]);

@@ -45,6 +45,10 @@ struct SunGridDev {
    float u0, v0, inv_cell;  // cell (ix, iy) covers u0 + [ix, ix+1) / inv_cell, v0 + [iy, iy+1) / inv_cell
    uint32_t nx, ny;
    uint32_t max_walk;            // cells with a longer list, and the border cells, hand their rays to the tree walk
+   // camera grid only: a list longer than max_walk (hence not sorted) but no longer than this is walked WHOLE, without the early
+   // exit - the same hit, a few more tests - and only longer ones go to the tree; when the grid's longest list fits (the usual
+   // case: a few dozen pixels see more than max_walk packets) the tree-walk launch behind the grid kernel is not made at all
+   uint32_t walk_whole;
    const uint32_t* cell_start;   // nx * ny + 1 records of two words: offset into entries | cover depth (float bits): a ray of the
                                  // cell that starts below the cover depth is occluded - some packet spans the whole cell in front of it
    const SunGridEntry* entries;
@@ -126,6 +130,7 @@ struct SunGridDevice {
    uint64_t num_entries = 0;
    double mean_list = 0.0, fallback_area = 0.0, build_ms = 0.0;
    uint32_t max_list = 0;
+   uint32_t max_list_interior = 0;  // the longest list of a cell a ray can be in (the border ring left out)
    std::string why_not;  // non-empty: refused, as the host builder refuses
    void release();
 };

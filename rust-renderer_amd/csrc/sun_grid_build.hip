@@ -509,31 +509,40 @@ __global__ __launch_bounds__(kBlock) void k_sg_bin(const SgProj* __restrict__ pr
 }
 
 // occupied cells and the longest list, from the counts (before the scan turns them into offsets)
-__global__ __launch_bounds__(kBlock) void k_sg_occupancy(const uint32_t* __restrict__ counts, uint32_t ncell, unsigned long long* __restrict__ occupied, uint32_t* __restrict__ longest) {
-   uint32_t occ = 0, mx = 0;
+// longest[0]: over all cells; longest[1]: over the interior cells (the ones a ray can be in: the border ring takes what projects
+// beyond the raster), nx x ny being the raster
+__global__ __launch_bounds__(kBlock) void k_sg_occupancy(const uint32_t* __restrict__ counts, uint32_t ncell, uint32_t nx, uint32_t ny, unsigned long long* __restrict__ occupied,
+                                                         uint32_t* __restrict__ longest) {
+   uint32_t occ = 0, mx = 0, mi = 0;
    for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < ncell; c += gridDim.x * kBlock) {
       const uint32_t v = counts[c];
       occ += v ? 1u : 0u;
       mx = v > mx ? v : mx;
+      const uint32_t ix = c % nx, iy = c / nx;
+      if (ix != 0 && iy != 0 && ix + 1 != nx && iy + 1 != ny) mi = v > mi ? v : mi;
    }
    for (int o = 32; o > 0; o >>= 1) {
       occ += __shfl_xor(occ, o);
-      const uint32_t other = __shfl_xor(mx, o);
+      const uint32_t other = __shfl_xor(mx, o), other_i = __shfl_xor(mi, o);
       mx = other > mx ? other : mx;
+      mi = other_i > mi ? other_i : mi;
    }
-   __shared__ uint32_t s_occ[kBlock / 64], s_mx[kBlock / 64];
+   __shared__ uint32_t s_occ[kBlock / 64], s_mx[kBlock / 64], s_mi[kBlock / 64];
    if ((threadIdx.x & 63) == 0) {
       s_occ[threadIdx.x >> 6] = occ;
       s_mx[threadIdx.x >> 6] = mx;
+      s_mi[threadIdx.x >> 6] = mi;
    }
    __syncthreads();
    if (threadIdx.x == 0) {  // one atomic per block
       for (int v = 1; v < kBlock / 64; v++) {
          occ += s_occ[v];
          mx = s_mx[v] > mx ? s_mx[v] : mx;
+         mi = s_mi[v] > mi ? s_mi[v] : mi;
       }
       if (occ) atomicAdd(occupied, (unsigned long long)occ);
       if (mx) atomicMax(longest, mx);
+      if (mi) atomicMax(longest + 1, mi);
    }
 }
 
@@ -856,11 +865,11 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       SG_TRY(hipMemsetAsync(d_tot.p, 0, 2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t), stream));
       const uint32_t bin_blocks = std::min<uint32_t>((n + (kBlock / 64) - 1) / (kBlock / 64), 1u << 16);
       k_sg_bin<false><<<bin_blocks, kBlock, 0, stream>>>(pr, n, g, counts, nullptr, nullptr);
-      k_sg_occupancy<<<std::min<uint32_t>((uint32_t)((ncell + kBlock - 1) / kBlock), 1024), kBlock, 0, stream>>>(counts, (uint32_t)ncell, d_occupied, d_longest);
+      k_sg_occupancy<<<std::min<uint32_t>((uint32_t)((ncell + kBlock - 1) / kBlock), 1024), kBlock, 0, stream>>>(counts, (uint32_t)ncell, prm.nx, prm.ny, d_occupied, d_longest);
       device_exclusive_scan_u32(counts, (uint32_t)ncell + 1, (uint32_t*)d_chunks.p, d_total, stream);
       struct {
          unsigned long long total, occupied;
-         uint32_t longest, pad;
+         uint32_t longest, longest_interior;
       } h;
       SG_TRY(hipMemcpyAsync(&h, d_tot.p, sizeof(h), hipMemcpyDeviceToHost, stream));
       SG_TRY(hipStreamSynchronize(stream));
@@ -868,6 +877,7 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       total = h.total;
       occupied = h.occupied;
       longest = h.longest;
+      out.max_list_interior = h.longest_interior;
       if (total <= lim.max_entries && total < 0xfffffff0ull) break;
       if (attempt >= 10 || forced) return refuse("entry budget exceeded");
       cell *= 1.3;

@@ -123,17 +123,28 @@ def test_all_scene_kinds_and_odd_frames(cornell):
         same(grid, tree, scene.name)
 
 
-def test_long_lists_go_to_the_tree(atrium):
-    """max_walk = 1: nearly every pixel hands its ray to the tree walk (the listed-positions form of k_trace_closest); same image"""
+@pytest.mark.parametrize("walk_whole", [0, 3, 512])
+def test_long_lists_go_to_the_tree_or_are_walked_whole(atrium, walk_whole):
+    """max_walk = 1: nearly every pixel's list is too long for the sorted walk. With camera_grid_walk_whole = 0 those pixels hand
+    their rays to the tree walk (the listed-positions form of k_trace_closest), with 512 the grid kernel walks the unsorted lists
+    whole (and the launch of the tree walk behind it is not made), with 3 some of each; same image either way"""
     W, H = 128, 72
     grid, tree = pair(atrium, W, H)
     grid.set_option("camera_grid_max_walk", 1)
+    grid.set_option("camera_grid_walk_whole", walk_whole)
     for r in (grid, tree):
         loop = rr.FrameLoop(r, atrium.make_view(W, H))
         loop.frames(10, rr.PASS_ALL)
+        loop.frame(rr.PASS_ALL)
     g = grid.get_stats()
-    assert g.camera_grid_cells == W * H and g.camera_tree_rays > 0.5 * g.rays[rr.RAY_PRIMARY] * 0.5
-    same(grid, tree, "max_walk 1")
+    assert g.camera_grid_cells == W * H
+    if walk_whole == 0:
+        assert g.camera_tree_rays > 0.5 * g.rays[rr.RAY_PRIMARY] * 0.5
+    elif walk_whole == 512:
+        assert g.camera_tree_rays == 0
+    else:
+        assert 0 < g.camera_tree_rays < g.rays[rr.RAY_PRIMARY]
+    same(grid, tree, f"max_walk 1, walk_whole {walk_whole}")
 
 
 def test_tile_partition_and_samples_per_frame(atrium):
@@ -164,7 +175,7 @@ def test_refused_when_the_lists_are_too_long(atrium):
 
 
 @pytest.mark.parametrize("max_walk", [48, 2])
-def test_primary_rays_without_stored_origin_and_throughput(atrium, max_walk):
+def test_primary_rays_without_stored_state(atrium, max_walk):
     """option primary_implicit (default 1: with the camera grid and one sample per frame the origin and throughput planes of bounce 0
     are neither written nor read - the camera position, 1.0 and the RNG word recomputed from the payload seed stand in) against the
     stored form and against the tree walk, also with most rays handed to the tree (their origins are written after all)"""
@@ -174,6 +185,7 @@ def test_primary_rays_without_stored_origin_and_throughput(atrium, max_walk):
     for opts in ({}, {"primary_implicit": 0}, {"camera_grid": 0}):
         r = atrium.upload(rr.Renderer(W, H))
         r.set_option("camera_grid_max_walk", max_walk)
+        r.set_option("camera_grid_walk_whole", 0)  # (most rays handed to the tree at max_walk 2: their records are written after all)
         for k, v in opts.items():
             r.set_option(k, v)
         loop = rr.FrameLoop(r, atrium.make_view(W, H, sky_enabled=1, sun_shadow_enabled=1, lights_enabled=1))
