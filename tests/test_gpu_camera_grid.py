@@ -147,13 +147,17 @@ def test_long_lists_go_to_the_tree_or_are_walked_whole(atrium, walk_whole):
     same(grid, tree, f"max_walk 1, walk_whole {walk_whole}")
 
 
-def test_tile_partition_and_samples_per_frame(atrium):
+@pytest.mark.parametrize("spp", [3, 1])
+def test_tile_partition_and_samples_per_frame(atrium, spp):
+    """a rank's tiles of a partition (path ids dense over its owned pixels), several samples per frame (the raygen RNG word carried
+    from sample to sample) and one (primary_implicit: the primary rays' state computed from the path id through the owned-pixel list)"""
     W, H = 128, 96
     grid, tree = pair(atrium, W, H)
     for r in (grid, tree):
         r.set_tile_partition(1, 3, 32)
-        loop = rr.FrameLoop(r, atrium.make_view(W, H, samples_per_frame=3))
+        loop = rr.FrameLoop(r, atrium.make_view(W, H, samples_per_frame=spp))
         loop.frames(9, rr.PASS_REFERENCE_PT)
+        loop.frame(rr.PASS_REFERENCE_PT)
     assert grid.get_stats().camera_grid_cells == W * H
     a, b = grid.read_accumulation(), tree.read_accumulation()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
