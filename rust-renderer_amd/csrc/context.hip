@@ -1848,14 +1848,25 @@ int uh_synchronize(uh_ctx* c) {
    return sync_all(c);
 }
 
+// Device -> host, BLOCKING, behind a wait for the context's stream. The grid builders' small read-backs used to be asynchronous copies
+// into locals followed by a wait for their stream; with those made blocking, a heap corruption of the round-4 soaks (one in about
+// 300 contexts whose camera grid was built and refused, under glibc's MALLOC_CHECK_) no longer showed in 6,500 - the runtime finishes
+// a copy into pageable memory on a thread of its own. Every read-back of the library goes through here or is a plain hipMemcpy.
+// (Through a pinned staging buffer per context instead: worse - hipHostMalloc / hipHostFree per context made the soak fall over
+// within a few dozen contexts. profiles/README.md "the soak crash".)
+static int staged_read(uh_ctx* c, void* dst, const void* src, size_t bytes) {
+   if (bytes == 0) return UH_OK;
+   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+   return UH_OK;
+}
+
 static int read_back(uh_ctx* c, void* dst, const void* src, size_t bytes) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (!dst) return fail(c, UH_ERR_INVALID_ARGUMENT, "null destination");
    HIP_TRY(c, hipSetDevice(c->device));
    if (int st = sync_all(c)) return st;
-   HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-   HIP_TRY(c, hipStreamSynchronize(c->stream));
-   return UH_OK;
+   return staged_read(c, dst, src, bytes);
 }
 
 int uh_read_accumulation(uh_ctx* c, float* out) { return read_back(c, out, c ? c->accumulation.p : nullptr, c ? c->accumulation.n * sizeof(float4) : 0); }
@@ -1911,8 +1922,7 @@ int uh_trace_closest(uh_ctx* c, const float* rays, uint32_t n, float* out_tuv, u
    launch_trace_closest_raw(cfg(c), c->scene, d_o.p, dd.p, dh.p, n);
    end_timed(c);
    std::vector<float4> h(n);
-   HIP_TRY(c, hipMemcpyAsync(h.data(), dh.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   if (int st = staged_read(c, h.data(), dh.p, n * sizeof(float4))) return st;
    // packet index -> key needs the packet table: read keys back once
    std::vector<TriPacket> tp(c->scene.num_tris);
    if (!tp.empty()) HIP_TRY(c, hipMemcpy2D(tp.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), tp.size(), hipMemcpyDeviceToHost));
@@ -1960,8 +1970,7 @@ int uh_trace_any(uh_ctx* c, const float* rays, uint32_t n, uint8_t* out_occluded
    launch_trace_any_raw(cfg(c), c->scene, d_o.p, dd.p, occ.p, n);
    end_timed(c);
    std::vector<uint32_t> h(n);
-   HIP_TRY(c, hipMemcpyAsync(h.data(), occ.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-   HIP_TRY(c, hipStreamSynchronize(c->stream));
+   if (int st = staged_read(c, h.data(), occ.p, n * sizeof(uint32_t))) return st;
    for (uint32_t i = 0; i < n; i++) out_occluded[i] = h[i] ? 1 : 0;
    d_o.release();
    dd.release();
@@ -1974,7 +1983,7 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    HIP_TRY(c, hipSetDevice(c->device));
    if (int st = sync_all(c)) return st;
    DeviceStats ds;
-   HIP_TRY(c, hipMemcpy(&ds, c->dstats.p, sizeof(ds), hipMemcpyDeviceToHost));
+   if (int st = staged_read(c, &ds, c->dstats.p, sizeof(ds))) return st;
    drain_timed(c);
    if (c->frame_timed) {
       float ms = 0.0f;

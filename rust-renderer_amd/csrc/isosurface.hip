@@ -254,9 +254,10 @@ extern "C" int uh_isosurface_cells(uh_ctx* ctx, uint32_t resolution, float lo, f
    }
    k_iso_cells<<<(uint32_t)((cells + kBlock - 1) / kBlock), kBlock, 0, stream>>>(q, d_a, d_b);
    int st = UH_OK;
-   if (out_cube_index && hipMemcpyAsync(out_cube_index, d_a, cells, hipMemcpyDeviceToHost, stream) != hipSuccess) st = UH_ERR_HIP;
-   if (out_triangle_count && hipMemcpyAsync(out_triangle_count, d_b, cells, hipMemcpyDeviceToHost, stream) != hipSuccess) st = UH_ERR_HIP;
    if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) st = UH_ERR_HIP;
+   // blocking copies behind the wait (context.hip read_back: asynchronous device-to-host copies into pageable memory can land late)
+   if (out_cube_index && hipMemcpy(out_cube_index, d_a, cells, hipMemcpyDeviceToHost) != hipSuccess) st = UH_ERR_HIP;
+   if (out_triangle_count && hipMemcpy(out_triangle_count, d_b, cells, hipMemcpyDeviceToHost) != hipSuccess) st = UH_ERR_HIP;
    (void)hipFree(d_a);
    (void)hipFree(d_b);
    return st;
@@ -295,8 +296,8 @@ extern "C" int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo
    // exclusive scan of the per-block counts, on the device
    device_exclusive_scan_u32(d_counts, blocks, d_chunks, d_total, stream);
    unsigned long long total = 0;
-   if (hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, stream) != hipSuccess) return fail(UH_ERR_HIP);
    if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail(UH_ERR_HIP);
+   if (hipMemcpy(&total, d_total, sizeof(total), hipMemcpyDeviceToHost) != hipSuccess) return fail(UH_ERR_HIP);  // blocking (a local)
    // a mesh holds at most 4 Mi triangles (key = mesh << 22 | primitive); `total` is the true 64-bit sum (device_scan.h), so a
    // grid whose count would wrap the 32-bit offsets is refused here, before the emit pass sizes anything by it
    if (total > (1ull << 22)) return fail(UH_ERR_CAPACITY);
@@ -304,8 +305,8 @@ extern "C" int uh_add_isosurface_mesh(uh_ctx* ctx, uint32_t resolution, float lo
    if (total) {
       if (hipMalloc(&d_verts, verts.size() * sizeof(UhVertex)) != hipSuccess) return fail(UH_ERR_OUT_OF_MEMORY);
       k_iso_emit<<<blocks, kBlock, 0, stream>>>(q, d_counts, d_verts);
-      if (hipMemcpyAsync(verts.data(), d_verts, verts.size() * sizeof(UhVertex), hipMemcpyDeviceToHost, stream) != hipSuccess) return fail(UH_ERR_HIP);
       if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail(UH_ERR_HIP);
+      if (hipMemcpy(verts.data(), d_verts, verts.size() * sizeof(UhVertex), hipMemcpyDeviceToHost) != hipSuccess) return fail(UH_ERR_HIP);  // blocking
    }
    (void)fail(0);
    if (out_triangles) *out_triangles = (uint32_t)total;

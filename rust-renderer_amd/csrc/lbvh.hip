@@ -372,8 +372,8 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
          device_exclusive_scan_u32(offsets, m, scan_chunks, scan_total, stream);
          k_ploc_compact<<<g, kBlock, 0, stream>>>(keep, offsets, bi, ci, bo, co, m);
          unsigned long long kept = 0;
-         LB_TRY(hipMemcpyAsync(&kept, scan_total, sizeof(kept), hipMemcpyDeviceToHost, stream));
          LB_TRY(hipStreamSynchronize(stream));
+         LB_TRY(hipMemcpy(&kept, scan_total, sizeof(kept), hipMemcpyDeviceToHost));  // blocking, behind the wait: an asynchronous copy into a local can land after the wait (context.hip read_back)
          if (kept == 0 || kept >= m) {
             cleanup();
             return hipErrorUnknown;
@@ -389,10 +389,10 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
          std::vector<Box6> hb(m);
          std::vector<uint32_t> hc(m);
          uint32_t made = 0;
-         LB_TRY(hipMemcpyAsync(hb.data(), bi, (size_t)m * sizeof(Box6), hipMemcpyDeviceToHost, stream));
-         LB_TRY(hipMemcpyAsync(hc.data(), ci, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-         LB_TRY(hipMemcpyAsync(&made, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
          LB_TRY(hipStreamSynchronize(stream));
+         LB_TRY(hipMemcpy(hb.data(), bi, (size_t)m * sizeof(Box6), hipMemcpyDeviceToHost));
+         LB_TRY(hipMemcpy(hc.data(), ci, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+         LB_TRY(hipMemcpy(&made, counter, sizeof(uint32_t), hipMemcpyDeviceToHost));
          std::vector<TopNode> top;
          build_sah_top(&hb[0].lo[0], m, top);
          if (top.size() != (size_t)m - 1 || (size_t)made + top.size() > (size_t)n) {
@@ -410,8 +410,8 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
          LB_TRY(hipStreamSynchronize(stream));  // `up` leaves scope
          binary_root = made;                    // TopNode 0 is the root
       } else {
-         LB_TRY(hipMemcpyAsync(&binary_root, ci, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
          LB_TRY(hipStreamSynchronize(stream));
+         LB_TRY(hipMemcpy(&binary_root, ci, sizeof(uint32_t), hipMemcpyDeviceToHost));
       }
    } else {
       k_lbvh_tree<<<grid, kBlock, 0, stream>>>(keys_out, node2, n);
@@ -431,8 +431,8 @@ hipError_t lbvh_build(const LbvhArgs& a, hipStream_t stream, std::vector<uint32_
       LB_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
       k_lbvh_collapse<<<dim3((level_count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(node2, cur, level_first, level_count, next_first, nxt, counter, counter + 1, order, a.nodes, by_area);
       uint32_t produced = 0;
-      LB_TRY(hipMemcpyAsync(&produced, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       LB_TRY(hipStreamSynchronize(stream));
+      LB_TRY(hipMemcpy(&produced, counter, sizeof(uint32_t), hipMemcpyDeviceToHost));
       level_start.push_back(next_first);
       level_first = next_first;
       level_count = produced;

@@ -723,8 +723,8 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       SG_TRY(hipMemsetAsync(d_keys.p, 0, 7 * sizeof(unsigned long long), stream));
       k_sg_bounds<<<std::min<uint32_t>(blocks_n, 512), kBlock, 0, stream>>>(d_tris, n, (unsigned long long*)d_keys.p);
       unsigned long long keys[7];
-      SG_TRY(hipMemcpyAsync(keys, d_keys.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
       SG_TRY(hipStreamSynchronize(stream));
+      SG_TRY(hipMemcpy(keys, d_keys.p, sizeof(keys), hipMemcpyDeviceToHost));  // (blocking: the destination is on this frame's stack / in a local vector)
       const double maxabs = keys[0] ? double_of(keys[0]) : 0.0;
       double S = 0.0;
       for (int a = 0; a < 3; a++)
@@ -758,8 +758,8 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       SG_TRY(d_sample.alloc((size_t)n_samples * 4 * sizeof(double)));
       k_sg_sample<<<(n_samples + kBlock - 1) / kBlock, kBlock, 0, stream>>>(pr, n, stride, n_samples, (double*)d_sample.p);
       std::vector<double> box(4 * (size_t)n_samples);
-      SG_TRY(hipMemcpyAsync(box.data(), d_sample.p, box.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
       SG_TRY(hipStreamSynchronize(stream));
+      SG_TRY(hipMemcpy(box.data(), d_sample.p, box.size() * sizeof(double), hipMemcpyDeviceToHost));  // (blocking: the destination is on this frame's stack / in a local vector)
       std::vector<double> cx, cy;
       for (uint32_t k = 0; k < n_samples; k++)
          if (box[4 * (size_t)k] == box[4 * (size_t)k]) {
@@ -855,8 +855,8 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
          SG_TRY(hipMemsetAsync(d_area.p, 0, 2 * sizeof(double), stream));
          k_sg_area<<<std::min<uint32_t>(blocks_n, 2048), kBlock, 0, stream>>>(d_tris, pr, n, g, nullptr, lim.max_walk, (double*)d_area.p);
          double area[2] = {0, 0};
-         SG_TRY(hipMemcpyAsync(area, d_area.p, sizeof(area), hipMemcpyDeviceToHost, stream));
          SG_TRY(hipStreamSynchronize(stream));
+         SG_TRY(hipMemcpy(area, d_area.p, sizeof(area), hipMemcpyDeviceToHost));  // (blocking: the destination is on this frame's stack / in a local vector)
          out.fallback_area = area[0] > 0 ? area[1] / area[0] : 0.0;
          if (out.fallback_area > lim.max_fallback_area)
             return refuse("too much of the scene's surface (" + std::to_string(out.fallback_area) + ") lies beyond the dense extent: its rays would walk the tree anyway");
@@ -871,8 +871,8 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
          unsigned long long total, occupied;
          uint32_t longest, longest_interior;
       } h;
-      SG_TRY(hipMemcpyAsync(&h, d_tot.p, sizeof(h), hipMemcpyDeviceToHost, stream));
       SG_TRY(hipStreamSynchronize(stream));
+      SG_TRY(hipMemcpy(&h, d_tot.p, sizeof(h), hipMemcpyDeviceToHost));  // (blocking: the destination is on this frame's stack / in a local vector)
       SG_TRY(hipGetLastError());
       total = h.total;
       occupied = h.occupied;
@@ -895,8 +895,8 @@ static bool build_grid_impl(void* stream_v, const void* d_packets, uint32_t n, c
       SG_TRY(hipMemsetAsync(d_area.p, 0, 2 * sizeof(double), stream));
       k_sg_area<<<std::min<uint32_t>(blocks_n, 2048), kBlock, 0, stream>>>(d_tris, pr, n, g, start, lim.max_walk, (double*)d_area.p);
       double area[2] = {0, 0};
-      SG_TRY(hipMemcpyAsync(area, d_area.p, sizeof(area), hipMemcpyDeviceToHost, stream));
       SG_TRY(hipStreamSynchronize(stream));
+      SG_TRY(hipMemcpy(area, d_area.p, sizeof(area), hipMemcpyDeviceToHost));  // (blocking: the destination is on this frame's stack / in a local vector)
       SG_TRY(hipGetLastError());
       out.fallback_area = area[0] > 0 ? area[1] / area[0] : 0.0;
       if (out.fallback_area > lim.max_fallback_area)

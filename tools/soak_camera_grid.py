@@ -17,6 +17,7 @@ scenes = [(rr.scenes.sponza_class_scene(detail=0.12, tex_size=32, with_spheres=T
           (rr.scenes.cornell_scene(subdivisions=3, tex_size=16), (-1, 0, -1), (1, 2, 2.5)),
           (rr.scenes.rtiow_scene(3), (-3, -0.4, -3), (3, 2, 3))]
 bad = built = 0
+KEEP = []
 t0 = time.time()
 for k in range(count):
     rng = np.random.default_rng(first + k)
@@ -41,11 +42,15 @@ for k in range(count):
     for grid_on in (1, 0):
         r = sc.upload(rr.Renderer(W, H))
         r.set_option("camera_grid", grid_on)
-        if rng.random() < 0.3 and grid_on:
+        if rng.random() < 0.3 and grid_on and not os.environ.get("UH_SOAK_NO_WALK"):
             r.set_option("camera_grid_max_walk", int(rng.integers(1, 16)))
+        for kv in filter(None, os.environ.get("UH_SOAK_OPTS", "").split(",")):
+            r.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         loop = rr.FrameLoop(r, sc.make_view(W, H))
-        loop.frames(9, rr.PASS_ALL)
+        loop.frames(9, rr.PASS_REFERENCE_PT if os.environ.get("UH_SOAK_PASS") == "pt" else rr.PASS_ALL)
         res.append((r.read_accumulation().copy(), r.read_gbuffer_position().copy(), [r.read_reservoirs(i).copy() for i in range(3)], r.get_stats()))
+        if os.environ.get("UH_SOAK_KEEP"):  # (diagnosis: never destroy a context)
+            KEEP.append((r, loop))
         del r
     (a, g, rv, s), (a2, g2, rv2, s2) = res
     ok = np.array_equal(a.view(np.uint32), a2.view(np.uint32)) and np.array_equal(g.view(np.uint32), g2.view(np.uint32)) and all(np.array_equal(x, y) for x, y in zip(rv, rv2)) \
