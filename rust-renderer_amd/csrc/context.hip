@@ -137,8 +137,10 @@ struct Slot {
       pixcol.release();
       for (auto& q : queues) q.release();
       control.release();
-      for (hipEvent_t ev : {ev_traced, ev_missed, ev_shaded, ev_shadowed, ev_side_done, ev_acc, frame_start, frame_stop})
-         if (ev) (void)hipEventDestroy(ev);
+      for (hipEvent_t* ev : {&ev_traced, &ev_missed, &ev_shaded, &ev_shadowed, &ev_side_done, &ev_acc, &frame_start, &frame_stop}) {
+         if (*ev) (void)hipEventDestroy(*ev);
+         *ev = nullptr;  // (a create() that fails half-way must not leave handles for the next destroy())
+      }
       if (side) (void)hipStreamDestroy(side);
       if (stream) (void)hipStreamDestroy(stream);
       stream = side = nullptr;
@@ -490,15 +492,9 @@ void uh_destroy(uh_ctx* c) {
    // stream still exists
    uh_rccl_detach(c);
    drop_sun_job(c);
-   if (c->restir_stream) {
-      (void)hipStreamSynchronize(c->restir_stream);
-      for (hipEvent_t ev : {c->ev_restir, c->rs_start, c->rs_stop})
-         if (ev) (void)hipEventDestroy(ev);
-      (void)hipStreamDestroy(c->restir_stream);
-      c->restir_stream = nullptr;
-   }
-   for (hipEvent_t ev : c->ev_band)
-      if (ev) (void)hipEventDestroy(ev);
+   // every stream idle before anything goes; the streams themselves go LAST, after every event that was recorded on or waited for by
+   // one of them (slot streams wait for the reservoir stream's event and the other way round)
+   (void)hipDeviceSynchronize();
    c->spatial_ring.release();
    c->gb_ray_o.release();
    c->gb_ray_d.release();
@@ -544,6 +540,14 @@ void uh_destroy(uh_ctx* c) {
    for (auto& r : c->reservoirs) r.release();
    c->dstats.release();
    for (auto& s : c->slots) s.destroy();
+   for (hipEvent_t ev : c->ev_band)
+      if (ev) (void)hipEventDestroy(ev);
+   if (c->restir_stream) {
+      for (hipEvent_t ev : {c->ev_restir, c->rs_start, c->rs_stop})
+         if (ev) (void)hipEventDestroy(ev);
+      (void)hipStreamDestroy(c->restir_stream);
+      c->restir_stream = nullptr;
+   }
    c->owned_pixels.release();
    delete c;
 }
