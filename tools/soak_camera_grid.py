@@ -18,6 +18,7 @@ scenes = [(rr.scenes.sponza_class_scene(detail=0.12, tex_size=32, with_spheres=T
           (rr.scenes.rtiow_scene(3), (-3, -0.4, -3), (3, 2, 3))]
 bad = built = 0
 KEEP = []
+HELD = []
 t0 = time.time()
 for k in range(count):
     rng = np.random.default_rng(first + k)
@@ -48,7 +49,14 @@ for k in range(count):
             r.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         loop = rr.FrameLoop(r, sc.make_view(W, H))
         loop.frames(9, rr.PASS_REFERENCE_PT if os.environ.get("UH_SOAK_PASS") == "pt" else rr.PASS_ALL)
-        res.append((r.read_accumulation().copy(), r.read_gbuffer_position().copy(), [r.read_reservoirs(i).copy() for i in range(3)], r.get_stats()))
+        raw = (r.read_accumulation(), r.read_gbuffer_position(), [r.read_reservoirs(i) for i in range(3)])
+        res.append((raw[0].copy(), raw[1].copy(), [x.copy() for x in raw[2]], r.get_stats()))
+        if os.environ.get("UH_SOAK_HOLD"):
+            HELD.append(raw)
+        if os.environ.get("UH_SOAK_HOLD"):  # (diagnosis: the arrays the read-backs filled stay allocated for a while)
+            HELD.append(res[-1])
+            if len(HELD) > 400:
+                HELD.pop(0)
         if os.environ.get("UH_SOAK_KEEP"):  # (diagnosis: never destroy a context)
             KEEP.append((r, loop))
         del r
