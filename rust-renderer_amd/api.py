@@ -86,8 +86,13 @@ def _preload_hip_runtime():
     """One HIP runtime per process. The PyTorch-ROCm wheel bundles its own libamdhip64.so (same
     soname as /opt/rocm's); if both get loaded the second one sees no devices. When torch is
     installed, load ITS copy first (by path, without importing torch): libutopian_hip.so then binds
-    to it by soname and a later `import torch` (bench.py's RCCL leg) reuses the same object."""
+    to it by soname and a later `import torch` (bench.py's RCCL leg) reuses the same object.
+    UH_HIP_RUNTIME=system skips this and lets the library's RUNPATH (/opt/rocm) decide - for processes that never import
+    torch (the soaks: profiles/README.md "the soak crash" compares the two runtimes)."""
     import importlib.util
+
+    if os.environ.get("UH_HIP_RUNTIME", "torch") == "system":
+        return
 
     try:
         spec = importlib.util.find_spec("torch")

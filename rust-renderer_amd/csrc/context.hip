@@ -1852,12 +1852,11 @@ int uh_synchronize(uh_ctx* c) {
    return sync_all(c);
 }
 
-// Device -> host, BLOCKING, behind a wait for the context's stream. The grid builders' small read-backs used to be asynchronous copies
-// into locals followed by a wait for their stream; with those made blocking, a heap corruption of the round-4 soaks (one in about
-// 300 contexts whose camera grid was built and refused, under glibc's MALLOC_CHECK_) no longer showed in 6,500 - the runtime finishes
-// a copy into pageable memory on a thread of its own. Every read-back of the library goes through here or is a plain hipMemcpy.
-// (Through a pinned staging buffer per context instead: worse - hipHostMalloc / hipHostFree per context made the soak fall over
-// within a few dozen contexts. profiles/README.md "the soak crash".)
+// Device -> host, BLOCKING, behind a wait for the context's stream: every read-back of the library goes through here or is a
+// plain hipMemcpy. (The round-4 soaks' heap corruption - profiles/README.md "the soak crash" - sits inside the HIP runtime copy
+// bundled with the PyTorch wheel and does not show against /opt/rocm's; under the bundled one, asynchronous copies into locals
+// followed by a wait for their stream made it twenty times as frequent, and a pinned staging buffer - per context or one for the
+// process - made it worse again. This form is the one that ran cleanest under both.)
 static int staged_read(uh_ctx* c, void* dst, const void* src, size_t bytes) {
    if (bytes == 0) return UH_OK;
    HIP_TRY(c, hipStreamSynchronize(c->stream));

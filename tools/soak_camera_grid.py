@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np
+if os.environ.get("UH_SOAK_BT"):  # (diagnosis: native stack at SIGSEGV / SIGABRT, tools/crash_bt.c)
+    import ctypes
+    ctypes.CDLL(os.environ["UH_SOAK_BT"]).crash_bt_install()
 import rust_renderer_amd as rr
 from rust_renderer_amd.camera import Camera
 
