@@ -44,6 +44,27 @@ def test_library_links_hip_and_carries_gfx950_code():
     assert b"liboracle" not in blob and b"orc_render_frame" not in blob, "the product must not reference the oracle"
 
 
+@pytest.mark.parametrize("which", ["torch", "system"])
+def test_one_hip_runtime_per_process_and_the_switch_between_them(which):
+    """api._preload_hip_runtime: by default the library binds to the runtime copy of the PyTorch wheel (so that a later
+    `import torch` finds one runtime in the process); UH_HIP_RUNTIME=system leaves it to the library's RUNPATH (/opt/rocm) -
+    the runtime a C / C++ / Rust host links, and the one the round-4 context-churn soaks ran clean against."""
+    code = ("import rust_renderer_amd as rr; rr.load_library(); "
+            "print(sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))")
+    env = dict(os.environ, UH_HIP_RUNTIME=which)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    paths = eval(out.stdout.strip().splitlines()[-1])
+    assert len(paths) == 1, f"two HIP runtimes in one process: {paths}"
+    import importlib.util
+    has_torch_copy = importlib.util.find_spec("torch") is not None and os.path.exists(
+        os.path.join(os.path.dirname(importlib.util.find_spec("torch").origin), "lib", "libamdhip64.so"))
+    if which == "torch" and has_torch_copy:
+        assert "/torch/lib/" in paths[0]
+    else:
+        assert "/torch/lib/" not in paths[0]
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
 def test_no_device_fails_loudly():
     lib = rr.load_library()
