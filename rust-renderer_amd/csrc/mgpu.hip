@@ -301,7 +301,16 @@ int uh_mgpu_compose(uh_mgpu* m) {
       if (i == 0) return uh_synchronize(m->ctx[0]);
       if (!m->pack_pixels[i]) return UH_OK;
       if (int s = uh_pack_tiles(m->ctx[i], m->packed[i], m->pack_pixels[i])) return s;
+      // hipMemcpyPeer between two device buffers may return before the copy has run (it is host-blocking only where host memory
+      // is involved), and it runs on the null stream of this thread's device, which the contexts' non-blocking streams do not
+      // wait for: without the wait below GPU 0's unpack kernel could read `staged` before the tiles had landed - whole tiles of
+      // the composed image stale, seen by tools/soak_group.py only with other processes on the same GPU (round 4).
       hipError_t e = hipMemcpyPeer(m->staged[i], m->device[0], m->packed[i], m->device[i], m->pack_pixels[i] * 16);
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // this thread's device is GPU i (uh_pack_tiles set it)
+      if (e == hipSuccess && m->device[i] != m->device[0]) {    // whichever end the runtime ran the copy on
+         e = hipSetDevice(m->device[0]);
+         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+      }
       return e == hipSuccess ? UH_OK : UH_ERR_HIP;
    });
    if (st != UH_OK) return st;

@@ -27,12 +27,24 @@ while done < count:
     group = scene.upload(rr.MultiGpuRenderer(W, H, devices=[0] * n, tile_size=tile))
     for r in (one, group):
         rr.FrameLoop(r, scene.make_view(W, H, use_ris_light_sampling=1)).frames(frames, rr.PASS_ALL)
-    ok = bool(np.array_equal(group.read_accumulation().view(np.uint32), one.read_accumulation().view(np.uint32)))
+    ga, oa = group.read_accumulation().view(np.uint32), one.read_accumulation().view(np.uint32)
+    ok = bool(np.array_equal(ga, oa))
+    detail = [] if ok else ["accumulation: %d of %d pixels, rows %s" % (int((ga != oa).any(axis=-1).sum()), W * H, sorted(set(np.nonzero((ga != oa).any(axis=-1))[0].tolist()))[:12])]
     for which in range(3):
-        ok &= group.read_reservoirs(which).tobytes() == one.read_reservoirs(which).tobytes()
-    ok &= list(group.get_stats().rays) == list(one.get_stats().rays)
+        gr, orr = group.read_reservoirs(which), one.read_reservoirs(which)
+        same = gr.tobytes() == orr.tobytes()
+        if not same:
+            gb, ob = np.frombuffer(gr.tobytes(), np.uint8).reshape(H * W, -1), np.frombuffer(orr.tobytes(), np.uint8).reshape(H * W, -1)
+            rows = sorted(set((np.nonzero((gb != ob).any(axis=1))[0] // W).tolist()))
+            detail.append("reservoirs[%d]: %d pixels, rows %s" % (which, int((gb != ob).any(axis=1).sum()), rows[:12]))
+        ok &= same
+    if list(group.get_stats().rays) != list(one.get_stats().rays):
+        ok = False
+        detail.append("rays %s against %s" % (list(group.get_stats().rays), list(one.get_stats().rays)))
     print("seed %d: %dx%d, %d contexts, tile %d, %d frames, %d triangles, %d lights: %s (%.0f s)" % (seed - 1, W, H, n, tile, frames, scene.num_triangles, len(scene.lights), "ok" if ok else "MISMATCH", time.time() - t0), flush=True)
     bad += 0 if ok else 1
+    for d in detail:
+        print("      " + d, flush=True)
     one.close()
     group.close()
 print("group soak: %d scenes, %d mismatches" % (count, bad))
