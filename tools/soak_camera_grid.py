@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np
+os.environ.setdefault("UH_HIP_RUNTIME", "system")  # torch-free process: /opt/rocm's HIP runtime (profiles/README.md "The soak crash")
 if os.environ.get("UH_SOAK_BT"):  # (diagnosis: native stack at SIGSEGV / SIGABRT, tools/crash_bt.c)
     import ctypes
     ctypes.CDLL(os.environ["UH_SOAK_BT"]).crash_bt_install()
