@@ -5,13 +5,16 @@
   N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
   or plainly (python bench.py --gpus N): the script then starts its N ranks itself, as child processes under
   torch.distributed.run on 127.0.0.1, before anything has touched a GPU, and exits with their status.
+  A rank is a GPU process and imports no torch: the ranks find each other through rust-renderer_amd/launch.py's Rendezvous
+  (TCP on 127.0.0.1), which hands the ncclUniqueId round, and every collective of the data path is RCCL inside the library.
 
 A step = one frame = one pass of reference_pt_pass over the 1920x1080 framebuffer at 1 sample per
 pixel and 5 bounces (the reference's per-frame dispatch, renderers/mod.rs:357; 64 steps = the
 64 spp headline image). The scene, BVH, textures and all path state are resident in HBM before the
 timed region. N > 1: the framebuffer is tile-partitioned (64x64 tiles, round-robin) — each rank
 traces only its tiles, and ONE RCCL gather of the RGBA32F accumulation tiles to rank 0 (inside the
-timed region, after the last step) composes the final image. Total work is fixed => "strong".
+timed region, after the last step; uh_rccl_gather_tiles, enqueued behind the frames) composes the final image. Total work is
+fixed => "strong".
 
 Prints ONE JSON line (rank 0). `roofline` is for the dominant kernel, k_trace_closest, timed live
 with HIP events on the library's own stream; `cpu_baseline` is the CPU oracle on this box's cores.
@@ -59,14 +62,13 @@ def parse():
     ap.add_argument("--no-alone", action="store_true", help="skip the untimed standalone-kernel calibration frames (profiling runs: every launch in the trace is then in the timed regime)")
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only one rank's tiles of an N-rank partition (what one rank sees at --gpus N)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="the rank --emulate-world stands in for")
-    ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="run the rendezvous + RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=0")
     ap.add_argument("--full-frame-reservoir-passes", action="store_true", help="N > 1: every rank runs the G-buffer cast and the reservoir passes for the whole frame (rounds 1-2) instead of its band of rows + one all-gather per frame")
     ap.add_argument("--spp", type=int, default=1, help="samples_per_frame (reference default 1, UI maximum 10); SURVEY 8d also asks for 64 spp as 8 frames x 8")
     ap.add_argument("--cook-torrance", action="store_true", help="extension (SURVEY 8f N2): the diffuse materials of configs 1-3 become Cook-Torrance (material type 4)")
     ap.add_argument("--cpu-sample", type=str, default="1920x1080x8", help="WxHx(max frames) rendered by the CPU oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline stops after the first frame that ends beyond this many seconds")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the composition gather (nccl = RCCL; gloo only rehearses the launch on a GPU-less box)")
     return ap.parse_args()
 
 
@@ -84,29 +86,13 @@ def main():
 
     import numpy as np
 
-    import rust_renderer_amd as rr  # binds libutopian_hip.so to torch's bundled HIP runtime (api._preload_hip_runtime)
+    import rust_renderer_amd as rr  # binds libutopian_hip.so to /opt/rocm's HIP runtime, the one it was built with (api._preload_hip_runtime)
 
-    dist = None
-    torch = None
     use_dist = world > 1 or args.force_dist
+    rdzv = None
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        import torch
-        import torch.distributed as dist
-
-        if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        print(f"[bench] rank {rank}/{world} joined the {args.backend} group", file=sys.stderr, flush=True)
-    rccl_ranks = None
-    if use_dist and args.backend == "nccl":
-        # what RCCL itself saw: every rank contributes a one through the communicator the tile gather uses
-        ones = torch.ones(1, dtype=torch.int32, device=f"cuda:{local_rank}")
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
+        rdzv = launch.Rendezvous.from_env()
+        print(f"[bench] rank {rank}/{world} joined the rendezvous", file=sys.stderr, flush=True)
 
     W, H = args.width, args.height
     kw = dict(tex_size=args.tex_size)
@@ -124,9 +110,9 @@ def main():
     restir = bool(pass_mask & rr.PASS_RESTIR) and not args.full_frame_reservoir_passes
     if use_dist:
         renderer.set_tile_partition(rank, world, args.tile)
-        if restir and args.backend == "nccl":
-            # the reservoir passes by bands of rows, their all-gather by RCCL inside the library (one broadcast of the id here)
-            rr.distributed.partition_reservoir_passes(renderer, rank, world, dist, torch)
+        # one communicator per rank, inside the library (the 128-byte id goes round through the rendezvous): the tile gather of every
+        # config, and for config 2 the reservoir passes by bands of rows with their all-gather per frame
+        rr.distributed.attach_ranks(renderer, rdzv, band_partition=restir)
     elif args.emulate_world > 1:
         renderer.set_tile_partition(args.emulate_rank % args.emulate_world, args.emulate_world, args.tile)
         if restir:
@@ -135,10 +121,14 @@ def main():
     loop = rr.FrameLoop(renderer, view)
 
     def sync_all():
-        renderer.synchronize()
+        renderer.synchronize()  # every stream of the context idle - the composition's sends, receives and kernels included
         if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
+            rdzv.barrier()
+
+    def compose():
+        # the ONE collective of the path tracer's data path: RCCL gather of the packed accumulation tiles to rank 0, which scatters
+        # them and recomputes pt_output_image in one launch (uh_rccl_gather_tiles: enqueued behind the frames, no host wait)
+        rr.distributed.gather_and_compose(renderer, rdzv, args.tile, resolve=(max(view.total_samples, 1), view.accumulation_limit))
 
     # ---- untimed: one counted frame gives nodes / triangles visited per ray of the dominant kernel (deterministic). A wavefront of
     # frames first: the sun grid and the camera grid exist from then on, as in the timed region - the primary rays then go through
@@ -230,9 +220,7 @@ def main():
     loop.frames(args.warmup, pass_mask)
     frames_rendered += 16 + args.warmup + args.steps
     if use_dist:
-        # warm the composition path too (RCCL connects its send/recv channels on first use, the
-        # caching allocator takes its first staging buffers): one untimed gather + resolve
-        rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}", resolve=(max(view.total_samples, 1), view.accumulation_limit))
+        compose()  # warm the composition path too (RCCL connects its send / recv channels on first use, the library allocates its tile buffers)
     loop.reset()
     renderer.reset_stats()
     renderer.set_option("time_kernels", 1)
@@ -245,9 +233,7 @@ def main():
         renderer.synchronize()
         print(f"[debug] frames done at {time.perf_counter() - t0:.4f} s", file=sys.stderr)
     if use_dist:
-        # the ONE collective of the data path: RCCL gather of the packed accumulation tiles to rank 0
-        # (rank 0 scatters the tiles and recomputes pt_output_image in one launch: uh_compose_tiles)
-        rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}", resolve=(view.total_samples, view.accumulation_limit))
+        compose()
     if os.environ.get("UH_BENCH_DEBUG"):
         renderer.synchronize()
         print(f"[debug] composition done at {time.perf_counter() - t0:.4f} s", file=sys.stderr)
@@ -281,7 +267,7 @@ def main():
         t1 = time.perf_counter()
         loop.frames(args.steps, pass_mask)
         if use_dist:
-            rr.distributed.gather_and_compose(renderer, rank, world, args.tile, dist, torch, f"cuda:{local_rank}", resolve=(view.total_samples, view.accumulation_limit))
+            compose()
         sync_all()
         elapsed_tree = time.perf_counter() - t1
         tree_rays = float(renderer.get_stats().path_rays)
@@ -289,12 +275,10 @@ def main():
         renderer.set_option("camera_grid", 1)
         frames_rendered += 16 + args.steps
     if use_dist:
-        t = torch.tensor([elapsed, my_rays, my_closest, st.trace_closest_ms, elapsed_tree or 0.0, tree_rays], dtype=torch.float64, device=f"cuda:{local_rank}")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, total_rays = float(tmax[0]), float(t[1])
-        elapsed_tree, tree_rays = (float(tmax[4]) if elapsed_tree is not None else None), float(t[5])
+        t = [elapsed, my_rays, my_closest, st.trace_closest_ms, elapsed_tree or 0.0, tree_rays]
+        tmax, tsum = rdzv.allreduce(t, "max"), rdzv.allreduce(t, "sum")
+        elapsed, total_rays = tmax[0], tsum[1]
+        elapsed_tree, tree_rays = (tmax[4] if elapsed_tree is not None else None), tsum[5]
     else:
         total_rays = my_rays
 
@@ -304,10 +288,10 @@ def main():
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
-            # ranks counted THROUGH RCCL (an all-reduce of ones over the tile gather's communicator), and the size of the library's own
-            # communicator for the reservoir all-gather (ncclCommCount; config 2 only); null = no RCCL in this run (single process)
-            "rccl_ranks": rccl_ranks,
-            "rccl_library_comm_ranks": (renderer.rccl_comm_count() or None) if use_dist and args.backend == "nccl" else None,
+            # ranks of the library's own RCCL communicator (ncclCommCount of what uh_rccl_attach made: the tile gather of every config
+            # and config 2's reservoir all-gather run over it); null = no RCCL in this run (single process)
+            "rccl_library_comm_ranks": (renderer.rccl_comm_count() or None) if use_dist else None,
+            "hip": dict(zip(("built_with", "runtime"), rr.hip_versions()), runtime_mismatch=(rr.load_library().uh_last_error(None) or b"").decode() or None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -329,7 +313,7 @@ def main():
                 f"{W}x{H}, {args.spp} spp/frame x {args.steps} frames, 5 bounces, sky + sun shadow rays"
                 + (f", {len(scene.lights)} lights " + ("ReSTIR DI" if view.use_ris_light_sampling else "uniform sampling") if view.lights_enabled else ", lights off"),
                 "rays_per_frame": total_rays / args.steps,
-                "partition": f"{args.tile}x{args.tile} tiles round-robin over {world} rank(s), 1 RCCL gather" if world > 1 else "single GPU",
+                "partition": f"{args.tile}x{args.tile} tiles round-robin over {world} rank(s), 1 RCCL gather inside the library (uh_rccl_gather_tiles)" if world > 1 else "single GPU",
                 "frame_by_frame_ms": frame_by_frame_ms,      # fully serial: one stream, one frame, per-kernel event timing on
                 "interactive_frame_ms": interactive_frame_ms,  # default options, a synchronisation after every frame
                 "pipelined_frame_ms": pipelined_frame_ms,      # one uh_render_frame per frame, four frames in flight, no batching: a moving camera
@@ -352,8 +336,9 @@ def main():
             print("[bench] PARITY FAILED: the timed workload's image differs from the oracle's beyond 1e-3 per pixel, or the ray counts differ", file=sys.stderr, flush=True)
             sys.exit(3)
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        rdzv.barrier()
+        renderer.rccl_detach()
+        rdzv.close()
 
 
 def signature(args, scene, W, H):

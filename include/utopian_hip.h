@@ -235,6 +235,7 @@ typedef struct uh_ctx uh_ctx;
  *        uh_write_reservoirs, uh_write_gbuffer_position, uh_build_acceleration, uh_refit_acceleration (also when uh_render_frame calls it for
  *        view->rebuild_tlas), uh_set_tile_partition, uh_set_restir_partition, uh_rccl_attach / uh_rccl_detach, uh_pack_tiles,
  *        uh_unpack_tiles, uh_compose_tiles, uh_resolve_output, uh_add_isosurface_mesh, uh_destroy;
+ *   enqueues like a frame, ordered behind the frames in flight and before those that follow:  uh_rccl_gather_tiles, uh_mgpu_compose;
  *        uh_set_option for "frames_in_flight" and for "time_kernels" 1 -> 0 (the others only change what the NEXT enqueued
  *        frame does: "furnace", "sun_grid*", "overlap_*", "batch_frames", "*_variant", "*_blocks_per_cu", "count_visits",
  *        "full_frame_restir", "primary_tiles"; "device_build", "spatial_splits", "ploc_*" invalidate the tree: the next frame
@@ -251,8 +252,14 @@ typedef struct uh_ctx uh_ctx;
 /* ---- lifetime -------------------------------------------------------------------------- */
 int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out);
 void uh_destroy(uh_ctx* ctx);
-const char* uh_last_error(uh_ctx* ctx); /* ctx may be NULL: returns the last creation error */
-const char* uh_version(void);
+const char* uh_last_error(uh_ctx* ctx); /* ctx may be NULL: the last creation error - or, after a SUCCESSFUL uh_create, "" or a
+                                         * "warning: ..." when the HIP runtime of the process is of another release (major.minor)
+                                         * than the one the library was built with (also printed to stderr once per process) */
+const char* uh_version(void);           /* "utopian-hip <v> (gfx950; built with HIP a.b.c; HIP runtime x.y.z)"; needs no GPU */
+/* the same two releases as numbers, HIP_VERSION style (major * 10000000 + minor * 100000 + patch): the hipcc that compiled the
+ * library, and hipRuntimeGetVersion() of the libamdhip64.so.7 this process bound (the soname covers every 7.x: a host that loaded
+ * another copy first - the PyTorch wheel bundles one - hands it to this library as well). Either pointer may be NULL. */
+int uh_hip_versions(int* built_with, int* runtime);
 
 /* ---- scene ----------------------------------------------------------------------------- */
 int uh_add_texture_rgba8(uh_ctx* ctx, const uint8_t* pixels, uint32_t w, uint32_t h, uint32_t* out_index);
@@ -392,14 +399,25 @@ typedef struct UhRestirRows {
    uint32_t rows_per_band;               /* B */
 } UhRestirRows;
 int uh_get_restir_rows(uh_ctx* ctx, UhRestirRows* out);
-/* The exchange over RCCL, built in (one process per GPU): librccl is opened at run time (the library does not link it).
- * Rank 0 makes an id, the job's launcher hands the 128 bytes to every rank (bench.py: one torch.distributed broadcast),
- * every rank attaches: ncclCommInitRank + uh_set_restir_partition(rank, world, <ncclAllGather on the reservoir stream>). */
+/* RCCL, built in (one process per GPU): librccl is opened at run time (the library does not link it). Rank 0 makes an id, the
+ * job's launcher hands the 128 bytes to every rank (rust-renderer_amd/launch.py: a TCP socket on 127.0.0.1 - no torch in a GPU
+ * process), every rank attaches: ncclCommInitRank + uh_set_restir_partition(rank, world, <ncclAllGather on the reservoir stream>);
+ * a job that wants full-frame reservoir passes calls uh_set_restir_partition(ctx, 0, 1, NULL, NULL) afterwards (the communicator
+ * stays for uh_rccl_gather_tiles). */
 int uh_rccl_unique_id(uint8_t out_id[128]);
 int uh_rccl_attach(uh_ctx* ctx, uint32_t rank, uint32_t world, const uint8_t id[128]);
 int uh_rccl_detach(uh_ctx* ctx);
 /* ranks of the communicator uh_rccl_attach made, as RCCL itself counts them (ncclCommCount); 0 when none is attached */
 int uh_rccl_comm_count(uh_ctx* ctx, uint32_t* out_ranks);
+/* The composition of a tile-partitioned frame over that communicator (ONE gather per composed image): every rank packs
+ * its tiles of pt_accumulation_image (uh_pack_tiles' layout) and sends them to `root` - grouped ncclSend / ncclRecv, the peers' tiles
+ * arrive on distinct xGMI links at once -, the root scatters them into its accumulation image and recomputes pt_output_image with
+ * (total_samples, accumulation_limit) in one launch (the two images of renderers/mod.rs:199-214,354-358, which the reference's
+ * single device holds whole). Collective: every rank of the communicator calls it, with the same root, after
+ * uh_set_tile_partition(rank, world, tile) with the communicator's rank and size. ENQUEUED on the context's stream behind the frames
+ * in flight - no host wait, no staging through the host; the root's uh_read_* (or uh_synchronize) waits for it, and frames enqueued
+ * after it accumulate behind it. */
+int uh_rccl_gather_tiles(uh_ctx* ctx, uint32_t root, uint32_t total_samples, uint32_t accumulation_limit);
 /* raw device pointers (zero-copy wrap by the caller, e.g. for RCCL): 0 accumulation RGBA32F,
  * 1 output BGRA8 */
 int uh_device_pointer(uh_ctx* ctx, int which, void** out);

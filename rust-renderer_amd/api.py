@@ -83,17 +83,17 @@ _lib_cache = {}
 
 
 def _preload_hip_runtime():
-    """One HIP runtime per process. The PyTorch-ROCm wheel bundles its own libamdhip64.so (same
-    soname as /opt/rocm's); if both get loaded the second one sees no devices. When torch is
-    installed, load ITS copy first (by path, without importing torch): libutopian_hip.so then binds
-    to it by soname and a later `import torch` (bench.py's RCCL leg) reuses the same object.
-    UH_HIP_RUNTIME=system skips this and lets the library's RUNPATH (/opt/rocm) decide - for processes that never import
-    torch (the soaks: profiles/README.md "the soak crash" compares the two runtimes)."""
+    """One HIP runtime per process, and by default the one the library was BUILT with: libutopian_hip.so carries a RUNPATH to
+    /opt/rocm's lib directory and binds libamdhip64.so.7 there - what a C / C++ / Rust host links. Nothing in a GPU
+    process of this package needs torch (the multi-GPU composition is RCCL inside the library, the launcher's rendezvous a TCP socket).
+    UH_HIP_RUNTIME=torch is the opt-in for a process that must share the GPU with PyTorch: the wheel bundles its own libamdhip64.so
+    (same soname, ROCm 7.0) and, loaded second, would see no devices - so its copy is loaded first, by path, without importing
+    torch, and the library binds to it by soname. That is a 7.2-built library on a 7.0 runtime: uh_version() / uh_last_error(NULL)
+    say so, and round 4's context-churn soaks corrupted the host heap in that configuration only (profiles/README.md)."""
     import importlib.util
 
-    if os.environ.get("UH_HIP_RUNTIME", "torch") == "system":
+    if os.environ.get("UH_HIP_RUNTIME", "system") != "torch":
         return
-
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
@@ -117,6 +117,7 @@ def load_library(path=LIB_PATH):
     lib.uh_create.restype = C.c_int
     lib.uh_last_error.argtypes, lib.uh_last_error.restype = [C.c_void_p], C.c_char_p
     lib.uh_version.restype = C.c_char_p
+    lib.uh_hip_versions.argtypes, lib.uh_hip_versions.restype = [C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int
     for name, extra in (
         ("uh_get_num_lights", [C.POINTER(C.c_uint32)]),
         ("uh_synchronize", []),
@@ -130,6 +131,16 @@ def load_library(path=LIB_PATH):
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = [C.c_void_p] + extra, C.c_int
     return lib
+
+
+def hip_versions():
+    """(built_with, runtime) as 'major.minor.patch' strings: the HIP release that compiled libutopian_hip.so and the one this
+    process runs it on (uh_hip_versions); they differ when another libamdhip64.so.7 was loaded first (UH_HIP_RUNTIME=torch)"""
+    lib = load_library()
+    b, r = C.c_int(0), C.c_int(0)
+    lib.uh_hip_versions(C.byref(b), C.byref(r))
+    fmt = lambda v: f"{v // 10000000}.{v // 100000 % 100}.{v % 100000}"
+    return fmt(b.value), fmt(r.value)
 
 
 def identity3x4():
@@ -472,6 +483,12 @@ class Renderer:
         self._lib.uh_rccl_comm_count.argtypes, self._lib.uh_rccl_comm_count.restype = [C.c_void_p, C.POINTER(C.c_uint32)], C.c_int
         self._check(self._lib.uh_rccl_comm_count(self._ctx, C.byref(n)))
         return n.value
+
+    def rccl_gather_tiles(self, root, total_samples, accumulation_limit=999999):
+        """uh_rccl_gather_tiles: every rank's tiles to `root` over the attached communicator, composed there; enqueued (no host wait)"""
+        fn = self._lib.uh_rccl_gather_tiles
+        fn.argtypes, fn.restype = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32], C.c_int
+        self._check(fn(self._ctx, root, total_samples, accumulation_limit))
 
     def rccl_detach(self):
         self._lib.uh_rccl_detach.argtypes, self._lib.uh_rccl_detach.restype = [C.c_void_p], C.c_int

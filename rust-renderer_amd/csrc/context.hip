@@ -322,6 +322,11 @@ struct uh_ctx {
    uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
    DevBuf<uint32_t> owned_pixels;  // ascending pixel ids this rank owns (empty = the whole frame)
    uint32_t n_owned = 0;
+   // composition of a partitioned frame without a host wait (uh_rccl_gather_tiles; the in-process group's uh_mgpu_compose): this
+   // rank's packed tiles, on the root every rank's, and the event behind the last pack / composition - the next frame's accumulate
+   // tail waits for it like for a frame's (last_acc)
+   DevBuf<float4> tile_send, tile_recv;
+   hipEvent_t ev_compose = nullptr;
 };
 
 namespace {
@@ -411,9 +416,39 @@ void drain_timed(uh_ctx* c) {
 
 }  // namespace
 
+namespace {
+std::string hip_version_string(int v) { return std::to_string(v / 10000000) + "." + std::to_string(v / 100000 % 100) + "." + std::to_string(v % 100000); }
+// "" when the runtime's major.minor is the one this library was built with
+std::string hip_skew_warning() {
+   int built = 0, rt = 0;
+   if (uh_hip_versions(&built, &rt) != UH_OK || rt / 100000 == built / 100000) return "";
+   return "warning: libutopian_hip.so was built with HIP " + hip_version_string(built) + " but this process runs it on HIP runtime " + hip_version_string(rt) +
+          " (another libamdhip64.so.7 was loaded first - e.g. the copy bundled with a PyTorch wheel); link or preload the ROCm release the library was built with";
+}
+}  // namespace
+
 extern "C" {
 
-const char* uh_version(void) { return "utopian-hip 0.1 (gfx950)"; }
+// The HIP release this library was compiled by (the hipcc whose headers and code objects are in it) and the one it RUNS on (whichever
+// libamdhip64.so.7 the process bound first). They can differ: the soname covers every 7.x, and a host that has another copy loaded -
+// the PyTorch wheel bundles ROCm 7.0's - hands that copy to this library too. Both go on record, and a differing major.minor is
+// said out loud (round 4's heap corruption under context churn showed with a 7.2-built library on the wheel's 7.0 runtime only).
+int uh_hip_versions(int* built, int* runtime) {
+   if (built) *built = HIP_VERSION;
+   int rt = 0;
+   const hipError_t e = hipRuntimeGetVersion(&rt);
+   if (runtime) *runtime = e == hipSuccess ? rt : 0;
+   return e == hipSuccess ? UH_OK : UH_ERR_HIP;
+}
+
+const char* uh_version(void) {
+   static const std::string s = [] {
+      int built = 0, rt = 0;
+      (void)uh_hip_versions(&built, &rt);
+      return "utopian-hip 0.5 (gfx950; built with HIP " + hip_version_string(built) + "; HIP runtime " + (rt ? hip_version_string(rt) : std::string("unknown")) + ")";
+   }();
+   return s.c_str();
+}
 
 const char* uh_last_error(uh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -479,6 +514,14 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    c->cam_limits.max_walk = 48;          // a pixel listing more packets than this hands its ray to the tree walk
    c->cam_limits.max_mean_list = 24.0;   // entries per occupied pixel beyond which the grid is refused (the tree walk costs about 20 records per ray)
    c->cam_limits.max_fallback_area = 2.0;
+   // a runtime of another release than the one the library was built with: uh_last_error(NULL) says so after a SUCCESSFUL create too,
+   // and stderr once per process
+   g_create_error = hip_skew_warning();
+   if (!g_create_error.empty()) {
+      static bool said = false;
+      if (!said) std::fprintf(stderr, "[libutopian_hip] %s\n", g_create_error.c_str());
+      said = true;
+   }
    *out = c;
    return UH_OK;
 }
@@ -549,6 +592,9 @@ void uh_destroy(uh_ctx* c) {
       c->restir_stream = nullptr;
    }
    c->owned_pixels.release();
+   c->tile_send.release();
+   c->tile_recv.release();
+   if (c->ev_compose) (void)hipEventDestroy(c->ev_compose);
    delete c;
 }
 
@@ -2271,6 +2317,10 @@ struct RcclApi {
    decltype(&ncclCommInitRank) CommInitRank = nullptr;
    decltype(&ncclCommDestroy) CommDestroy = nullptr;
    decltype(&ncclAllGather) AllGather = nullptr;
+   decltype(&ncclSend) Send = nullptr;
+   decltype(&ncclRecv) Recv = nullptr;
+   decltype(&ncclGroupStart) GroupStart = nullptr;
+   decltype(&ncclGroupEnd) GroupEnd = nullptr;
    decltype(&ncclCommCount) CommCount = nullptr;
    decltype(&ncclGetErrorString) GetErrorString = nullptr;
    std::string why;
@@ -2292,10 +2342,14 @@ RcclApi* rccl_api() {
    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.so, "ncclCommInitRank");
    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.so, "ncclCommDestroy");
    api.AllGather = (decltype(api.AllGather))dlsym(api.so, "ncclAllGather");
+   api.Send = (decltype(api.Send))dlsym(api.so, "ncclSend");
+   api.Recv = (decltype(api.Recv))dlsym(api.so, "ncclRecv");
+   api.GroupStart = (decltype(api.GroupStart))dlsym(api.so, "ncclGroupStart");
+   api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.so, "ncclGroupEnd");
    api.CommCount = (decltype(api.CommCount))dlsym(api.so, "ncclCommCount");
    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.so, "ncclGetErrorString");
-   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
-      api.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd) {
+      api.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd";
       api.so = nullptr;
    }
    return &api;
@@ -2303,6 +2357,7 @@ RcclApi* rccl_api() {
 struct RcclLink {
    ncclComm_t comm = nullptr;
    int last = 0;
+   uint32_t rank = 0, world = 1;
 };
 // UhRestirExchangeFn: in-place all-gather of the bands, enqueued on the reservoir stream
 int rccl_exchange(void* user, void* stream, void* base, uint64_t band_bytes, uint32_t rank, uint32_t) {
@@ -2338,6 +2393,8 @@ int uh_rccl_attach(uh_ctx* c, uint32_t rank, uint32_t world, const uint8_t id[12
       delete l;
       return fail(c, UH_ERR_HIP, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(r) : "failed"));
    }
+   l->rank = rank;
+   l->world = world;
    c->rccl = l;
    return uh_set_restir_partition(c, rank, world, rccl_exchange, l);
 }
@@ -2367,6 +2424,94 @@ int uh_rccl_comm_count(uh_ctx* c, uint32_t* out_ranks) {
    if (!rccl_api()->CommCount || rccl_api()->CommCount(l->comm, &n) != ncclSuccess) return fail(c, UH_ERR_HIP, "ncclCommCount failed");
    *out_ranks = (uint32_t)n;
    return UH_OK;
+}
+
+// ---- composition of a tile-partitioned frame, ENQUEUED: nothing below waits on the host ----
+namespace {
+uint64_t max_pack_pixels(uh_ctx* c) {
+   uint64_t need = 0;
+   for (uint32_t r = 0; r < c->tp_world; r++) {
+      uint64_t n = 0;
+      uh_tile_pack_count(c, r, &n);
+      need = n > need ? n : need;
+   }
+   return need;
+}
+// what was just enqueued on the context's stream read or wrote the accumulation image: the next frame's accumulate tail
+// (enqueue_path_trace) and the next composition wait for it
+int mark_composed(uh_ctx* c) {
+   if (!c->ev_compose) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_compose, hipEventDisableTiming));
+   HIP_TRY(c, hipEventRecord(c->ev_compose, c->stream));
+   c->last_acc = c->ev_compose;
+   return UH_OK;
+}
+}  // namespace
+
+// this context's owned tiles, packed into `device_out` (>= uh_tile_pack_count pixels), on the context's stream behind the accumulate
+// tail of every frame in flight
+int uhi_enqueue_pack_tiles(uh_ctx* c, void* device_out, void** out_stream) {
+   if (!c || !device_out) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));
+   if (c->last_acc) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->last_acc, 0));
+   launch_pack_tiles(cfg(c), c->accumulation.p, (float4*)device_out, c->W, c->H, c->tp_rank, c->tp_world, c->tp_tile);
+   HIP_TRY(c, hipGetLastError());
+   if (out_stream) *out_stream = (void*)c->stream;
+   return mark_composed(c);
+}
+// the root's composition (k_compose_tiles over `device_all`: world buffers of stride_pixels, uh_compose_tiles' layout) on the context's
+// stream, behind its own frames in flight and behind the `n_waits` events (hipEvent_t) that say the other ranks' tiles have landed
+int uhi_enqueue_compose_tiles(uh_ctx* c, const void* device_all, uint64_t stride_pixels, uint32_t total_samples, uint32_t accumulation_limit, void* const* wait_events,
+                              int n_waits) {
+   if (!c || !device_all || stride_pixels < max_pack_pixels(c)) return UH_ERR_INVALID_ARGUMENT;
+   HIP_TRY(c, hipSetDevice(c->device));
+   if (c->last_acc) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->last_acc, 0));
+   for (int k = 0; k < n_waits; k++)
+      if (wait_events[k]) HIP_TRY(c, hipStreamWaitEvent(c->stream, (hipEvent_t)wait_events[k], 0));
+   launch_compose_tiles(cfg(c), c->im, (const float4*)device_all, stride_pixels, c->W, c->H, c->tp_rank, c->tp_world, c->tp_tile, total_samples, accumulation_limit);
+   HIP_TRY(c, hipGetLastError());
+   return mark_composed(c);
+}
+// the event behind this context's last pack / composition (hipEvent_t; null before the first)
+void* uhi_composed_event(uh_ctx* c) { return c ? (void*)c->ev_compose : nullptr; }
+
+// One process per GPU: the ONE collective of the path tracer's data path. Every rank packs its tiles of
+// pt_accumulation_image and sends them to `root` over the communicator uh_rccl_attach made (grouped ncclSend / ncclRecv: the peers'
+// buffers arrive on distinct xGMI links at once; the root's own tiles take the same way, a local copy); the root scatters them and
+// recomputes pt_output_image in one launch (renderers/mod.rs:199-214,354-358: the two images a single device holds). All of it on
+// the context's stream, behind the frames in flight; the call returns at once and the next uh_read_* / uh_synchronize waits.
+int uh_rccl_gather_tiles(uh_ctx* c, uint32_t root, uint32_t total_samples, uint32_t accumulation_limit) {
+   if (!c) return UH_ERR_INVALID_ARGUMENT;
+   RcclLink* l = (RcclLink*)c->rccl;
+   if (!l) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_rccl_gather_tiles: no communicator attached (uh_rccl_attach)");
+   if (c->tp_world != l->world || c->tp_rank != l->rank)
+      return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_rccl_gather_tiles: uh_set_tile_partition(rank, world) must be the communicator's rank and size");
+   if (root >= l->world) return fail(c, UH_ERR_INVALID_ARGUMENT, "uh_rccl_gather_tiles: root >= world");
+   HIP_TRY(c, hipSetDevice(c->device));
+   const uint64_t stride = max_pack_pixels(c);
+   const bool is_root = l->rank == root;
+   if (c->tile_send.n < stride || (is_root && c->tile_recv.n < stride * l->world)) {
+      if (int st = sync_all(c)) return st;  // (first call, or another partition: the old buffers may still be read)
+      HIP_TRY(c, c->tile_send.alloc(stride ? stride : 1));
+      if (is_root) HIP_TRY(c, c->tile_recv.alloc((stride ? stride : 1) * l->world));
+   }
+   if (int st = uhi_enqueue_pack_tiles(c, c->tile_send.p, nullptr)) return st;
+   RcclApi* api = rccl_api();
+   ncclResult_t r = api->GroupStart();
+   uint64_t mine = 0;
+   uh_tile_pack_count(c, l->rank, &mine);
+   if (r == ncclSuccess && mine) r = api->Send(c->tile_send.p, (size_t)mine * 4, ncclFloat, (int)root, l->comm, c->stream);
+   if (is_root)
+      for (uint32_t k = 0; k < l->world && r == ncclSuccess; k++) {
+         uint64_t n = 0;
+         uh_tile_pack_count(c, k, &n);
+         if (n) r = api->Recv(c->tile_recv.p + (size_t)k * stride, (size_t)n * 4, ncclFloat, (int)k, l->comm, c->stream);
+      }
+   const ncclResult_t e = api->GroupEnd();
+   if (r == ncclSuccess) r = e;
+   l->last = (int)r;
+   if (r != ncclSuccess) return fail(c, UH_ERR_HIP, std::string("uh_rccl_gather_tiles: ") + (api->GetErrorString ? api->GetErrorString(r) : "RCCL error"));
+   if (is_root) return uhi_enqueue_compose_tiles(c, c->tile_recv.p, stride, total_samples, accumulation_limit, nullptr, 0);
+   return mark_composed(c);
 }
 
 // diagnostics: the grid in use (built on the device) against the host builder on the same raster - see utopian_hip.h

@@ -18,4 +18,11 @@ void uhi_batch_abandon(uh_batch*);
 // behind it (hipEvent_t), the stream the passes run on (hipStream_t), bytes per band
 int uhi_exchange_endpoints(uh_ctx*, void** spatial_base, void** band_event, void** stream, uint64_t* band_bytes);
 int uhi_iso_reference_triangulation(uh_ctx*);  // option "iso_reference_triangulation" (isosurface.hip)
+// composition of a tile-partitioned frame without a host wait (uh_rccl_gather_tiles, uh_mgpu_compose):
+// pack this context's tiles into device_out on the context's stream (returned as hipStream_t), behind its frames in flight
+int uhi_enqueue_pack_tiles(uh_ctx*, void* device_out, void** out_stream);
+// the root: k_compose_tiles over device_all (world buffers of stride_pixels) on the context's stream, behind its frames in flight
+// and behind the n_waits events (hipEvent_t) that say the other ranks' tiles have landed
+int uhi_enqueue_compose_tiles(uh_ctx*, const void* device_all, uint64_t stride_pixels, uint32_t total_samples, uint32_t accumulation_limit, void* const* wait_events, int n_waits);
+void* uhi_composed_event(uh_ctx*);  // hipEvent_t behind the context's last pack / composition (null before the first)
 }

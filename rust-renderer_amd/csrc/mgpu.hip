@@ -21,7 +21,9 @@ struct uh_mgpu {
    std::vector<uh_ctx*> ctx;
    std::vector<int> device;
    std::vector<void*> packed;  // on device[i]: this GPU's tiles, packed
-   std::vector<void*> staged;  // on device[0]: the copy of packed[i] (i > 0)
+   void* staged = nullptr;     // on device[0]: every GPU's packed tiles, GPU i's at i * stride_pixels (uh_compose_tiles' layout)
+   uint64_t stride_pixels = 0;
+   std::vector<void*> landed;  // hipEvent_t on device[i]: GPU i's tiles of the current composition have been copied into `staged`
    std::vector<uint64_t> pack_pixels;
    uint32_t W = 0, H = 0, tile = 0;
    uint32_t total_samples = 1, accumulation_limit = 999999;  // of the last frame, for the resolve
@@ -93,16 +95,27 @@ int uh_mgpu_create(int ngpus, const int* device_ordinals, uint32_t width, uint32
    }
    m->restir_partition = ngpus > 1;
    m->packed.assign(ngpus, nullptr);
-   m->staged.assign(ngpus, nullptr);
+   m->landed.assign(ngpus, nullptr);
    m->pack_pixels.assign(ngpus, 0);
    for (int i = 0; i < ngpus; i++) {
       uh_tile_pack_count(m->ctx[i], (uint32_t)i, &m->pack_pixels[i]);
+      m->stride_pixels = std::max(m->stride_pixels, m->pack_pixels[i]);
+   }
+   if (ngpus > 1 && m->stride_pixels) {
+      hipError_t e = hipSetDevice(m->device[0]);
+      if (e == hipSuccess) e = hipMalloc(&m->staged, (size_t)m->stride_pixels * 16 * ngpus);
+      if (e != hipSuccess) {
+         g_create_error = std::string("uh_mgpu_create: ") + hipGetErrorString(e);
+         uh_mgpu_destroy(m);
+         return e == hipErrorOutOfMemory ? UH_ERR_OUT_OF_MEMORY : UH_ERR_HIP;
+      }
+   }
+   for (int i = 0; i < ngpus; i++) {
       if (i == 0 || m->pack_pixels[i] == 0) continue;
       const size_t bytes = m->pack_pixels[i] * 16;
       hipError_t e = hipSetDevice(m->device[i]);
       if (e == hipSuccess) e = hipMalloc(&m->packed[i], bytes);
-      if (e == hipSuccess) e = hipSetDevice(m->device[0]);
-      if (e == hipSuccess) e = hipMalloc(&m->staged[i], bytes);
+      if (e == hipSuccess) e = hipEventCreateWithFlags((hipEvent_t*)&m->landed[i], hipEventDisableTiming);
       if (e == hipSuccess && m->device[i] != m->device[0]) {
          // direct xGMI copies; "already enabled" / "not supported" leave hipMemcpyPeer to stage by itself
          (void)hipDeviceEnablePeerAccess(m->device[i], 0);
@@ -122,15 +135,17 @@ int uh_mgpu_create(int ngpus, const int* device_ordinals, uint32_t width, uint32
 
 void uh_mgpu_destroy(uh_mgpu* m) {
    if (!m) return;
+   for (uh_ctx* c : m->ctx) (void)uh_synchronize(c);  // the copies and the composition run on the contexts' streams
    for (size_t i = 0; i < m->ctx.size(); i++) {
-      if (m->packed[i]) {
+      if (i < m->packed.size() && (m->packed[i] || m->landed[i])) {
          (void)hipSetDevice(m->device[i]);
-         (void)hipFree(m->packed[i]);
+         if (m->packed[i]) (void)hipFree(m->packed[i]);
+         if (m->landed[i]) (void)hipEventDestroy((hipEvent_t)m->landed[i]);
       }
-      if (m->staged[i]) {
-         (void)hipSetDevice(m->device[0]);
-         (void)hipFree(m->staged[i]);
-      }
+   }
+   if (m->staged) {
+      (void)hipSetDevice(m->device[0]);
+      (void)hipFree(m->staged);
    }
    for (uh_ctx* c : m->ctx) uh_destroy(c);
    delete m;
@@ -293,31 +308,35 @@ int uh_mgpu_synchronize(uh_mgpu* m) {
    return UH_OK;
 }
 
-// gather every GPU's tiles into GPU 0's accumulation image and recompute pt_output_image there
+// Gather every GPU's tiles into GPU 0's accumulation image and recompute pt_output_image there - ENQUEUED, every step ordered by
+// an event, nothing waits on the host: GPU i packs its tiles on its context's stream (behind its frames in flight), the peer copy
+// into GPU 0's staging buffer follows ON THAT STREAM (behind the pack; and behind GPU 0's previous composition, which may still
+// read the buffer), an event recorded behind the copy says "landed", and GPU 0's stream waits for every such event before the one
+// launch that scatters the tiles and resolves the output. (Round 4's form copied with hipMemcpyPeer on the null stream, which the
+// contexts' non-blocking streams do not wait for - stale tiles in 2 % of the scenes when the GPU was shared - and was patched
+// with host waits on both devices' null streams: ordering by guesswork.) The read-backs wait for GPU 0's streams as ever.
 int uh_mgpu_compose(uh_mgpu* m) {
    if (!m) return UH_ERR_INVALID_ARGUMENT;
    if (m->composed) return UH_OK;
-   int st = for_all(m, [&](int i) -> int {
-      if (i == 0) return uh_synchronize(m->ctx[0]);
-      if (!m->pack_pixels[i]) return UH_OK;
-      if (int s = uh_pack_tiles(m->ctx[i], m->packed[i], m->pack_pixels[i])) return s;
-      // hipMemcpyPeer between two device buffers may return before the copy has run (it is host-blocking only where host memory
-      // is involved), and it runs on the null stream of this thread's device, which the contexts' non-blocking streams do not
-      // wait for: without the wait below GPU 0's unpack kernel could read `staged` before the tiles had landed - whole tiles of
-      // the composed image stale, seen by tools/soak_group.py only with other processes on the same GPU (round 4).
-      hipError_t e = hipMemcpyPeer(m->staged[i], m->device[0], m->packed[i], m->device[i], m->pack_pixels[i] * 16);
-      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // this thread's device is GPU i (uh_pack_tiles set it)
-      if (e == hipSuccess && m->device[i] != m->device[0]) {    // whichever end the runtime ran the copy on
-         e = hipSetDevice(m->device[0]);
-         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-      }
-      return e == hipSuccess ? UH_OK : UH_ERR_HIP;
-   });
-   if (st != UH_OK) return st;
-   for (size_t i = 1; i < m->ctx.size(); i++)
-      if (m->pack_pixels[i])
-         if (int s = uh_unpack_tiles(m->ctx[0], (uint32_t)i, m->staged[i], m->pack_pixels[i])) return fail(m, s, "uh_mgpu_compose: unpack", m->ctx[0]);
-   if (int s = uh_resolve_output(m->ctx[0], m->total_samples, m->accumulation_limit)) return fail(m, s, "uh_mgpu_compose: resolve", m->ctx[0]);
+   const size_t n = m->ctx.size();
+   if (n == 1) {
+      m->composed = true;  // one GPU holds the whole frame: its own tail wrote both images
+      return UH_OK;
+   }
+   void* const reader_done = uhi_composed_event(m->ctx[0]);  // GPU 0's previous composition (or null)
+   for (size_t i = 1; i < n; i++) {
+      if (!m->pack_pixels[i]) continue;
+      void* stream = nullptr;
+      if (int s = uhi_enqueue_pack_tiles(m->ctx[i], m->packed[i], &stream)) return fail(m, s, "uh_mgpu_compose: pack", m->ctx[i]);
+      hipError_t e = hipSuccess;  // (this thread's device is GPU i: uhi_enqueue_pack_tiles set it)
+      if (reader_done) e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)reader_done, 0);
+      if (e == hipSuccess)
+         e = hipMemcpyPeerAsync((char*)m->staged + (size_t)i * m->stride_pixels * 16, m->device[0], m->packed[i], m->device[i], m->pack_pixels[i] * 16, (hipStream_t)stream);
+      if (e == hipSuccess) e = hipEventRecord((hipEvent_t)m->landed[i], (hipStream_t)stream);
+      if (e != hipSuccess) return fail(m, UH_ERR_HIP, std::string("uh_mgpu_compose: peer copy: ") + hipGetErrorString(e));
+   }
+   if (int s = uhi_enqueue_compose_tiles(m->ctx[0], m->staged, m->stride_pixels, m->total_samples, m->accumulation_limit, m->landed.data(), (int)n))
+      return fail(m, s, "uh_mgpu_compose: compose", m->ctx[0]);
    m->composed = true;
    return UH_OK;
 }

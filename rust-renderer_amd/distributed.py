@@ -2,6 +2,9 @@
 round-robin (tile id % world == rank); every rank path-traces only its tiles and ONE gather of the
 packed RGBA32F accumulation tiles to rank 0 composes the frame. The reference is single-device
 (utopian/src/device.rs:45); this is the build's own addition.
+On GPUs the gather is RCCL INSIDE the library (uh_rccl_gather_tiles); what is left here is the job-level glue - handing the
+ncclUniqueId round through the launcher's rendezvous (launch.Rendezvous: TCP on 127.0.0.1, no torch in a GPU process) - and the
+numpy twin of the index math for the CPU oracle.
 
 The reservoir passes (config 2) are partitioned differently - by bands of rows, with ONE all-gather of
 spatial_reuse_reservoirs per frame (partition_reservoir_passes below; include/utopian_hip.h uh_set_restir_partition).
@@ -54,77 +57,71 @@ def unpack_tiles_host(acc, packed, tile, rank, world):
     return acc
 
 
-def gather_and_compose(renderer, rank, world, tile, dist, torch, device, resolve=None):
-    """One collective per composed frame. HIP renderers pack on the device and hand RCCL a device
-    buffer; CPU (oracle / gloo) renderers go through the numpy restatement. Returns, on rank 0, the
-    composed (H, W, 4) accumulation as numpy for CPU renderers, or None after composing in place
-    on the device for HIP renderers. `resolve` = (total_samples, accumulation_limit): the root also recomputes
-    pt_output_image, in the same launch that scatters the tiles (uh_compose_tiles)."""
-    counts = [c * tile * tile for c in tile_counts(renderer.width, renderer.height, tile, world)]
+def gather_and_compose(renderer, rdzv, tile, resolve=None, root=0):
+    """One collective per composed frame. `rdzv`: the job's launch.Rendezvous (rank, world, and - for CPU renderers - the transport).
+    HIP renderers: uh_rccl_gather_tiles - pack, grouped ncclSend / ncclRecv over the communicator uh_rccl_attach made, composition on
+    the root, all enqueued on the context's stream inside the library (no torch, no host wait; `resolve` = (total_samples,
+    accumulation_limit) is what the root recomputes pt_output_image with). Returns None: the root's images hold the frame.
+    CPU renderers (the oracle in the CPU tests): the numpy restatement of the same pack / unpack index math, the tiles travelling
+    through the rendezvous' sockets; returns the composed (H, W, 4) accumulation on the root, None elsewhere."""
+    rank, world = rdzv.rank, rdzv.world
     if renderer.backend == "hip":
-        buf = torch.empty((max(counts), 4), dtype=torch.float32, device=device)
-        renderer.pack_tiles(buf.data_ptr(), buf.shape[0])
-        every = torch.empty((world, max(counts), 4), dtype=torch.float32, device=device) if rank == 0 else None
-        dist.gather(buf, list(every.unbind(0)) if rank == 0 else None, dst=0)
-        if rank == 0:
-            torch.cuda.synchronize()
-            if resolve is not None:
-                renderer.compose_tiles(every.data_ptr(), max(counts), resolve[0], resolve[1])
-            else:
-                for r in range(1, world):
-                    renderer.unpack_tiles(r, every[r].data_ptr(), counts[r])
+        total, limit = resolve if resolve is not None else (1, 999999)
+        renderer.rccl_gather_tiles(root, total, limit)
         return None
     acc = renderer.read_accumulation()
-    buf = torch.zeros((max(counts), 4), dtype=torch.float32)
-    buf[: counts[rank]] = torch.from_numpy(pack_tiles_host(acc, tile, rank, world))
-    parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, parts, dst=0)
-    if rank == 0:
-        for r in range(1, world):
-            unpack_tiles_host(acc, parts[r].numpy(), tile, r, world)
-        return acc
-    return None
+    parts = rdzv.gather(pack_tiles_host(acc, tile, rank, world).tobytes(), dst=root)
+    if rank != root:
+        return None
+    for r in range(world):
+        if r != root:
+            unpack_tiles_host(acc, np.frombuffer(parts[r], dtype=np.float32).reshape(-1, 4), tile, r, world)
+    return acc
 
 
-def partition_reservoir_passes(renderer, rank, world, dist, torch):
+def attach_ranks(renderer, rdzv, band_partition=True):
+    """HIP renderers: rank 0 makes the ncclUniqueId, the rendezvous hands its 128 bytes to every rank, every rank attaches
+    (uh_rccl_attach: ncclCommInitRank + the reservoir passes by bands of rows with an in-library all-gather per frame).
+    band_partition = False: full-frame reservoir passes on every rank (rounds 1-2), the communicator stays for the tile gather."""
+    ident = rdzv.broadcast(renderer.rccl_unique_id() if rdzv.rank == 0 else None)
+    renderer.rccl_attach(rdzv.rank, rdzv.world, ident)
+    if not band_partition:
+        renderer.set_restir_partition(0, 1)
+
+
+def partition_reservoir_passes(renderer, rdzv):
     """The G-buffer cast and the reservoir passes of `renderer` cover rank's band of rows from now on, and every spatial
     pass is followed by an all-gather of the bands, so that every rank holds the whole spatial_reuse_reservoirs of every
     frame (temporal_reuse.rgen:90-99 reads it at a reprojected pixel, the path tracer at its own tiles).
-    HIP renderers: RCCL inside the library, on the stream the passes run on (uh_rccl_attach; the 128-byte id travels through
-    ONE torch.distributed broadcast, then torch is out of the loop). CPU renderers (the oracle under gloo, in the CPU tests):
-    the same library hook calls back into Python, synchronously, and gloo moves the bands."""
+    HIP renderers: RCCL inside the library, on the stream the passes run on (attach_ranks). CPU renderers (the oracle, in the CPU
+    tests): the same library hook calls back into Python, synchronously, and the rendezvous' sockets move the bands."""
+    rank, world = rdzv.rank, rdzv.world
     if world <= 1:
         renderer.set_restir_partition(0, 1)
         return
     if renderer.backend == "hip":
-        ident = [renderer.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        renderer.rccl_attach(rank, world, ident[0])
+        attach_ranks(renderer, rdzv)
         return
     import ctypes as C
 
     def exchange(stream, base, band_bytes, r, w):
         whole = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_uint8)), shape=(w * band_bytes,))
-        mine = torch.from_numpy(whole[r * band_bytes:(r + 1) * band_bytes].copy())
-        parts = [torch.empty_like(mine) for _ in range(w)]
-        dist.all_gather(parts, mine)
+        parts = rdzv.allgather(whole[r * band_bytes:(r + 1) * band_bytes].tobytes())
         for k in range(w):
             if k != r:
-                whole[k * band_bytes:(k + 1) * band_bytes] = parts[k].numpy()
+                whole[k * band_bytes:(k + 1) * band_bytes] = np.frombuffer(parts[k], dtype=np.uint8)
         return 0
 
     renderer.set_restir_partition(rank, world, exchange)
 
 
-def gather_reservoir_rows(renderer, which, rank, world, dist, torch):
+def gather_reservoir_rows(renderer, which, rdzv):
     """initial (0) / temporal (1) reservoirs of the whole frame on every rank, from the bands the ranks computed (tests)."""
     rows = renderer.restir_rows()
     mine = renderer.read_reservoirs(which)
     B, W = rows.rows_per_band, renderer.width
     send = np.zeros((B, W), dtype=mine.dtype)
     send[: rows.band_rows] = mine[rows.band_row0:rows.band_row0 + rows.band_rows]
-    t = torch.from_numpy(send.view(np.uint8).reshape(-1).copy())
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t)
-    out = np.concatenate([p.numpy().view(mine.dtype).reshape(B, W) for p in parts])[: renderer.height]
+    parts = rdzv.allgather(send.tobytes())
+    out = np.concatenate([np.frombuffer(p, dtype=mine.dtype).reshape(B, W) for p in parts])[: renderer.height]
     return out

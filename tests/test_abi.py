@@ -34,6 +34,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in utopian_hip.h but not exported: {missing}"
     assert b"gfx950" in lib.uh_version()
+    assert hasattr(lib, "uh_rccl_gather_tiles") and hasattr(lib, "uh_hip_versions")
 
 
 def test_library_links_hip_and_carries_gfx950_code():
@@ -44,25 +45,42 @@ def test_library_links_hip_and_carries_gfx950_code():
     assert b"liboracle" not in blob and b"orc_render_frame" not in blob, "the product must not reference the oracle"
 
 
-@pytest.mark.parametrize("which", ["torch", "system"])
-def test_one_hip_runtime_per_process_and_the_switch_between_them(which):
-    """api._preload_hip_runtime: by default the library binds to the runtime copy of the PyTorch wheel (so that a later
-    `import torch` finds one runtime in the process); UH_HIP_RUNTIME=system leaves it to the library's RUNPATH (/opt/rocm) -
-    the runtime a C / C++ / Rust host links, and the one the round-4 context-churn soaks ran clean against."""
-    code = ("import rust_renderer_amd as rr; rr.load_library(); "
-            "print(sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))")
-    env = dict(os.environ, UH_HIP_RUNTIME=which)
+@pytest.mark.parametrize("which", [None, "system", "torch"])
+def test_one_hip_runtime_per_process_and_it_is_the_one_the_library_was_built_with(which):
+    """api._preload_hip_runtime: by DEFAULT (and with UH_HIP_RUNTIME=system) the library binds the HIP runtime of its RUNPATH -
+    /opt/rocm's, the release whose hipcc compiled it, what a C / C++ / Rust host links - and it is the only one in the process;
+    uh_hip_versions then reports the same major.minor twice. UH_HIP_RUNTIME=torch is the opt-in for sharing a process with PyTorch:
+    the wheel's bundled copy is loaded first and the library binds to it - still ONE runtime, but of another release, and
+    uh_version() says which (round 4's heap corruption under context churn showed in that configuration only)."""
+    code = ("import sys, rust_renderer_amd as rr; lib = rr.load_library(); "
+            "print(sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})); "
+            "print(rr.hip_versions()); print(lib.uh_version().decode()); print('torch' in sys.modules)")
+    env = {k: v for k, v in os.environ.items() if k != "UH_HIP_RUNTIME"}
+    if which:
+        env["UH_HIP_RUNTIME"] = which
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    paths = eval(out.stdout.strip().splitlines()[-1])
+    lines = out.stdout.strip().splitlines()
+    paths, (built, runtime), version, torch_imported = eval(lines[-4]), eval(lines[-3]), lines[-2], eval(lines[-1])
     assert len(paths) == 1, f"two HIP runtimes in one process: {paths}"
+    assert not torch_imported, "loading the library must not import torch"
+    assert built in version and runtime in version
     import importlib.util
     has_torch_copy = importlib.util.find_spec("torch") is not None and os.path.exists(
         os.path.join(os.path.dirname(importlib.util.find_spec("torch").origin), "lib", "libamdhip64.so"))
     if which == "torch" and has_torch_copy:
         assert "/torch/lib/" in paths[0]
     else:
-        assert "/torch/lib/" not in paths[0]
+        assert "/torch/lib/" not in paths[0] and os.path.realpath(paths[0]).startswith(os.path.realpath("/opt/rocm") + "/"), paths
+        assert built.split(".")[:2] == runtime.split(".")[:2], f"built with HIP {built}, running on {runtime}"
+
+
+def test_versions_are_reported_without_a_gpu():
+    lib = rr.load_library()
+    b, r = C.c_int(0), C.c_int(0)
+    assert lib.uh_hip_versions(C.byref(b), C.byref(r)) == 0 and lib.uh_hip_versions(None, None) == 0
+    assert b.value // 10000000 >= 7 and r.value // 10000000 >= 7
+    assert b"built with HIP" in lib.uh_version() and b"HIP runtime" in lib.uh_version()
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")

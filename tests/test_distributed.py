@@ -1,9 +1,12 @@
-"""CPU: the N > 1 path with world_size 2 over gloo - each rank traces only its tiles (CPU oracle
-backend), one gather composes the frame on rank 0, which must equal the single-rank frame bit for
-bit (RNG is keyed on absolute pixel coordinates)."""
+"""CPU: the N > 1 path with 2 and 3 ranks - each rank is a process of its own that traces only its tiles (CPU oracle backend)
+and finds the others through the launcher's rendezvous (rust-renderer_amd/launch.py: TCP on 127.0.0.1, no torch); one gather
+composes the frame on rank 0, which must equal the single-rank frame bit for bit (RNG is keyed on absolute pixel coordinates,
+SURVEY.md section 8e). On GPUs the same gather is RCCL inside the library (uh_rccl_gather_tiles; tests/test_gpu_restir_partition.py
+rehearses it with one rank, tests/test_gpu_parity.py holds the device branch of the composition with three contexts)."""
+import multiprocessing as mp
 import os
-import socket
 import sys
+import uuid
 
 import numpy as np
 import pytest
@@ -11,27 +14,30 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _spawn(target, world, *args):
+    """`world` fresh processes (spawn, not fork: each loads the libraries itself); every one must exit 0"""
+    ctx = mp.get_context("spawn")
+    key = "test_" + uuid.uuid4().hex
+    procs = [ctx.Process(target=target, args=(r, world, key) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    assert [p.exitcode for p in procs] == [0] * world
 
 
-def _worker(rank, world, port, out_path):
+def _paths():
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    import torch
-    import torch.distributed as dist
 
+
+def _worker(rank, world, key, out_path):
+    _paths()
     import oracle_api as oa
     import rust_renderer_amd as rr
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rdzv = rr.launch.Rendezvous(rank, world, key)
     W, H, tile = 80, 48, 16
     scene = rr.scenes.cornell_scene(subdivisions=1, tex_size=8)
     o = scene.upload(oa.OracleRenderer(W, H, threads=2))
@@ -39,25 +45,23 @@ def _worker(rank, world, port, out_path):
     loop = rr.FrameLoop(o, scene.make_view(W, H))
     for _ in range(2):
         loop.frame(rr.PASS_REFERENCE_PT)
-    rays = torch.tensor([float(o.get_stats().path_rays)], dtype=torch.float64)
-    dist.all_reduce(rays)
-    composed = rr.distributed.gather_and_compose(o, rank, world, tile, dist, torch, "cpu")
+    rays = rdzv.allreduce([float(o.get_stats().path_rays)], "sum")
+    composed = rr.distributed.gather_and_compose(o, rdzv, tile)
     if rank == 0:
         np.save(out_path, composed)
-        np.save(out_path + ".rays.npy", rays.numpy())
-    dist.barrier()
-    dist.destroy_process_group()
+        np.save(out_path + ".rays.npy", np.float64(rays))
+    rdzv.barrier()
+    rdzv.close()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_tile_partition_over_gloo(tmp_path):
-    import torch.multiprocessing as mp
-
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_partition_over_the_rendezvous(tmp_path, world):
     import oracle_api as oa
     import rust_renderer_amd as rr
 
     out = str(tmp_path / "composed.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    _spawn(_worker, world, out)
     composed = np.load(out)
     W, H = 80, 48
     scene = rr.scenes.cornell_scene(subdivisions=1, tex_size=8)
@@ -67,6 +71,66 @@ def test_two_rank_tile_partition_over_gloo(tmp_path):
         loop.frame(rr.PASS_REFERENCE_PT)
     assert np.array_equal(composed.view(np.uint32), ref.read_accumulation().view(np.uint32))
     assert float(np.load(out + ".rays.npy")[0]) == float(ref.get_stats().path_rays), "the ranks' ray counts add up to the full frame's"
+
+
+def _rdzv_worker(rank, world, key, out_path):
+    _paths()
+    import rust_renderer_amd as rr
+
+    rdzv = rr.launch.Rendezvous(rank, world, key)
+    got = {
+        "bcast": rdzv.broadcast(bytes(range(128)) if rank == 0 else None),
+        "bcast_from_last": rdzv.broadcast(b"x" * (1 << 20) if rank == world - 1 else None, src=world - 1),
+        "all": rdzv.allgather(bytes([rank]) * (rank + 1)),
+        "gathered": rdzv.gather(bytes([rank]), dst=1),
+        "sum": rdzv.allreduce([rank + 0.5, 1.0], "sum"),
+        "max": rdzv.allreduce([float(rank), -float(rank)], "max"),
+    }
+    rdzv.barrier()
+    rdzv.close()
+    assert got["bcast"] == bytes(range(128)) and got["bcast_from_last"] == b"x" * (1 << 20)
+    assert got["all"] == [bytes([r]) * (r + 1) for r in range(world)]
+    assert got["gathered"] == ([bytes([r]) for r in range(world)] if rank == 1 else None)
+    assert got["sum"] == [sum(r + 0.5 for r in range(world)), float(world)] and got["max"] == [float(world - 1), 0.0]
+    open(out_path + f".{rank}", "w").write("ok")
+
+
+@pytest.mark.timeout(120)
+def test_rendezvous_collectives_with_four_ranks(tmp_path):
+    """what a GPU rank uses instead of torch.distributed: the id broadcast, the barrier and the reductions around the timed region"""
+    out = str(tmp_path / "rdzv")
+    _spawn(_rdzv_worker, 4, out)
+    assert all(os.path.exists(out + f".{r}") for r in range(4))
+
+
+def test_rendezvous_ignores_a_stale_port_file(tmp_path):
+    """a file an earlier job of the same key left behind (dead port) must not keep the ranks apart"""
+    import tempfile
+
+    import rust_renderer_amd as rr
+
+    key = "stale_" + uuid.uuid4().hex
+    with open(os.path.join(tempfile.gettempdir(), f"utopian_rdzv_{key}"), "w") as f:
+        f.write(str(rr.launch.free_port()))  # nobody listens there
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_stale_worker, args=(r, 2, key)) for r in (1, 0)]  # rank 1 first: it meets the stale file
+    procs[0].start()
+    import time
+
+    time.sleep(0.5)
+    procs[1].start()
+    for p in procs:
+        p.join(60)
+    assert [p.exitcode for p in procs] == [0, 0]
+
+
+def _stale_worker(rank, world, key):
+    _paths()
+    import rust_renderer_amd as rr
+
+    rdzv = rr.launch.Rendezvous(rank, world, key, timeout=30)
+    assert rdzv.allgather(bytes([rank])) == [b"\x00", b"\x01"]
+    rdzv.close()
 
 
 def _launch_module():
@@ -81,7 +145,8 @@ def _launch_module():
 @pytest.mark.timeout(300)
 def test_launcher_runs_two_ranks(tmp_path):
     """the launcher bench.py uses for a plain `--gpus N` (rust-renderer_amd/launch.py: N child processes under
-    torch.distributed.run on 127.0.0.1) runs a 2-rank gloo job whose composed frame equals the single-rank one"""
+    torch.distributed.run on 127.0.0.1) runs a 2-rank job - the ranks torch-free, meeting through launch.Rendezvous.from_env() -
+    whose composed frame equals the single-rank one"""
     import oracle_api as oa
     import rust_renderer_amd as rr
 
@@ -101,7 +166,7 @@ def test_launcher_runs_two_ranks(tmp_path):
 
 @pytest.mark.timeout(300)
 def test_bench_gpus_2_launches_its_own_ranks():
-    """`python bench.py --gpus 2` without a launcher around it must start two ranks that reach the process group
+    """`python bench.py --gpus 2` without a launcher around it must start two ranks that find each other
     (it used to sys.exit). On this GPU-less box each rank then stops at uh_create: NO_DEVICE - there is no CPU
     fallback in the product path - and the parent hands that failure on."""
     import subprocess
@@ -114,60 +179,50 @@ def test_bench_gpus_2_launches_its_own_ranks():
         lib.uh_destroy(ctx)
         pytest.skip("a GPU is visible: the 2-rank run is the GPU box's job")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
                        capture_output=True, text=True, env=env, timeout=280)
     assert p.returncode != 0
-    assert "rank 0/2 joined the gloo group" in p.stderr and "rank 1/2 joined the gloo group" in p.stderr, p.stderr[-2000:]
+    assert "rank 0/2 joined the rendezvous" in p.stderr and "rank 1/2 joined the rendezvous" in p.stderr, p.stderr[-2000:]
     assert "NO_DEVICE" in p.stderr
 
 
-def _restir_worker(rank, world, port, out_path):
+def _restir_worker(rank, world, key, out_path):
     """config-2 style job on `world` ranks: tiles for the path tracer, bands of rows for the reservoir passes with one
     all-gather of spatial_reuse_reservoirs per frame (rust-renderer_amd/distributed.py partition_reservoir_passes)"""
-    for p in (ROOT, os.path.join(ROOT, "oracle")):
-        if p not in sys.path:
-            sys.path.insert(0, p)
-    import torch
-    import torch.distributed as dist
-
+    _paths()
     import oracle_api as oa
     import rust_renderer_amd as rr
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rdzv = rr.launch.Rendezvous(rank, world, key)
     W, H, tile = 72, 50, 16  # 50 rows over 3 ranks: bands of 17, 17, 16; the first band also needs the last row
     scene = rr.scenes.cornell_scene(subdivisions=1, tex_size=8)
     o = scene.upload(oa.OracleRenderer(W, H, threads=2))
     o.set_tile_partition(rank, world, tile)
-    rr.distributed.partition_reservoir_passes(o, rank, world, dist, torch)
+    rr.distributed.partition_reservoir_passes(o, rdzv)
     loop = rr.FrameLoop(o, scene.make_view(W, H, use_ris_light_sampling=1))
     for _ in range(3):
         loop.frame(rr.PASS_ALL)
-    rays = torch.tensor([float(x) for x in o.get_stats().rays], dtype=torch.float64)
-    dist.all_reduce(rays)
+    rays = rdzv.allreduce([float(x) for x in o.get_stats().rays], "sum")
     spatial = o.read_reservoirs(2)  # whole frame on every rank
-    initial = rr.distributed.gather_reservoir_rows(o, 0, rank, world, dist, torch)
-    temporal = rr.distributed.gather_reservoir_rows(o, 1, rank, world, dist, torch)
-    composed = rr.distributed.gather_and_compose(o, rank, world, tile, dist, torch, "cpu")
-    np.savez(out_path + f".rank{rank}.npz", spatial=spatial, initial=initial, temporal=temporal, rays=rays.numpy(),
+    initial = rr.distributed.gather_reservoir_rows(o, 0, rdzv)
+    temporal = rr.distributed.gather_reservoir_rows(o, 1, rdzv)
+    composed = rr.distributed.gather_and_compose(o, rdzv, tile)
+    np.savez(out_path + f".rank{rank}.npz", spatial=spatial, initial=initial, temporal=temporal, rays=np.float64(rays),
              composed=composed if rank == 0 else np.zeros(0))
-    dist.barrier()
-    dist.destroy_process_group()
+    rdzv.barrier()
+    rdzv.close()
 
 
 @pytest.mark.timeout(600)
-def test_three_rank_reservoir_band_partition_over_gloo(tmp_path):
+def test_three_rank_reservoir_band_partition(tmp_path):
     """every rank ends every frame with the single-rank spatial_reuse_reservoirs, bit for bit; the initial and temporal
     buffers assemble from the bands; the composed frame and the ray counts equal the single-rank run's"""
-    import torch.multiprocessing as mp
-
     import oracle_api as oa
     import rust_renderer_amd as rr
 
     world = 3
     out = str(tmp_path / "restir")
-    mp.spawn(_restir_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    _spawn(_restir_worker, world, out)
     W, H = 72, 50
     scene = rr.scenes.cornell_scene(subdivisions=1, tex_size=8)
     ref = scene.upload(oa.OracleRenderer(W, H))
@@ -208,56 +263,3 @@ def test_reservoir_rows_cover_what_the_passes_read():
             if world == 1:
                 assert (r.band_rows, r.reuse_rows, r.cast_rows) == (H, H, H)
         assert (covered == 1).all(), (H, world)
-
-
-class _MailboxGather:
-    """torch.distributed.gather for ranks that live in ONE process: the non-root ranks' calls leave their device tensor in a
-    shared mailbox, the root's call (made last) copies them into its gather list - device to device, as RCCL would deliver them"""
-
-    def __init__(self, rank, mailbox):
-        self.rank, self.mailbox = rank, mailbox
-
-    def gather(self, tensor, gather_list=None, dst=0):
-        if self.rank != dst:
-            assert gather_list is None
-            self.mailbox[self.rank] = tensor.clone()
-            return
-        for r, slot in enumerate(gather_list):
-            slot.copy_(tensor if r == self.rank else self.mailbox[r])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("resolve", [True, False])
-def test_device_branch_of_the_composition_with_three_ranks_in_one_process(resolve):
-    """the HIP branch of distributed.gather_and_compose (uh_pack_tiles -> gather of DEVICE tensors ->
-    uh_compose_tiles / uh_unpack_tiles on the root) had only ever run at world = 1. Three contexts on GPU 0 stand for three
-    ranks; the tensors travel through a mailbox in place of the RCCL gather; the root's image must be the single context's."""
-    torch = pytest.importorskip("torch")
-    import rust_renderer_amd as rr
-
-    W, H, tile, world, frames = 200, 120, 32, 3, 5  # 7 x 4 tiles, the last column and row partial; 28 tiles over 3 ranks: 10 / 9 / 9
-    scene = rr.scenes.cornell_scene(subdivisions=2, tex_size=16)
-    single = scene.upload(rr.Renderer(W, H, device=0))
-    loop = rr.FrameLoop(single, scene.make_view(W, H))
-    loop.frames(frames, rr.PASS_REFERENCE_PT)
-    want_acc, want_out, want_rays = single.read_accumulation(), single.read_output_bgra8(), single.get_stats().path_rays
-    total = loop.view.total_samples
-    ranks, mailbox, rays = [], {}, 0
-    for r in range(world):
-        ctx = scene.upload(rr.Renderer(W, H, device=0))
-        ctx.set_tile_partition(r, world, tile)
-        lp = rr.FrameLoop(ctx, scene.make_view(W, H))
-        lp.frames(frames, rr.PASS_REFERENCE_PT)
-        rays += ctx.get_stats().path_rays
-        ranks.append(ctx)
-    assert rays == want_rays, "the ranks' ray counts add up to the full frame's"
-    for r in (2, 1, 0):  # the root last: its gather finds the others' tiles in the mailbox
-        rr.distributed.gather_and_compose(ranks[r], r, world, tile, _MailboxGather(r, mailbox), torch, "cuda:0",
-                                          resolve=(total, loop.view.accumulation_limit) if resolve else None)
-    got = ranks[0].read_accumulation()
-    assert np.array_equal(got.view(np.uint32), want_acc.view(np.uint32))
-    if resolve:
-        assert np.array_equal(ranks[0].read_output_bgra8(), want_out)  # uh_compose_tiles recomputed pt_output_image for every pixel
-    else:
-        ranks[0].resolve_output(total, loop.view.accumulation_limit)
-        assert np.array_equal(ranks[0].read_output_bgra8(), want_out)

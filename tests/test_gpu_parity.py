@@ -144,45 +144,49 @@ def test_restir_flags_off_copy_through(atrium):
     assert np.array_equal(r2.view(np.uint8), cpu.read_reservoirs(2).view(np.uint8))
 
 
-def test_tile_partition_composes_to_full_frame(cornell):
-    W, H = 96, 80
-    world, tile = 3, 16
+@pytest.mark.parametrize("W,H,tile", [(96, 80, 16), (200, 120, 32)])  # the second: 7 x 4 tiles, last column and row partial, 10 / 9 / 9 per rank
+def test_tile_partition_composes_to_full_frame(cornell, W, H, tile):
+    """the device side of the composition with three contexts standing for three ranks: uh_pack_tiles -> device-to-device copies (what
+    the grouped ncclSend / ncclRecv of uh_rccl_gather_tiles deliver) -> uh_unpack_tiles + uh_resolve_output, and the one-launch form
+    uh_compose_tiles the in-library gather ends with, on another root"""
+    from util import DeviceBuffer
+
+    world, frames = 3, 2
     full = cornell.upload(rr.Renderer(W, H))
-    run_frames(full, cornell, W, H, 2, rr.PASS_REFERENCE_PT)
+    run_frames(full, cornell, W, H, frames, rr.PASS_REFERENCE_PT)
     ref = full.read_accumulation()
     root = None
-    import torch  # device staging buffers only (the tiles travel as plain device pointers)
-
-    parts = []
+    parts, rays = [], 0
     for rank in range(world):
         r = cornell.upload(rr.Renderer(W, H))
         r.set_tile_partition(rank, world, tile)
-        run_frames(r, cornell, W, H, 2, rr.PASS_REFERENCE_PT)
+        run_frames(r, cornell, W, H, frames, rr.PASS_REFERENCE_PT)
+        rays += r.get_stats().path_rays
         n = r.tile_pack_count(rank)
-        buf = torch.empty((n, 4), dtype=torch.float32, device="cuda:0")
-        r.pack_tiles(buf.data_ptr(), n)
-        parts.append((rank, buf))
+        buf = DeviceBuffer(n * 16)
+        r.pack_tiles(buf.ptr, n)
+        parts.append((rank, buf, n))
         if rank == 0:
             root = r
-    for rank, buf in parts[1:]:
-        root.unpack_tiles(rank, buf.data_ptr(), buf.shape[0])
-    # the same composition in one launch (uh_compose_tiles: what bench.py's rank 0 does after the RCCL gather), on rank 1 as the root
-    stride = max(buf.shape[0] for _, buf in parts)
-    every = torch.zeros((world, stride, 4), dtype=torch.float32, device="cuda:0")
-    for rank, buf in parts:
-        every[rank, : buf.shape[0]] = buf
+    assert rays == full.get_stats().path_rays, "the ranks' ray counts add up to the full frame's"
+    for rank, buf, n in parts[1:]:
+        root.unpack_tiles(rank, buf.ptr, n)
+    # the same composition in one launch (uh_compose_tiles: what the root of uh_rccl_gather_tiles runs behind the receives), on rank 1 as the root
+    stride = max(n for _, _, n in parts)
+    every = DeviceBuffer(world * stride * 16)
+    for rank, buf, n in parts:
+        if rank != 1:  # the root's own slot is not read: left zeroed
+            every.copy_from(buf, n * 16, dst_offset=rank * stride * 16)
     other = cornell.upload(rr.Renderer(W, H))
     other.set_tile_partition(1, world, tile)
-    run_frames(other, cornell, W, H, 2, rr.PASS_REFERENCE_PT)
-    every[1].zero_()  # the root's own slot is not read
-    torch.cuda.synchronize()
-    other.compose_tiles(every.data_ptr(), stride, 2)
-    root.resolve_output(2)
+    run_frames(other, cornell, W, H, frames, rr.PASS_REFERENCE_PT)
+    other.compose_tiles(every.ptr, stride, frames)
+    root.resolve_output(frames)
     for r in (root, other):
         assert np.array_equal(r.read_accumulation().view(np.uint32), ref.view(np.uint32)), "tile-partitioned frame must be bit-identical"
         assert np.array_equal(r.read_output_bgra8(), full.read_output_bgra8())
     with pytest.raises(rr.UtopianError):
-        other.compose_tiles(every.data_ptr(), 16, 2)  # stride smaller than a rank's tiles
+        other.compose_tiles(every.ptr, 16, frames)  # stride smaller than a rank's tiles
 
 
 def test_error_paths():
@@ -484,6 +488,41 @@ def test_gpu_group_errors():
     g = rr.MultiGpuRenderer(32, 32, devices=[0, 0])
     with pytest.raises(rr.UtopianError):
         g.render_frame(rr.types.ViewUniformData(), rr.PASS_REFERENCE_PT)  # nothing built
+
+
+def test_group_composition_is_ordered_by_events(atrium):
+    """uh_mgpu_compose with the copy LATE BY CONSTRUCTION (round 4's soak saw stale tiles in 2 % of its scenes, only with other
+    processes on the GPU): GPUs 1 and 2 are slowed down (one block per CU, one frame in flight) and asked for 24 frames, the
+    composition is enqueued at once - nothing has been waited for -, so when GPU 0's share is done the other two are still tracing:
+    their packs, the peer copies behind them and GPU 0's one-launch composition are held in order by events alone. Then more frames
+    and another composition behind the first (the staging buffer is reused), again without a wait."""
+    import ctypes as C
+
+    W, H, tile = 256, 144, 32
+    single = atrium.upload(rr.Renderer(W, H))
+    group = atrium.upload(rr.MultiGpuRenderer(W, H, devices=[0, 0, 0], tile_size=tile))
+    lib = rr.load_library()
+    lib.uh_set_option.argtypes, lib.uh_set_option.restype = [C.c_void_p, C.c_char_p, C.c_int], C.c_int
+    for i in (1, 2):
+        ctx = lib.uh_mgpu_context(group._ctx, i)
+        for name, value in ((b"closest_blocks_per_cu", 1), (b"shadow_blocks_per_cu", 1), (b"frames_in_flight", 1), (b"batch_frames", 2)):
+            assert lib.uh_set_option(ctx, name, value) == 0
+    loops = {r: rr.FrameLoop(r, atrium.make_view(W, H, lights_enabled=0)) for r in (single, group)}
+    for r in (single, group):
+        loops[r].frames(24, rr.PASS_REFERENCE_PT)
+    group.compose()  # enqueued behind 24 frames still in flight on GPUs 1 and 2
+    want24 = single.read_accumulation()
+    got24 = group.read_accumulation()  # (composed already: reads GPU 0)
+    assert np.array_equal(got24.view(np.uint32), want24.view(np.uint32)), "stale tiles: the composition ran ahead of a peer copy"
+    assert np.array_equal(group.read_output_bgra8(), single.read_output_bgra8())
+    for r in (single, group):
+        loops[r].frames(6, rr.PASS_REFERENCE_PT)
+    group.compose()
+    for r in (single, group):
+        loops[r].frames(2, rr.PASS_REFERENCE_PT)  # frames enqueued BEHIND a composition accumulate behind it
+    assert np.array_equal(group.read_accumulation().view(np.uint32), single.read_accumulation().view(np.uint32))
+    assert np.array_equal(group.read_output_bgra8(), single.read_output_bgra8())
+    assert list(group.get_stats().rays) == list(single.get_stats().rays)
 
 
 # ---- geometric torture: the intersection contract (min t, ties -> smaller mesh<<22|prim) -------------

@@ -106,18 +106,37 @@ def test_one_rank_of_four_without_exchange_first_frame(atrium):
 
 
 def test_rccl_link_with_one_rank(atrium):
-    """the built-in exchange: librccl opened at run time, ncclCommInitRank with one rank, ncclAllGather in place on the
-    reservoir stream after every spatial pass (a one-rank all-gather moves nothing: results equal the plain context's)"""
+    """the built-in collectives with ONE rank (all a one-GPU box allows): librccl opened at run time, ncclCommInitRank, the in-place
+    ncclAllGather on the reservoir stream after every spatial pass (moves nothing: results equal the plain context's), and the tile
+    gather - uh_rccl_gather_tiles: pack, a grouped ncclSend / ncclRecv of the rank to itself, the root's one-launch composition,
+    enqueued behind frames in flight with nothing waiting on the host - after which both images still equal the plain context's"""
     W, H = 96, 54
     plain = atrium.upload(rr.Renderer(W, H))
     linked = atrium.upload(rr.Renderer(W, H))
+    linked.set_tile_partition(0, 1, 16)
     linked.rccl_attach(0, 1, rr.Renderer.rccl_unique_id())
+    assert linked.rccl_comm_count() == 1
+    loops = {}
     for r in (plain, linked):
-        rr.FrameLoop(r, atrium.make_view(W, H)).frames(10, rr.PASS_ALL)
+        loops[r] = rr.FrameLoop(r, atrium.make_view(W, H))
+        loops[r].frames(10, rr.PASS_ALL)
+    # no synchronisation in between: the gather is ordered behind the wavefront by events, the frames after it behind the gather
+    linked.rccl_gather_tiles(0, loops[linked].view.total_samples)
+    for r in (plain, linked):
+        loops[r].frames(3, rr.PASS_ALL)
+    linked.rccl_gather_tiles(0, loops[linked].view.total_samples)
     assert np.array_equal(plain.read_accumulation().view(np.uint32), linked.read_accumulation().view(np.uint32))
+    assert np.array_equal(plain.read_output_bgra8(), linked.read_output_bgra8())
     for which in range(3):
         assert same_reservoirs(plain.read_reservoirs(which), linked.read_reservoirs(which))
+    # the communicator's rank and size are the partition's, or the call is refused
+    linked.set_tile_partition(0, 2, 16)
+    with pytest.raises(rr.UtopianError, match="communicator"):
+        linked.rccl_gather_tiles(0, 1)
+    linked.set_tile_partition(0, 1, 16)
     linked.rccl_detach()
+    with pytest.raises(rr.UtopianError, match="no communicator"):
+        linked.rccl_gather_tiles(0, 1)
     rr.FrameLoop(linked, atrium.make_view(W, H)).frames(2, rr.PASS_ALL)  # and goes on without the link
     linked.close()
 

@@ -34,6 +34,49 @@ def image_rms(a, b):
     return float(np.sqrt(np.mean(np.sum(d * d, axis=-1)))) if d.size else 0.0
 
 
+class DeviceBuffer:
+    """a plain device allocation for tests that hand the library raw device pointers (uh_pack_tiles / uh_compose_tiles): hipMalloc
+    through ctypes on the HIP runtime the library itself bound (soname libamdhip64.so.7: the object already in the process) - no
+    torch in a GPU test process"""
+
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes as C
+
+            rr.load_library()
+            cls._hip = C.CDLL("libamdhip64.so.7")
+            cls._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            cls._hip.hipFree.argtypes = [C.c_void_p]
+            cls._hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+            cls._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        return cls._hip
+
+    def __init__(self, nbytes):
+        import ctypes as C
+
+        p = C.c_void_p()
+        assert self.hip().hipMalloc(C.byref(p), max(int(nbytes), 1)) == 0
+        self.ptr, self.nbytes = p.value, int(nbytes)
+        assert self.hip().hipMemset(self.ptr, 0, max(self.nbytes, 1)) == 0 and self.hip().hipDeviceSynchronize() == 0
+
+    def copy_from(self, other, nbytes, dst_offset=0, src_offset=0):
+        assert self.hip().hipMemcpy(self.ptr + dst_offset, other.ptr + src_offset, nbytes, 3) == 0  # hipMemcpyDeviceToDevice
+        assert self.hip().hipDeviceSynchronize() == 0
+
+    def zero(self, offset, nbytes):
+        assert self.hip().hipMemset(self.ptr + offset, 0, nbytes) == 0 and self.hip().hipDeviceSynchronize() == 0
+
+    def free(self):
+        if self.ptr:
+            self.hip().hipFree(self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
 def random_rays(scene_bounds, n, seed, tmin=0.001, tmax=10000.0):
     lo, hi = (np.asarray(x, dtype=np.float32) for x in scene_bounds)
     u = rr.scenes.hash_floats(seed, 6 * n).reshape(n, 6)
