@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only one rank's tiles of an N-rank partition (what one rank sees at --gpus N)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="the rank --emulate-world stands in for")
     ap.add_argument("--force-dist", action="store_true", help="run the rendezvous + RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
-    ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. trace_variant=0")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. sun_grid=0")
     ap.add_argument("--full-frame-reservoir-passes", action="store_true", help="N > 1: every rank runs the G-buffer cast and the reservoir passes for the whole frame (rounds 1-2) instead of its band of rows + one all-gather per frame")
     ap.add_argument("--spp", type=int, default=1, help="samples_per_frame (reference default 1, UI maximum 10); SURVEY 8d also asks for 64 spp as 8 frames x 8")
     ap.add_argument("--cook-torrance", action="store_true", help="extension (SURVEY 8f N2): the diffuse materials of configs 1-3 become Cook-Torrance (material type 4)")
@@ -148,6 +148,8 @@ def main():
         "build_ms": cs.sun_grid_build_ms,          # once per (geometry, sun direction), OUTSIDE the timed region: see value_with_sun_grid_build
         "cells": cs.sun_grid_cells,
         "entries": cs.sun_grid_entries,
+        "bytes": cs.sun_grid_bytes,                # device memory of the structure (cells + lists + coarse cover + the 64-byte records when within sun_grid_inline_max_mb)
+        "bytes_over_packet_array": cs.sun_grid_bytes / max(64.0 * scene.num_triangles, 1.0),
         "mean_list": cs.sun_grid_mean_list,
         "tests_per_ray": cs.shadow_tris_tested / sun_rays_counted,   # triangle tests per sun shadow ray (grid walk + the tree walk of the handed-over rays)
         "handed_to_tree": cs.sun_tree_rays / sun_rays_counted,       # share of the sun rays the grid gives back to the tree (border cells, long lists)
@@ -160,7 +162,7 @@ def main():
     # the timed ones (one wavefront of the library's default batch): its serialised launch duration, without co-scheduled kernels
     frames_rendered = 17  # the wavefront that builds the grids + the counted frame
     renderer.set_option("time_kernels", 1)
-    serial = (("frames_in_flight", 1), ("overlap_miss", 0), ("overlap_shadow", 0))
+    serial = (("frames_in_flight", 1), ("overlap", 0))
     for k, v in serial:
         renderer.set_option(k, v)
     alone_ms = alone_rays = 0.0
@@ -185,7 +187,7 @@ def main():
         frame_by_frame_ms = (time.perf_counter() - t_fbf) / 8 * 1e3
         frames_rendered += 40
     renderer.set_option("time_kernels", 0)
-    for k, v in (("frames_in_flight", 4), ("overlap_miss", 1), ("overlap_shadow", 1), ("batch_frames", 0)):
+    for k, v in (("frames_in_flight", 4), ("overlap", 1), ("batch_frames", 0)):
         renderer.set_option(k, v)
     for kv in args.opt:
         k, v = kv.split("=")
@@ -252,6 +254,7 @@ def main():
         "build_ms": st.camera_grid_build_ms,       # once per camera at rest (and geometry), on the device, OUTSIDE the timed region
         "pixels": st.camera_grid_cells,
         "entries": st.camera_grid_entries,
+        "bytes": st.camera_grid_bytes,
         "mean_list": st.camera_grid_mean_list,
         "handed_to_tree": st.camera_tree_rays / max(st.rays[rr.RAY_PRIMARY], 1),  # share of the primary rays whose pixel lists too many packets
         "tests_per_ray": camera_tests_per_ray,     # triangle tests per primary ray served by the grid (no node visit)
@@ -284,7 +287,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": f"Mrays/s (path rays: primary + bounce + sun-shadow + light-shadow) at {W}x{H}, {args.steps * args.spp} spp = {args.steps} frames x {args.spp} spp",
+            "metric": f"Mrays/s (path rays: primary + bounce + sun-shadow + light-shadow) at {W}x{H}, {args.steps * args.spp} spp = {args.steps} frames x {args.spp} spp; "
+                      "camera and sun at rest, the one-off builds of the camera grid and the sun grid outside the timed region (value_with_grid_builds charges them to these frames, value_tree_walk uses neither grid)",
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,

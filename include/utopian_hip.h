@@ -222,6 +222,8 @@ typedef struct UhStats {
    float camera_grid_ms;        /* summed hipEvent time of the primary rays' launches when they go through the grid (option "time_kernels") */
    uint32_t reserved0;
    uint64_t sun_covered_rays;   /* sun shadow rays answered by their cell's cover depth alone (option "count_visits") */
+   uint64_t sun_grid_bytes;     /* device memory of the sun grid in use: cell records + entry lists + coarse cover + the lists as 64-byte records (when within "sun_grid_inline_max_mb") */
+   uint64_t camera_grid_bytes;  /* device memory of the camera grid in use: cell offsets + entry lists */
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;
@@ -237,8 +239,8 @@ typedef struct uh_ctx uh_ctx;
  *        uh_unpack_tiles, uh_compose_tiles, uh_resolve_output, uh_add_isosurface_mesh, uh_destroy;
  *   enqueues like a frame, ordered behind the frames in flight and before those that follow:  uh_rccl_gather_tiles, uh_mgpu_compose;
  *        uh_set_option for "frames_in_flight" and for "time_kernels" 1 -> 0 (the others only change what the NEXT enqueued
- *        frame does: "furnace", "sun_grid*", "overlap_*", "batch_frames", "*_variant", "*_blocks_per_cu", "count_visits",
- *        "full_frame_restir", "primary_tiles"; "device_build", "spatial_splits", "ploc_*" invalidate the tree: the next frame
+ *        frame does: "furnace", "sun_grid*", "camera_grid*", "overlap", "batch_frames", "trace_blocks_per_cu", "count_visits",
+ *        "full_frame_restir", "primary_implicit"; "device_build", "ploc_sah_top" invalidate the tree: the next frame
  *        needs uh_build_acceleration, which waits);
  *   host state only (no device access, nothing to wait for):  uh_add_mesh, uh_add_light, uh_set_instance_transform,
  *        uh_get_num_lights, uh_mesh_info, uh_read_mesh, uh_get_restir_rows, uh_tile_pack_count, uh_last_error;
@@ -246,8 +248,7 @@ typedef struct uh_ctx uh_ctx;
  *        next uh_build_acceleration) and is complete on return;
  *   uh_trace_closest / uh_trace_any run on the context's first stream, in order with the frames of that stream, read the scene
  *        only, and are complete on return.
- * The sun-direction grid is (re)built inside the first frame call that wants it, after a wait for the frames in flight
- * (option "sun_grid_async": on a host thread, adopted - after such a wait - by the first later frame call that finds it done). */
+ * The sun-direction grid and the camera grid are (re)built inside the first frame call that wants them, after a wait for the frames in flight. */
 
 /* ---- lifetime -------------------------------------------------------------------------- */
 int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out);
@@ -315,36 +316,36 @@ int uh_trace_any(uh_ctx* ctx, const float* rays, uint32_t n, uint8_t* out_occlud
 /* ---- stats / options ------------------------------------------------------------------- */
 int uh_get_stats(uh_ctx* ctx, UhStats* out);
 int uh_reset_stats(uh_ctx* ctx);
-/* options: "count_visits" (0/1), "time_kernels" (0/1), "full_frame_restir" (0/1; 1 = documented
- * divergence: use the reservoir for every pixel instead of the reference's x > W/2 split),
- * "iso_reference_triangulation" (0/1, default 1: see uh_add_isosurface_mesh),
- * "furnace" (0/1: the reference's FURNACE_TEST build of the miss shader, reference.rmiss:14-28 - a path ray that leaves the
- * scene returns white whatever view->sky_enabled says; with albedo-1 materials, sun and lights off every sample is exactly 1 or,
- * for a path still inside the scene after view->num_bounces hits, 0),
- * "device_build" (0/1/2; 1 or 2 = uh_build_acceleration builds the tree ON THE DEVICE in a few ms instead of the host SAH
- * tree in tens to hundreds: same hits bit for bit, about 10 % (1: clusters under a SAH top) or 30 % (2: radix tree) more
- * traversal work per ray - for geometry that changes every few frames),
- * "bvh_optimise" (0..16, default 0: passes of insertion-based optimisation of the host-built tree, about a second each for 262 k
- * triangles; hits unchanged),
- * "interleave" (0..8, default 0 = off: a uh_render_frame call - one frame - is split by tiles into this many wavefronts on as many of
- * the "frames_in_flight" slots; same image bit for bit; measured slower than the whole wavefront on MI355X, kept for experiments),
- * "camera_grid" (0/1, default 1: the primary rays of a camera that has been the same for two consecutive frame calls - or for a
- * call of 8 or more frames - go through a per-camera grid of packet lists, one cell per pixel, instead of the tree; same hit records
- * bit for bit), "camera_grid_max_walk", "camera_grid_walk_whole", "camera_grid_max_mean_list_x10",
- * "primary_implicit" (0/1, default 1: with that grid in use and one sample per frame, the primary rays' state is not stored - the
- * kernels of the first bounce compute it from the path id; same images),
- * "sun_grid" (0/1, default 1: sun shadow rays through a per-direction visibility grid once the direction has settled; same
- * images), "sun_grid_build" (0/1, default 1: that grid is built on the device in a few milliseconds; 0: by the host builder, the
- * reference implementation, in 130-550 ms), "sun_grid_async" (0/1, host builder only: the grid is built on a host thread and no frame
- * call waits for it), "sun_grid_density", "sun_grid_max_mb", "sun_grid_max_walk", "sun_grid_max_mean_list_x10",
- * "sun_grid_inline" (0/1, default 1: the grid's lists are kept a second time as 64-byte records that carry their triangle packet - one
- * round trip per triangle test instead of two), "sun_grid_inline_max_mb" (default 8192: beyond it the plain lists serve),
- * "sun_grid_coarse" (0..6, default 2: a cover depth per block of 4 x 4 cells, small enough to stay in the L2, asked before the cell's own
- * record; 0: none), "sun_grid_fused" (0/1, default 0: the shading kernel asks that coarse cover itself and the grid kernel serves the
- * rays it could not answer; same images, measured level),
- * tuning knobs documented in DESIGN.md section 7 ("frames_in_flight", "batch_frames", "closest_variant", "shadow_variant",
- * "*_blocks_per_cu", "overlap_miss", "overlap_shadow", "spatial_splits", "primary_tiles", "ploc_radius", "ploc_sah_top").
- * Unknown names return UH_ERR_INVALID_ARGUMENT. */
+/* The 25 options (DESIGN.md section 7 has the defaults and what was measured); unknown names return UH_ERR_INVALID_ARGUMENT.
+ *  diagnostics   "count_visits" (0/1: UhStats' node / triangle / cover counters), "time_kernels" (0/1: hipEvent time per kernel kind)
+ *  results       "full_frame_restir" (0/1; 1 = documented divergence: the reservoir for every pixel instead of the reference's
+ *                x > W/2 split), "furnace" (0/1: the reference's FURNACE_TEST build of the miss shader, reference.rmiss:14-28 - a path
+ *                ray that leaves the scene returns white whatever view->sky_enabled says), "iso_reference_triangulation" (0/1,
+ *                default 1: see uh_add_isosurface_mesh)
+ *  the tree      "device_build" (0/1/2; 1 or 2 = uh_build_acceleration builds the tree ON THE DEVICE in a few ms instead of the host
+ *                SAH tree in tens to hundreds: same hits bit for bit, about 10 % (1: clusters under a SAH top) or 30 % (2: radix tree)
+ *                more traversal work per ray - for geometry that changes every few frames), "ploc_sah_top" (clusters the PLOC rounds
+ *                stop at; 0 = PLOC to the root)
+ *  sun grid      "sun_grid" (0/1, default 1: sun shadow rays through a per-direction visibility grid once the direction has settled;
+ *                same images), "sun_grid_build" (0/1, default 1: built on the device in a few milliseconds; 0: by the host builder,
+ *                the reference implementation, in 130-550 ms), "sun_grid_density" (entries per triangle the cell size aims at),
+ *                "sun_grid_max_mb" (budget of the entry lists), "sun_grid_max_walk" (longest list a ray tests itself),
+ *                "sun_grid_max_mean_list_x10", "sun_grid_max_fallback_pct" (refusal thresholds), "sun_grid_inline_max_mb" (the lists a
+ *                second time as 64-byte records that carry their triangle packet - one round trip per triangle test instead of two:
+ *                budget in MB, -1 = default = four times the packet array, 0 = never), "sun_grid_coarse" (0..6, default 2: a cover
+ *                depth per block of 4 x 4 cells, small enough to stay in the L2, asked before the cell's own record; 0: none)
+ *  camera grid   "camera_grid" (0/1, default 1: the primary rays of a camera that has been the same for two consecutive frame calls -
+ *                or for a call of 8 or more frames - go through a per-camera grid of packet lists, one cell per pixel, instead of
+ *                the tree; same hit records bit for bit), "camera_grid_max_walk", "camera_grid_walk_whole",
+ *                "camera_grid_max_mean_list_x10", "primary_implicit" (0/1, default 1: with that grid in use and one sample per frame,
+ *                the primary rays' state is not stored - the kernels of the first bounce compute it from the path id; same images)
+ *  scheduling    "frames_in_flight" (1..8, default 4), "batch_frames" (0 = auto), "overlap" (0/1, default 1: the miss shader and the
+ *                shadow traversals on a second stream beside the next bounce's traversal), "trace_blocks_per_cu" (1..8: persistent
+ *                grid of the traversal kernels)
+ * Removed in round 5 with the measured-negative variants they selected: "closest_variant" / "shadow_variant" / "trace_variant" (batch
+ * traversal kernels), "primary_tiles", "interleave", "sun_grid_fused", "sun_leftover_batch", "sun_grid_async", "sun_grid_inline",
+ * "spatial_splits", "bvh_optimise", "raw_visit_counts", "ploc_radius", "overlap_miss" / "overlap_shadow" (now "overlap"),
+ * "closest_blocks_per_cu" / "shadow_blocks_per_cu" (now "trace_blocks_per_cu"), "single_frame_blocks_per_cu", "miss_blocks_per_cu". */
 int uh_set_option(uh_ctx* ctx, const char* name, int value);
 
 /* diagnostics: the sun-direction grid in use (built on the device, option "sun_grid_build" = 1) read back and held against the host

@@ -84,23 +84,8 @@ struct BuildInput {
    const float* corners;
    const uint32_t* keys;
    uint32_t count;
-   // optional: the boxes to build over (6 floats each: lo xyz, hi xyz), `count` of them, instead of the corners' own boxes -
-   // the references of split_references() below. Leaves then refer to REFERENCES (tri_order holds reference indices).
-   const float* boxes6 = nullptr;
-   // passes of insertion-based optimisation over the binary tree before the collapse (Bittner, Hapala, Havran 2013; 0 = none).
-   // About a second per pass and 262 k triangles; worth 1 % of the bounce rays' steps on the regularly tessellated config scenes
-   // (profiles/README.md round 4), more on irregular ones. Hits do not depend on it.
-   int optimise_passes = 0;
 };
 
-// Spatial splits ("early split clipping", Ernst & Greiner 2007; the reference-duplication idea of SBVH, Stich et al. 2009):
-// a triangle whose box is much larger than the scene's typical triangle is cut, along the longest axis of its box, into
-// pieces - each piece a REFERENCE to the same triangle with the box of the triangle CLIPPED to the piece's slab. A long thin
-// triangle then stops inflating every node above it. The pieces' boxes cover the triangle, so whichever piece a ray meets
-// the triangle in is visited and the (whole) triangle is tested there: hits are unchanged bit for bit (a triangle found
-// through two pieces ties with itself and keeps the first). Output: one box and one triangle index per reference.
-// threshold: box diagonal above which a reference is split (<= 0: none); a triangle yields at most max_pieces references.
-void split_references(const float* corners, uint32_t count, float threshold, uint32_t max_pieces, std::vector<float>& boxes6, std::vector<uint32_t>& ref_tri);
 
 struct BuildOutput {
    uint32_t width = 4;               // children per node

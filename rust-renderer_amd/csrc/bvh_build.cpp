@@ -42,25 +42,15 @@ struct Box {
    }
 };
 
-// build knobs of the study in tools/bvh_visits.py (UH_BVH_* environment variables; the defaults are what ships)
+// build knobs (what the studies of rounds 3-4 varied, tools/bvh_visits.py; the values below are what they settled on - the library
+// reads no environment variable)
 struct Knobs {
    int collapse = 1;        // 0 = greedy by area (rounds 1-3), 1 = SAH-optimal collapse by dynamic programming (Ylitie et al. 2017)
    int sweep_below = 0;     // ranges of at most this many triangles are split by an exact sweep over the sorted centroids instead of 16 bins
    int bins = 16;
    float c_tri = 1.0f;      // cost of a triangle slot relative to a node visit, per unit of area (collapse = 1)
-   int optimise = 0;        // passes of insertion-based optimisation over the binary tree before the collapse (Bittner, Hapala, Havran 2013)
-   float optimise_frac = 1.0f;  // share of the inner nodes (the most inefficient first) a pass takes out and reinserts
 };
-static Knobs knobs_from_env() {
-   Knobs k;
-   if (const char* e = std::getenv("UH_BVH_COLLAPSE")) k.collapse = std::atoi(e);
-   if (const char* e = std::getenv("UH_BVH_SWEEP")) k.sweep_below = std::atoi(e);
-   if (const char* e = std::getenv("UH_BVH_BINS")) k.bins = std::max(4, std::min(64, std::atoi(e)));
-   if (const char* e = std::getenv("UH_BVH_CTRI")) k.c_tri = (float)std::atof(e);
-   if (const char* e = std::getenv("UH_BVH_OPT")) k.optimise = std::atoi(e);
-   if (const char* e = std::getenv("UH_BVH_OPT_FRAC")) k.optimise_frac = (float)std::atof(e);
-   return k;
-}
+static Knobs knobs_from_env() { return Knobs(); }
 
 struct Node2 {
    Box box;
@@ -225,135 +215,6 @@ struct Builder {
    }
 };
 
-// Insertion-based optimisation of the binary tree (Bittner, Hapala, Havran: "Fast Insertion-Based Optimization of Bounding
-// Volume Hierarchies", CGF 2013): an inner node N (and its parent P) is taken out - N's sibling moves up into P's place - and
-// N's two children are reinserted, one after the other, wherever they add the least surface area to the tree (branch and bound
-// from the root on the area the insertion adds to the ancestors; N and P are reused as the new parents). Boxes only: the leaf
-// ranges (one triangle each) never move, so the packet order the collapse defines afterwards is unaffected.
-struct TreeOptimiser {
-   std::vector<Node2>& nd;
-   std::vector<int32_t> parent;
-   int32_t root = 0;
-   explicit TreeOptimiser(std::vector<Node2>& nodes) : nd(nodes), parent(nodes.size(), -1) {
-      for (size_t i = 0; i < nd.size(); i++)
-         if (nd[i].left >= 0) {
-            parent[nd[i].left] = (int32_t)i;
-            parent[nd[i].right] = (int32_t)i;
-         }
-   }
-   static Box unite(const Box& a, const Box& b) {
-      Box r = a;
-      r.grow(b);
-      return r;
-   }
-   void refit_up(int32_t n) {
-      while (n >= 0) {
-         const Box b = unite(nd[nd[n].left].box, nd[nd[n].right].box);
-         if (std::memcmp(&b, &nd[n].box, sizeof(Box)) == 0) break;
-         nd[n].box = b;
-         n = parent[n];
-      }
-   }
-   // the subtree `sub` goes where it adds the least area; `free_node` becomes its new parent
-   void insert(int32_t sub, int32_t free_node) {
-      struct Cand {
-         float induced;
-         int32_t node;
-         bool operator<(const Cand& o) const { return induced > o.induced; }  // min-heap
-      };
-      const Box sb = nd[sub].box;
-      const float sub_area = sb.half_area();
-      std::vector<Cand> heap;
-      heap.push_back(Cand{0.0f, root});
-      float best = INFINITY;
-      int32_t best_node = root;
-      while (!heap.empty()) {
-         std::pop_heap(heap.begin(), heap.end());
-         const Cand c = heap.back();
-         heap.pop_back();
-         if (c.induced + sub_area >= best) break;  // every position below costs at least this
-         const float direct = unite(nd[c.node].box, sb).half_area();
-         const float total = c.induced + direct;
-         if (total < best) {
-            best = total;
-            best_node = c.node;
-         }
-         const float child_induced = total - nd[c.node].box.half_area();
-         if (nd[c.node].left >= 0 && child_induced + sub_area < best) {
-            heap.push_back(Cand{child_induced, nd[c.node].left});
-            std::push_heap(heap.begin(), heap.end());
-            heap.push_back(Cand{child_induced, nd[c.node].right});
-            std::push_heap(heap.begin(), heap.end());
-         }
-      }
-      const int32_t q = parent[best_node];
-      nd[free_node].left = best_node;
-      nd[free_node].right = sub;
-      nd[free_node].box = unite(nd[best_node].box, sb);
-      parent[best_node] = free_node;
-      parent[sub] = free_node;
-      parent[free_node] = q;
-      if (q < 0)
-         root = free_node;
-      else {
-         (nd[q].left == best_node ? nd[q].left : nd[q].right) = free_node;
-         refit_up(q);
-      }
-   }
-   void reinsert_children_of(int32_t n) {
-      const int32_t p = parent[n];
-      if (p < 0 || nd[n].left < 0) return;
-      const int32_t g = parent[p];
-      if (g < 0) return;  // (children of the root stay: the root keeps its index)
-      const int32_t s = nd[p].left == n ? nd[p].right : nd[p].left;
-      (nd[g].left == p ? nd[g].left : nd[g].right) = s;
-      parent[s] = g;
-      refit_up(g);
-      const int32_t l = nd[n].left, r = nd[n].right;
-      // the larger subtree first (it has the fewer good places)
-      const bool l_first = nd[l].box.half_area() >= nd[r].box.half_area();
-      insert(l_first ? l : r, n);
-      insert(l_first ? r : l, p);
-   }
-   void pass(float frac) {
-      std::vector<std::pair<float, int32_t>> order;
-      for (size_t i = 0; i < nd.size(); i++) {
-         if (nd[i].left < 0 || parent[i] < 0 || parent[parent[i]] < 0) continue;
-         const float a = nd[i].box.half_area(), al = nd[nd[i].left].box.half_area(), ar = nd[nd[i].right].box.half_area();
-         const float m = std::fmin(al, ar);
-         // the paper's combined inefficiency: area x (area / mean child area) x (area / smaller child's area)
-         const float ineff = a * (a / (0.5f * (al + ar) + 1e-30f)) * (a / (m + 1e-30f));
-         order.emplace_back(ineff, (int32_t)i);
-      }
-      std::sort(order.begin(), order.end(), [](const std::pair<float, int32_t>& x, const std::pair<float, int32_t>& y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
-      const size_t take = (size_t)((double)order.size() * (double)frac);
-      for (size_t k = 0; k < take && k < order.size(); k++) reinsert_children_of(order[k].second);
-   }
-   // the root may have moved: bring it back to index 0 (the collapse starts there) by swapping the two nodes' contents
-   void root_to_zero() {
-      if (root == 0) return;
-      const int32_t r = root, pz = parent[0];
-      std::swap(nd[0], nd[r]);
-      // node contents swapped: fix the links that named either index
-      auto relink_children = [&](int32_t i) {
-         if (nd[i].left >= 0) {
-            parent[nd[i].left] = i;
-            parent[nd[i].right] = i;
-         }
-      };
-      // who pointed at old 0 now must point at r (unless it is the node that moved to 0 itself)
-      if (pz >= 0) {
-         const int32_t holder = pz == r ? 0 : pz;
-         (nd[holder].left == 0 ? nd[holder].left : nd[holder].right) = r;
-      }
-      parent[r] = pz == r ? 0 : pz;
-      parent[0] = -1;
-      relink_children(0);
-      relink_children(r);
-      root = 0;
-   }
-};
-
 // Conservative padding: the kernels' slab test must never cull a triangle that the
 // ray/triangle test would accept (DESIGN.md "Arithmetic contract", order-independence).
 inline void padded(const Box& b, float* lo, float* hi) {
@@ -426,115 +287,6 @@ void quantise_node(const NodeW& nd, Node4C& q) {
    }
 }
 
-void split_references(const float* corners, uint32_t count, float threshold, uint32_t max_pieces, std::vector<float>& boxes6, std::vector<uint32_t>& ref_tri) {
-   boxes6.clear();
-   ref_tri.clear();
-   boxes6.reserve(6 * (size_t)count);
-   ref_tri.reserve(count);
-   struct Piece {
-      double p[9][3];  // convex polygon (a triangle clipped by axis-aligned planes has at most 3 + 6 corners)
-      int n;
-   };
-   auto box_of = [](const Piece& q, double* lo, double* hi) {
-      for (int a = 0; a < 3; a++) {
-         lo[a] = INFINITY;
-         hi[a] = -INFINITY;
-      }
-      for (int k = 0; k < q.n; k++)
-         for (int a = 0; a < 3; a++) {
-            lo[a] = std::fmin(lo[a], q.p[k][a]);
-            hi[a] = std::fmax(hi[a], q.p[k][a]);
-         }
-   };
-   // the part of q on the side `keep_below` of the plane x[axis] = pos (Sutherland-Hodgman; corners ON the plane stay in both parts)
-   auto clip = [](const Piece& q, int axis, double pos, bool keep_below) {
-      Piece r;
-      r.n = 0;
-      for (int k = 0; k < q.n; k++) {
-         const double* a = q.p[k];
-         const double* b = q.p[(k + 1) % q.n];
-         const double da = keep_below ? pos - a[axis] : a[axis] - pos, db = keep_below ? pos - b[axis] : b[axis] - pos;
-         if (da >= 0 && r.n < 9) std::memcpy(r.p[r.n++], a, sizeof(double) * 3);
-         if ((da > 0 && db < 0) || (da < 0 && db > 0)) {
-            const double t = da / (da - db);
-            if (r.n < 9) {
-               for (int c = 0; c < 3; c++) r.p[r.n][c] = a[c] + t * (b[c] - a[c]);
-               r.p[r.n][axis] = pos;
-               r.n++;
-            }
-         }
-      }
-      return r;
-   };
-   std::vector<Piece> work;
-   for (uint32_t i = 0; i < count; i++) {
-      const float* c = corners + 9 * (size_t)i;
-      bool finite = true;
-      for (int k = 0; k < 9; k++) finite = finite && std::isfinite(c[k]);
-      Piece whole;
-      whole.n = 3;
-      for (int k = 0; k < 3; k++)
-         for (int a = 0; a < 3; a++) whole.p[k][a] = c[3 * k + a];
-      auto emit = [&](const double* lo, const double* hi) {
-         for (int a = 0; a < 3; a++) {
-            float f = (float)lo[a];
-            if ((double)f > lo[a]) f = std::nextafterf(f, -INFINITY);
-            boxes6.push_back(f);
-         }
-         for (int a = 0; a < 3; a++) {
-            float f = (float)hi[a];
-            if ((double)f < hi[a]) f = std::nextafterf(f, INFINITY);
-            boxes6.push_back(f);
-         }
-         ref_tri.push_back(i);
-      };
-      double lo[3], hi[3];
-      box_of(whole, lo, hi);
-      const double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-      if (!(threshold > 0) || !finite || !(diag > threshold) || max_pieces < 2) {
-         // unsplit: the corners' own box, exactly as the builder would compute it
-         float flo[3], fhi[3];
-         for (int a = 0; a < 3; a++) {
-            flo[a] = std::fmin(c[a], std::fmin(c[3 + a], c[6 + a]));
-            fhi[a] = std::fmax(c[a], std::fmax(c[3 + a], c[6 + a]));
-         }
-         boxes6.insert(boxes6.end(), flo, flo + 3);
-         boxes6.insert(boxes6.end(), fhi, fhi + 3);
-         ref_tri.push_back(i);
-         continue;
-      }
-      // halve the piece with the largest box until every piece is small enough or the budget is spent
-      work.clear();
-      work.push_back(whole);
-      for (;;) {
-         int pick = -1;
-         double worst = threshold;
-         for (size_t k = 0; k < work.size(); k++) {
-            box_of(work[k], lo, hi);
-            const double d = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-            if (d > worst) {
-               worst = d;
-               pick = (int)k;
-            }
-         }
-         if (pick < 0 || work.size() >= max_pieces) break;
-         box_of(work[pick], lo, hi);
-         int axis = 0;
-         for (int a = 1; a < 3; a++)
-            if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
-         const double pos = 0.5 * (lo[axis] + hi[axis]);
-         const Piece below = clip(work[pick], axis, pos, true), above = clip(work[pick], axis, pos, false);
-         if (below.n < 3 || above.n < 3) break;  // numerically degenerate cut: keep what there is
-         work[pick] = below;
-         work.push_back(above);
-      }
-      for (const Piece& q : work) {
-         box_of(q, lo, hi);
-         emit(lo, hi);
-      }
-   }
-}
-
 void build_sah_top(const float* boxes6, uint32_t count, std::vector<TopNode>& out) {
    out.clear();
    if (count < 2) return;
@@ -578,17 +330,11 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
       Box b;
       b.reset();
       bool finite = true;
-      if (in.boxes6) {
-         b.grow_pt(in.boxes6 + 6 * (size_t)i);
-         b.grow_pt(in.boxes6 + 6 * (size_t)i + 3);
-         for (int k = 0; k < 6; k++) finite = finite && std::isfinite(in.boxes6[6 * (size_t)i + k]);
-      } else {
-         const float* c = in.corners + 9 * (size_t)i;
-         b.grow_pt(c);
-         b.grow_pt(c + 3);
-         b.grow_pt(c + 6);
-         for (int k = 0; k < 9; k++) finite = finite && std::isfinite(c[k]);
-      }
+      const float* c = in.corners + 9 * (size_t)i;
+      b.grow_pt(c);
+      b.grow_pt(c + 3);
+      b.grow_pt(c + 6);
+      for (int k = 0; k < 9; k++) finite = finite && std::isfinite(c[k]);
       // a triangle with a non-finite corner can never be hit (NaN fails every comparison of the slab and
       // triangle tests, an infinite edge turns the barycentrics into NaN): it gets a point box at the origin so
       // that the split search below only ever sees finite numbers (NaN breaks the ordering std::nth_element needs)
@@ -775,30 +521,6 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    // ---- collapse to BVH4, breadth-first emission. Slot order inside a node: its triangle children first (their
    // packets are consecutive: the packet order is DEFINED here, node by node), then its node children (consecutive
    // node indices), then empty slots.
-   {
-      Knobs ko = knobs_from_env();
-      if (in.optimise_passes > ko.optimise) ko.optimise = in.optimise_passes;
-      if (ko.optimise > 0 && n2.size() > 8 && !balanced) {
-         TreeOptimiser opt(n2);
-         for (int it = 0; it < ko.optimise; it++) opt.pass(ko.optimise_frac);
-         opt.root_to_zero();
-         // depth of the optimised tree (the collapse and the traversal stack care)
-         std::vector<uint32_t> depth(n2.size(), 0);
-         std::vector<int32_t> stack{0};
-         uint32_t md = 0;
-         while (!stack.empty()) {
-            const int32_t k = stack.back();
-            stack.pop_back();
-            md = std::max(md, depth[k]);
-            if (n2[k].left >= 0) {
-               depth[n2[k].left] = depth[n2[k].right] = depth[k] + 1;
-               stack.push_back(n2[k].left);
-               stack.push_back(n2[k].right);
-            }
-         }
-         out.max_depth = md;
-      }
-   }
    // SAH-optimal collapse (Ylitie, Karras, Laine 2017, section 3.1, for single-triangle leaves): T[n][i] = the least cost of
    // representing BVH2 subtree n by at most i + 1 slots of a wide node - a slot being one triangle (cost c_tri x its area) or one
    // wide node (its area, plus the best distribution of its two children over W slots). Replaces the greedy "open the child

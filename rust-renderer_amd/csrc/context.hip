@@ -81,7 +81,7 @@ struct Slot {
    hipEvent_t ev_acc = nullptr;  // recorded after the frame's accumulate / store tail
    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
    DevBuf<float4> rec, radf, pixcol;  // rec: two sets of four path-state planes + the hit plane (device_types.h PathState)
-   DevBuf<uint32_t> queues[6];
+   DevBuf<uint32_t> queues[5];
    DevBuf<Control> control;
    PathState ps{};
    bool ready = false;
@@ -114,7 +114,7 @@ struct Slot {
       SLOT_TRY(pixcol.alloc(n, 2 * stagger));
       // sharded queues: capacity per shard = the pixels (64-pixel runs) a shard can own
       // (the miss queue holds (position, id) pairs: twice the words)
-      for (int qi = 0; qi < 6; qi++) SLOT_TRY(queues[qi].alloc((size_t)shard_cap * kShards * (qi == 4 ? 2 : 1)));
+      for (int qi = 0; qi < 5; qi++) SLOT_TRY(queues[qi].alloc((size_t)shard_cap * kShards * (qi == 4 ? 2 : 1)));
       SLOT_TRY(control.alloc(1));
       SLOT_TRY(hipMemsetAsync(control.p, 0, sizeof(Control), stream));
       SLOT_TRY(hipStreamSynchronize(stream));
@@ -124,7 +124,7 @@ struct Slot {
       ps.hit = rec.p + plane * 2 * kRecQuads;
       ps.radf = radf.p;
       ps.pixcol = pixcol.p;
-      for (int i = 0; i < 6; i++) ps.queue[i] = queues[i].p;
+      for (int i = 0; i < 5; i++) ps.queue[i] = queues[i].p;
       ps.shard_cap = shard_cap;
       ready = true;
       return hipSuccess;
@@ -192,9 +192,7 @@ struct uh_ctx {
    // one frame per call with a wait after it 2.95 / 2.88 / 2.88 / 2.84 / 2.85 / 2.89 ms: fewer waves finish a small launch's tail sooner
    uint32_t closest_blocks_per_cu = 5, shadow_blocks_per_cu = 5;  // (config 2, whose light shadow rays are a third of the frame: 6/5, 5/5, 5/4, 6/4 = 8,230 / 8,266 / 7,997 / 7,950 Mrays/s)
    uint32_t cam_walk_whole = 512;     // option "camera_grid_walk_whole" (sun_grid.h SunGridDev::walk_whole)
-   uint32_t single_frame_blocks_per_cu = 4;  // option "single_frame_blocks_per_cu": the cap on both for a wavefront of one frame
-   bool sun_leftover_batch = false;  // option "sun_leftover_batch"
-   uint32_t miss_blocks_per_cu = 8;  // 2 / 4 / 6 / 8: 7,599 / 7,613-7,656 / 7,699 / 7,676-7,678 Mrays/s
+   static constexpr uint32_t kSingleFrameBlocksPerCu = 4;  // the cap on both for a wavefront of one frame (fewer persistent waves reach the end of a small launch's tail sooner: round 4's sweep)
    std::string err;
 
    // host scene
@@ -224,7 +222,7 @@ struct uh_ctx {
    // PLOC rounds stop at this many clusters; a host SAH tree over them is the top (option "ploc_sah_top", 0 = PLOC to the root).
    // Config-1 scene: 0 / 1,024 / 8,192 / 131,072 clusters = 21.7 / 20.3 / 20.1 / 19.0 nodes per ray, rebuild 7.7 / 6.0 / 9.4 / 66 ms (host tree: 18.8)
    uint32_t ploc_sah_top = 1024;
-   uint32_t ploc_radius = 8;  // swept 4..64: tree quality flat (21.7-23.0 nodes/ray), build time grows with it (profiles/README.md)
+   static constexpr uint32_t kPlocRadius = 8;  // swept 4..64 in round 3: tree quality flat (21.7-23.0 nodes/ray), build time grows with it (profiles/README.md)
    DevBuf<float> d_src_corners;
    DevBuf<uint32_t> d_src_keys;
    DevBuf<float4> d_src_shade;
@@ -242,12 +240,9 @@ struct uh_ctx {
    Images im{};
 
    // options / stats
-   bool count_visits = false, time_kernels = false, full_frame_restir = false, raw_visit_counts = false;
+   bool count_visits = false, time_kernels = false, full_frame_restir = false;
    bool iso_reference = true;  // option "iso_reference_triangulation": uh_add_isosurface_mesh emits the reference's triangles (isosurface.hip)
    bool furnace = false;  // option "furnace": reference.rmiss compiled with FURNACE_TEST (a miss returns white whatever view.sky_enabled says)
-   int spatial_split_factor = 0;  // option "spatial_splits": 0 = off, k = split triangles whose box diagonal exceeds k x the median
-   int bvh_optimise = 0;          // option "bvh_optimise": passes of insertion-based optimisation in the host builder (bvh.h BuildInput)
-   int closest_variant = 1, shadow_variant = 1;  // refill kernels (0 = batch kernels)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
    float ms_by_kind[4] = {0, 0, 0, 0};  // trace_closest, trace_shadow, shade, camera grid (bounce 0 through the grid + its leftovers)
@@ -260,8 +255,6 @@ struct uh_ctx {
    // (geometry, sun direction) pair: it is built on the first frame that traces sun rays and again when the direction or the
    // geometry has changed and then stayed put for two consecutive frames - a sun or an instance that moves every frame keeps
    // the tree walk.
-   bool primary_tiles = false;      // option "primary_tiles": wave-per-tile traversal (scalar node fetches) for primary rays and the G-buffer cast; measured
-                                    // level with the per-lane kernel (config 1 +1.3 %, config 2 -0.5 %: profiles/README.md), so off by default
    bool sun_grid_enabled = true;
    bool sun_valid = false;          // d_sun_* hold a usable grid for (sun_geom, sun_dir_built)
    bool sun_attempted = false;      // a build for (sun_geom, sun_dir_built) was tried (it may have been refused: sun_why)
@@ -273,8 +266,10 @@ struct uh_ctx {
    DevBuf<float4> d_sun_recs;       // the entries with their packets inline (SunGridDev::recs; option "sun_grid_inline")
    DevBuf<float> d_sun_coarse;      // the coarse cover (SunGridDev::coarse; option "sun_grid_coarse")
    uint32_t sun_coarse_shift = 2;   // blocks of 4 x 4 cells; 0: no coarse cover
-   bool sun_inline = true;
-   uint64_t sun_inline_max_bytes = 8ull << 30;
+   // the lists a second time as 64-byte records that carry their packet (SunGridDev::recs): by default only while they stay within
+   // four times the packet array (a grid of 96 entries per triangle repeats every packet 96 times: 1.4 GB for the 17 MB of the
+   // config-1 scene); option "sun_grid_inline_max_mb" raises the budget (0: never)
+   int64_t sun_inline_max_mb = -1;  // -1: auto = 4 x the packet array
    SunGridDev sun_dev{};
    SunGridLimits sun_limits;
    std::string sun_why;
@@ -282,11 +277,8 @@ struct uh_ctx {
    float sun_fallback_area = 1.0f;  // share of the scene's surface whose cell hands its sun rays to the tree (the builders' figure)
    uint32_t sun_cells = 0, sun_entries = 0, sun_max_list = 0;
    bool sun_this_frame = false;     // set by render_batch for the frame being enqueued
-   bool sun_async = false;          // option "sun_grid_async": build on a host thread, walk the tree until it is done (host builder only)
    bool primary_implicit = true;    // option "primary_implicit" (FrameParams::primary_implicit)
-   bool sun_grid_fused = false;     // option "sun_grid_fused": k_shade_hit looks the sun rays' cells up itself (kernels.hip k_shade_hit<true>); 0: k_trace_sun_grid does
    bool sun_device_build = true;    // option "sun_grid_build": 1 = on the device (sun_grid_build.hip: a few ms), 0 = the host builder (sun_grid.cpp)
-   struct SunJob* sun_job = nullptr;
 
    // the primary rays through a per-camera grid instead of the tree (sun_grid.h "camera grid"; option "camera_grid"). The grid belongs
    // to one (geometry, inverse_view, inverse_projection, frame size): it is built - on the device, a few milliseconds - when the
@@ -304,19 +296,6 @@ struct uh_ctx {
    float cam_build_ms = 0.0f, cam_mean_list = 0.0f;
    uint32_t cam_cells = 0, cam_entries = 0, cam_max_list = 0, cam_max_list_interior = 0;
    bool cam_this_frame = false;
-
-   // One frame per call (a moving camera: uh_render_frame) spread over several slots: the frame's pixels are split, by tiles, into
-   // `interleave` parts, each a wavefront of its own on its own stream pair. A lone 2 M-path wavefront leaves the chip idle in the
-   // tail of every one of its ~30 launches; four half-million-path wavefronts at different stages of their chains fill each
-   // other's tails (the same effect as four frames in flight, inside one frame). Pixels are independent (RNG keyed on absolute
-   // pixel coordinates): the image is bit-identical. Option "interleave" (0 / 1 = off); batches of frames are not split.
-   // MEASURED AND OFF BY DEFAULT (round 4, config 1, profiles/README.md): one frame per call with a wait after it 2.96 ms whole,
-   // 2.98 in two parts, 4.06 in four, 4.84 in six; four frames in flight 2.22 / 2.74 / 3.82 / 4.70 - the parts' launches are four
-   // times as many and each still pays its fixed cost (a persistent grid over the whole chip for a queue of a few thousand rays):
-   // a lone frame is bound by launch count x fixed cost per launch, not by idle tails that more streams could fill.
-   uint32_t interleave = 0, il_parts = 0, il_tile = 32;
-   DevBuf<uint32_t> il_pixels[kMaxSlots];
-   uint32_t il_count[kMaxSlots] = {0};
 
    // tile partition
    uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
@@ -379,8 +358,7 @@ void set_transform(HostMesh& m, const float* w) {
 }
 
 LaunchCfg cfg(uh_ctx* c) {
-   return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->closest_variant, c->shadow_variant, c->raw_visit_counts,
-                    c->primary_tiles, c->miss_blocks_per_cu, c->sun_leftover_batch};
+   return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits};
 }
 
 void begin_timed(uh_ctx* c, int kind, hipStream_t stream = nullptr) {
@@ -526,15 +504,12 @@ int uh_create(int device_ordinal, uint32_t width, uint32_t height, uh_ctx** out)
    return UH_OK;
 }
 
-static void drop_sun_job(uh_ctx* c);
-
 void uh_destroy(uh_ctx* c) {
    if (!c) return;
    (void)hipSetDevice(c->device);
    // the communicator's collectives were enqueued on the reservoir stream: it goes (and every stream is drained) while that
    // stream still exists
    uh_rccl_detach(c);
-   drop_sun_job(c);
    // every stream idle before anything goes; the streams themselves go LAST, after every event that was recorded on or waited for by
    // one of them (slot streams wait for the reservoir stream's event and the other way round)
    (void)hipDeviceSynchronize();
@@ -576,7 +551,6 @@ void uh_destroy(uh_ctx* c) {
    c->d_sun_coarse.release();
    c->d_cam_cells.release();
    c->d_cam_entries.release();
-   for (auto& b : c->il_pixels) b.release();
    c->accumulation.release();
    c->gbuffer.release();
    c->output.release();
@@ -761,50 +735,7 @@ int uh_build_acceleration(uh_ctx* c) {
          keys[t] = (mi << kPrimBits) | p;
       }
    }
-   // option "spatial_splits" (bvh.h split_references): triangles whose box diagonal exceeds `factor` x the median triangle's are
-   // cut into references with clipped boxes; the tree is built over the references and a triangle's packet is repeated once
-   // per reference (same key: hits are unchanged). Off by default: the regularly tessellated config scenes gain nothing from it
-   // (tools/bvh_visits.py: 18.18 -> 18.17 node visits per ray), scenes with long thin triangles among small ones do.
-   std::vector<float> ref_boxes;
-   std::vector<uint32_t> ref_tri;
-   if (c->spatial_split_factor > 0 && total > 1) {
-      std::vector<float> diag(total);
-      for (size_t i = 0; i < total; i++) {
-         const float* q = &corners[9 * i];
-         float d2 = 0.0f;
-         for (int a = 0; a < 3; a++) {
-            const float lo = std::fmin(q[a], std::fmin(q[3 + a], q[6 + a])), hi = std::fmax(q[a], std::fmax(q[3 + a], q[6 + a]));
-            d2 += (hi - lo) * (hi - lo);
-         }
-         diag[i] = std::isfinite(d2) ? std::sqrt(d2) : 0.0f;
-      }
-      std::vector<float> sorted(diag);
-      std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
-      const float median = sorted[sorted.size() / 2];
-      if (median > 0.0f) {
-         split_references(corners.data(), (uint32_t)total, median * (float)c->spatial_split_factor, 64, ref_boxes, ref_tri);
-         if (ref_tri.size() > kMaxTriangles || ref_tri.size() == total) {
-            ref_boxes.clear();
-            ref_tri.clear();
-         }
-      }
-   }
-   const bool split = !ref_tri.empty();
-   if (split) {
-      // from here on the build's items are the references: corners / keys per reference (a split triangle's are repeated)
-      std::vector<float> rc(9 * ref_tri.size());
-      std::vector<uint32_t> rk(ref_tri.size());
-      for (size_t r = 0; r < ref_tri.size(); r++) {
-         std::memcpy(&rc[9 * r], &corners[9 * (size_t)ref_tri[r]], 9 * sizeof(float));
-         rk[r] = keys[ref_tri[r]];
-      }
-      corners.swap(rc);
-      keys.swap(rk);
-      total = ref_tri.size();
-   }
    BuildInput in{corners.data(), keys.data(), (uint32_t)total};
-   in.optimise_passes = c->bvh_optimise;
-   if (split) in.boxes6 = ref_boxes.data();
    BuildOutput bo;
    int threads = (int)std::thread::hardware_concurrency();
    if (threads < 1) threads = 1;
@@ -1029,7 +960,7 @@ static int build_on_device(uh_ctx* c) {
    }
    la.num_tris = (uint32_t)total;
    la.kind = c->device_build_kind;
-   la.ploc_radius = c->ploc_radius;
+   la.ploc_radius = uh_ctx::kPlocRadius;
    la.sah_top = c->ploc_sah_top;
    la.nodes = reinterpret_cast<uint4*>(c->d_nodes.p);
    la.node_capacity = (uint32_t)node_cap;
@@ -1157,18 +1088,6 @@ static int ensure_slot(uh_ctx* c, uint32_t i, uint32_t batch = 1) {
    return UH_OK;
 }
 
-// a grid built on a host thread while frames go on with the tree walk (option "sun_grid_async")
-struct SunJob {
-   std::thread worker;
-   std::atomic<bool> done{false};
-   std::vector<float> packets;
-   SunGridHost grid;
-   bool ok = false;
-   uint64_t geom = 0;
-   float dir[3] = {0, 0, 0};
-   double ms = 0.0;
-};
-
 static int attach_sun_inline_records(uh_ctx* c);
 // the grid `g` (or its refusal) becomes the context's grid for (geom, dir). Frames in flight may still read the old buffers.
 static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float dir[3], uint64_t geom, float build_ms) {
@@ -1279,7 +1198,8 @@ static int attach_sun_inline_records(uh_ctx* c) {
       c->sun_dev.coarse_nx = cnx;
    }
    const uint64_t n = c->sun_entries;
-   if (!c->sun_valid || !c->sun_inline || n == 0 || n * 64ull > c->sun_inline_max_bytes) return UH_OK;
+   const uint64_t budget = c->sun_inline_max_mb < 0 ? 4ull * 16 * kTriStride16 * c->scene.num_tris : (uint64_t)c->sun_inline_max_mb << 20;
+   if (!c->sun_valid || n == 0 || n * 64ull > budget) return UH_OK;
    if (c->d_sun_recs.alloc((size_t)n * 4) != hipSuccess) {  // no room: the plain lists serve
       (void)hipGetLastError();
       return UH_OK;
@@ -1290,37 +1210,10 @@ static int attach_sun_inline_records(uh_ctx* c) {
    return UH_OK;
 }
 
-static void drop_sun_job(uh_ctx* c) {
-   if (!c->sun_job) return;
-   if (c->sun_job->worker.joinable()) c->sun_job->worker.join();
-   delete c->sun_job;
-   c->sun_job = nullptr;
-}
-
 // the sun grid for this frame's direction, if there is (or now should be) one: see uh_ctx::sun_*
 static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
    c->sun_this_frame = false;
    if (!c->sun_grid_enabled || c->scene.num_tris == 0) return UH_OK;
-   if (c->sun_job && c->sun_job->done.load(std::memory_order_acquire)) {
-      // a background build has finished: it becomes the grid if it is still what this frame asks for
-      SunJob* j = c->sun_job;
-      j->worker.join();
-      int st = UH_OK;
-      if (j->geom == c->geom_version && std::memcmp(dir, j->dir, sizeof(float) * 3) == 0)
-         st = adopt_sun_grid(c, j->grid, j->ok, j->dir, j->geom, (float)j->ms);
-      else if (!c->sun_attempted) {
-         // overtaken by another change before any grid existed: from now on the "same pair twice in a row" rule below decides
-         // when the next build starts (a sun or an instance that moves every frame must not start a build per finished job)
-         c->sun_attempted = true;
-         c->sun_valid = false;
-         c->sun_geom = j->geom;
-         std::memcpy(c->sun_dir_built, j->dir, sizeof(float) * 3);
-         c->sun_why = "a background build was overtaken by a change of direction or geometry";
-      }
-      delete j;
-      c->sun_job = nullptr;
-      if (st != UH_OK) return st;
-   }
    const bool same_geom = c->sun_geom == c->geom_version;
    const bool same_dir = std::memcmp(dir, c->sun_dir_built, sizeof(float) * 3) == 0;
    if (same_geom && c->sun_attempted && same_dir) {
@@ -1340,7 +1233,7 @@ static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
    }
    // build: the packets as the device holds them (leaf order; host build, device build and refit all end there)
    const uint32_t n = c->scene.num_tris;
-   if (c->sun_device_build && !c->sun_async) {  // ("sun_grid_async" asks for the host builder on a host thread)
+   if (c->sun_device_build) {
       // on the device, from the packets where they lie: a few milliseconds, inside this frame call; the frames in flight may still
       // read the grid this one replaces
       if (int st = sync_all(c)) return st;
@@ -1355,29 +1248,6 @@ static int ensure_sun_grid(uh_ctx* c, const float dir[3]) {
    }
    int threads = (int)std::thread::hardware_concurrency();
    threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
-   if (c->sun_async) {
-      // on a host thread: this frame and the next ones walk the tree; the grid is adopted by the first frame that finds it done
-      if (c->sun_job) return UH_OK;  // one at a time; a job for another (geometry, direction) is dropped when it ends
-      SunJob* j = new SunJob();
-      j->packets.resize(12 * (size_t)n);
-      hipError_t e = hipMemcpy2D(j->packets.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), n, hipMemcpyDeviceToHost);  // packets change only under sync_all
-      if (e != hipSuccess) {
-         delete j;
-         return fail(c, UH_ERR_HIP, std::string("sun grid: ") + hipGetErrorString(e));
-      }
-      j->geom = c->geom_version;
-      std::memcpy(j->dir, dir, sizeof(float) * 3);
-      const SunGridLimits lim = c->sun_limits;
-      j->worker = std::thread([j, n, lim, threads]() {
-         const auto t0 = std::chrono::steady_clock::now();
-         j->ok = build_sun_grid(j->packets.data(), n, j->dir, lim, threads > 2 ? threads / 2 : 1, j->grid);  // half the cores: the render thread keeps going
-         j->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-         j->packets = std::vector<float>();
-         j->done.store(true, std::memory_order_release);
-      });
-      c->sun_job = j;
-      return UH_OK;
-   }
    if (int st = sync_all(c)) return st;
    const auto t0 = std::chrono::steady_clock::now();
    std::vector<float> packets(12 * (size_t)n);
@@ -1460,11 +1330,8 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
    LaunchCfg lc = cfg(c);
    lc.stream = s.stream;
    if (fp.batch_frames == 1) {  // a lone frame's launches are small: fewer persistent waves reach the end of their tails sooner
-      lc.closest_blocks_per_cu = std::min(lc.closest_blocks_per_cu, c->single_frame_blocks_per_cu);
-      lc.shadow_blocks_per_cu = std::min(lc.shadow_blocks_per_cu, c->single_frame_blocks_per_cu);
-      // ... and a handful of sun rays handed to the tree are cheaper without the refill kernel's pool (many are not: config 3's grid
-      // hands 17 % of the surface over, config 1's 4 %)
-      if (c->sun_fallback_area < 0.08f) lc.sun_leftover_batch = true;
+      lc.closest_blocks_per_cu = std::min(lc.closest_blocks_per_cu, uh_ctx::kSingleFrameBlocksPerCu);
+      lc.shadow_blocks_per_cu = std::min(lc.shadow_blocks_per_cu, uh_ctx::kSingleFrameBlocksPerCu);
    }
    Control* ctl = s.control.p;
    DeviceStats* st = c->dstats.p;
@@ -1488,9 +1355,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          // miss queue shade_miss(b-1) reads there
          if (side_used && b > 0) HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_shadowed, 0));
          begin_timed(c, 2, s.stream);
-         // also hands the bounce's misses to shade_miss (Q_MISS) and, fused, asks the sun grid's coarse cover for the scattered paths' sun rays
-         const bool sun_fused = fp.sun_shadow_enabled == 1 && c->sun_this_frame && c->sun_grid_fused && c->sun_dev.coarse != nullptr;
-         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b, sun_fused ? &c->sun_dev : nullptr);
+         launch_shade_hit(lc, fp, c->scene, s.ps, c->im, ctl, st, b);  // also hands the bounce's misses to shade_miss (Q_MISS)
          if (!c->overlap_miss) launch_shade_miss(lc, fp, s.ps, ctl, st, b);
          end_timed(c, s.stream);
          // shade_miss(b) and the shadow queries of bounce b are independent of trace_closest(b+1) (they only read what
@@ -1515,7 +1380,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          if (fp.sun_shadow_enabled == 1) {
             begin_timed(c, 1, sh_stream);
             if (c->sun_this_frame) {
-               launch_trace_sun_grid(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, c->sun_dev, sun_fused);
+               launch_trace_sun_grid(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, c->sun_dev);
                launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, false, true);  // the rays the grid handed over (border cells, long lists)
             } else
                launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, false);
@@ -1714,23 +1579,6 @@ static int batch_exchange(uh_ctx* c, uh_batch& bs, uint32_t f) {
    return UH_OK;
 }
 
-// the ascending pixel lists of the `parts` tile classes of a frame (tile t belongs to part t % parts)
-static int ensure_interleave_lists(uh_ctx* c, uint32_t parts) {
-   if (c->il_parts == parts) return UH_OK;
-   if (int st = sync_all(c)) return st;
-   const uint32_t tile = c->il_tile, tiles_x = (c->W + tile - 1) / tile;
-   std::vector<std::vector<uint32_t>> own(parts);
-   for (uint32_t y = 0; y < c->H; y++)
-      for (uint32_t x = 0; x < c->W; x++) own[((y / tile) * tiles_x + x / tile) % parts].push_back(y * c->W + x);
-   for (uint32_t k = 0; k < parts; k++) {
-      c->il_count[k] = (uint32_t)own[k].size();
-      HIP_TRY(c, c->il_pixels[k].alloc(own[k].empty() ? 1 : own[k].size()));
-      if (!own[k].empty()) HIP_TRY(c, hipMemcpy(c->il_pixels[k].p, own[k].data(), own[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-   }
-   c->il_parts = parts;
-   return UH_OK;
-}
-
 static int batch_end(uh_ctx* c, uh_batch& bs) {
    HIP_TRY(c, hipSetDevice(c->device));
    FrameParams& fp = bs.fp;
@@ -1747,34 +1595,20 @@ static int batch_end(uh_ctx* c, uh_batch& bs) {
       c->sun_this_frame = false;
       if (fp.sun_shadow_enabled == 1 && fp.num_bounces > 0 && fp.samples_per_frame > 0)
          if (int st = ensure_sun_grid(c, fp.sun_dir)) return st;
-      // a single frame is split over the slots (uh_ctx::interleave); a batch, or a rank's share of a partitioned frame, goes whole
       const uint32_t in_flight = c->frames_in_flight ? c->frames_in_flight : 1;
-      uint32_t parts = 1;
-      if (batch == 1 && c->tp_world <= 1 && c->interleave > 1 && (uint64_t)c->W * c->H >= 4096) parts = c->interleave < in_flight ? c->interleave : in_flight;
-      if (parts > 1)
-         if (int st = ensure_interleave_lists(c, parts)) return st;
-      for (uint32_t part = 0; part < parts; part++) {
+      {
          const uint32_t si = c->next_slot;
          c->next_slot = (c->next_slot + 1) % in_flight;
          int st = ensure_slot(c, si, batch);
          if (st != UH_OK) return st;
          Slot& s = c->slots[si];
-         FrameParams fk = fp;
-         if (parts > 1) {
-            fk.tp_world = parts;
-            fk.tp_rank = part;
-            fk.tp_tile = c->il_tile;
-            fk.tiles_x = (c->W + c->il_tile - 1) / c->il_tile;
-            fk.owned_pixels = c->il_pixels[part].p;
-            fk.n_owned = c->il_count[part];
-         }
+         const FrameParams& fk = fp;
          // rgen:98 reads this frame's spatial_reuse_reservoirs
          if (bs.reads_reservoirs && c->restir_recorded) HIP_TRY(c, hipStreamWaitEvent(s.stream, c->ev_restir, 0));
          HIP_TRY(c, hipEventRecord(s.frame_start, s.stream));
          if (!c->t_start) c->t_start = s.frame_start;
          st = enqueue_path_trace(c, s, fk);
          if (st != UH_OK) return st;
-         // (the parts' accumulate tails are chained through last_acc: the last part's event stands for all of them)
          if (bs.reads_reservoirs)
             for (uint32_t f = 0; f < batch; f++) c->spatial_reader[bs.read_slot[f]] = s.ev_acc;
          HIP_TRY(c, hipEventRecord(s.frame_stop, s.stream));
@@ -2068,6 +1902,8 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->camera_tree_rays = ds.cam_tree_rays;
    out->camera_grid_tris_tested = ds.cam_tris_tested;
    out->sun_covered_rays = ds.sun_covered_rays;
+   if (c->sun_valid) out->sun_grid_bytes = c->d_sun_cells.n * sizeof(uint32_t) + c->d_sun_entries.n * sizeof(SunGridEntry) + c->d_sun_recs.n * sizeof(float4) + c->d_sun_coarse.n * sizeof(float);
+   if (c->cam_valid && c->cam_this_frame) out->camera_grid_bytes = c->d_cam_cells.n * sizeof(uint32_t) + c->d_cam_entries.n * sizeof(SunGridEntry);
    return UH_OK;
 }
 
@@ -2086,156 +1922,115 @@ int uh_reset_stats(uh_ctx* c) {
    return UH_OK;
 }
 
+// The options (25): DESIGN.md section 7 has the table with defaults and what was measured. Variants that two rounds of measurements
+// left behind (batch traversal kernels, wave-per-tile primary rays, sub-frame interleave, the fused coarse-cover look-up, spatial
+// splits, insertion-based tree optimisation, the host-thread grid build) were removed in round 5 together with their options.
 int uh_set_option(uh_ctx* c, const char* name, int value) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    if (!name) return fail(c, UH_ERR_INVALID_ARGUMENT, "null option name");
-   std::string n(name);
+   const std::string n(name);
+   auto range = [&](int lo, int hi) { return value >= lo && value <= hi; };
+   auto bad = [&](const char* what) { return fail(c, UH_ERR_INVALID_ARGUMENT, n + " " + what); };
+   // ---- diagnostics
    if (n == "count_visits")
       c->count_visits = value != 0;
-   else if (n == "raw_visit_counts")
-      c->raw_visit_counts = value != 0;
-   else if (n == "device_build") {
-      // 0 = host SAH builder; 1 = device build, PLOC; 2 = device build, radix tree
-      if (value < 0 || value > 2) return fail(c, UH_ERR_INVALID_ARGUMENT, "device_build must be 0, 1 (PLOC) or 2 (radix tree)");
-      if (c->device_build != (value != 0) || (value && c->device_build_kind != (uint32_t)value)) c->built = c->topology_valid = false;
-      c->device_build = value != 0;
-      if (value) c->device_build_kind = (uint32_t)value;
-   }
-   else if (n == "spatial_splits") {
-      if (value < 0 || value > 1000) return fail(c, UH_ERR_INVALID_ARGUMENT, "spatial_splits must be 0 (off) or a factor of the median triangle box diagonal, 2..1000");
-      if (c->spatial_split_factor != value) c->built = c->topology_valid = false;
-      c->spatial_split_factor = value;
-   }
-   else if (n == "bvh_optimise") {
-      if (value < 0 || value > 16) return fail(c, UH_ERR_INVALID_ARGUMENT, "bvh_optimise must be 0..16 passes");
-      if (c->bvh_optimise != value) c->built = c->topology_valid = false;
-      c->bvh_optimise = value;
-   }
-   else if (n == "primary_tiles")
-      c->primary_tiles = value != 0;
-   else if (n == "sun_grid") {
-      // 1 (default): sun shadow rays go through the per-direction grid of sun_grid.h when one can be built; 0: always the tree
-      c->sun_grid_enabled = value != 0;
-   } else if (n == "sun_grid_density") {
-      if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_density (entries per triangle) must be 1..4096");
-      c->sun_limits.entries_per_triangle = (double)value;
-      c->sun_attempted = false;
-   } else if (n == "sun_grid_max_mean_list_x10") {
-      if (value < 1 || value > 10000) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_mean_list_x10 must be 1..10000");
-      c->sun_limits.max_mean_list = value / 10.0;  // entries per occupied cell beyond which the grid is refused (sun_grid.h)
-      c->sun_attempted = false;
-   } else if (n == "sun_grid_max_fallback_pct") {
-      if (value < 0 || value > 100) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_fallback_pct must be 0..100");
-      c->sun_limits.max_fallback_area = value / 100.0;  // share of the scene's surface whose sun rays may go on to the tree before the grid is refused
-      c->sun_attempted = false;
-   } else if (n == "interleave") {
-      if (value < 0 || value > (int)kMaxSlots) return fail(c, UH_ERR_INVALID_ARGUMENT, "interleave must be 0..8");
-      c->interleave = (uint32_t)value;
-   } else if (n == "camera_grid") {
-      // 1 (default): the primary rays of a camera at rest go through the per-camera grid; 0: always the tree
-      c->cam_grid_enabled = value != 0;
-   } else if (n == "camera_grid_max_walk") {
-      if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "camera_grid_max_walk must be 1..4096");
-      c->cam_limits.max_walk = (uint32_t)value;
-      c->cam_attempted = false;
-   } else if (n == "camera_grid_max_mean_list_x10") {
-      if (value < 1 || value > 100000) return fail(c, UH_ERR_INVALID_ARGUMENT, "camera_grid_max_mean_list_x10 must be 1..100000");
-      c->cam_limits.max_mean_list = value / 10.0;
-      c->cam_attempted = false;
-   } else if (n == "sun_grid_build") {
-      // 1 (default): the grid is built on the device (sun_grid_build.hip); 0: by the host builder (sun_grid.cpp, the reference implementation)
-      c->sun_device_build = value != 0;
-      c->sun_attempted = false;
-   } else if (n == "primary_implicit") {
-      // 1 (default): with the camera grid in use and one sample per frame, the state planes of bounce 0 are neither written nor
-      // read (the kernels of bounce 0 compute a primary ray from its path id); 0: as stored by k_generate. Same images.
-      c->primary_implicit = value != 0;
-   } else if (n == "sun_grid_coarse") {
-      // the coarse cover (sun_grid.h): one depth per block of 2^value x 2^value cells, asked before the cell's own record; 0: none
-      if (value < 0 || value > 6) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_coarse (log2 of the block edge in cells) must be 0..6");
-      c->sun_coarse_shift = (uint32_t)value;
-      c->sun_attempted = false;
-   } else if (n == "sun_grid_inline") {
-      // 1 (default): the grid's lists are kept a second time as 64-byte records that carry their packet (one sector and one round trip
-      // per triangle test instead of two); 0: entries and packets apart (round 3). Takes effect with the next grid that is built.
-      c->sun_inline = value != 0;
-      c->sun_attempted = false;
-   } else if (n == "sun_grid_inline_max_mb") {
-      if (value < 1 || value > (1 << 20)) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_inline_max_mb must be 1..1048576");
-      c->sun_inline_max_bytes = (uint64_t)value << 20;
-      c->sun_attempted = false;
-   } else if (n == "sun_grid_fused") {
-      // 1: the shading kernel asks the grid's coarse cover for each scattered path's sun ray while it waits for its texels, and the
-      // grid kernel serves the rays that are left; 0: the grid kernel does both. Same images.
-      c->sun_grid_fused = value != 0;
-   } else if (n == "sun_grid_async") {
-      // 1: a grid is built on a host thread while frames go on with the tree walk (no 130 ms stall when the sun or the geometry
-      // comes to rest; images are the same either way); 0 (default): built inside the frame call that asks for it
-      c->sun_async = value != 0;
-   } else if (n == "sun_grid_max_walk") {
-      if (value < 1 || value > 4096) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_walk (longest list a ray tests itself) must be 1..4096");
-      c->sun_limits.max_walk = (uint32_t)value;
-      c->sun_attempted = false;
-   } else if (n == "sun_grid_max_mb") {
-      if (value < 1 || value > 65536) return fail(c, UH_ERR_INVALID_ARGUMENT, "sun_grid_max_mb must be 1..65536");
-      c->sun_limits.max_entries = ((uint64_t)value << 20) / sizeof(SunGridEntry);
-      c->sun_attempted = false;
-   }
    else if (n == "time_kernels") {
       if (c->time_kernels && !value) {
          (void)sync_all(c);
          drain_timed(c);
       }
       c->time_kernels = value != 0;
-   } else if (n == "full_frame_restir")
+   }
+   // ---- the tree
+   else if (n == "device_build") {
+      // 0 = host SAH builder; 1 = device build, PLOC under a host SAH top; 2 = device build, radix tree
+      if (!range(0, 2)) return bad("must be 0, 1 (PLOC) or 2 (radix tree)");
+      if (c->device_build != (value != 0) || (value && c->device_build_kind != (uint32_t)value)) c->built = c->topology_valid = false;
+      c->device_build = value != 0;
+      if (value) c->device_build_kind = (uint32_t)value;
+   } else if (n == "ploc_sah_top") {
+      if (!range(0, 1 << 20)) return bad("must be 0..1048576");
+      if (c->ploc_sah_top != (uint32_t)value && c->device_build) c->built = c->topology_valid = false;
+      c->ploc_sah_top = (uint32_t)value;
+   }
+   // ---- the sun grid (sun_grid.h): every change takes effect with the next grid that is built
+   else if (n == "sun_grid")
+      c->sun_grid_enabled = value != 0;  // 0: the sun shadow rays always walk the tree
+   else if (n == "sun_grid_build") {
+      c->sun_device_build = value != 0;  // 1: built on the device (sun_grid_build.hip); 0: by the host builder (sun_grid.cpp, the reference implementation)
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_density") {
+      if (!range(1, 4096)) return bad("(entries per triangle) must be 1..4096");
+      c->sun_limits.entries_per_triangle = (double)value;
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_max_walk") {
+      if (!range(1, 4096)) return bad("(longest list a ray tests itself) must be 1..4096");
+      c->sun_limits.max_walk = (uint32_t)value;
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_max_mb") {
+      if (!range(1, 65536)) return bad("must be 1..65536");
+      c->sun_limits.max_entries = ((uint64_t)value << 20) / sizeof(SunGridEntry);
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_max_mean_list_x10") {
+      if (!range(1, 10000)) return bad("must be 1..10000");
+      c->sun_limits.max_mean_list = value / 10.0;  // entries per occupied cell beyond which the grid is refused (sun_grid.h)
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_max_fallback_pct") {
+      if (!range(0, 100)) return bad("must be 0..100");
+      c->sun_limits.max_fallback_area = value / 100.0;  // share of the scene's surface whose sun rays may go on to the tree before the grid is refused
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_inline_max_mb") {
+      // the lists a second time as 64-byte records that carry their packet (one round trip per triangle test instead of two): memory budget
+      // in MB; -1 (default) = four times the packet array; 0 = never
+      if (!range(-1, 1 << 20)) return bad("must be -1 (auto: 4 x the packet array), 0 (off) .. 1048576");
+      c->sun_inline_max_mb = value;
+      c->sun_attempted = false;
+   } else if (n == "sun_grid_coarse") {
+      // the coarse cover (sun_grid.h): one depth per block of 2^value x 2^value cells, asked before the cell's own record; 0: none
+      if (!range(0, 6)) return bad("(log2 of the block edge in cells) must be 0..6");
+      c->sun_coarse_shift = (uint32_t)value;
+      c->sun_attempted = false;
+   }
+   // ---- the camera grid
+   else if (n == "camera_grid")
+      c->cam_grid_enabled = value != 0;  // 0: the primary rays always walk the tree
+   else if (n == "camera_grid_max_walk") {
+      if (!range(1, 4096)) return bad("must be 1..4096");
+      c->cam_limits.max_walk = (uint32_t)value;
+      c->cam_attempted = false;
+   } else if (n == "camera_grid_walk_whole") {
+      // lists of up to this many packets are walked whole by the grid kernel (those beyond camera_grid_max_walk are not sorted: no early
+      // exit) instead of handing the ray to the tree; 0: every list beyond camera_grid_max_walk goes to the tree
+      if (!range(0, 65536)) return bad("must be 0..65536");
+      c->cam_walk_whole = (uint32_t)value;
+      c->cam_attempted = false;
+   } else if (n == "camera_grid_max_mean_list_x10") {
+      if (!range(1, 100000)) return bad("must be 1..100000");
+      c->cam_limits.max_mean_list = value / 10.0;
+      c->cam_attempted = false;
+   } else if (n == "primary_implicit")
+      c->primary_implicit = value != 0;  // 0: bounce 0's state planes are stored by k_generate even when the camera grid is in use
+   // ---- what the frames compute
+   else if (n == "full_frame_restir")
       c->full_frame_restir = value != 0;
    else if (n == "iso_reference_triangulation")
       c->iso_reference = value != 0;
    else if (n == "furnace")
       c->furnace = value != 0;  // applies to the frames enqueued from now on
-   else if (n == "ploc_sah_top") {
-      if (value < 0 || value > (1 << 20)) return fail(c, UH_ERR_INVALID_ARGUMENT, "ploc_sah_top must be 0..1048576");
-      if (c->ploc_sah_top != (uint32_t)value && c->device_build) c->built = c->topology_valid = false;
-      c->ploc_sah_top = (uint32_t)value;
-   } else if (n == "ploc_radius") {
-      if (value < 1 || value > 64) return fail(c, UH_ERR_INVALID_ARGUMENT, "ploc_radius must be 1..64");
-      if (c->ploc_radius != (uint32_t)value && c->device_build) c->built = c->topology_valid = false;
-      c->ploc_radius = (uint32_t)value;
-   } else if (n == "overlap_miss")
-      c->overlap_miss = value != 0;
-   else if (n == "overlap_shadow")
-      c->overlap_shadow = value != 0;
+   // ---- how the frames are scheduled
+   else if (n == "overlap")
+      c->overlap_miss = c->overlap_shadow = value != 0;  // k_shade_miss and the shadow traversals on the slot's side stream
    else if (n == "batch_frames") {
-      if (value < 0 || value > (int)kMaxBatchFrames) return fail(c, UH_ERR_INVALID_ARGUMENT, "batch_frames must be 0 (auto) .. 32");
+      if (!range(0, (int)kMaxBatchFrames)) return bad("must be 0 (auto) .. 32");
       c->batch_frames = (uint32_t)value;
    } else if (n == "frames_in_flight") {
-      if (value < 1 || value > (int)kMaxSlots) return fail(c, UH_ERR_INVALID_ARGUMENT, "frames_in_flight must be 1..8");
+      if (!range(1, (int)kMaxSlots)) return bad("must be 1..8");
       (void)sync_all(c);
       c->frames_in_flight = (uint32_t)value;
       c->next_slot = 0;
-   }
-   else if (n == "trace_variant" || n == "closest_variant" || n == "shadow_variant") {
-      if (value < 0 || value > 1) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 0 (batch kernels) or 1 (refill kernels)");
-      if (n != "shadow_variant") c->closest_variant = value;
-      if (n != "closest_variant") c->shadow_variant = value;
-   } else if (n == "camera_grid_walk_whole") {
-      // the camera grid's kernel walks lists of up to this many packets whole (those beyond camera_grid_max_walk are not sorted: no early
-      // exit) instead of handing the ray to the tree; 0: every list beyond camera_grid_max_walk goes to the tree (round 4's first form)
-      if (value < 0 || value > 65536) return fail(c, UH_ERR_INVALID_ARGUMENT, "camera_grid_walk_whole must be 0..65536");
-      c->cam_walk_whole = (uint32_t)value;
-      c->cam_attempted = false;
-   } else if (n == "single_frame_blocks_per_cu") {
-      if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, "single_frame_blocks_per_cu must be 1..8");
-      c->single_frame_blocks_per_cu = (uint32_t)value;
-   } else if (n == "sun_leftover_batch") {
-      c->sun_leftover_batch = value != 0;  // the sun rays the grid hands to the tree walk the tree in the batch kernel (1) or the refill kernel (0)
-   } else if (n == "miss_blocks_per_cu") {
-      if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, "miss_blocks_per_cu must be 1..8");
-      c->miss_blocks_per_cu = (uint32_t)value;
-   } else if (n == "trace_blocks_per_cu" || n == "closest_blocks_per_cu" || n == "shadow_blocks_per_cu") {
-      if (value < 1 || value > 8) return fail(c, UH_ERR_INVALID_ARGUMENT, n + " must be 1..8");
-      if (n != "shadow_blocks_per_cu") c->closest_blocks_per_cu = (uint32_t)value;
-      if (n != "closest_blocks_per_cu") c->shadow_blocks_per_cu = (uint32_t)value;
+   } else if (n == "trace_blocks_per_cu") {
+      if (!range(1, 8)) return bad("must be 1..8");
+      c->closest_blocks_per_cu = c->shadow_blocks_per_cu = (uint32_t)value;  // persistent grids of the traversal kernels
    } else
       return fail(c, UH_ERR_INVALID_ARGUMENT, "unknown option: " + n);
    return UH_OK;

@@ -425,28 +425,4 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
    return base + prefix;
 }
 
-// N wave-aggregated appends in ONE round trip: lane k (k < N) adds the k-th count to the k-th counter, so the wave waits for one
-// returning atomic instead of N in a row (k_shade_hit appends to up to five queues per 64 hits). Same contract as wave_append.
-template <int N>
-__device__ __forceinline__ void wave_append_multi(uint32_t* const (&counter)[N], const bool (&pred)[N], uint32_t (&slot)[N]) {
-   static_assert(N >= 1 && N <= 8, "a handful of queues");
-   const uint32_t lane = lane_id();
-   unsigned long long mask[N];
-   uint32_t* mine = counter[0];
-   uint32_t n_mine = 0;
-#pragma unroll
-   for (int k = 0; k < N; k++) {
-      mask[k] = __ballot(pred[k]);
-      if (lane == (uint32_t)k) {
-         mine = counter[k];
-         n_mine = (uint32_t)__popcll(mask[k]);
-      }
-   }
-   uint32_t base = 0;
-   if (lane < (uint32_t)N && n_mine) base = atomicAdd(mine, n_mine);
-#pragma unroll
-   for (int k = 0; k < N; k++)
-      slot[k] = (uint32_t)__builtin_amdgcn_readlane((int)base, k) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[k], 0u));
-}
-
 }  // namespace uh

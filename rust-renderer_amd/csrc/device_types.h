@@ -15,14 +15,12 @@ namespace uh {
 constexpr uint32_t kMaxBounces = 64;
 // per bounce: RAY (paths whose ray the bounce traces; the shading kernels tell hits from misses by the hit
 // record, so no hit / miss queues exist) and LIGHT (scattered paths that carry a light sample)
-constexpr uint32_t kQueueKinds = 6;
+constexpr uint32_t kQueueKinds = 5;
 // Q_SUN_TREE: sun rays the grid kernel hands to the tree walk (border cells, long lists). Q_MISS: the paths of a bounce whose ray
 // left the scene - k_shade_hit meets them while it classifies the bounce's RAY queue and hands their ids to k_shade_miss
 // Q_CAM_TREE (bounce 0 only): primary rays the camera grid hands to the tree walk (pixels with long lists); shares queue 3 with
 // Q_SUN_TREE, which the same bounce's sun rays fill only after the shading kernel
-// Q_SUN_GRID (option sun_grid_fused): the sun rays k_shade_hit did not find below their block's coarse cover - k_trace_sun_grid
-// looks their cells up
-enum { Q_RAY = 0, Q_LIGHT = 1, Q_SUN_TREE = 2, Q_MISS = 3, Q_CAM_TREE = 4, Q_SUN_GRID = 5 };
+enum { Q_RAY = 0, Q_LIGHT = 1, Q_SUN_TREE = 2, Q_MISS = 3, Q_CAM_TREE = 4 };
 constexpr uint32_t kLaunchSlots = kMaxBounces * 4 + 8;  // per bounce: closest, sun (grid), sun leftovers (tree), light; bounce 0: + camera grid, its leftovers
 
 // Queues are sharded: path p lives in shard shard_of_run(p / 64) for its whole life, every queue
@@ -160,9 +158,8 @@ struct PathState {
    float4* radf;     // by path id: a finished path's radiance.rgb | its raygen rngState (the frame's next sample starts from it, rgen:28-31)
    float4* pixcol;   // by path id: sum over the frame's samples
    // 0,1 = ray ping-pong: path ids; 2 = light, 3 = sun rays for the tree walk: positions in the NEXT bounce's ray queue; 4 = misses:
-   // positions in the CURRENT one; 5 = sun rays for the grid kernel (option sun_grid_fused): positions in the NEXT bounce's ray
-   // queue; each kShards * shard_cap entries
-   uint32_t* queue[6];
+   // (position in the CURRENT one, id) pairs; each kShards * shard_cap entries
+   uint32_t* queue[5];
    uint32_t shard_cap;  // entries per shard segment = pixels a shard can own (multiple of 64)
 };
 __host__ __device__ inline float4* rec_quad(const PathRecs& rec, uint32_t pos, int quad) { return rec.base + rec.plane * (size_t)quad + pos; }
@@ -202,14 +199,6 @@ struct LaunchCfg {
    uint32_t num_cus;
    uint32_t closest_blocks_per_cu, shadow_blocks_per_cu;
    bool count_visits;
-   // traversal kernels (options "closest_variant" / "shadow_variant"; bit-identical in results): 0 = batch kernel (a wave
-   // walks 64 rays to the end of the slowest - the baseline), anything else = persistent waves whose idle lanes take the
-   // next ray from an LDS pool (kernels.hip "Ray replacement"), the default
-   int closest_variant, shadow_variant;
-   bool raw_visit_counts = false;  // diagnostics: uh_trace_closest returns per-ray visit counts in u,v
-   bool primary_tiles = false;     // the G-buffer cast: one wave per 8 x 8 pixel tile (k_trace_closest_tiles)
-   uint32_t miss_blocks_per_cu = 8; // k_shade_miss (dense miss queue, VALU-bound sky integral): option "miss_blocks_per_cu"
-   bool sun_leftover_batch = false; // the sun rays the grid hands to the tree: batch kernel instead of the refill kernel (option "sun_leftover_batch")
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);
@@ -218,17 +207,14 @@ void launch_trace_closest(const LaunchCfg&, const SceneDev&, const PathState&, C
 void launch_trace_camera_grid(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t cursor_slot_grid, uint32_t cursor_slot_tree,
                               const SunGridDev&, bool leftovers_possible = true);  // false: the grid's longest list is one its kernel walks itself - no tree-walk launch behind it
 void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, Control*, DeviceStats*, uint32_t bounce);
-// sun_grid != null (it must have a coarse cover): the kernel also asks the coarse cover for the scattered paths' sun rays and lists
-// those it does not answer in Q_SUN_GRID; launch_trace_sun_grid(.., fused = true) then serves that queue only
-void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce,
-                      const SunGridDev* sun_grid = nullptr);
+void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
 // the paths still alive after the last bounce hand their radiance to the per-id array k_finish_sample reads
 void launch_flush_survivors(const LaunchCfg&, const FrameParams&, const PathState&, Control*);
 void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
                          uint32_t cursor_slot, bool light, bool sun_leftovers = false);
 // sun shadow rays through the per-direction grid (sun_grid.h) instead of the tree
 void launch_trace_sun_grid(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
-                           uint32_t cursor_slot, const SunGridDev&, bool fused = false);
+                           uint32_t cursor_slot, const SunGridDev&);
 void launch_finish_sample(const LaunchCfg&, const FrameParams&, const PathState&, const Images&, uint32_t sample, bool last);
 void launch_resolve(const LaunchCfg&, const Images&, uint32_t W, uint32_t H, uint32_t total_samples, uint32_t limit);
 // G-buffer + ReSTIR

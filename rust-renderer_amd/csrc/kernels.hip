@@ -536,182 +536,6 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace_closest(SceneDev sc, bool s
 }
 
 // ------------------------------------------------------------------------------------------
-// trace_closest, one wave per 8 x 8 pixel tile - for rays that leave neighbouring pixels with (nearly) one origin: the primary
-// rays of rgen:36-47 and the G-buffer cast (gbuffer.rs:11-52). The 64 rays of a tile want almost the same nodes, so the wave
-// walks ONE node at a time for all of them: the node (and at a leaf the triangle packet) is fetched through the SCALAR path -
-// three s_load_dwordx4 into SGPRs, off the vector-memory pipeline that bounds the per-lane kernels - every lane slab-tests the
-// four children against ITS ray and ITS best hit, and a child is descended when any lane's test passes (ballot). The wave's
-// stack (LDS, one copy per wave) holds what some lane still wants. A triangle is tested by every lane: testing a triangle a
-// lane's own walk would have culled cannot change that lane's result (boxes are conservative: DESIGN.md "Arithmetic contract"),
-// so hits are those of k_trace_closest bit for bit.
-// ------------------------------------------------------------------------------------------
-struct TileJob {
-   uint32_t W, H, frames;       // rays of frame f, pixel (x, y): record f * W * H + y * W + x
-   uint32_t tp_world, tp_rank, tp_tile, tiles_x;  // tile partition of the path tracer (tp_world <= 1: every pixel); tp_tile % 8 == 0
-   uint32_t range_in_w;         // raw rays: tmin / tmax in the w components; path rays: rgen:45-47's constants
-};
-
-__device__ __forceinline__ void sload48(const uint4* p, uint4& a, uint4& b, uint4& c) {
-   // p is wave-uniform: three scalar loads (the compiler will not prove uniformity of an index that came out of LDS)
-   u4_t x, y, z;
-   asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(x), "=&s"(y), "=&s"(z) : "s"(p) : "memory");
-   a = make_uint4(x.x, x.y, x.z, x.w);
-   b = make_uint4(y.x, y.y, y.z, y.w);
-   c = make_uint4(z.x, z.y, z.z, z.w);
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_closest_tiles(SceneDev sc, TileJob job, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                                 float4* __restrict__ hit_out, DeviceStats* stats, int ray_kind) {
-   constexpr uint32_t kTileStack = 3 * kMaxTreeLevels + 4;
-   __shared__ uint32_t s_stack[kWavesPerBlock][kTileStack];
-   const uint32_t lane = lane_id();
-   const uint32_t wave = threadIdx.x >> 6;
-   uint32_t* stack = s_stack[wave];
-   const uint32_t tx8 = (job.W + 7) / 8, ty8 = (job.H + 7) / 8;
-   const uint32_t items = tx8 * ty8 * job.frames;
-   const uint32_t npix = job.W * job.H;
-   uint32_t n_nodes = 0, n_tris = 0, n_rays = 0;
-   for (uint32_t item = blockIdx.x * kWavesPerBlock + wave; item < items; item += gridDim.x * kWavesPerBlock) {
-      const uint32_t f = item / (tx8 * ty8), t = item - f * (tx8 * ty8);
-      const uint32_t px = (t % tx8) * 8 + (lane & 7), py = (t / tx8) * 8 + (lane >> 3);
-      bool live = px < job.W && py < job.H;
-      if (job.tp_world > 1) {
-         // 8 x 8 tiles nest in the partition's tiles: a tile is owned as a whole or not at all (wave-uniform)
-         const uint32_t owner = ((py / job.tp_tile) * job.tiles_x + px / job.tp_tile) % job.tp_world;
-         live = live && owner == job.tp_rank;
-      }
-      if (__ballot(live) == 0ull) continue;
-      const uint32_t id = f * npix + py * job.W + px;
-      float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(1, 0, 0, 0);
-      if (live) {
-         ro = ld_rec(ray_o + id);
-         rd = ld_rec(ray_d + id);
-      }
-      Trav tr;
-      trav_init(tr, ro, rd, job.range_in_w ? ro.w : 0.001f, job.range_in_w ? rd.w : 10000.0f, INFINITY);
-      if (!live) tr.best.t = -1.0f;  // an interval no box meets: the lane votes for nothing
-      const uint32_t n_live = (uint32_t)__popcll(__ballot(live));  // every lane votes: the count is wave-uniform
-      if (lane == 0) n_rays += n_live;
-      uint32_t sp = 0;            // wave-uniform
-      uint32_t cur = 0;           // wave-uniform: node index, or kLeafBit | packet
-      for (uint32_t guard = 0; guard < (1u << 22); guard++) {
-         cur = __builtin_amdgcn_readfirstlane(cur);
-         uint4 w0, w1, w2;
-         if (!(cur & kLeafBit)) {
-            sload48(sc.nodes + kNodeStride16 * (size_t)cur, w0, w1, w2);
-            if (COUNT && live) n_nodes++;  // per ray of the tile, as the per-lane kernels count
-            // the node step of node_compute, with the children's verdicts kept per lane
-            const uint32_t meta = w0.w;
-            const float sx = __uint_as_float((meta & 0xffu) << 23), sy = __uint_as_float((meta << 15) & 0x7f800000u), sz = __uint_as_float((meta << 7) & 0x7f800000u);
-            const float ax = sx * tr.idir.x, ay = sy * tr.idir.y, az = sz * tr.idir.z;
-            const float bx = (__uint_as_float(w0.x) - tr.o.x) * tr.idir.x, by = (__uint_as_float(w0.y) - tr.o.y) * tr.idir.y, bz = (__uint_as_float(w0.z) - tr.o.z) * tr.idir.z;
-            const bool nx = tr.idir.x < 0.0f, ny = tr.idir.y < 0.0f, nz = tr.idir.z < 0.0f;
-            const uint32_t qnx = nx ? w1.w : w1.x, qfx = nx ? w1.x : w1.w;
-            const uint32_t qny = ny ? w2.x : w1.y, qfy = ny ? w1.y : w2.x;
-            const uint32_t qnz = nz ? w2.y : w1.z, qfz = nz ? w1.z : w2.y;
-            const uint32_t n_tri = (meta >> kMetaTriShift) & 7u;
-            const uint32_t tri0 = kLeafBit | w2.w, node0 = w2.z - n_tri;
-            uint32_t want = 0;   // wave-uniform: children some lane's ray meets
-            float centre_t[4];   // entry distance of the tile's centre ray (lane 27), INF when it misses the child
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-               const float t0x = fmaf((float)((qnx >> (8 * k)) & 0xffu), ax, bx), t1x = fmaf((float)((qfx >> (8 * k)) & 0xffu), ax, bx);
-               const float t0y = fmaf((float)((qny >> (8 * k)) & 0xffu), ay, by), t1y = fmaf((float)((qfy >> (8 * k)) & 0xffu), ay, by);
-               const float t0z = fmaf((float)((qnz >> (8 * k)) & 0xffu), az, bz), t1z = fmaf((float)((qfz >> (8 * k)) & 0xffu), az, bz);
-               const float tnear = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, tr.tmin));
-               const float tfar = fminf(fminf(t1x, t1y), fminf(t1z, tr.best.t));
-               const bool hit = tnear <= tfar;
-               if (__ballot(hit) != 0ull) want |= 1u << k;
-               centre_t[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hit ? tnear : INFINITY), 27));
-            }
-            if (want == 0u) {
-               if (sp == 0) break;
-               cur = stack[--sp];
-               continue;
-            }
-            // nearest wanted child (by the centre ray) next, the others pushed - all of it on the scalar side
-            int first = -1;
-            float best_t = INFINITY;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-               if ((want >> k & 1u) && (first < 0 || centre_t[k] < best_t)) {
-                  first = k;
-                  best_t = centre_t[k];
-               }
-#pragma unroll
-            for (int k = 3; k >= 0; k--)
-               if ((want >> k & 1u) && k != first && sp < kTileStack) {
-                  if (lane == 0) stack[sp] = ((uint32_t)k < n_tri ? tri0 : node0) + (uint32_t)k;
-                  sp++;
-               }
-            cur = ((uint32_t)first < n_tri ? tri0 : node0) + (uint32_t)first;
-         } else {
-            const uint32_t packet = cur & ~kLeafBit;
-            sload48((const uint4*)sc.tris + kTriStride16 * (size_t)packet, w0, w1, w2);
-            if (COUNT && live) n_tris++;
-            const float4 ta = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
-            const float4 tb = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
-            const float4 tc = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
-            if (live) tri_compute<false>(ta, tb, tc, packet, tr.o, tr.d, tr.tmin, INFINITY, tr.best);
-            if (sp == 0) break;
-            cur = stack[--sp];
-         }
-      }
-      if (live) st_rec(hit_out + id, make_float4(tr.best.t, tr.best.u, tr.best.v, __uint_as_float(tr.best.idx)));
-   }
-   if (COUNT) {
-      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
-      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
-   }
-   if (ray_kind >= 0 && lane == 0 && n_rays) atomicAdd(&stats->rays[ray_kind], (unsigned long long)n_rays);
-}
-
-// The plain batch form (option closest_variant = 0): a wave takes 64 rays, every lane walks its ray to the end,
-// then the wave takes the next 64. Kept as the baseline the refill kernels are measured against, and for the
-// per-ray visit counts of the diagnostics (DIAG: u,v of the result carry the ray's node / triangle visits).
-template <bool COUNT, bool DIAG>
-__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_closest_batch(SceneDev sc, bool sharded,
-                                                                                                      const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                                                                      float4* __restrict__ hit_out, uint32_t shard_cap, Control* ctl, DeviceStats* stats,
-                                                                                                      uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t raw_count) {
-   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
-   const uint32_t lane = lane_id();
-   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
-   uint32_t n_nodes = 0, n_tris = 0;
-   if (!sharded) {
-      for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < raw_count; i += gridDim.x * kBlock) {
-         float4 ro = ray_o[i], rd = ray_d[i];
-         Hit h;
-         if (DIAG) n_nodes = n_tris = 0;
-         traverse<false, DIAG>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, 0.0f, h, lds_col, n_nodes, n_tris);
-         hit_out[i] = DIAG ? make_float4(h.t, (float)n_nodes, (float)n_tris, __uint_as_float(h.idx)) : make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));
-      }
-      return;
-   }
-   const ShardCtx sx = shard_ctx();
-   const uint32_t seg = sx.shard * shard_cap;
-   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   const uint32_t count = ctl->q_count[qc_index(bounce, Q_RAY, sx.shard)];
-   for (;;) {
-      uint32_t base = next_batch(cursor);
-      if (base >= count) break;
-      uint32_t i = base + lane;
-      if (i < count) {
-         float4 ro = ray_o[seg + i], rd = ray_d[seg + i];  // path state by queue position: w = RNG words, range = rgen:45-47's constants
-         Hit h;
-         traverse<false, COUNT>(sc, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), 0.001f, 10000.0f, 0.0f, h, lds_col, n_nodes, n_tris);
-         hit_out[seg + i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.idx));  // by queue position, as the refill kernel
-      }
-   }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[ray_kind], (unsigned long long)count);
-   if (COUNT) {
-      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
-      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
-   }
-}
-
-// ------------------------------------------------------------------------------------------
 // trace_shadow — reference.rgen:67 (sun) and :115 (light): visibility only. The reference runs
 // its closest-hit / miss shaders on these rays too, but the raygen reads nothing except
 // colorDistance.w (rgen:69,118-119), so the sky integral and material fetch are dead work here.
@@ -797,42 +621,6 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    }
 }
 
-// batch form (option shadow_variant = 0), the baseline of the refill kernel
-template <bool COUNT, bool LIGHT>
-__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void k_trace_shadow_batch(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats,
-                                                                                                     uint32_t bounce, uint32_t cursor_slot, bool leftovers = false) {
-   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
-   const uint32_t lane = lane_id();
-   uint32_t* lds_col = &s_stack[threadIdx.x >> 6][0][lane];
-   const ShardCtx sx = shard_ctx();
-   const uint32_t seg = sx.shard * ps.shard_cap;
-   // light rays: positions in the next bounce's ray queue; sun rays: every position - or, leftovers, the positions the grid kernel listed
-   const uint32_t* __restrict__ queue = ps.queue[leftovers ? 3 : 2] + seg;
-   const uint32_t count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : leftovers ? ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   const PathRecs rec = ps.set[(bounce + 1) & 1];
-   uint32_t n_nodes = 0, n_tris = 0;
-   for (;;) {
-      uint32_t base = next_batch(cursor);
-      if (base >= count) break;
-      uint32_t i = base + lane;
-      if (i < count) {
-         const uint32_t pos = seg + ((LIGHT || leftovers) ? queue[i] : i);
-         const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, *rec_quad(rec, pos, REC_ORIGIN), *rec_quad(rec, pos, REC_THR), *rec_quad(rec, pos, REC_RAD));
-         Hit h;
-         if (!traverse<true, COUNT>(sc, xyz(s.ro), xyz(s.rd), s.ro.w, s.rd.w, s.tlimit, h, lds_col, n_nodes, n_tris)) *rec_quad(rec, pos, REC_RAD) = s.lit;
-      }
-   }
-   if (sx.lb == 0 && threadIdx.x == 0) {
-      if (!leftovers) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)count);
-      else if (count) atomicAdd(&stats->sun_tree_rays, (unsigned long long)count);  // counted as sun rays by the grid kernel already
-   }
-   if (COUNT) {
-      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
-      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
-   }
-}
-
 // ------------------------------------------------------------------------------------------
 // trace_sun_grid - the sun shadow rays of reference.rgen:63-79 through the per-direction grid of sun_grid.h instead of the
 // tree: one cell look-up, then the cell's packets front (sun side) to back through the same tri_compute<ANY> until one
@@ -840,45 +628,10 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 // triangle accepts the ray with 0.001 < t < 10000 - bit for bit, the grid only prunes (conservatively) which triangles are asked.
 // Batch form: rays do a handful of steps, and their lengths (0..a few tests) differ little inside a wave.
 // ------------------------------------------------------------------------------------------
-// The walk down a cell's list, entries [e, end), not empty: true = some packet occludes the ray.
-// INLINE (option sun_grid_inline, the default): the list is an array of 64-byte records that CARRY their packet (SunGridDev::recs:
-// v0 e1 e2 key | this entry's far depth | the next entry's) - one sector and one round trip per test where the entry (packet
-// index, far depth) and then the packet were two of each; the next record is only asked for when the ray has to go on.
-template <bool COUNT, bool INLINE>
-__device__ __forceinline__ bool sun_walk(const SunGridDev& g, const float4* __restrict__ tris, uint32_t e, uint32_t end, V3 o, V3 d, float pw, uint32_t& n_tris) {
-   Hit best;
-   best.t = 10000.0f;  // tmax (rgen:66)
-   best.u = best.v = 0.0f;
-   best.idx = kEmptyRef;
-   best.key = 0xffffffffu;
-   if (INLINE) {
-      const float4* r = reinterpret_cast<const float4*>(g.recs) + 4 * (size_t)e;
-      for (;;) {
-         const float4 a = r[0], b = r[1], c = r[2];
-         // sorted by far depth, descending: from here on every packet ends behind the origin (t < 0 for all of them)
-         if (c.z < pw) return false;
-         if (COUNT) n_tris++;
-         if (tri_compute<true>(a, b, c, 0u, o, d, 0.001f, INFINITY, best)) return true;
-         e++;
-         if (e >= end || c.w < pw) return false;
-         r += 4;
-      }
-   }
-   uint2 en = reinterpret_cast<const uint2*>(g.entries)[e];
-   while (e < end) {
-      if (__uint_as_float(en.y) < pw) break;
-      const uint32_t pk = en.x;
-      uint2 nxt = make_uint2(0u, 0u);
-      if (e + 1 < end) nxt = reinterpret_cast<const uint2*>(g.entries)[e + 1];  // in flight with the packet
-      const float4 a = tris[kTriStride16 * (size_t)pk + 0], b = tris[kTriStride16 * (size_t)pk + 1], c = tris[kTriStride16 * (size_t)pk + 2];
-      if (COUNT) n_tris++;
-      if (tri_compute<true>(a, b, c, pk, o, d, 0.001f, INFINITY, best)) return true;
-      en = nxt;
-      e++;
-   }
-   return false;
-}
-
+// The lists come in two forms (SunGridDev). Plain: 8-byte entries (packet index, far depth) beside the packet array - two dependent
+// reads per test. INLINE: 64-byte records that CARRY their packet (v0 e1 e2 key | this entry's far depth | the next entry's) - one
+// sector and one round trip per test; sixty-four bytes per entry where the plain list has eight, so by default only while the records
+// stay within four times the packet array (context.hip attach_sun_inline_records, option "sun_grid_inline_max_mb").
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop the compiler cannot leave rolled (arrays indexed by its
 // counter stay in registers whatever the body holds)
 template <int N, int I = 0, typename F>
@@ -905,207 +658,201 @@ __device__ __forceinline__ void sun_cell_of(const SunGridDev& g, float pu, float
 // records (23 MB) are a request to the memory side per ray.
 __device__ __forceinline__ bool sun_coarse_covered(float coarse, float pw) { return pw < coarse && coarse - pw < kSunCoarseReach; }
 
-// LISTED (option sun_grid_fused): k_shade_hit<true> has asked the coarse cover already and listed the rays it did not answer in
-// Q_SUN_GRID (positions in the next bounce's ray queue); otherwise every position of that queue is a ray, and the coarse cover -
-// when the grid has one - is asked here first.
-template <bool COUNT, bool LISTED, bool INLINE>
+// Every position of the next bounce's ray queue is a ray; the coarse cover - when the grid has one - is asked first. (Round 4 also had
+// k_shade_hit ask the coarse cover and list the rays it did not answer - level on the frame - and a one-ray-per-lane loop for the plain
+// lists: both removed in round 5.)
+template <bool COUNT, bool INLINE>
 __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                                                             uint32_t cursor_slot, SunGridDev g) {
    const uint32_t lane = lane_id();
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
    const PathRecs rec = ps.set[(bounce + 1) & 1];  // a sun ray leaves every scattered path: every position of the next bounce's ray queue
-   const uint32_t all = ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
-   const uint32_t count = LISTED ? ctl->q_count[qc_index(bounce, Q_SUN_GRID, sx.shard)] : all;
-   const uint32_t* __restrict__ q_listed = ps.queue[5] + seg;
+   const uint32_t count = ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   const float4* __restrict__ tris = sc.tris;
    const V3 d = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);  // rgen:64
    uint32_t n_tris = 0, n_covered = 0;
    uint32_t* q_tree = ps.queue[3] + seg;
    uint32_t* n_tree = &ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)];
-   if (INLINE) {
-      // K rays per lane, each step of the chain (origin -> cell record -> first list record -> throughput / radiance) requested for
-      // all K before the first is used: the kernel is a chain of dependent round trips with a few instructions between them, and
-      // a wave that keeps K chains in flight hides K times the latency (registers are no constraint here: 40 at K = 1)
-      constexpr int K = UH_SUN_RAYS_PER_LANE;
-      const float4* __restrict__ recs = reinterpret_cast<const float4*>(g.recs);
-      const uint2* __restrict__ cells = reinterpret_cast<const uint2*>(g.cell_start);
-      for (;;) {
-         uint32_t base = 0;
-         if (lane == 0) base = atomicAdd(cursor, 64u * K);
-         base = __builtin_amdgcn_readfirstlane(base);
-         if (base >= count) break;
-         uint32_t id[K];
-         bool valid[K];
+   // K rays per lane, each step of the chain (origin -> coarse cover -> cell record -> first list entry [-> its packet] -> throughput /
+   // radiance) requested for all K before the first is used: the kernel is a chain of dependent round trips with a few instructions
+   // between them, and a wave that keeps K chains in flight hides K times the latency (registers are no constraint: 40 at K = 1)
+   constexpr int K = UH_SUN_RAYS_PER_LANE;
+   typedef float f4_t __attribute__((ext_vector_type(4)));  // (arrays of HIP's float4 struct assigned under a condition end up in scratch)
+   const f4_t* __restrict__ recs = reinterpret_cast<const f4_t*>(g.recs);       // INLINE
+   const f4_t* __restrict__ tris = reinterpret_cast<const f4_t*>(sc.tris);      // plain lists: the packets
+   const uint2* __restrict__ entries = reinterpret_cast<const uint2*>(g.entries);
+   const uint2* __restrict__ cells = reinterpret_cast<const uint2*>(g.cell_start);
+   for (;;) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(cursor, 64u * K);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base >= count) break;
+      uint32_t id[K];  // the path's position in the next bounce's queue: its state lies there (a wave reads and writes contiguous kilobytes)
+      bool valid[K];
+      static_for<K>([&](auto kc) {
+         constexpr int k = decltype(kc)::value;
+         id[k] = base + 64u * k + lane;
+         valid[k] = id[k] < count;
+      });
+      float4 ro[K];
+      static_for<K>([&](auto kc) {
+         constexpr int k = decltype(kc)::value;
+         ro[k] = valid[k] ? ld_rec(rec_quad(rec, seg + id[k], REC_ORIGIN)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      });
+      float pw[K];
+      uint32_t cx[K], cy[K];
+      bool covered[K], ask[K];
+      static_for<K>([&](auto kc) {
+         constexpr int k = decltype(kc)::value;
+         const V3 o = v3(ro[k].x, ro[k].y, ro[k].z);
+         const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o);
+         pw[k] = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
+         sun_cell_of(g, pu, pv, cx[k], cy[k]);
+         covered[k] = false;
+      });
+      if (g.coarse) {
+         float cw[K];
          static_for<K>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            const uint32_t i = base + 64u * k + lane;
-            valid[k] = i < count;
-            id[k] = i;
-            if (LISTED && valid[k]) id[k] = ld_stream(q_listed + i);
+            cw[k] = valid[k] ? g.coarse[(cy[k] >> g.coarse_shift) * g.coarse_nx + (cx[k] >> g.coarse_shift)] : -INFINITY;
          });
-         float4 ro[K];
          static_for<K>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            ro[k] = valid[k] ? ld_rec(rec_quad(rec, seg + id[k], REC_ORIGIN)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            covered[k] = valid[k] && sun_coarse_covered(cw[k], pw[k]);
          });
-         float pw[K];
-         uint32_t cx[K], cy[K];
-         bool covered[K], ask[K];
-         static_for<K>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const V3 o = v3(ro[k].x, ro[k].y, ro[k].z);
-            const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o);
-            pw[k] = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
-            sun_cell_of(g, pu, pv, cx[k], cy[k]);
-            covered[k] = false;
-         });
-         if (!LISTED && g.coarse) {
-            float cw[K];
-            static_for<K>([&](auto kc) {
-               constexpr int k = decltype(kc)::value;
-               cw[k] = valid[k] ? g.coarse[(cy[k] >> g.coarse_shift) * g.coarse_nx + (cx[k] >> g.coarse_shift)] : -INFINITY;
-            });
-            static_for<K>([&](auto kc) {
-               constexpr int k = decltype(kc)::value;
-               covered[k] = valid[k] && sun_coarse_covered(cw[k], pw[k]);
-            });
+      }
+      uint2 cs[K];  // offset into the entries | cover depth
+      uint32_t end[K];
+      static_for<K>([&](auto kc) {
+         constexpr int k = decltype(kc)::value;
+         ask[k] = valid[k] && !covered[k];
+         cs[k] = make_uint2(0u, 0u);
+         end[k] = 0u;
+         if (ask[k]) {
+            const uint32_t cell = cy[k] * g.nx + cx[k];
+            cs[k] = cells[cell];
+            end[k] = cells[cell + 1].x;
          }
-         uint2 cs[K];
-         uint32_t end[K];
-         static_for<K>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            ask[k] = valid[k] && !covered[k];
-            cs[k] = make_uint2(0u, 0u);
-            end[k] = 0u;
-            if (ask[k]) {
-               const uint32_t cell = cy[k] * g.nx + cx[k];
-               cs[k] = cells[cell];
-               end[k] = cells[cell + 1].x;
+      });
+      bool defer[K], walk[K], lit[K];
+      f4_t ra[K], rb[K], rc[K];  // the first packet; INLINE: rc.z / rc.w = this entry's far depth / the next one's
+      uint2 en[K], nxt[K];       // plain lists: this entry (packet, far depth) and the next
+      static_for<K>([&](auto kc) {
+         constexpr int k = decltype(kc)::value;
+         // the cell's cover: some packet spans the whole cell (with the margins to spare) and every ray that starts below this depth has
+         // it in front, further than tmin away and nearer than tmax (sun_grid.h kSunCoverReach) - occluded, as the tree walk would say
+         const float cover = __uint_as_float(cs[k].y);
+         const bool cov = ask[k] && pw[k] < cover && cover - pw[k] < kSunCoverReach;
+         covered[k] = covered[k] || cov;
+         // a border cell stands for everything beyond the dense part of the scene, and some interior cells list a great many packets
+         // (walls edge-on to the sun): such a ray is cheaper in the tree - k_trace_shadow takes it from queue 3
+         defer[k] = ask[k] && !cov && (cx[k] == 0 || cy[k] == 0 || cx[k] + 1 == g.nx || cy[k] + 1 == g.ny || end[k] - cs[k].x > g.max_walk);
+         walk[k] = ask[k] && !cov && !defer[k] && cs[k].x < end[k];
+         lit[k] = ask[k] && !cov && !defer[k] && !walk[k];  // nothing projects into the cell
+         if (walk[k]) {
+            if constexpr (INLINE) {
+               const f4_t* r = recs + 4 * (size_t)cs[k].x;
+               ra[k] = r[0];
+               rb[k] = r[1];
+               rc[k] = r[2];
+            } else {
+               en[k] = entries[cs[k].x];
+               nxt[k] = cs[k].x + 1 < end[k] ? entries[cs[k].x + 1] : make_uint2(0u, 0u);  // adjacent: the same sector most of the time
             }
-         });
-         bool defer[K], walk[K], lit[K];
-         typedef float f4_t __attribute__((ext_vector_type(4)));  // (arrays of HIP's float4 struct assigned under a condition end up in scratch)
-         f4_t ra[K], rb[K], rc[K];
+         }
+         if (COUNT) n_covered += covered[k] ? 1u : 0u;
+      });
+      if constexpr (!INLINE) {
          static_for<K>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            const float cover = __uint_as_float(cs[k].y);
-            const bool cov = ask[k] && pw[k] < cover && cover - pw[k] < kSunCoverReach;  // as below
-            covered[k] = covered[k] || cov;
-            defer[k] = ask[k] && !cov && (cx[k] == 0 || cy[k] == 0 || cx[k] + 1 == g.nx || cy[k] + 1 == g.ny || end[k] - cs[k].x > g.max_walk);
-            walk[k] = ask[k] && !cov && !defer[k] && cs[k].x < end[k];
-            lit[k] = ask[k] && !cov && !defer[k] && !walk[k];  // nothing projects into the cell
+            // sorted by far depth, descending: a list whose first entry ends behind the origin has nothing in front of the ray
+            if (walk[k] && __uint_as_float(en[k].y) < pw[k]) {
+               walk[k] = false;
+               lit[k] = true;
+            }
             if (walk[k]) {
-               const f4_t* r = reinterpret_cast<const f4_t*>(recs + 4 * (size_t)cs[k].x);
+               const f4_t* r = tris + kTriStride16 * (size_t)en[k].x;
                ra[k] = r[0];
                rb[k] = r[1];
                rc[k] = r[2];
             }
-            if (COUNT) n_covered += covered[k] ? 1u : 0u;
          });
-         static_for<K>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if (walk[k]) {
-               const V3 o = v3(ro[k].x, ro[k].y, ro[k].z);
-               Hit best;
-               best.t = 10000.0f;  // tmax (rgen:66)
-               best.u = best.v = 0.0f;
-               best.idx = kEmptyRef;
-               best.key = 0xffffffffu;
-               uint32_t e = cs[k].x;
-               const float4* r = recs + 4 * (size_t)e;
-               float4 a = make_float4(ra[k].x, ra[k].y, ra[k].z, ra[k].w), b = make_float4(rb[k].x, rb[k].y, rb[k].z, rb[k].w), c = make_float4(rc[k].x, rc[k].y, rc[k].z, rc[k].w);
-               bool occluded = false;
-               for (;;) {  // sun_walk<.., true>, its first record already here
-                  if (c.z < pw[k]) break;
+      }
+      static_for<K>([&](auto kc) {
+         constexpr int k = decltype(kc)::value;
+         if (walk[k]) {
+            const V3 o = v3(ro[k].x, ro[k].y, ro[k].z);
+            Hit best;
+            best.t = 10000.0f;  // tmax (rgen:66)
+            best.u = best.v = 0.0f;
+            best.idx = kEmptyRef;
+            best.key = 0xffffffffu;
+            uint32_t e = cs[k].x;
+            float4 a = make_float4(ra[k].x, ra[k].y, ra[k].z, ra[k].w), b = make_float4(rb[k].x, rb[k].y, rb[k].z, rb[k].w), c = make_float4(rc[k].x, rc[k].y, rc[k].z, rc[k].w);
+            bool occluded = false;
+            if constexpr (INLINE) {
+               const f4_t* r = recs + 4 * (size_t)e;
+               for (;;) {
+                  if (c.z < pw[k]) break;  // from here on every packet ends behind the origin (t < 0 for all of them)
                   if (COUNT) n_tris++;
                   if (tri_compute<true>(a, b, c, 0u, o, d, 0.001f, INFINITY, best)) {
                      occluded = true;
                      break;
                   }
                   e++;
-                  if (e >= end[k] || c.w < pw[k]) break;
+                  if (e >= end[k] || c.w < pw[k]) break;  // the next record is only asked for when the ray has to go on
                   r += 4;
-                  a = r[0];
-                  b = r[1];
-                  c = r[2];
+                  const f4_t na = r[0], nb = r[1], nc = r[2];
+                  a = make_float4(na.x, na.y, na.z, na.w);
+                  b = make_float4(nb.x, nb.y, nb.z, nb.w);
+                  c = make_float4(nc.x, nc.y, nc.z, nc.w);
                }
-               lit[k] = !occluded;
-            }
-         });
-         float4 thr[K], rad[K];
-         static_for<K>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if (lit[k]) {  // rgen:69-78: radiance += throughput
-               thr[k] = ld_rec(rec_quad(rec, seg + id[k], REC_THR));
-               rad[k] = ld_rec(rec_quad(rec, seg + id[k], REC_RAD));
-            }
-         });
-         static_for<K>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if (lit[k]) st_rec(rec_quad(rec, seg + id[k], REC_RAD), make_float4(rad[k].x + thr[k].x, rad[k].y + thr[k].y, rad[k].z + thr[k].z, rad[k].w));
-         });
-         static_for<K>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if (__ballot(defer[k]) != 0ull) {  // wave-uniform: every lane of the wave takes part in the append
-               const uint32_t slot = wave_append(n_tree, defer[k]);
-               if (defer[k]) st_stream(q_tree + slot, id[k]);
-            }
-         });
-      }
-   } else
-   for (;;) {
-      const uint32_t base = next_batch(cursor);
-      if (base >= count) break;
-      const uint32_t i = base + lane;
-      const bool valid = i < count;
-      // the path's position in the next bounce's queue: its state lies there (unlisted: a wave reads and writes contiguous kilobytes)
-      uint32_t id = i;
-      if (LISTED && valid) id = ld_stream(q_listed + i);
-      bool defer = false;
-      if (valid) {
-         const float4 ro = ld_rec(rec_quad(rec, seg + id, REC_ORIGIN));
-         const V3 o = v3(ro.x, ro.y, ro.z);
-         const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o), pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
-         uint32_t cx, cy;
-         sun_cell_of(g, pu, pv, cx, cy);
-         bool covered = false;
-         if (!LISTED && g.coarse) covered = sun_coarse_covered(g.coarse[(cy >> g.coarse_shift) * g.coarse_nx + (cx >> g.coarse_shift)], pw);
-         if (!covered) {
-            const uint32_t cell = cy * g.nx + cx;
-            const uint2 cs = reinterpret_cast<const uint2*>(g.cell_start)[cell];  // offset into the entries | cover depth
-            const uint32_t e = cs.x;
-            const uint32_t end = reinterpret_cast<const uint2*>(g.cell_start)[cell + 1].x;
-            // the cell's cover: some packet spans the whole cell (with the margins to spare) and every ray that starts below this
-            // depth has it in front, further than tmin away - occluded, and the tree walk would have said so too
-            // (... and nearer than tmax: sun_grid.h kSunCoverReach)
-            const float cover = __uint_as_float(cs.y);
-            covered = pw < cover && cover - pw < kSunCoverReach;
-            // a border cell stands for everything beyond the dense part of the scene, and some interior cells list a great many
-            // packets (walls edge-on to the sun): such a ray is cheaper in the tree - k_trace_shadow takes it from queue 3
-            defer = !covered && (cx == 0 || cy == 0 || cx + 1 == g.nx || cy + 1 == g.ny || end - e > g.max_walk);
-            if (!defer && !covered) {
-               const bool occluded = e < end && sun_walk<COUNT, INLINE>(g, tris, e, end, o, d, pw, n_tris);
-               if (!occluded) {  // rgen:69-78: radiance += throughput
-                  const float4 thr = ld_rec(rec_quad(rec, seg + id, REC_THR)), rad = ld_rec(rec_quad(rec, seg + id, REC_RAD));
-                  st_rec(rec_quad(rec, seg + id, REC_RAD), make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, rad.w));
+            } else {
+               uint2 cur = en[k], nx = nxt[k];
+               for (;;) {
+                  if (COUNT) n_tris++;
+                  if (tri_compute<true>(a, b, c, cur.x, o, d, 0.001f, INFINITY, best)) {
+                     occluded = true;
+                     break;
+                  }
+                  e++;
+                  if (e >= end[k] || __uint_as_float(nx.y) < pw[k]) break;
+                  cur = nx;
+                  if (e + 1 < end[k]) nx = entries[e + 1];  // in flight with the packet
+                  const f4_t* r = tris + kTriStride16 * (size_t)cur.x;
+                  const f4_t na = r[0], nb = r[1], nc = r[2];
+                  a = make_float4(na.x, na.y, na.z, na.w);
+                  b = make_float4(nb.x, nb.y, nb.z, nb.w);
+                  c = make_float4(nc.x, nc.y, nc.z, nc.w);
                }
             }
+            lit[k] = !occluded;
          }
-         if (COUNT) n_covered += covered ? 1u : 0u;
-      }
-      if (__ballot(defer) != 0ull) {  // wave-uniform: every lane of the wave takes part in the append
-         const uint32_t slot = wave_append(n_tree, defer);
-         if (defer) st_stream(q_tree + slot, id);
-      }
+      });
+      float4 thr[K], rad[K];
+      static_for<K>([&](auto kc) {
+         constexpr int k = decltype(kc)::value;
+         if (lit[k]) {  // rgen:69-78: radiance += throughput
+            thr[k] = ld_rec(rec_quad(rec, seg + id[k], REC_THR));
+            rad[k] = ld_rec(rec_quad(rec, seg + id[k], REC_RAD));
+         }
+      });
+      static_for<K>([&](auto kc) {
+         constexpr int k = decltype(kc)::value;
+         if (lit[k]) st_rec(rec_quad(rec, seg + id[k], REC_RAD), make_float4(rad[k].x + thr[k].x, rad[k].y + thr[k].y, rad[k].z + thr[k].z, rad[k].w));
+      });
+      static_for<K>([&](auto kc) {
+         constexpr int k = decltype(kc)::value;
+         if (__ballot(defer[k]) != 0ull) {  // wave-uniform: every lane of the wave takes part in the append
+            const uint32_t slot = wave_append(n_tree, defer[k]);
+            if (defer[k]) st_stream(q_tree + slot, id[k]);
+         }
+      });
    }
    if (sx.lb == 0 && threadIdx.x == 0) {
-      atomicAdd(&stats->rays[UH_RAY_SUN_SHADOW], (unsigned long long)all);
-      if (COUNT) {  // every sun ray looked one cell up (here, or its block's coarse cover in k_shade_hit: those it did not list were covered)
-         atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)all);
-         atomicAdd(&stats->sun_covered_rays, (unsigned long long)(all - count));
-      }
+      atomicAdd(&stats->rays[UH_RAY_SUN_SHADOW], (unsigned long long)count);
+      if (COUNT) atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)count);  // every sun ray looked one cell (or its block's coarse cover) up
    }
    if (COUNT) {
       atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
@@ -1390,14 +1137,7 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
    return I * eta - N * (eta * dn + sqrtf(k));
 }
 
-// SUN (option sun_grid_fused): the sun rays of the scattered paths (rgen:63-79) ask the grid's COARSE COVER here (sun_grid.h: one
-// depth per block of cells, 0.7 MB: L2-resident) - the word rides with the texels, the ray's origin is known before them, so the
-// look-up costs the kernel no round trip of its own. A ray that starts below it is occluded: no queue entry, nothing to do. The
-// others are listed in Q_SUN_GRID (positions in the next bounce's ray queue) for k_trace_sun_grid<.., true, ..>, whose waves then
-// hold only rays that have a cell to look up. Same verdicts: the coarse cover lies below every cell's own cover depth.
-template <bool SUN>
-__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
-                                                                           SunGridDev g) {
+__global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
    // c / 255.0f table in LDS: the 12 per-fetch table gathers were texture-addresser traffic (the
    // kernel ran 86 % TA-busy at 2 % VALU, profiles/r01c_*); LDS serves them at no TA cost
    __shared__ float s_lut[256];
@@ -1428,8 +1168,6 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    uint32_t* n_light = &ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)];
    uint2* q_miss = reinterpret_cast<uint2*>(ps.queue[4]) + seg;
    uint32_t* n_miss = &ctl->q_count[qc_index(bounce, Q_MISS, sx.shard)];
-   uint32_t* q_sun_grid = ps.queue[5] + seg;
-   uint32_t* n_sun_grid = &ctl->q_count[qc_index(bounce, Q_SUN_GRID, sx.shard)];
    const uint32_t stride = sx.nb * kBlock;
    const uint32_t rounds = (count + stride - 1) / stride;
    uint32_t n_hits = 0;
@@ -1438,7 +1176,6 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
    auto shade = [&](uint32_t id, uint32_t pos, float4 hr, bool valid) {
       const uint32_t pk = __float_as_uint(hr.w);
       bool scattered = false, want_light = false;
-      bool sun_listed = false;  // SUN: the scattered path's sun ray is not below its block's coarse cover: k_trace_sun_grid takes it
       uint32_t slot = 0;        // the scattered path's position in the next bounce's queue
       float4 n_o = make_float4(0, 0, 0, 0), n_d = make_float4(0, 0, 0, 0), n_t = make_float4(0, 0, 0, 0), n_r = make_float4(0, 0, 0, 0);  // the scattered path's new state
       if (valid) {
@@ -1489,15 +1226,6 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          const unsigned long long scat_mask = __ballot(scattered);
          const int scat_leader = __ffsll((long long)scat_mask) - 1;
          uint32_t scat_base = 0;
-         float sun_pw = 0.0f, sun_coarse = 0.0f;
-         const float* sun_coarse_at = g.coarse;
-         if (SUN) {  // k_trace_sun_grid's cell arithmetic, word for word
-            const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), origin), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), origin);
-            sun_pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), origin);
-            uint32_t cx, cy;
-            sun_cell_of(g, pu, pv, cx, cy);
-            sun_coarse_at = g.coarse + ((cy >> g.coarse_shift) * g.coarse_nx + (cx >> g.coarse_shift));
-         }
          float uu = (uv0x * bx + uv1x * by) + uv2x * bz;                               // rchit:39
          float vv = (uv0y * bx + uv1y * by) + uv2y * bz;
          V3 color = sample_texture_pre(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex, [&] {  // rchit:40
@@ -1507,7 +1235,6 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
             global_u32_t counter = (global_u32_t)n_next;
             asm volatile("" : "+v"(counter));
             if (scattered && (int)lane_id() == scat_leader) scat_base = __hip_atomic_fetch_add(counter, (uint32_t)__popcll(scat_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (SUN) sun_coarse = *sun_coarse_at;
          });
          color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
 
@@ -1577,21 +1304,12 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
             n_d = make_float4(scatter.x, scatter.y, scatter.z, __uint_as_float(rng.y));  // rgen:61
             n_t = make_float4(thr.x, thr.y, thr.z, f);
             n_r = make_float4(rad4.x, rad4.y, rad4.z, __uint_as_float((uint32_t)light_index));  // the radiance travels with the path
-            if (SUN) sun_listed = !sun_coarse_covered(sun_coarse, sun_pw);  // rgen:63-79; covered: occluded, nothing to add
          }
       }
       // a wave's scattered paths get consecutive positions: their new state leaves as contiguous stores, and the next bounce's
       // traversal, sun-ray and shading kernels read it back as streams
-      // the light queue (and, fused, the sun-grid queue): one round trip for both - none at all when neither has an entry
-      uint32_t lslot;
-      {
-         uint32_t* const counters[2] = {n_light, n_sun_grid};
-         const bool preds[2] = {want_light, SUN && sun_listed};
-         uint32_t slots[2];
-         wave_append_multi<2>(counters, preds, slots);
-         lslot = slots[0];
-         if (SUN && sun_listed) st_stream(q_sun_grid + slots[1], slot);
-      }
+      // the light queue: one round trip - none at all when no lane has an entry
+      const uint32_t lslot = wave_append(n_light, want_light);
       if (scattered) {
          st_stream(q_next + slot, id);
          st_rec(rec_quad(nxt, seg + slot, REC_ORIGIN), n_o);
@@ -1965,8 +1683,8 @@ static inline dim3 shade_grid(const LaunchCfg& c, uint32_t n) {
 
 uint32_t query_trace_occupancy() {
    int a = 0, b = 0;
-   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest_batch<false, false>, kBlock, 0) != hipSuccess) a = 4;
-   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow_batch<false, false>, kBlock, 0) != hipSuccess) b = 4;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_closest<false>, kBlock, 0) != hipSuccess) a = 4;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kBlock, 0) != hipSuccess) b = 4;
    int m = a < b ? a : b;
    if (m < 1) m = 1;
    if (m > 8) m = 8;
@@ -1977,54 +1695,20 @@ void launch_generate(const LaunchCfg& c, const FrameParams& fp, const PathState&
    k_generate<<<stream_grid(c, fp.n_owned * fp.batch_frames), kBlock, 0, c.stream>>>(fp, ps, ctl, sample);
 }
 
-// closest-hit traversal over a sharded queue of path ids (queue != null) or over n raw rays (queue == null).
-// Variant 0 = batch kernel (the baseline), anything else = refill kernel (the default).
+// closest-hit traversal over a sharded queue of path ids (sharded) or over n raw rays
 static void launch_closest(const LaunchCfg& c, dim3 grid, const SceneDev& sc, bool sharded, const float4* ray_o, const float4* ray_d, float4* hit,
-                           uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n, bool diag,
+                           uint32_t shard_cap, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot, int ray_kind, uint32_t n,
                            const uint32_t* listed = nullptr) {
-#define UH_BATCH(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, sharded, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n)
-#define UH_CLOSEST(KERNEL) KERNEL<<<grid, kBlock, 0, c.stream>>>(sc, sharded, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n, listed)
-   const bool count = c.count_visits && sharded;
-   if (diag) {
-      UH_BATCH((k_trace_closest_batch<false, true>));
-      return;
-   }
-   if (c.closest_variant == 0 && !listed) {
-      if (count) UH_BATCH((k_trace_closest_batch<true, false>));
-      else UH_BATCH((k_trace_closest_batch<false, false>));
-   } else {
-      if (count) UH_CLOSEST((k_trace_closest<true>));
-      else UH_CLOSEST((k_trace_closest<false>));
-   }
-#undef UH_CLOSEST
-#undef UH_BATCH
+   if (c.count_visits && sharded)
+      k_trace_closest<true><<<grid, kBlock, 0, c.stream>>>(sc, sharded, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n, listed);
+   else
+      k_trace_closest<false><<<grid, kBlock, 0, c.stream>>>(sc, sharded, ray_o, ray_d, hit, shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, n, listed);
 }
 
 void launch_trace_closest(const LaunchCfg& c, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
                           uint32_t cursor_slot, int ray_kind) {
    const PathRecs& rec = ps.set[bounce & 1];
-   launch_closest(c, closest_grid(c), sc, true, rec_quad(rec, 0, REC_ORIGIN), rec_quad(rec, 0, REC_DIR), ps.hit, ps.shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, 0, false);
-}
-
-static TileJob tile_job(const FrameParams& fp, uint32_t frames, bool raw) {
-   TileJob j;
-   j.W = fp.W;
-   j.H = fp.H;
-   j.frames = frames;
-   j.tp_world = raw ? 1u : fp.tp_world;
-   j.tp_rank = fp.tp_rank;
-   j.tp_tile = fp.tp_tile;
-   j.tiles_x = fp.tiles_x;
-   j.range_in_w = raw ? 1u : 0u;
-   return j;
-}
-static void launch_tiles(const LaunchCfg& c, const SceneDev& sc, const TileJob& j, const float4* ray_o, const float4* ray_d, float4* hit, DeviceStats* stats, int ray_kind, bool count) {
-   const uint32_t items = ((j.W + 7) / 8) * ((j.H + 7) / 8) * j.frames, need = (items + kWavesPerBlock - 1) / kWavesPerBlock, full = c.num_cus * 8;
-   const dim3 grid(need < full ? (need ? need : 1) : full);
-   if (count)
-      k_trace_closest_tiles<true><<<grid, kBlock, 0, c.stream>>>(sc, j, ray_o, ray_d, hit, stats, ray_kind);
-   else
-      k_trace_closest_tiles<false><<<grid, kBlock, 0, c.stream>>>(sc, j, ray_o, ray_d, hit, stats, ray_kind);
+   launch_closest(c, closest_grid(c), sc, true, rec_quad(rec, 0, REC_ORIGIN), rec_quad(rec, 0, REC_DIR), ps.hit, ps.shard_cap, ctl, stats, bounce, cursor_slot, ray_kind, 0);
 }
 
 // bounce 0 of the path tracer through the camera grid, then the tree walk for the rays of the pixels with long lists
@@ -2037,23 +1721,19 @@ void launch_trace_camera_grid(const LaunchCfg& c, const FrameParams& fp, const S
       k_trace_camera_grid<false><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, cursor_slot_grid, g);
    if (!leftovers_possible) return;  // no pixel lists more than the grid kernel walks itself
    const PathRecs& rec = ps.set[0];
-   launch_closest(c, closest_grid(c), sc, true, rec_quad(rec, 0, REC_ORIGIN), rec_quad(rec, 0, REC_DIR), ps.hit, ps.shard_cap, ctl, stats, 0, cursor_slot_tree, UH_RAY_PRIMARY, 0, false,
-                  ps.queue[3]);
+   launch_closest(c, closest_grid(c), sc, true, rec_quad(rec, 0, REC_ORIGIN), rec_quad(rec, 0, REC_DIR), ps.hit, ps.shard_cap, ctl, stats, 0, cursor_slot_tree, UH_RAY_PRIMARY, 0, ps.queue[3]);
 }
 
 void launch_shade_miss(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
    // the bounce's misses are a dense queue (Q_MISS, written by k_shade_hit): every lane shades one; the count is on the
    // device, so the grid is sized for the paths the wavefront started with
-   const dim3 full = shade_grid(c, fp.n_owned * fp.batch_frames), lean = sharded_grid(c.num_cus * c.miss_blocks_per_cu);
+   const dim3 full = shade_grid(c, fp.n_owned * fp.batch_frames), lean = sharded_grid(c.num_cus * 8);  // blocks per CU 2 / 4 / 6 / 8: 7,599 / 7,613-7,656 / 7,699 / 7,676-7,678 Mrays/s (round 4)
    k_shade_miss<<<full.x < lean.x ? full : lean, kBlock, 0, c.stream>>>(fp, ps, ctl, stats, bounce);
 }
 
 void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, const Images& im, Control* ctl,
-                      DeviceStats* stats, uint32_t bounce, const SunGridDev* sun_grid) {
-   if (sun_grid)
-      k_shade_hit<true><<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce, *sun_grid);
-   else
-      k_shade_hit<false><<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce, SunGridDev{});
+                      DeviceStats* stats, uint32_t bounce) {
+   k_shade_hit<<<shade_grid(c, fp.W * fp.H), kBlock, 0, c.stream>>>(fp, sc, ps, ctl, stats, bounce);
 }
 void launch_flush_survivors(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl) {
    k_flush_survivors<<<shade_grid(c, fp.n_owned * fp.batch_frames), kBlock, 0, c.stream>>>(fp, ps, ctl);
@@ -2061,56 +1741,29 @@ void launch_flush_survivors(const LaunchCfg& c, const FrameParams& fp, const Pat
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
                          uint32_t bounce, uint32_t cursor_slot, bool light, bool sun_leftovers) {
-   if (sun_leftovers && c.sun_leftover_batch) {  // what the sun grid handed to the tree (queue 3), through the batch kernel
-      if (c.count_visits)
-         k_trace_shadow_batch<true, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, true);
-      else
-         k_trace_shadow_batch<false, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, true);
-      return;
-   }
-   if (sun_leftovers) {  // ... or the refill kernel
-      if (c.count_visits)
-         k_trace_shadow<true, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, true);
-      else
-         k_trace_shadow<false, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, true);
-      return;
-   }
-#define UH_SHADOW(KERNEL) KERNEL<<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot)
-   if (c.shadow_variant == 0) {
-      if (light) {
-         if (c.count_visits) UH_SHADOW((k_trace_shadow_batch<true, true>));
-         else UH_SHADOW((k_trace_shadow_batch<false, true>));
-      } else {
-         if (c.count_visits) UH_SHADOW((k_trace_shadow_batch<true, false>));
-         else UH_SHADOW((k_trace_shadow_batch<false, false>));
-      }
-   } else if (light) {
-      if (c.count_visits) k_trace_shadow<true, true><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, false);
-      else k_trace_shadow<false, true><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, false);
+   // sun_leftovers: what the sun grid handed to the tree (queue 3)
+#define UH_SHADOW(COUNT, LIGHT) k_trace_shadow<COUNT, LIGHT><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, sun_leftovers)
+   if (light) {
+      if (c.count_visits) UH_SHADOW(true, true);
+      else UH_SHADOW(false, true);
    } else {
-      if (c.count_visits) k_trace_shadow<true, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, false);
-      else k_trace_shadow<false, false><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, false);
+      if (c.count_visits) UH_SHADOW(true, false);
+      else UH_SHADOW(false, false);
    }
 #undef UH_SHADOW
 }
 
 void launch_trace_sun_grid(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
-                           uint32_t cursor_slot, const SunGridDev& g, bool fused) {
+                           uint32_t cursor_slot, const SunGridDev& g) {
    const dim3 grid = sharded_grid(c.num_cus * 8);
-#define UH_SUN_GRID(COUNT, FUSED, INLINE) k_trace_sun_grid<COUNT, FUSED, INLINE><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, g)
-#define UH_SUN_GRID2(COUNT, FUSED)            \
-   do {                                       \
-      if (g.recs) UH_SUN_GRID(COUNT, FUSED, true); \
-      else UH_SUN_GRID(COUNT, FUSED, false);  \
-   } while (0)
-   if (fused) {
-      if (c.count_visits) UH_SUN_GRID2(true, true);
-      else UH_SUN_GRID2(false, true);
+#define UH_SUN_GRID(COUNT, INLINE) k_trace_sun_grid<COUNT, INLINE><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, g)
+   if (g.recs) {
+      if (c.count_visits) UH_SUN_GRID(true, true);
+      else UH_SUN_GRID(false, true);
    } else {
-      if (c.count_visits) UH_SUN_GRID2(true, false);
-      else UH_SUN_GRID2(false, false);
+      if (c.count_visits) UH_SUN_GRID(true, false);
+      else UH_SUN_GRID(false, false);
    }
-#undef UH_SUN_GRID2
 #undef UH_SUN_GRID
 }
 
@@ -2126,15 +1779,12 @@ void launch_gbuffer(const LaunchCfg& c, const FrameParams& fp, const SceneDev& s
                     const SunGridDev* camera_grid) {
    const uint32_t n = spans.total();
    if (n == 0) return;
-   const bool whole = n == fp.W * fp.H;
    k_gbuffer_generate<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, spans);
    if (camera_grid)
       k_gbuffer_camera_grid<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ps, spans, fp.W, *camera_grid);
-   else if (c.primary_tiles && whole)  // the tile kernel addresses rays by pixel: whole frames only
-      launch_tiles(c, sc, tile_job(fp, 1, true), ps.ray_o, ps.ray_d, ps.hit, stats, -1, false);
    else {
       const uint32_t full = c.num_cus * c.closest_blocks_per_cu, need = (n + kBlock - 1) / kBlock;
-      launch_closest(c, dim3(need < full ? need : full), sc, false, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n, false);
+      launch_closest(c, dim3(need < full ? need : full), sc, false, ps.ray_o, ps.ray_d, ps.hit, 0, nullptr, stats, 0, 0, 0, n);
    }
    k_gbuffer_resolve<<<stream_grid(c, n), kBlock, 0, c.stream>>>(fp, ps, im, stats, spans, counted);
 }
@@ -2160,7 +1810,7 @@ void launch_spatial_reuse(const LaunchCfg& c, const FrameParams& fp, const Scene
 void launch_trace_closest_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, float4* hit, uint32_t n) {
    // a grid that fills the chip once; smaller queries get one block per 256 rays
    const uint32_t full = c.num_cus * c.closest_blocks_per_cu, need = (n + kBlock - 1) / kBlock;
-   launch_closest(c, dim3(need < full ? (need ? need : 1) : full), sc, false, ray_o, ray_d, hit, 0, nullptr, nullptr, 0, 0, 0, n, c.raw_visit_counts);
+   launch_closest(c, dim3(need < full ? (need ? need : 1) : full), sc, false, ray_o, ray_d, hit, 0, nullptr, nullptr, 0, 0, 0, n);
 }
 void launch_trace_any_raw(const LaunchCfg& c, const SceneDev& sc, const float4* ray_o, const float4* ray_d, uint32_t* occluded, uint32_t n) {
    k_trace_any_raw<<<stream_grid(c, n), kBlock, 0, c.stream>>>(sc, ray_o, ray_d, occluded, n);

@@ -137,6 +137,8 @@ class Stats(C.Structure):
         ("camera_grid_ms", C.c_float),
         ("reserved0", C.c_uint32),
         ("sun_covered_rays", C.c_uint64),
+        ("sun_grid_bytes", C.c_uint64),
+        ("camera_grid_bytes", C.c_uint64),
     ]
 
     @property

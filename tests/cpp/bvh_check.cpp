@@ -23,15 +23,11 @@ static float rnd() {
    return (float)w / 4294967296.0f;
 }
 
-static int check(const std::vector<float>& corners, int threads, const char* name, bool geometry = true, int optimise_passes = -1);
-static int check(const std::vector<float>& corners, int threads, const char* name, bool geometry, int optimise_passes) {
-   if (optimise_passes < 0)  // every scene of this check: as built, and after two passes of the insertion-based optimiser
-      return check(corners, threads, name, geometry, 0) + check(corners, threads, name, geometry, 2);
+static int check(const std::vector<float>& corners, int threads, const char* name, bool geometry = true) {
    const uint32_t n = (uint32_t)(corners.size() / 9);
    std::vector<uint32_t> keys(n);
    for (uint32_t i = 0; i < n; i++) keys[i] = i;
    BuildInput in{corners.data(), keys.data(), n};
-   in.optimise_passes = optimise_passes;
    BuildOutput out;
    build_bvh4(in, out, threads);
    int errors = 0;
@@ -221,78 +217,6 @@ int main() {
                   bal.level_start.size() - 1, kMaxTreeLevels);
       if (keys.size() < 65536 || bal.level_start.size() - 1 > kMaxTreeLevels) {
          std::printf("FAIL: threaded balanced tree deeper than the traversal stack\n");
-         errors++;
-      }
-   }
-   {
-      // split_references: every triangle keeps at least one reference, a split triangle's pieces cover it (every point of the
-      // triangle lies in some piece's box), boxes stay inside the triangle's own box, and the tree over references is a tree
-      std::vector<float> tris;
-      g_state = 77;
-      for (int i = 0; i < 4000; i++) {
-         const bool big = i % 50 == 0;
-         float c[3] = {rnd() * 20 - 10, rnd() * 20 - 10, rnd() * 20 - 10};
-         for (int v = 0; v < 3; v++)
-            for (int a = 0; a < 3; a++) tris.push_back(c[a] + (rnd() - 0.5f) * (big ? 9.0f : 0.3f));
-      }
-      const uint32_t n = (uint32_t)(tris.size() / 9);
-      std::vector<float> boxes;
-      std::vector<uint32_t> ref_tri;
-      split_references(tris.data(), n, 1.0f, 64, boxes, ref_tri);
-      std::vector<uint32_t> per(n, 0);
-      int bad = 0;
-      for (size_t r = 0; r < ref_tri.size(); r++) {
-         per[ref_tri[r]]++;
-         const float* t = &tris[9 * (size_t)ref_tri[r]];
-         for (int a = 0; a < 3; a++) {
-            const float lo = std::fmin(t[a], std::fmin(t[3 + a], t[6 + a])), hi = std::fmax(t[a], std::fmax(t[3 + a], t[6 + a]));
-            if (!(boxes[6 * r + a] >= lo - 1e-5f) || !(boxes[6 * r + 3 + a] <= hi + 1e-5f) || !(boxes[6 * r + a] <= boxes[6 * r + 3 + a])) bad++;
-         }
-      }
-      uint32_t split = 0;
-      for (uint32_t i = 0; i < n; i++) {
-         if (per[i] == 0 || per[i] > 64) bad++;
-         split += per[i] > 1;
-      }
-      // coverage: random points of every triangle lie in one of its pieces' boxes
-      for (uint32_t i = 0; i < n && bad == 0; i++) {
-         if (per[i] == 1) continue;
-         const float* t = &tris[9 * (size_t)i];
-         for (int s = 0; s < 40; s++) {
-            float u = rnd(), v = rnd();
-            if (u + v > 1) {
-               u = 1 - u;
-               v = 1 - v;
-            }
-            double p[3];
-            for (int a = 0; a < 3; a++) p[a] = (double)t[a] + u * ((double)t[3 + a] - t[a]) + v * ((double)t[6 + a] - t[a]);
-            bool in = false;
-            for (size_t r = 0; r < ref_tri.size() && !in; r++) {
-               if (ref_tri[r] != i) continue;
-               in = true;
-               for (int a = 0; a < 3; a++) in = in && p[a] >= boxes[6 * r + a] - 1e-6 && p[a] <= boxes[6 * r + 3 + a] + 1e-6;
-            }
-            if (!in) bad++;
-         }
-      }
-      std::vector<uint32_t> keys(ref_tri.size());
-      BuildInput in{tris.data(), keys.data(), (uint32_t)ref_tri.size()};
-      in.boxes6 = boxes.data();
-      BuildOutput out;
-      build_bvh4(in, out, 3);
-      std::vector<uint32_t> seen(ref_tri.size(), 0);
-      for (uint32_t r : out.tri_order)
-         if (r < seen.size()) seen[r]++;
-      for (uint32_t x : seen) bad += x != 1;
-      std::printf("split_references: %u triangles (%u split) -> %zu references, tree of %zu nodes, %s\n", n, split, ref_tri.size(), out.nodes.size(), bad ? "FAILED" : "ok");
-      if (bad || split < 40 || ref_tri.size() <= n) {
-         std::printf("FAIL: split references\n");
-         errors++;
-      }
-      // threshold 0 = no splits: boxes are the corners' own
-      split_references(tris.data(), n, 0.0f, 64, boxes, ref_tri);
-      if (ref_tri.size() != n) {
-         std::printf("FAIL: threshold 0 must not split\n");
          errors++;
       }
    }

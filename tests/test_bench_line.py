@@ -91,5 +91,7 @@ def test_metric_names_the_real_step_count():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "64 frames x 1 spp" not in src
     assert "{args.steps} frames x {args.spp} spp" in src
-    for key in ('"value_tree_walk"', '"sun_grid"', '"camera_grid"', '"value_with_grid_builds"', '"rccl_ranks"'):
+    for key in ('"value_tree_walk"', '"sun_grid"', '"camera_grid"', '"value_with_grid_builds"', '"rccl_library_comm_ranks"', '"hip"'):
         assert key in src, key
+    assert "camera and sun at rest" in src and "outside the timed region" in src  # the headline says what regime it is measured in
+    assert "import torch" not in src, "a rank is a GPU process and imports no torch"

@@ -221,21 +221,6 @@ def test_instance_transform_rebuild(cornell):
     assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
 
 
-@pytest.mark.parametrize("variant", [0])
-def test_traversal_variants_are_bit_identical(atrium, variant):
-    """the batch kernels (option trace_variant = 0: the baseline kept for A/B) and the default refill kernels must produce the same image and the same ray counts"""
-    W, H = 160, 90
-    ref = atrium.upload(rr.Renderer(W, H))
-    alt = atrium.upload(rr.Renderer(W, H))
-    alt.set_option("trace_variant", variant)
-    for r in (ref, alt):
-        r.set_option("count_visits", 1)
-        run_frames(r, atrium, W, H, 2, rr.PASS_ALL)
-    assert np.array_equal(ref.read_accumulation().view(np.uint32), alt.read_accumulation().view(np.uint32))
-    a, b = ref.get_stats(), alt.get_stats()
-    assert list(a.rays) == list(b.rays) and a.closest_hits == b.closest_hits and a.misses == b.misses
-
-
 @pytest.mark.parametrize("batch,in_flight,spp,limit", [(3, 2, 1, 999999), (8, 3, 1, 999999), (4, 1, 2, 999999), (3, 3, 1, 4)])
 def test_batched_frames_equal_frame_by_frame(cornell, batch, in_flight, spp, limit):
     """uh_render_frames (several frames per wavefront, several wavefronts in flight) must equal the
@@ -505,7 +490,7 @@ def test_group_composition_is_ordered_by_events(atrium):
     lib.uh_set_option.argtypes, lib.uh_set_option.restype = [C.c_void_p, C.c_char_p, C.c_int], C.c_int
     for i in (1, 2):
         ctx = lib.uh_mgpu_context(group._ctx, i)
-        for name, value in ((b"closest_blocks_per_cu", 1), (b"shadow_blocks_per_cu", 1), (b"frames_in_flight", 1), (b"batch_frames", 2)):
+        for name, value in ((b"trace_blocks_per_cu", 1), (b"frames_in_flight", 1), (b"batch_frames", 2)):
             assert lib.uh_set_option(ctx, name, value) == 0
     loops = {r: rr.FrameLoop(r, atrium.make_view(W, H, lights_enabled=0)) for r in (single, group)}
     for r in (single, group):
@@ -853,51 +838,6 @@ def test_cook_torrance_extension_matches_oracle(atrium):
     assert gpu.read_accumulation()[..., :3].max() > 0.0
 
 
-# ---- spatial splits (option "spatial_splits"): references with clipped boxes for long triangles; hits unchanged -----------
-def _atrium_with_cables():
-    from rust_renderer_amd.scenes import Mesh, Model, _pack_vertices
-    scene = rr.scenes.sponza_class_scene(detail=0.12, tex_size=16, num_lights=0)
-    rng = np.random.default_rng(3)
-    pos, idx = [], []
-    for k in range(40):  # long thin diagonal slivers through the whole atrium: each one's box spans a large part of the scene
-        a = np.array([rng.uniform(-15, 15), rng.uniform(0.5, 12), rng.uniform(-7, 7)])
-        b = np.array([rng.uniform(-15, 15), rng.uniform(0.5, 12), rng.uniform(-7, 7)])
-        w = np.cross(b - a, [0.3, 1.0, 0.2])
-        w = 0.02 * w / np.linalg.norm(w)
-        base = len(pos)
-        pos += [a, b, b + w, a + w]
-        idx += [base, base + 1, base + 2, base, base + 2, base + 3]
-    pos = np.float32(pos)
-    m = Mesh(_pack_vertices(pos, np.tile(np.float32([0, 1, 0]), (len(pos), 1)), np.zeros((len(pos), 2), np.float32)), np.uint32(idx), name="cables")
-    scene.models.append((Model([m], []), None))
-    return scene
-
-
-def test_spatial_splits_keep_every_hit_and_cut_visits():
-    scene = _atrium_with_cables()
-    W, H = 160, 90
-    out = {}
-    rays = random_rays(((-15, 0, -7), (15, 12, 7)), 40_000, seed=21)
-    for factor in (0, 8):
-        r = rr.Renderer(W, H)
-        r.set_option("spatial_splits", factor)
-        scene.upload(r)
-        r.set_option("count_visits", 1)
-        run_frames(r, scene, W, H, 2, rr.PASS_REFERENCE_PT)
-        s = r.get_stats()
-        out[factor] = (r.read_accumulation(), list(s.rays), s.nodes_visited / (s.rays[0] + s.rays[1]), s.bvh_triangles, r.trace_closest(rays), r.trace_any(rays))
-    (a0, r0, v0, n0, c0, o0), (a8, r8, v8, n8, c8, o8) = out[0], out[8]
-    assert n8 > n0, "long triangles became several references"
-    assert np.array_equal(a0.view(np.uint32), a8.view(np.uint32)) and r0 == r8
-    for x, y in zip(c0, c8):
-        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
-    assert np.array_equal(o0, o8)
-    assert v8 < 0.97 * v0, (v0, v8)
-    cpu = scene.upload(oa.OracleRenderer(W, H))
-    run_frames(cpu, scene, W, H, 2, rr.PASS_REFERENCE_PT)
-    assert per_pixel_l2(a8, cpu.read_accumulation()) <= L2_TOL and r8[:4] == list(cpu.get_stats().rays)[:4]
-
-
 @pytest.mark.parametrize("kind", [1, 2])
 def test_device_build_falls_back_to_the_host_builder_on_overflowing_geometry(kind):
     """finite coordinates around 1e19: surface-area products overflow to inf, a PLOC round finds no pair to merge - the device
@@ -920,42 +860,3 @@ def test_device_build_falls_back_to_the_host_builder_on_overflowing_geometry(kin
     assert dev.get_stats().bvh_triangles == 400  # built, not refused
     for a, b in zip(host.trace_closest(rays), dev.trace_closest(rays)):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))  # (at this scale the triangle test itself overflows: all miss, on both)
-
-
-@pytest.mark.parametrize("size,world", [((97, 61), 1), ((128, 72), 1), ((192, 128), 3)])
-def test_wave_per_tile_traversal_is_bit_identical(atrium, size, world):
-    """option primary_tiles: primary rays and the G-buffer cast walked one wave per 8 x 8 pixel tile with the nodes fetched through the
-    scalar path (k_trace_closest_tiles) - same hits, reservoirs, images and counts as the per-lane kernel, also on frames whose
-    size is no multiple of 8; under a tile partition (dense path ids) the path tracer's rays stay with the per-lane kernel and
-    only the full-frame G-buffer cast goes through the tiles"""
-    W, H = size
-    out = []
-    for tiles in (0, 1):
-        r = atrium.upload(rr.Renderer(W, H))
-        r.set_option("primary_tiles", tiles)
-        if world > 1:
-            r.set_tile_partition(1, world, 64)
-        rr.FrameLoop(r, atrium.make_view(W, H)).frames(5, rr.PASS_ALL)
-        out.append((r.read_accumulation(), r.read_gbuffer_position(), [r.read_reservoirs(k) for k in range(3)], list(r.get_stats().rays)))
-    (a0, g0, r0, c0), (a1, g1, r1, c1) = out
-    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and np.array_equal(g0.view(np.uint32), g1.view(np.uint32))
-    assert all(x.tobytes() == y.tobytes() for x, y in zip(r0, r1)) and c0 == c1
-
-
-def test_insertion_optimised_tree_gives_the_same_hits(atrium):
-    """option bvh_optimise (Bittner et al. 2013: subtrees taken out and reinserted where they add the least surface area, before the
-    collapse to 4-wide nodes): another tree over the same triangles - hits, images and ray counts do not change (the closest
-    hit does not depend on the tree, DESIGN.md "Arithmetic contract")"""
-    W, H = 96, 54
-    plain, opt = atrium.upload(rr.Renderer(W, H)), rr.Renderer(W, H)
-    opt.set_option("bvh_optimise", 3)
-    atrium.upload(opt)
-    rays = random_rays(((-14, 0, -7), (14, 11, 7)), 4000, seed=11)
-    for a, b in zip(plain.trace_closest(rays), opt.trace_closest(rays)):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    assert np.array_equal(plain.trace_any(rays), opt.trace_any(rays))
-    for r in (plain, opt):
-        run_frames(r, atrium, W, H, 3, rr.PASS_ALL)
-    assert np.array_equal(plain.read_accumulation().view(np.uint32), opt.read_accumulation().view(np.uint32))
-    assert list(plain.get_stats().rays) == list(opt.get_stats().rays)
-    assert plain.get_stats().bvh_triangles == opt.get_stats().bvh_triangles

@@ -41,8 +41,8 @@ def v_write_reservoirs(r, loop):
 
 
 def v_options(r, loop):
-    for k, v in (("furnace", 1), ("overlap_miss", 0), ("sun_grid", 0), ("frames_in_flight", 2), ("batch_frames", 1), ("count_visits", 1), ("time_kernels", 1),
-                 ("time_kernels", 0), ("closest_variant", 0), ("full_frame_restir", 1)):
+    for k, v in (("furnace", 1), ("overlap", 0), ("sun_grid", 0), ("frames_in_flight", 2), ("batch_frames", 1), ("count_visits", 1), ("time_kernels", 1),
+                 ("time_kernels", 0), ("trace_blocks_per_cu", 3), ("full_frame_restir", 1)):
         r.set_option(k, v)
 
 
@@ -119,28 +119,3 @@ def test_verb_between_frames_in_flight_equals_the_serial_sequence(cornell, name,
         for k in range(3):
             assert np.array_equal(got[1][k], want[1][k]), f"{name}: reservoir buffer {k} differs (repetition {rep})"
         assert got[2:] == want[2:], f"{name}: counters differ (repetition {rep}): {got[2:]} != {want[2:]}"
-
-
-@pytest.mark.parametrize("passes", [rr.PASS_ALL, rr.PASS_REFERENCE_PT])
-def test_a_single_frame_split_over_the_slots_equals_the_whole_wavefront(cornell, passes):
-    """option interleave (default 4): uh_render_frame spreads one frame's pixels, by tiles, over four wavefronts on four slots;
-    the image, the reservoirs and the ray counts are those of the single wavefront (interleave = 0), bit for bit - also when frames
-    of both kinds alternate and when the frame does not divide into whole tiles"""
-    Wd, Hd = 150, 100
-    out = []
-    for il in (4, 0, 3):
-        r = cornell.upload(rr.Renderer(Wd, Hd, device=0))
-        r.set_option("interleave", il)
-        loop = rr.FrameLoop(r, cornell.make_view(Wd, Hd, samples_per_frame=2))
-        for _ in range(3):
-            loop.frame(passes)
-        loop.frames(5, passes)  # a batch goes whole
-        loop.frame(passes)
-        s = r.get_stats()
-        out.append((r.read_accumulation().copy(), r.read_output_bgra8().copy(), [r.read_reservoirs(k).copy() for k in range(3)], list(s.rays), int(s.closest_hits), int(s.misses)))
-    for other in out[1:]:
-        assert np.array_equal(out[0][0].view(np.uint32), other[0].view(np.uint32))
-        assert np.array_equal(out[0][1], other[1])
-        for k in range(3):
-            assert np.array_equal(out[0][2][k], other[2][k])
-        assert out[0][3:] == other[3:]

@@ -149,80 +149,6 @@ def test_instances_moving_every_frame_never_rebuild_the_grid(cornell):
     assert changed == [6], (changed, builds)  # frames 2-5 move; frame 6 is the second in a row with frame 5's geometry: the rebuild
 
 
-def test_grid_built_on_a_host_thread(atrium):
-    """option sun_grid_async: the frame that asks for a grid starts a host thread and walks the tree; the grid is adopted by the
-    first frame that finds it done; a job overtaken by a change of direction is dropped. Every frame equals the oracle's."""
-    import time
-
-    W, H = 96, 54
-    gpu, cpu = make_pair(atrium, W, H)
-    gpu.set_option("sun_grid_async", 1)
-    loops = [rr.FrameLoop(r, atrium.make_view(W, H, sun_shadow_enabled=1, sky_enabled=0, lights_enabled=0)) for r in (gpu, cpu)]
-
-    def frame(sun):
-        for loop in loops:
-            loop.view.sun_dir[:] = list(sun)
-            loop.frame(rr.PASS_REFERENCE_PT)
-            loop.reset()
-        assert np.array_equal(gpu.read_accumulation().view(np.uint32), cpu.read_accumulation().view(np.uint32)), sun
-        return gpu.get_stats().sun_grid_cells
-
-    A, B = (0.0, 0.9, 0.15), (0.4, 0.7, -0.3)
-    assert frame(A) == 0, "the first frame does not wait for the build"
-    cells, tries = 0, 0
-    while cells == 0 and tries < 400:  # the build takes some tens of milliseconds on this scene
-        time.sleep(0.01)
-        cells = frame(A)
-        tries += 1
-    assert cells > 0, "the grid arrives"
-    first = cells
-    # B asked twice starts a job for B; going back to A before it is done drops it: A's grid is still there and used
-    frame(B)
-    frame(B)
-    assert frame(A) == first
-    for _ in range(30):
-        time.sleep(0.01)
-        assert frame(A) == first
-    gpu.close()
-
-
-def test_background_build_overtaken_by_a_moved_instance(cornell):
-    """sun_grid_async + geometry that changes while a grid is being built: the finished grid belongs to packets that no longer
-    exist and is dropped; frames stay equal to the oracle's throughout; a grid for the new geometry follows once it rests"""
-    import time
-
-    W, H = 80, 60
-    gpu, cpu = make_pair(cornell, W, H)
-    gpu.set_option("sun_grid_async", 1)
-    loops = [rr.FrameLoop(r, cornell.make_view(W, H, sun_shadow_enabled=1, lights_enabled=0)) for r in (gpu, cpu)]
-    n = cornell.num_meshes
-
-    def frame(move=None):
-        for r, loop in zip((gpu, cpu), loops):
-            if move is not None:
-                r.set_instance_transform(n - 2, rr.transform3x4((0.3,) * 3, move))
-                r.rebuild_tlas()
-            loop.frame(rr.PASS_REFERENCE_PT)
-            loop.reset()
-        assert per_pixel_l2(gpu.read_accumulation(), cpu.read_accumulation()) <= L2_TOL
-        assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays)
-        return gpu.get_stats().sun_grid_cells
-
-    frame()                      # starts the first build
-    frame(move=(0.2, 0.9, 0.1))  # the geometry changes under it
-    for k in range(3):
-        frame(move=(0.2 + 0.05 * k, 0.9, 0.1))
-    cells, tries = 0, 0
-    while cells == 0 and tries < 400:
-        time.sleep(0.01)
-        cells = frame()
-        tries += 1
-    assert cells > 0, "a grid for the geometry at rest arrives"
-    for _ in range(5):
-        assert frame() == cells
-    gpu.close()
-
-
 def test_rays_beyond_the_dense_extent_walk_the_tree(atrium):
     """a long strip of ground that leaves the atrium through its end wall (two triangles, little area: the grid is not refused as
     a whole): rays that start out there land in border cells and are handed to the tree walk (queue 3); the image equals the
@@ -334,12 +260,13 @@ def test_host_builder_is_still_selectable(atrium):
     assert list(dev.get_stats().rays) == list(host.get_stats().rays) == list(tree.get_stats().rays)
 
 
-@pytest.mark.parametrize("options", [{"sun_grid_inline": 0}, {"sun_grid_fused": 1}, {"sun_grid_fused": 1, "sun_grid_inline": 0}, {"sun_grid_coarse": 0}, {"sun_grid_coarse": 4, "sun_grid_fused": 1},
-                                     {"sun_grid_inline_max_mb": 1}, {"sun_grid_density": 24, "sun_grid_max_walk": 8}])
+@pytest.mark.parametrize("options", [{"sun_grid_inline_max_mb": 0}, {"sun_grid_inline_max_mb": 8192}, {"sun_grid_coarse": 0}, {"sun_grid_coarse": 4, "sun_grid_inline_max_mb": 8192},
+                                     {"sun_grid_inline_max_mb": 1}, {"sun_grid_density": 24, "sun_grid_max_walk": 8, "sun_grid_inline_max_mb": 8192}])
 @pytest.mark.parametrize("sun", [SUNS[0], SUNS[2], SUNS[8]])
-def test_round4_variants_of_the_grid_walk_change_nothing(atrium, sun, options):
-    """options sun_grid_inline (the lists as 64-byte records that carry their packet), sun_grid_fused (k_shade_hit looks the cell and
-    its cover depth up itself and sorts the sun rays into covered / lit at once / list walk / tree walk): same images, ray counts and counted visits as the default path and as the tree walk"""
+def test_variants_of_the_grid_walk_change_nothing(atrium, sun, options):
+    """the two forms of the lists - plain (8-byte entries beside the packet array: the default while the 64-byte records would exceed
+    four times the packet array, as on this scene) and as 64-byte records that carry their packet (sun_grid_inline_max_mb raised) -,
+    with and without the coarse cover: same images, ray counts and counted visits as the default path and as the tree walk"""
     W, H = 160, 90
     out = []
     for opts in ({}, options, {"sun_grid": 0}):
@@ -358,13 +285,12 @@ def test_round4_variants_of_the_grid_walk_change_nothing(atrium, sun, options):
         assert (s0.shadow_nodes_visited, s0.shadow_tris_tested, s0.sun_tree_rays, s0.sun_covered_rays) == (s1.shadow_nodes_visited, s1.shadow_tris_tested, s1.sun_tree_rays, s1.sun_covered_rays)
 
 
-def test_round4_variants_with_lights_and_batches(atrium):
-    """the fused look-up appends to five queues in one round trip (ray, light, grid walk, tree walk, lit at once): config-2 style
-    frames (lights on, reservoir passes, batches of frames) against the default path"""
+def test_variants_with_lights_and_batches(atrium):
+    """config-2 style frames (lights on, reservoir passes, batches of frames): the lists as records that carry their packet against the plain lists"""
     scene = rr.scenes.sponza_class_scene(detail=0.12, tex_size=32, with_spheres=True, num_lights=48, sphere_subdivisions=2)
     W, H = 128, 72
     images = []
-    for opts in ({}, {"sun_grid_fused": 1}):
+    for opts in ({}, {"sun_grid_inline_max_mb": 8192}):
         r = scene.upload(rr.Renderer(W, H))
         for k, v in opts.items():
             r.set_option(k, v)

@@ -37,6 +37,25 @@ def test_sun_grid_builder_under_asan_ubsan_never_hides_an_occluder(tmp_path):
     assert "SUN GRID CHECK OK" in r.stdout and "MISMATCH" not in r.stdout
 
 
+def test_camera_grid_builder_under_asan_ubsan_against_brute_force(tmp_path):
+    """csrc/camera_grid.h (product code: the host + device functions the camera grid's kernels run per packet and per cell) under
+    ASan + UBSan: for twelve cameras - inside, above, two centimetres above a floor, IN its plane, far outside, narrow and wide fields
+    of view, packets behind and across the camera plane, matrices that must be refused - the walk of k_trace_camera_grid, replayed on
+    the host in the kernels' float arithmetic for rays through every pixel's corners, edge midpoints and centre, gives the hit record of
+    brute force over all packets bit for bit; every accepting packet is listed in the ray's pixel and its sort key is a lower bound of
+    the float t (tests/cpp/camera_grid_check.cpp)."""
+    exe = str(tmp_path / "camera_grid_check")
+    csrc = os.path.join(ROOT, "rust-renderer_amd", "csrc")
+    subprocess.run(
+        ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-ffp-contract=off", "-mfma", "-Wall",
+         "-Wextra", "-I", csrc, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "camera_grid_check.cpp"), "-o", exe],
+        check=True,
+    )
+    r = subprocess.run([exe, "500", "32", "20"], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "0 not listed, 0 bounds above t, 0 hit records differ: ok" in r.stdout and r.stdout.count("refused") == 2
+
+
 def test_oracle_under_asan_ubsan_matches_the_plain_build(tmp_path):
     """the oracle itself, compiled with ASan + UBSan (threads on), renders the Cornell-class scene with
     the ReSTIR chain and all four material types; its image equals the -O2 library's bit for bit.

@@ -45,20 +45,10 @@ int main(int argc, char** argv) {
    if (std::fread(corners.data(), 4, corners.size(), f) != corners.size() || std::fread(rays.data(), sizeof(Ray), nr, f) != nr) return 1;
    std::fclose(f);
    std::vector<uint32_t> keys(nt);
-   // argv[2]: split threshold (box diagonal, 0 = no spatial splits); argv[3]: pieces per triangle at most
-   const float threshold = argc > 2 ? (float)std::atof(argv[2]) : 0.0f;
-   const uint32_t max_pieces = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 16u;
-   std::vector<float> boxes;
-   std::vector<uint32_t> ref_tri;
-   split_references(corners.data(), nt, threshold, max_pieces, boxes, ref_tri);
-   std::printf("split threshold %.3f: %zu references for %u triangles\n", threshold, ref_tri.size(), nt);
-   keys.resize(ref_tri.size());
-   BuildInput in{corners.data(), keys.data(), (uint32_t)ref_tri.size()};
-   in.boxes6 = boxes.data();
+   BuildInput in{corners.data(), keys.data(), nt};
    for (uint32_t width : {4u}) {
       BuildOutput bo;
       build_bvh4(in, bo, 8, false, width);
-      for (uint32_t& t : bo.tri_order) t = ref_tri[t];
       double fill = 0;
       for (const NodeW& n : bo.nodes) fill += n.count;
       std::printf("width %u: %zu nodes, %zu levels, %.2f children per node\n", width, bo.nodes.size(), bo.level_start.size() - 1, fill / bo.nodes.size());

@@ -47,7 +47,7 @@ def main():
         k, v = kv.split("=")
         r.set_option(k, int(v))
     scene.upload(r)
-    for k, v in (("frames_in_flight", 1), ("overlap_miss", 0), ("overlap_shadow", 0)):
+    for k, v in (("frames_in_flight", 1), ("overlap", 0)):
         r.set_option(k, v)
     mask = rr.PASS_ALL if a.config == 2 else rr.PASS_REFERENCE_PT
     loop = rr.FrameLoop(r, scene.make_view(W, H))

@@ -25,7 +25,7 @@ for opts in sweeps:
           "tests/ray", s.shadow_tris_tested / s.rays[2], "rays", s.rays[2], "handed to the tree", s.sun_tree_rays)
     r.set_option("count_visits", 0)
     r.set_option("time_kernels", 1)
-    for k, v in (("frames_in_flight", 1), ("overlap_miss", 0), ("overlap_shadow", 0)): r.set_option(k, v)
+    for k, v in (("frames_in_flight", 1), ("overlap", 0)): r.set_option(k, v)
     loop.frames(16, rr.PASS_REFERENCE_PT)
     r.reset_stats()
     loop.frames(16, rr.PASS_REFERENCE_PT)
