@@ -33,21 +33,32 @@ struct NodeW {
    uint32_t count;             // number of used child slots
 };
 
-// Device node. The children's boxes are quantised to 8 bits per plane relative to the node's own box
-// (plane = origin + 2^(e-127) * q), rounded outwards, so the slab test stays conservative and hits do not change.
+// Device node. The children's boxes are quantised to 8 bits per plane in the node's FRAME (plane = origin + 2^(e-127) * q), rounded
+// outwards, so the slab test stays conservative and hits do not change.
 // Slots [0, n_tri) are triangles: packet tri_base + slot. Slots [n_tri, n_child) are nodes: node child_base + (slot - n_tri).
 // The remaining slots are empty: an inverted box (qlo = 255, qhi = 0) that no ray hits.
+// The first 16 bytes are the node's frame; everything else a visit needs lies in the other 32 (n_tri rides in the top bits of
+// child_base), so that a build with UH_INHERIT_FRAME = 1 - the frame a function of the parent's frame and of this node's quantised box
+// there, node_quant.h qn_inherit - can derive the frame in registers and load 32 bytes only. Measured slower (the derivation's ~45 VALU
+// instructions cost more than the load they save): the default build gives every node its own frame.
 struct alignas(16) Node4C {
-   float origin[3];    // lower corner of the node's own (padded) box
-   uint32_t meta;      // bits 0-7 / 8-15 / 16-23: biased exponent of the x / y / z quantisation step (a power of two);
-                       // bits 24-26: n_tri; bits 28-30: n_child
+   float origin[3];    // the frame's origin: at or below the lower corner of the node's own (padded) box
+   uint32_t meta;      // bits 0-7 / 8-15 / 16-23: biased exponent of the x / y / z quantisation step (a power of two, byte >= 1);
+                       // bits 24-26: n_tri; bits 28-30: n_child (both for the builders and the refit: the traversal reads neither here)
    uint32_t qlo[3];    // per axis: child slot k's quantised lower plane in byte k
    uint32_t qhi[3];    // per axis: upper plane
-   uint32_t child_base;
+   uint32_t child_base;  // bits 0-28: first node child; bits 29-31: n_tri
    uint32_t tri_base;
 };
-static_assert(sizeof(Node4C) == 48, "device node = three 16-byte loads");
+static_assert(sizeof(Node4C) == 48, "device node = three 16-byte loads (two when the frame is inherited)");
 constexpr uint32_t kMetaTriShift = 24, kMetaChildShift = 28;
+// Build-time experiment (round 5, measured SLOWER and therefore off: profiles/README.md "inherited frames"): 1 = a node's frame is inherited
+// from its parent (node_quant.h) and a traversal that descends into a child derives it in registers instead of loading the child's
+// first quad. 0 = every node's frame is its own and every visit loads the three quads.
+#ifndef UH_INHERIT_FRAME
+#define UH_INHERIT_FRAME 0
+#endif
+constexpr uint32_t kChildBaseBits = 29, kChildBaseMask = (1u << kChildBaseBits) - 1;  // (node counts stay below 2^29: kMaxTriangles nodes at most, far fewer in practice)
 // Stride of the device arrays in 16-byte units. A 48-byte record at a 48-byte stride straddles two 64-byte cache
 // sectors half of the time; at a 64-byte stride (the last 16 bytes unused) every record is one sector - more bytes of
 // working set against fewer sector fetches per record. Measured (profiles/README.md "record stride"): neutral for both
@@ -114,7 +125,9 @@ void build_sah_top(const float* boxes6, uint32_t count, std::vector<TopNode>& ou
 constexpr uint32_t kTraversalStackEntries = 16 + 96;
 constexpr uint32_t kMaxTreeLevels = kTraversalStackEntries / 3;
 
-// the quantiser shared by the host builder and (restated, same arithmetic) the refit kernel: child boxes of one node -> Node4C planes
-void quantise_node(const NodeW& nd, Node4C& q);
+// the full-precision tree (BFS order, node 0 the root) -> the device nodes: every node's frame is its own (UH_INHERIT_FRAME = 1: only the
+// root's, the others' inherited from their parents - node_quant.h, shared with the refit kernels); children's planes rounded outwards in
+// the node's frame
+void quantise_tree(const std::vector<NodeW>& nodes, std::vector<Node4C>& out);
 
 }  // namespace uh

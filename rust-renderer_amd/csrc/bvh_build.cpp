@@ -4,6 +4,7 @@
 // driver. Binned SAH (16 bins, 3 axes) -> BVH2 down to single triangles -> greedy collapse to 4-wide nodes by surface
 // area, emitted breadth-first with every node's triangle children and node children in contiguous slots (bvh.h).
 #include "bvh.h"
+#include "node_quant.h"
 
 #include <algorithm>
 #include <atomic>
@@ -48,7 +49,10 @@ struct Knobs {
    int collapse = 1;        // 0 = greedy by area (rounds 1-3), 1 = SAH-optimal collapse by dynamic programming (Ylitie et al. 2017)
    int sweep_below = 0;     // ranges of at most this many triangles are split by an exact sweep over the sorted centroids instead of 16 bins
    int bins = 16;
-   float c_tri = 1.0f;      // cost of a triangle slot relative to a node visit, per unit of area (collapse = 1)
+#ifndef UH_BVH_CTRI
+#define UH_BVH_CTRI 1.0f
+#endif
+   float c_tri = UH_BVH_CTRI;  // cost of a triangle slot relative to a node visit, per unit of area (collapse = 1); build-time switch for tools/bvh_visits.py
 };
 static Knobs knobs_from_env() { return Knobs(); }
 
@@ -227,63 +231,49 @@ inline void padded(const Box& b, float* lo, float* hi) {
 
 }  // namespace
 
-void quantise_node(const NodeW& nd, Node4C& q) {
-   // origin = min over the children, step = 2^e with e minimal such that the node's extent fits 255 steps;
-   // lower planes round down, upper planes round up (in double). refit.hip restates this arithmetic.
-   const float* lo[3] = {nd.lo[0], nd.lo[1], nd.lo[2]};
-   const float* hi[3] = {nd.hi[0], nd.hi[1], nd.hi[2]};
-   uint32_t exps = 0;
-   for (int a = 0; a < 3; a++) {
-      double mn = INFINITY, mx = -INFINITY;
-      for (int k = 0; k < 4; k++)
-         if (nd.child[k] != kEmptyRef) {
-            mn = std::fmin(mn, (double)lo[a][k]);
-            mx = std::fmax(mx, (double)hi[a][k]);
-         }
-      if (!(mn <= mx)) mn = mx = 0.0;
-      float origin = (float)mn;
-      if ((double)origin > mn) origin = std::nextafterf(origin, -INFINITY);
-      double ext = mx - (double)origin;
-      int e = -100;
-      if (!(ext < 1e38)) {
-         e = 120;  // non-finite or overflowing extent (only from non-finite world-space geometry): no search
-      } else if (ext > 0) {
-         e = (int)std::ceil(std::log2(ext / 255.0));
-         while (std::ldexp(255.0, e) < ext) e++;
-         if (e < -100) e = -100;
-      }
-      double scale = std::ldexp(1.0, e);
-      uint32_t wlo = 0, whi = 0;
+void quantise_tree(const std::vector<NodeW>& nodes, std::vector<Node4C>& out) {
+   out.assign(nodes.size(), Node4C{});
+   if (nodes.empty()) return;
+   // BFS order: a node's children lie behind it, so one pass in index order meets every node after its parent has set its frame
+   std::vector<uint8_t> framed(nodes.size(), 0);
+   for (size_t i = 0; i < nodes.size(); i++) {
+      const NodeW& nd = nodes[i];
+      Node4C& q = out[i];
+      uint32_t n_tri = 0, n_child = 0;
+      float lo[4][3], hi[4][3];
       for (int k = 0; k < 4; k++) {
-         if (nd.child[k] == kEmptyRef) {
-            wlo |= 0xffu << (8 * k);  // inverted box: the slab test fails for every ray
-            continue;
+         for (int a = 0; a < 3; a++) {
+            lo[k][a] = nd.lo[a][k];
+            hi[k][a] = nd.hi[a][k];
          }
-         double a0 = std::floor(((double)lo[a][k] - (double)origin) / scale);
-         double a1 = std::ceil(((double)hi[a][k] - (double)origin) / scale);
-         if (a0 < 0) a0 = 0;
-         if (a1 > 255) a1 = 255;  // cannot trigger: ext <= 255 * scale
-         if (a0 > 255) a0 = 255;
-         wlo |= (uint32_t)a0 << (8 * k);
-         whi |= (uint32_t)a1 << (8 * k);
-      }
-      q.origin[a] = origin;
-      q.qlo[a] = wlo;
-      q.qhi[a] = whi;
-      exps |= (uint32_t)(e + 127) << (8 * a);  // e in [-100, 120]: a normal float's biased exponent
-   }
-   uint32_t n_tri = 0, n_child = 0;
-   for (int k = 0; k < 4; k++)
-      if (nd.child[k] != kEmptyRef) {
+         if (nd.child[k] == kEmptyRef) continue;
          n_child++;
          if (nd.child[k] & kLeafBit) n_tri++;
       }
-   q.meta = exps | (n_tri << kMetaTriShift) | (n_child << kMetaChildShift);
-   q.child_base = q.tri_base = 0;
-   for (int k = 0; k < 4; k++) {
-      if (nd.child[k] == kEmptyRef) continue;
-      if ((nd.child[k] & kLeafBit) && k == 0) q.tri_base = nd.child[k] & ~kLeafBit;
-      if (!(nd.child[k] & kLeafBit) && (uint32_t)k == n_tri) q.child_base = nd.child[k];
+      if (!framed[i] || !UH_INHERIT_FRAME) {  // the root takes its own frame (and so does every node of a build without inherited frames)
+         uint32_t exps = 0;
+         qn_own_frame(lo, hi, n_child, q.origin, exps);
+         q.meta = exps;
+      }
+      float child_origin[4][3];
+      uint32_t child_exps[4] = {0, 0, 0, 0};
+      qn_quantise(q.origin, q.meta & 0xffffffu, lo, hi, n_tri, n_child, q.qlo, q.qhi, child_origin, child_exps, UH_INHERIT_FRAME != 0);
+      q.meta = (q.meta & 0xffffffu) | (n_tri << kMetaTriShift) | (n_child << kMetaChildShift);
+      uint32_t child_base = 0;
+      q.tri_base = 0;
+      for (int k = 0; k < 4; k++) {
+         if (nd.child[k] == kEmptyRef) continue;
+         if ((nd.child[k] & kLeafBit) && k == 0) q.tri_base = nd.child[k] & ~kLeafBit;
+         if (!(nd.child[k] & kLeafBit)) {
+            if ((uint32_t)k == n_tri) child_base = nd.child[k];
+            if (!UH_INHERIT_FRAME) continue;
+            Node4C& c = out[nd.child[k]];
+            for (int a = 0; a < 3; a++) c.origin[a] = child_origin[k][a];
+            c.meta = child_exps[k];
+            framed[nd.child[k]] = 1;
+         }
+      }
+      q.child_base = (child_base & kChildBaseMask) | (n_tri << kChildBaseBits);
    }
 }
 
@@ -356,9 +346,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
       for (int k = 0; k < kMaxWidth; k++) root.child[k] = kEmptyRef;
       out.nodes.push_back(root);
       if (width == 4) {
-         Node4C q;  // empty scene: a root whose four slots are empty (every ray misses)
-         quantise_node(root, q);
-         out.cnodes.push_back(q);
+         quantise_tree(std::vector<NodeW>{root}, out.cnodes);  // empty scene: a root whose four slots are empty (every ray misses)
       }
       return;
    }
@@ -727,7 +715,7 @@ void build_bvh4(const BuildInput& in, BuildOutput& out, int num_threads, bool ba
    // ---- quantise
    if (width == 4) {
       out.cnodes.resize(out.nodes.size());
-      for (size_t i = 0; i < out.nodes.size(); i++) quantise_node(out.nodes[i], out.cnodes[i]);
+      quantise_tree(out.nodes, out.cnodes);
    }
 }
 

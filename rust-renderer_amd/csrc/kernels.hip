@@ -29,6 +29,16 @@ constexpr int kWavesPerBlock = kBlock / 64;
 #ifndef UH_LDS_STACK
 #define UH_LDS_STACK 16
 #endif
+// Build-time experiments of round 5 on the traversal step (profiles/README.md "k_trace_closest, round 5"; tools/ab.sh compares builds):
+#ifndef UH_PK_SLAB
+#define UH_PK_SLAB 0  // 1: the slab test's 24 fused multiply-adds as 12 v_pk_fma_f32 (near and far plane of an axis in one instruction)
+#endif
+#ifndef UH_GATE_LEAVES
+#define UH_GATE_LEAVES 0  // k > 0: lanes at a leaf wait (no load, no test) until k lanes of the wave stand at one, a lane has waited UH_GATE_WAIT iterations, or no lane is at a node
+#endif
+#ifndef UH_GATE_WAIT
+#define UH_GATE_WAIT 3
+#endif
 constexpr int kLdsStack = UH_LDS_STACK;      // per-lane traversal stack entries kept in LDS (16 KiB per 256-thread block)
 constexpr int kSpillStack = (int)kTraversalStackEntries - kLdsStack;             // overflow entries in private memory (rarely touched); the host refuses trees deeper than the two together hold
 
@@ -98,6 +108,15 @@ struct Trav {
    Hit best;
    int sp;
    uint32_t cur;
+   // the quantisation frame of `cur` when the lane DESCENDED into it from its parent (node_quant.h qn_inherit): origin, and the three
+   // step exponent bytes - 0 = none (cur was popped, is a leaf, or is the root: the visit loads the record's first quad)
+#if UH_INHERIT_FRAME
+   float fx, fy, fz;
+   uint32_t fexp;
+#endif
+#if UH_GATE_LEAVES
+   uint32_t wait;  // iterations this lane has stood at a leaf without testing it
+#endif
 };
 
 __device__ __forceinline__ void trav_init(Trav& t, float4 ro, float4 rd, float tmin, float tmax, float tlimit) {
@@ -112,6 +131,13 @@ __device__ __forceinline__ void trav_init(Trav& t, float4 ro, float4 rd, float t
    t.best.key = 0xffffffffu;
    t.sp = 0;
    t.cur = 0;
+#if UH_GATE_LEAVES
+   t.wait = 0;
+#endif
+#if UH_INHERIT_FRAME
+   t.fx = t.fy = t.fz = 0.0f;
+   t.fexp = 0u;
+#endif
 }
 
 __device__ __forceinline__ void trav_push(Trav& t, uint32_t* lds_col, uint32_t* spill, uint32_t ref) {
@@ -140,12 +166,31 @@ __device__ __forceinline__ uint32_t trav_pop(Trav& t, const uint32_t* lds_col, c
 
 // one interior node (Node4C, 48 B = three loads): slab-test the 4 children, continue with the nearest, push
 // the other hits. plane = origin + scale * q  =>  t = q * (scale * idir) + (origin - o) * idir.
-//   w0 = origin.xyz, meta (step exponents, n_tri, n_child) ; w1 = qlo.xyz, qhi.x ; w2 = qhi.y, qhi.z, child_base, tri_base
+//   w0 = origin.xyz, step exponents (the node's FRAME) ; w1 = qlo.xyz, qhi.x ; w2 = qhi.y, qhi.z, child_base | n_tri << 29, tri_base
 // Child references are implicit (bvh.h): slot k is triangle packet tri_base + k below n_tri, node child_base + k - n_tri above.
+// The frame of the child the lane continues with is derived here (node_quant.h qn_inherit, restated: v_cvt_f32_ubyte, v_fma_f32,
+// v_ffbh_u32) and left in t.fx .. t.fexp: the next visit does not load that node's first quad.
 // Instruction diet: the near / far plane words are picked once per axis by the sign of idir instead of min/max per
 // plane; an empty slot is an inverted box (no child != empty test); only the nearest child is fully ordered
 // (3 comparators); pushes are branch-free (write always, advance the stack pointer by the hit bit).
 // Returns false when no child was hit: the caller pops (trav_step pops once for its node lanes and its leaf lanes together).
+// the frame of node child `next` (= node0 + slot) of the node (w0, w1, w2), or none when `next` is no node child that was hit
+__device__ __forceinline__ void inherit_frame(const uint4 w0, const uint4 w1, const uint4 w2, float sx, float sy, float sz, uint32_t node0, uint32_t next, bool to_node, Trav& t) {
+#if UH_INHERIT_FRAME
+   const uint32_t sh = ((next - node0) & 3u) << 3;
+   const uint32_t lx = (w1.x >> sh) & 0xffu, ly = (w1.y >> sh) & 0xffu, lz = (w1.z >> sh) & 0xffu;
+   const uint32_t hx = (w1.w >> sh) & 0xffu, hy = (w2.x >> sh) & 0xffu, hz = (w2.y >> sh) & 0xffu;
+   t.fx = fmaf((float)lx, sx, __uint_as_float(w0.x));
+   t.fy = fmaf((float)ly, sy, __uint_as_float(w0.y));
+   t.fz = fmaf((float)lz, sz, __uint_as_float(w0.z));
+   // exponent byte + bit length of the box's width in steps - 8, at least 1 (bit length of 0 is 0: __clz(0) = 32)
+   const int ex = (int)(w0.w & 0xffu) + (24 - __clz((int)((hx - lx) & 0xffu))), ey = (int)((w0.w >> 8) & 0xffu) + (24 - __clz((int)((hy - ly) & 0xffu))),
+             ez = (int)((w0.w >> 16) & 0xffu) + (24 - __clz((int)((hz - lz) & 0xffu)));
+   const uint32_t packed = (uint32_t)(ex < 1 ? 1 : ex) | ((uint32_t)(ey < 1 ? 1 : ey) << 8) | ((uint32_t)(ez < 1 ? 1 : ez) << 16);
+   t.fexp = to_node ? packed : 0u;
+#endif
+}
+
 template <bool ANY>
 __device__ __forceinline__ bool node_compute(const uint4 w0, const uint4 w1, const uint4 w2, Trav& t, uint32_t* lds_col, uint32_t* spill) {
    const uint32_t meta = w0.w;
@@ -160,17 +205,28 @@ __device__ __forceinline__ bool node_compute(const uint4 w0, const uint4 w1, con
    const uint32_t qnz = nz ? w2.y : w1.z, qfz = nz ? w1.z : w2.y;
    const float tcap = ANY ? fminf(t.best.t, t.tlimit) : t.best.t;  // closest: tlimit is +inf
    float tn[4];
-   const uint32_t n_tri = (meta >> kMetaTriShift) & 7u;
-   const uint32_t tri0 = kLeafBit | w2.w, node0 = w2.z - n_tri;
+   const uint32_t n_tri = w2.z >> kChildBaseBits;
+   const uint32_t tri0 = kLeafBit | w2.w, node0 = (w2.z & kChildBaseMask) - n_tri;
    uint32_t cr[4];
 #pragma unroll
    for (int k = 0; k < 4; k++) cr[k] = ((uint32_t)k < n_tri ? tri0 : node0) + (uint32_t)k;
    bool hit[4];
+#if UH_PK_SLAB
+   typedef float f2_t __attribute__((ext_vector_type(2)));
+   const f2_t ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
+#endif
 #pragma unroll
    for (int k = 0; k < 4; k++) {
+#if UH_PK_SLAB
+      const f2_t qx = {(float)((qnx >> (8 * k)) & 0xffu), (float)((qfx >> (8 * k)) & 0xffu)}, qy = {(float)((qny >> (8 * k)) & 0xffu), (float)((qfy >> (8 * k)) & 0xffu)},
+                 qz = {(float)((qnz >> (8 * k)) & 0xffu), (float)((qfz >> (8 * k)) & 0xffu)};
+      const f2_t tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2), tz = __builtin_elementwise_fma(qz, az2, bz2);
+      const float t0x = tx.x, t1x = tx.y, t0y = ty.x, t1y = ty.y, t0z = tz.x, t1z = tz.y;
+#else
       const float t0x = fmaf((float)((qnx >> (8 * k)) & 0xffu), ax, bx), t1x = fmaf((float)((qfx >> (8 * k)) & 0xffu), ax, bx);
       const float t0y = fmaf((float)((qny >> (8 * k)) & 0xffu), ay, by), t1y = fmaf((float)((qfy >> (8 * k)) & 0xffu), ay, by);
       const float t0z = fmaf((float)((qnz >> (8 * k)) & 0xffu), az, bz), t1z = fmaf((float)((qfz >> (8 * k)) & 0xffu), az, bz);
+#endif
       const float tnear = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, t.tmin));
       const float tfar = fminf(fminf(t1x, t1y), fminf(t1z, tcap));
       hit[k] = tnear <= tfar;
@@ -199,6 +255,7 @@ __device__ __forceinline__ bool node_compute(const uint4 w0, const uint4 w1, con
          if (p2) trav_push(t, lds_col, spill, cr[2]);
       }
       t.cur = next;
+      inherit_frame(w0, w1, w2, sx, sy, sz, node0, next, any && !(next & kLeafBit), t);
       return any;
    }
    {
@@ -232,13 +289,14 @@ __device__ __forceinline__ bool node_compute(const uint4 w0, const uint4 w1, con
       if (tn[1] < INFINITY) trav_push(t, lds_col, spill, cr[1]);
    }
    t.cur = cr[0];
+   inherit_frame(w0, w1, w2, sx, sy, sz, node0, cr[0], tn[0] < INFINITY && !(cr[0] & kLeafBit), t);
    return tn[0] < INFINITY;
 }
 
 template <bool ANY>
 __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, Trav& t, uint32_t* lds_col, uint32_t* spill) {
    const uint4* n = nodes + kNodeStride16 * (size_t)t.cur;
-   const uint4 w0 = n[0], w1 = n[1], w2 = n[2];
+   const uint4 w0 = n[0], w1 = n[1], w2 = n[2];  // (this walk loads every node whole: the stored frame is the inherited one, bit for bit)
    if (!node_compute<ANY>(w0, w1, w2, t, lds_col, spill)) t.cur = trav_pop(t, lds_col, spill);
 }
 
@@ -437,11 +495,31 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
                                           uint32_t& n_nodes, uint32_t& n_tris) {
    const bool at_node = !(t.cur & kLeafBit);
    const uint32_t packet = t.cur & ~kLeafBit;
+#if UH_GATE_LEAVES
+   {  // the triangle branch (~70 instructions for the handful of lanes that stand at a leaf) only when enough lanes want it
+      const unsigned long long leaves = __ballot(!at_node), at_nodes = __ballot(at_node);
+      const bool run = (uint32_t)__popcll(leaves) >= (uint32_t)UH_GATE_LEAVES || at_nodes == 0ull || __ballot(!at_node && t.wait >= (uint32_t)UH_GATE_WAIT) != 0ull;
+      if (!at_node) {
+         if (!run) {
+            t.wait++;
+            return false;
+         }
+         t.wait = 0;
+      }
+   }
+#endif
    // nodes and triangle packets are both three-quad records: ONE address and ONE set of loads for the whole wave.
    // (Written as two branches, each with its own loads, the compiler gave the second branch's address the first
    // branch's destination registers and made it wait for them: the two groups' loads ran one after the other.)
    const uint4* rec = at_node ? nodes + kNodeStride16 * (size_t)packet : (const uint4*)tris + kTriStride16 * (size_t)packet;
+   // a lane that descended into this node brought the node's frame along (node_compute): it loads two quads, not three
+#if UH_INHERIT_FRAME
+   uint4 w0 = make_uint4(__float_as_uint(t.fx), __float_as_uint(t.fy), __float_as_uint(t.fz), t.fexp);
+   if (!(at_node && t.fexp != 0u)) w0 = rec[0];
+   uint4 w1 = rec[1], w2 = rec[2];
+#else
    uint4 w0 = rec[0], w1 = rec[1], w2 = rec[2];
+#endif
    // the packet's last two dwords are padding: without this the compiler loads them in the node branch only (a fourth load)
    asm volatile("" : "+v"(w2.z), "+v"(w2.w));
    bool pop;  // one pop for both groups: an LDS read and its wait once per iteration, not once per branch
@@ -460,7 +538,12 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
          pop = false;
       }
    }
-   if (pop) t.cur = trav_pop(t, lds_col, spill);
+   if (pop) {
+      t.cur = trav_pop(t, lds_col, spill);
+#if UH_INHERIT_FRAME
+      t.fexp = 0u;  // a popped node's frame is in its record
+#endif
+   }
    return t.cur == kEmptyRef;
 }
 

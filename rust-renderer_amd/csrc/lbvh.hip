@@ -215,7 +215,7 @@ __device__ __forceinline__ void write_topology(uint4* nd, uint32_t n_tri, uint32
    const uint32_t meta = (127u | (127u << 8) | (127u << 16)) | (n_tri << kMetaTriShift) | (n_child << kMetaChildShift);
    nd[0] = make_uint4(0u, 0u, 0u, meta);
    nd[1] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
-   nd[2] = make_uint4(0u, 0u, child_base, tri_base);
+   nd[2] = make_uint4(0u, 0u, (child_base & kChildBaseMask) | (n_tri << kChildBaseBits), tri_base);  // (bvh.h: the traversal reads n_tri here)
 }
 
 // one BFS level of the 4-wide tree: level node `idx` (global index level_first + idx) collapses the

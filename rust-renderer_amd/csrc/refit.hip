@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
+#include "node_quant.h"
 
 namespace uh {
 
@@ -49,21 +50,14 @@ __global__ __launch_bounds__(kBlock) void k_refit_triangles(const float* __restr
    pk[2] = make_float4(c[8] - c[2], __uint_as_float(key), 0.0f, 0.0f);
 }
 
-// one thread per node of one BFS level (deepest level first): tight box of every child, the node's
-// own tight box for its parent, and the re-quantised 48-byte node (bvh.h Node4C; child slots are implicit:
-// triangles tri_base + k below n_tri, nodes child_base + k - n_tri up to n_child, empty slots above)
-__global__ __launch_bounds__(kBlock) void k_refit_level(uint4* __restrict__ nodes, float* __restrict__ node_box, const float* __restrict__ world_corners, uint32_t first,
-                                                        uint32_t count) {
-   uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-   if (j >= count) return;
-   const uint32_t ni = first + j;
-   uint4* nd = nodes + kNodeStride16 * (size_t)ni;
-   const uint32_t meta = nd[0].w;
-   const uint4 w2 = nd[2];
-   const uint32_t n_tri = (meta >> kMetaTriShift) & 7u, n_child = (meta >> kMetaChildShift) & 7u;
-   const uint32_t child_base = w2.z, tri_base = w2.w;
-   float lo[4][3], hi[4][3];
-   float tlo[3] = {INFINITY, INFINITY, INFINITY}, thi[3] = {-INFINITY, -INFINITY, -INFINITY};
+// what a node's children span: slot k's tight box (node children: from node_box, triangle children: from the baked corners), padded
+// as bvh_build.cpp padded() does - the slab test must never cull what the triangle test accepts
+__device__ __forceinline__ void child_boxes(const float* __restrict__ node_box, const float* __restrict__ world_corners, uint32_t n_tri, uint32_t n_child, uint32_t child_base,
+                                            uint32_t tri_base, float lo[4][3], float hi[4][3], float tlo[3], float thi[3]) {
+   for (int a = 0; a < 3; a++) {
+      tlo[a] = INFINITY;
+      thi[a] = -INFINITY;
+   }
    for (uint32_t k = 0; k < 4; k++) {
       float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
       if (k >= n_child) {
@@ -87,63 +81,62 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(uint4* __restrict__ node
       for (int a = 0; a < 3; a++) {
          tlo[a] = fminf(tlo[a], blo[a]);
          thi[a] = fmaxf(thi[a], bhi[a]);
-         // bvh_build.cpp padded(): the slab test must never cull what the triangle test accepts
          float pad = 1e-4f + 1e-5f * fmaxf(fabsf(blo[a]), fabsf(bhi[a]));
          lo[k][a] = blo[a] - pad;
          hi[k][a] = bhi[a] + pad;
       }
    }
+}
+
+// pass 1, one thread per node of one BFS level, deepest level first: the node's own tight box for its parent
+// (bvh.h Node4C; child slots are implicit: triangles tri_base + k below n_tri, nodes child_base + k - n_tri up to n_child, empty slots above)
+__global__ __launch_bounds__(kBlock) void k_refit_boxes(const uint4* __restrict__ nodes, float* __restrict__ node_box, const float* __restrict__ world_corners, uint32_t first,
+                                                        uint32_t count) {
+   uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+   if (j >= count) return;
+   const uint32_t ni = first + j;
+   const uint4* nd = nodes + kNodeStride16 * (size_t)ni;
+   const uint32_t meta = nd[0].w;
+   const uint4 w2 = nd[2];
+   const uint32_t n_tri = (meta >> kMetaTriShift) & 7u, n_child = (meta >> kMetaChildShift) & 7u;
+   float lo[4][3], hi[4][3], tlo[3], thi[3];
+   child_boxes(node_box, world_corners, n_tri, n_child, w2.z & kChildBaseMask, w2.w, lo, hi, tlo, thi);
    float* nb = node_box + 6 * (size_t)ni;
    for (int a = 0; a < 3; a++) {
       nb[a] = tlo[a];
       nb[3 + a] = thi[a];
    }
-   // quantise exactly as bvh_build.cpp quantise_node does: origin = min lower plane, step = smallest power of two
-   // whose 255 steps cover the extent, lower planes round down and upper planes up (in double)
-   float origin[3];
-   uint32_t qlo[3], qhi[3], exps = 0;
-   for (int a = 0; a < 3; a++) {
-      double mn = INFINITY, mx = -INFINITY;
-      for (uint32_t k = 0; k < n_child; k++) {
-         mn = fmin(mn, (double)lo[k][a]);
-         mx = fmax(mx, (double)hi[k][a]);
-      }
-      if (!(mn <= mx)) mn = mx = 0.0;
-      const float org = (float)mn;
-      const double ext = mx - (double)org;
-      int e = -100;
-      if (!(ext < 1e38)) {
-         e = 120;  // non-finite or overflowing extent (only from non-finite world-space geometry): no search
-      } else if (ext > 0) {
-         int x;
-         double mant = frexp(ext / 255.0, &x);  // ext/255 = mant * 2^x, mant in [0.5, 1)
-         e = (mant == 0.5) ? x - 1 : x;
-         while (ldexp(255.0, e) < ext) e++;
-         if (e < -100) e = -100;
-      }
-      const double s = ldexp(1.0, e);
-      uint32_t wlo = 0, whi = 0;
-      for (uint32_t k = 0; k < 4; k++) {
-         if (k >= n_child) {
-            wlo |= 0xffu << (8 * k);
-            continue;
-         }
-         double a0 = floor(((double)lo[k][a] - (double)org) / s);
-         double a1 = ceil(((double)hi[k][a] - (double)org) / s);
-         if (a0 < 0) a0 = 0;
-         if (a1 > 255) a1 = 255;
-         if (a0 > 255) a0 = 255;
-         wlo |= (uint32_t)a0 << (8 * k);
-         whi |= (uint32_t)a1 << (8 * k);
-      }
-      origin[a] = org;
-      exps |= (uint32_t)(e + 127) << (8 * a);
-      qlo[a] = wlo;
-      qhi[a] = whi;
-   }
+}
+
+// pass 2, one thread per node of one BFS level, root level first: the node takes its own frame (UH_INHERIT_FRAME = 1: the frame is in
+// its record already - written by its parent's thread one level up; only the root takes its own), its children's padded boxes are quantised in it exactly as bvh_build.cpp
+// quantise_tree does (node_quant.h: the same functions), and the frame every node child inherits goes into that child's record
+__global__ __launch_bounds__(kBlock) void k_refit_quantise(uint4* __restrict__ nodes, const float* __restrict__ node_box, const float* __restrict__ world_corners, uint32_t first,
+                                                           uint32_t count) {
+   uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+   if (j >= count) return;
+   const uint32_t ni = first + j;
+   uint4* nd = nodes + kNodeStride16 * (size_t)ni;
+   const uint4 w0 = nd[0], w2 = nd[2];
+   const uint32_t meta = w0.w;
+   const uint32_t n_tri = (meta >> kMetaTriShift) & 7u, n_child = (meta >> kMetaChildShift) & 7u;
+   const uint32_t child_base = w2.z & kChildBaseMask, tri_base = w2.w;
+   float lo[4][3], hi[4][3], tlo[3], thi[3];
+   child_boxes(node_box, world_corners, n_tri, n_child, child_base, tri_base, lo, hi, tlo, thi);
+   float origin[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+   uint32_t exps = meta & 0xffffffu;
+   if (ni == 0 || !UH_INHERIT_FRAME) qn_own_frame(lo, hi, n_child, origin, exps);
+   uint32_t qlo[3], qhi[3], child_exps[4] = {0, 0, 0, 0};
+   float child_origin[4][3];
+   qn_quantise(origin, exps, lo, hi, n_tri, n_child, qlo, qhi, child_origin, child_exps, UH_INHERIT_FRAME != 0);
    nd[0] = make_uint4(__float_as_uint(origin[0]), __float_as_uint(origin[1]), __float_as_uint(origin[2]), (meta & 0xff000000u) | exps);
    nd[1] = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
-   nd[2] = make_uint4(qhi[1], qhi[2], child_base, tri_base);
+   nd[2] = make_uint4(qhi[1], qhi[2], child_base | (n_tri << kChildBaseBits), tri_base);
+   for (uint32_t k = n_tri; UH_INHERIT_FRAME && k < n_child && k < 4; k++) {
+      uint4* cd = nodes + kNodeStride16 * (size_t)(child_base + k - n_tri);
+      const uint32_t cmeta = cd[0].w;  // the child's own counts stay
+      cd[0] = make_uint4(__float_as_uint(child_origin[k][0]), __float_as_uint(child_origin[k][1]), __float_as_uint(child_origin[k][2]), (cmeta & 0xff000000u) | child_exps[k]);
+   }
 }
 
 }  // namespace
@@ -151,9 +144,13 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(uint4* __restrict__ node
 void launch_refit(const LaunchCfg& c, const RefitArgs& a) {
    if (a.num_tris == 0) return;
    k_refit_triangles<<<dim3((a.num_tris + kBlock - 1) / kBlock), kBlock, 0, c.stream>>>(a.obj_corners, a.meshes, a.tris, a.world_corners, a.num_tris);
-   for (uint32_t l = a.num_levels; l-- > 0;) {
+   for (uint32_t l = a.num_levels; l-- > 0;) {  // boxes: leaves to root
       const uint32_t first = a.level_start[l], count = a.level_start[l + 1] - first;
-      if (count) k_refit_level<<<dim3((count + kBlock - 1) / kBlock), kBlock, 0, c.stream>>>(a.nodes, a.node_box, a.world_corners, first, count);
+      if (count) k_refit_boxes<<<dim3((count + kBlock - 1) / kBlock), kBlock, 0, c.stream>>>(a.nodes, a.node_box, a.world_corners, first, count);
+   }
+   for (uint32_t l = 0; l < a.num_levels; l++) {  // frames and planes: root to leaves (a node's frame is inherited from its parent's)
+      const uint32_t first = a.level_start[l], count = a.level_start[l + 1] - first;
+      if (count) k_refit_quantise<<<dim3((count + kBlock - 1) / kBlock), kBlock, 0, c.stream>>>(a.nodes, a.node_box, a.world_corners, first, count);
    }
 }
 

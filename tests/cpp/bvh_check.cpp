@@ -8,10 +8,12 @@
 //   the full-precision box; empty slots are inverted boxes; level_start describes the breadth-first levels.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
 #include "bvh.h"
+#include "node_quant.h"
 
 using namespace uh;
 
@@ -60,9 +62,12 @@ static int check(const std::vector<float>& corners, int threads, const char* nam
       for (int a = 0; a < 3; a++) scale[a] = std::ldexp(1.0f, (int)((q.meta >> (8 * a)) & 0xff) - 127);
       const uint32_t n_tri = (q.meta >> kMetaTriShift) & 7, n_child = (q.meta >> kMetaChildShift) & 7;
       if (n_tri > n_child || n_child > 4) fail("child counts", n_tri, n_child);
+      if ((q.child_base >> kChildBaseBits) != n_tri) fail("n_tri is not in the top bits of child_base (what the traversal reads)", ni, q.child_base >> kChildBaseBits);
+      for (int a = 0; a < 3; a++)
+         if (((q.meta >> (8 * a)) & 0xff) < 1 || ((q.meta >> (8 * a)) & 0xff) > 254) fail("step exponent byte out of range", ni, (uint32_t)a);
       for (int k = 0; k < 4; k++) {
          uint32_t c = nd.child[k];
-         const uint32_t implicit = (uint32_t)k < n_tri ? (kLeafBit | (q.tri_base + (uint32_t)k)) : ((uint32_t)k < n_child ? q.child_base + ((uint32_t)k - n_tri) : kEmptyRef);
+         const uint32_t implicit = (uint32_t)k < n_tri ? (kLeafBit | (q.tri_base + (uint32_t)k)) : ((uint32_t)k < n_child ? (q.child_base & kChildBaseMask) + ((uint32_t)k - n_tri) : kEmptyRef);
          if (implicit != c) fail("implicit child address differs from the explicit ref", ni, (uint32_t)k);
          if (c == kEmptyRef) {
             for (int a = 0; a < 3; a++)
@@ -96,6 +101,22 @@ static int check(const std::vector<float>& corners, int threads, const char* nam
                continue;
             }
             node_refs[c]++;
+            {  // the child's stored frame IS the one a traversal derives from this node's frame and the child's quantised box here
+               // (node_quant.h qn_inherit - kernels.hip inherit_frame restates it), and 255 of its steps cover the child's padded box
+               uint32_t ql[3], qh[3], ce = 0;
+               float co[3];
+               for (int a = 0; a < 3; a++) {
+                  ql[a] = (q.qlo[a] >> (8 * k)) & 0xff;
+                  qh[a] = (q.qhi[a] >> (8 * k)) & 0xff;
+               }
+               qn_inherit(q.origin, q.meta & 0xffffffu, ql, qh, co, ce);
+               const Node4C& cq = out.cnodes[c];
+               if (UH_INHERIT_FRAME && std::memcmp(co, cq.origin, sizeof(co)) != 0 || ce != (cq.meta & 0xffffffu)) fail("a child's stored frame is not the inherited one", ni, c);
+               for (int a = 0; a < 3; a++) {
+                  const double top = (double)co[a] + 255.0 * std::ldexp(1.0, (int)((ce >> (8 * a)) & 0xff) - 127);
+                  if (UH_INHERIT_FRAME && geometry && (!((double)co[a] <= (double)lo[a]) || !(top >= (double)hi[a]))) fail("the inherited frame does not cover the child's padded box", ni, c);
+               }
+            }
             // child's own children must lie inside this slot's box (boxes are padded outwards at every level)
             const NodeW& ch = out.nodes[c];
             for (int j = 0; j < 4; j++)

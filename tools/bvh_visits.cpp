@@ -58,7 +58,10 @@ int main(int argc, char** argv) {
          // a neighbouring sample's hit instead of the ray's own): what testing a cached triangle first buys a primary ray
          const bool hint_pass = policy == 3;
          const int pol = policy == 3 ? 1 : policy;
-         double nodes = 0, tris = 0, pushes = 0, maxsp = 0;
+         double nodes = 0, tris = 0, pushes = 0, maxsp = 0, node_pushes = 0, pops = 0;
+         // the stack by depth: how often a pop (policy 1) finds it this deep, counting all entries and counting node entries only (a stack that
+         // carries a node's quantisation frame beside its reference needs the room for the node entries only)
+         std::vector<double> depth_all(64, 0.0), depth_nodes(64, 0.0);
          std::vector<uint32_t> iters(nr);
          for (uint32_t ri = 0; ri < nr; ri++) {
             const Ray& r = rays[ri];
@@ -78,6 +81,13 @@ int main(int argc, char** argv) {
                      if (pol == 2) done = true;
                   }
                   if (st.empty()) break;
+                  {
+                     size_t nn = 0;
+                     for (uint32_t e : st) nn += !(e & kLeafBit);
+                     depth_all[std::min<size_t>(st.size(), 63)]++;
+                     depth_nodes[std::min<size_t>(nn, 63)]++;
+                     pops++;
+                  }
                   cur = st.back();
                   st.pop_back();
                   continue;
@@ -102,6 +112,13 @@ int main(int argc, char** argv) {
                }
                if (nh == 0) {
                   if (st.empty()) break;
+                  {
+                     size_t nn = 0;
+                     for (uint32_t e : st) nn += !(e & kLeafBit);
+                     depth_all[std::min<size_t>(st.size(), 63)]++;
+                     depth_nodes[std::min<size_t>(nn, 63)]++;
+                     pops++;
+                  }
                   cur = st.back();
                   st.pop_back();
                   continue;
@@ -118,7 +135,10 @@ int main(int argc, char** argv) {
                   for (int k = 1; k < nh; k++)
                      if (tn[k] < tn[near]) near = k;
                   for (int k = nh - 1; k >= 0; k--)
-                     if (k != near) st.push_back(cr[k]);
+                     if (k != near) {
+                        st.push_back(cr[k]);
+                        node_pushes += !(cr[k] & kLeafBit);
+                     }
                   cur = cr[near];
                }
                pushes += nh - 1;
@@ -138,6 +158,15 @@ int main(int argc, char** argv) {
          }
          std::printf("  policy %d: nodes/ray %.2f tris/ray %.2f iterations/ray %.2f pushes/ray %.2f max stack %.0f | batch-of-64 utilisation %.3f\n", policy, nodes / nr, tris / nr,
                      (nodes + tris) / nr, pushes / nr, maxsp, lane_iters / (64.0 * wave_iters));
+         if (pol == 1 && pops > 0) {
+            std::printf("    node pushes/ray %.2f, pops/ray %.2f; share of pops that find the stack deeper than d (all entries | node entries):", node_pushes / nr, pops / nr);
+            for (int d : {2, 3, 4, 5, 6, 8, 10, 12, 16}) {
+               double a = 0, b = 0;
+               for (int k = d + 1; k < 64; k++) a += depth_all[k], b += depth_nodes[k];
+               std::printf(" d>%d: %.3f|%.3f", d, a / pops, b / pops);
+            }
+            std::printf("\n");
+         }
       }
    }
    return 0;

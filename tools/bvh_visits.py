@@ -38,12 +38,12 @@ rnd = np.where((np.sum(rnd * -dirs[hit], 1) < 0)[:, None], -rnd, rnd)
 b = np.empty((len(P), 8), np.float32)
 b[:, 0:3] = P + 1e-3 * rnd; b[:, 3] = 0.001; b[:, 4:7] = rnd; b[:, 7] = 10000.0
 exe = "/tmp/bvh_visits"
-subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rust-renderer_amd/csrc"), os.path.join(ROOT, "tools/bvh_visits.cpp"),
+flags = [a for a in sys.argv[1:] if a.startswith("-D")]  # e.g. -DUH_BVH_CTRI=0.5f: the builder's cost of a triangle slot against a node visit
+subprocess.run(["g++", "-O2", "-std=c++17"] + flags + ["-I", os.path.join(ROOT, "rust-renderer_amd/csrc"), os.path.join(ROOT, "tools/bvh_visits.cpp"),
                 os.path.join(ROOT, "rust-renderer_amd/csrc/bvh_build.cpp"), "-o", exe, "-pthread"], check=True)
 for name, rs in (("primary", rays), ("bounce", b)):
     path = f"/tmp/bvh_visits_{name}.bin"
     with open(path, "wb") as f:
         f.write(np.uint32(len(corners)).tobytes()); f.write(np.uint32(len(rs)).tobytes()); f.write(corners.tobytes()); f.write(rs.tobytes())
     print(f"== {name}: {len(rs)} rays, {len(corners)} triangles", flush=True)
-    for extra in ([], ["1.0", "16"], ["0.6", "16"], ["0.4", "32"], ["0.25", "64"]):
-        subprocess.run([exe, path] + extra + sys.argv[1:1], check=True)
+    subprocess.run([exe, path], check=True)
