@@ -111,7 +111,7 @@ static int check(const std::vector<float>& corners, int threads, const char* nam
                }
                qn_inherit(q.origin, q.meta & 0xffffffu, ql, qh, co, ce);
                const Node4C& cq = out.cnodes[c];
-               if (UH_INHERIT_FRAME && std::memcmp(co, cq.origin, sizeof(co)) != 0 || ce != (cq.meta & 0xffffffu)) fail("a child's stored frame is not the inherited one", ni, c);
+               if (UH_INHERIT_FRAME && (std::memcmp(co, cq.origin, sizeof(co)) != 0 || ce != (cq.meta & 0xffffffu))) fail("a child's stored frame is not the inherited one", ni, c);
                for (int a = 0; a < 3; a++) {
                   const double top = (double)co[a] + 255.0 * std::ldexp(1.0, (int)((ce >> (8 * a)) & 0xff) - 127);
                   if (UH_INHERIT_FRAME && geometry && (!((double)co[a] <= (double)lo[a]) || !(top >= (double)hi[a]))) fail("the inherited frame does not cover the child's padded box", ni, c);

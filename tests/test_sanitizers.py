@@ -5,14 +5,19 @@ where ASan/UBSan run."""
 import os
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bvh_builder_invariants_under_asan_ubsan(tmp_path):
+@pytest.mark.parametrize("inherit", [0, 1])
+def test_bvh_builder_invariants_under_asan_ubsan(tmp_path, inherit):
+    """inherit = 1: the build-time experiment UH_INHERIT_FRAME (bvh.h, node_quant.h: a node's quantisation frame derived from its parent's) -
+    off in the shipped library, but its quantiser stays held to its invariants: every stored frame is the derived one and covers the node's children"""
     exe = str(tmp_path / "bvh_check")
     csrc = os.path.join(ROOT, "rust-renderer_amd", "csrc")
     subprocess.run(
-        ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-Wall", "-Wextra",
+        ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-Wall", "-Wextra", f"-DUH_INHERIT_FRAME={inherit}",
          "-I", csrc, os.path.join(ROOT, "tests", "cpp", "bvh_check.cpp"), os.path.join(csrc, "bvh_build.cpp"), "-o", exe, "-pthread"],
         check=True,
     )
