@@ -224,6 +224,7 @@ typedef struct UhStats {
    uint64_t sun_covered_rays;   /* sun shadow rays answered by their cell's cover depth alone (option "count_visits") */
    uint64_t sun_grid_bytes;     /* device memory of the sun grid in use: cell records + entry lists + coarse cover + the lists as 64-byte records (when within "sun_grid_inline_max_mb") */
    uint64_t camera_grid_bytes;  /* device memory of the camera grid in use: cell offsets + entry lists */
+   uint64_t light_cache_hits;   /* light shadow rays answered by the occluder cache (option "light_cache"): part of rays[UH_RAY_LIGHT_SHADOW], they walk no tree */
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;
@@ -330,7 +331,7 @@ int uh_reset_stats(uh_ctx* ctx);
  *                same images), "sun_grid_build" (0/1, default 1: built on the device in a few milliseconds; 0: by the host builder,
  *                the reference implementation, in 130-550 ms), "sun_grid_density" (entries per triangle the cell size aims at),
  *                "sun_grid_max_mb" (budget of the entry lists), "sun_grid_max_walk" (longest list a ray tests itself),
- *                "sun_grid_max_mean_list_x10", "sun_grid_max_fallback_pct" (refusal thresholds), "sun_grid_inline_max_mb" (the lists a
+ *                "sun_grid_force" (0/1: 1 = never refused for its worth - long lists, much of the surface handed to the tree), "sun_grid_inline_max_mb" (the lists a
  *                second time as 64-byte records that carry their triangle packet - one round trip per triangle test instead of two:
  *                budget in MB, -1 = default = four times the packet array, 0 = never), "sun_grid_coarse" (0..6, default 2: a cover
  *                depth per block of 4 x 4 cells, small enough to stay in the L2, asked before the cell's own record; 0: none)
@@ -339,12 +340,16 @@ int uh_reset_stats(uh_ctx* ctx);
  *                the tree; same hit records bit for bit), "camera_grid_max_walk", "camera_grid_walk_whole",
  *                "camera_grid_max_mean_list_x10", "primary_implicit" (0/1, default 1: with that grid in use and one sample per frame,
  *                the primary rays' state is not stored - the kernels of the first bounce compute it from the path id; same images)
+ *  light rays    "light_cache" (0/1, default 1: a light shadow ray (reference.rgen:106-124) first asks the packet that last occluded a ray
+ *                from its neighbourhood towards its light - if that packet occludes this ray too, no tree is walked; same images and
+ *                counts; takes effect with the next uh_build_acceleration)
  *  scheduling    "frames_in_flight" (1..8, default 4), "batch_frames" (0 = auto), "overlap" (0/1, default 1: the miss shader and the
  *                shadow traversals on a second stream beside the next bounce's traversal), "trace_blocks_per_cu" (1..8: persistent
  *                grid of the traversal kernels)
  * Removed in round 5 with the measured-negative variants they selected: "closest_variant" / "shadow_variant" / "trace_variant" (batch
  * traversal kernels), "primary_tiles", "interleave", "sun_grid_fused", "sun_leftover_batch", "sun_grid_async", "sun_grid_inline",
  * "spatial_splits", "bvh_optimise", "raw_visit_counts", "ploc_radius", "overlap_miss" / "overlap_shadow" (now "overlap"),
+ * "sun_grid_max_mean_list_x10" / "sun_grid_max_fallback_pct" (now "sun_grid_force"),
  * "closest_blocks_per_cu" / "shadow_blocks_per_cu" (now "trace_blocks_per_cu"), "single_frame_blocks_per_cu", "miss_blocks_per_cu". */
 int uh_set_option(uh_ctx* ctx, const char* name, int value);
 

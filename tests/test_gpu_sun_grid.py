@@ -212,8 +212,7 @@ def test_scene_deeper_than_tmax_along_the_sun():
     scene = Scene("deep", [(Model(meshes, []), None)], [], cam, dict(sky_enabled=0, sun_shadow_enabled=1, lights_enabled=0, num_bounces=2))
     W, H = 96, 96
     grid = scene.upload(rr.Renderer(W, H))
-    grid.set_option("sun_grid_max_mean_list_x10", 10000)  # margins at |y| = 20000 are half a unit wide: long lists, and this test wants the grid
-    grid.set_option("sun_grid_max_fallback_pct", 100)
+    grid.set_option("sun_grid_force", 1)  # margins at |y| = 20000 are half a unit wide: long lists, and this test wants the grid
     tree = scene.upload(rr.Renderer(W, H))
     tree.set_option("sun_grid", 0)
     cpu = scene.upload(oa.OracleRenderer(W, H))
@@ -235,8 +234,7 @@ def test_device_built_grid_equals_the_host_built_one(atrium, sun):
     walk into the same order."""
     W, H = 96, 54
     r = atrium.upload(rr.Renderer(W, H))
-    r.set_option("sun_grid_max_fallback_pct", 100)
-    r.set_option("sun_grid_max_mean_list_x10", 10000)
+    r.set_option("sun_grid_force", 1)
     render(r, atrium, W, H, sun, frames=1, sky_enabled=0, lights_enabled=0)
     s = r.get_stats()
     assert s.sun_grid_cells > 0 and s.sun_grid_entries > 0, "no grid was built"

@@ -8,9 +8,9 @@ scene = rr.scenes.scene_for_config(cfg, tex_size=64)
 W, H = (256, 256) if cfg == 0 else (1920, 1080)
 sweeps = ([("sun_grid", 0)], [], [("sun_grid_density", 12)], [("sun_grid_density", 200), ("sun_grid_max_mb", 2048)])
 if len(sys.argv) > 2 and sys.argv[2] == "lists":
-    sweeps = [[("sun_grid", 0)], [("sun_grid_max_mean_list_x10", 200), ("sun_grid_max_fallback_pct", 100)], [("sun_grid_max_mean_list_x10", 200), ("sun_grid_max_fallback_pct", 100), ("sun_grid_density", 96), ("sun_grid_max_mb", 2048)]]
+    sweeps = [[("sun_grid", 0)], [("sun_grid_force", 1)], [("sun_grid_force", 1), ("sun_grid_density", 96), ("sun_grid_max_mb", 2048)]]
 elif len(sys.argv) > 2 and sys.argv[2] == "fallback":
-    sweeps = [[("sun_grid", 0)]] + [[("sun_grid_max_fallback_pct", w)] for w in (20, 50, 100)]
+    sweeps = [[("sun_grid", 0)], [("sun_grid_force", 1)]]
 elif len(sys.argv) > 2 and sys.argv[2] == "walk":
     sweeps = [[("sun_grid_max_walk", w)] for w in (8, 16, 32, 64, 128)]
 for opts in sweeps:
