@@ -310,9 +310,6 @@ def main():
             "value_with_grid_builds": total_rays / (elapsed + ((sun_grid["build_ms"] if sun_grid["in_use"] else 0.0) + (camera_grid["build_ms"] if camera_grid["in_use"] else 0.0)) * 1e-3) / 1e6,
             "sun_grid": sun_grid,
             "camera_grid": camera_grid,
-            # light shadow rays answered by the occluder cache (option light_cache): they walk no tree; share of the timed region's light rays
-            "light_cache": ({"answered": int(st.light_cache_hits), "share_of_light_rays": st.light_cache_hits / max(st.rays[rr.RAY_LIGHT_SHADOW], 1)}
-                            if st.rays[rr.RAY_LIGHT_SHADOW] else None),
             "dtype": "f32",
             "data": "synthetic",
             "config": {

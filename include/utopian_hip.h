@@ -224,7 +224,6 @@ typedef struct UhStats {
    uint64_t sun_covered_rays;   /* sun shadow rays answered by their cell's cover depth alone (option "count_visits") */
    uint64_t sun_grid_bytes;     /* device memory of the sun grid in use: cell records + entry lists + coarse cover + the lists as 64-byte records (when within "sun_grid_inline_max_mb") */
    uint64_t camera_grid_bytes;  /* device memory of the camera grid in use: cell offsets + entry lists */
-   uint64_t light_cache_hits;   /* light shadow rays answered by the occluder cache (option "light_cache"): part of rays[UH_RAY_LIGHT_SHADOW], they walk no tree */
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;
@@ -317,7 +316,7 @@ int uh_trace_any(uh_ctx* ctx, const float* rays, uint32_t n, uint8_t* out_occlud
 /* ---- stats / options ------------------------------------------------------------------- */
 int uh_get_stats(uh_ctx* ctx, UhStats* out);
 int uh_reset_stats(uh_ctx* ctx);
-/* The 25 options (DESIGN.md section 7 has the defaults and what was measured); unknown names return UH_ERR_INVALID_ARGUMENT.
+/* The 24 options (DESIGN.md section 7 has the defaults and what was measured); unknown names return UH_ERR_INVALID_ARGUMENT.
  *  diagnostics   "count_visits" (0/1: UhStats' node / triangle / cover counters), "time_kernels" (0/1: hipEvent time per kernel kind)
  *  results       "full_frame_restir" (0/1; 1 = documented divergence: the reservoir for every pixel instead of the reference's
  *                x > W/2 split), "furnace" (0/1: the reference's FURNACE_TEST build of the miss shader, reference.rmiss:14-28 - a path
@@ -340,9 +339,6 @@ int uh_reset_stats(uh_ctx* ctx);
  *                the tree; same hit records bit for bit), "camera_grid_max_walk", "camera_grid_walk_whole",
  *                "camera_grid_max_mean_list_x10", "primary_implicit" (0/1, default 1: with that grid in use and one sample per frame,
  *                the primary rays' state is not stored - the kernels of the first bounce compute it from the path id; same images)
- *  light rays    "light_cache" (0/1, default 1: a light shadow ray (reference.rgen:106-124) first asks the packet that last occluded a ray
- *                from its neighbourhood towards its light - if that packet occludes this ray too, no tree is walked; same images and
- *                counts; takes effect with the next uh_build_acceleration)
  *  scheduling    "frames_in_flight" (1..8, default 4), "batch_frames" (0 = auto), "overlap" (0/1, default 1: the miss shader and the
  *                shadow traversals on a second stream beside the next bounce's traversal), "trace_blocks_per_cu" (1..8: persistent
  *                grid of the traversal kernels)

@@ -81,7 +81,7 @@ struct Slot {
    hipEvent_t ev_acc = nullptr;  // recorded after the frame's accumulate / store tail
    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
    DevBuf<float4> rec, radf, pixcol;  // rec: two sets of four path-state planes + the hit plane (device_types.h PathState)
-   DevBuf<uint32_t> queues[6];
+   DevBuf<uint32_t> queues[5];
    DevBuf<Control> control;
    PathState ps{};
    bool ready = false;
@@ -114,7 +114,7 @@ struct Slot {
       SLOT_TRY(pixcol.alloc(n, 2 * stagger));
       // sharded queues: capacity per shard = the pixels (64-pixel runs) a shard can own
       // (the miss queue holds (position, id) pairs: twice the words)
-      for (int qi = 0; qi < 6; qi++) SLOT_TRY(queues[qi].alloc((size_t)shard_cap * kShards * (qi == 4 ? 2 : 1)));
+      for (int qi = 0; qi < 5; qi++) SLOT_TRY(queues[qi].alloc((size_t)shard_cap * kShards * (qi == 4 ? 2 : 1)));
       SLOT_TRY(control.alloc(1));
       SLOT_TRY(hipMemsetAsync(control.p, 0, sizeof(Control), stream));
       SLOT_TRY(hipStreamSynchronize(stream));
@@ -124,7 +124,7 @@ struct Slot {
       ps.hit = rec.p + plane * 2 * kRecQuads;
       ps.radf = radf.p;
       ps.pixcol = pixcol.p;
-      for (int i = 0; i < 6; i++) ps.queue[i] = queues[i].p;
+      for (int i = 0; i < 5; i++) ps.queue[i] = queues[i].p;
       ps.shard_cap = shard_cap;
       ready = true;
       return hipSuccess;
@@ -296,13 +296,6 @@ struct uh_ctx {
    float cam_build_ms = 0.0f, cam_mean_list = 0.0f;
    uint32_t cam_cells = 0, cam_entries = 0, cam_max_list = 0, cam_max_list_interior = 0;
    bool cam_this_frame = false;
-
-   // the light shadow rays' occluder cache (device_types.h LightCacheDev; option "light_cache"): one packet index per (light, cell of a
-   // coarse grid over the scene's box), about two million entries; (re)made empty by every build - packet indices are the tree's
-   bool light_cache_enabled = true;
-   DevBuf<uint32_t> d_light_cache;
-   LightCacheDev light_cache{};
-   float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};  // box of the world-space corners (host build) / of the meshes' boxes (device build)
 
    // tile partition
    uint32_t tp_rank = 0, tp_world = 1, tp_tile = 64;
@@ -558,7 +551,6 @@ void uh_destroy(uh_ctx* c) {
    c->d_sun_coarse.release();
    c->d_cam_cells.release();
    c->d_cam_entries.release();
-   c->d_light_cache.release();
    c->accumulation.release();
    c->gbuffer.release();
    c->output.release();
@@ -708,51 +700,6 @@ static int upload_scene_tables(uh_ctx* c) {
 
 static int build_on_device(uh_ctx* c);
 
-// the occluder cache of the light shadow rays, empty, for the scene as it is now: called by both builds after their geometry is in place
-// (the frames in flight are done: the builds wait for them). No room for it is no error: the light rays walk the tree.
-static int reset_light_cache(uh_ctx* c) {
-   c->light_cache = LightCacheDev{};
-   const uint32_t nl = (uint32_t)c->lights.size();
-   if (!c->light_cache_enabled || nl == 0 || c->scene.num_tris == 0) {
-      c->d_light_cache.release();
-      return UH_OK;
-   }
-   float ext[3];
-   for (int a = 0; a < 3; a++) {
-      ext[a] = c->scene_hi[a] - c->scene_lo[a];
-      if (!(ext[a] > 1e-6f) || !std::isfinite(ext[a])) ext[a] = 1e-6f;
-   }
-   // about 2 Mi entries in all: cells = 2 Mi / lights, cubical cells (a scene twice as long as high gets twice the cells along it)
-   const double cells = std::max(8.0, std::min(262144.0, (double)(2u << 20) / nl));
-   const double edge = std::cbrt((double)ext[0] * ext[1] * ext[2] / cells);
-   uint32_t n[3];
-   for (int a = 0; a < 3; a++) {
-      const double k = std::ceil(ext[a] / edge);
-      n[a] = (uint32_t)std::max(1.0, std::min(256.0, k));
-   }
-   const size_t total = (size_t)nl * n[0] * n[1] * n[2];
-   if (c->d_light_cache.n != total) {
-      if (c->d_light_cache.alloc(total) != hipSuccess) {
-         (void)hipGetLastError();
-         c->d_light_cache.release();
-         return UH_OK;
-      }
-   }
-   HIP_TRY(c, hipMemsetAsync(c->d_light_cache.p, 0xff, total * sizeof(uint32_t), c->stream));  // kEmptyRef
-   HIP_TRY(c, hipStreamSynchronize(c->stream));
-   LightCacheDev& lc = c->light_cache;
-   lc.entries = c->d_light_cache.p;
-   for (int a = 0; a < 3; a++) {
-      lc.lo[a] = c->scene_lo[a];
-      lc.inv_cell[a] = (float)((double)n[a] / ext[a]);
-   }
-   lc.nx = n[0];
-   lc.ny = n[1];
-   lc.nz = n[2];
-   lc.num_lights = nl;
-   return UH_OK;
-}
-
 int uh_build_acceleration(uh_ctx* c) {
    if (!c) return UH_ERR_INVALID_ARGUMENT;
    HIP_TRY(c, hipSetDevice(c->device));
@@ -788,15 +735,6 @@ int uh_build_acceleration(uh_ctx* c) {
          keys[t] = (mi << kPrimBits) | p;
       }
    }
-   for (int a = 0; a < 3; a++) {
-      c->scene_lo[a] = INFINITY;
-      c->scene_hi[a] = -INFINITY;
-   }
-   for (size_t i = 0; i < corners.size(); i++)
-      if (std::isfinite(corners[i])) {
-         c->scene_lo[i % 3] = std::fmin(c->scene_lo[i % 3], corners[i]);
-         c->scene_hi[i % 3] = std::fmax(c->scene_hi[i % 3], corners[i]);
-      }
    BuildInput in{corners.data(), keys.data(), (uint32_t)total};
    BuildOutput bo;
    int threads = (int)std::thread::hardware_concurrency();
@@ -867,7 +805,6 @@ int uh_build_acceleration(uh_ctx* c) {
    for (size_t i = 0; i < total; i++) c->packet_keys[i] = tp[i].key;
    c->level_start = bo.level_start;
    c->d_obj_corners.release();  // leaf order changed: the next refit re-creates its inputs
-   if (int st = reset_light_cache(c)) return st;
    c->geom_version++;
    c->topology_valid = true;
    c->built = true;
@@ -1073,11 +1010,6 @@ static int build_on_device(uh_ctx* c) {
    c->bvh_nodes = num_nodes;
    c->bvh_tris = (uint32_t)total;
    c->packet_keys.assign(total, 0u);  // only its size is used once d_obj_corners exists (uh_refit_acceleration)
-   for (int a = 0; a < 3; a++) {
-      c->scene_lo[a] = lo[a];
-      c->scene_hi[a] = hi[a];
-   }
-   if (int st = reset_light_cache(c)) return st;
    c->geom_version++;
    c->topology_valid = true;
    c->built = true;
@@ -1456,13 +1388,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          }
          if (fp.lights_enabled == 1) {
             begin_timed(c, 1, sh_stream);
-            const bool cached = c->light_cache_enabled && c->light_cache.entries && c->light_cache.num_lights == c->scene.num_lights;
-            if (cached) {
-               // the cached occluder of the ray's (light, cell) first; what it does not occlude walks the tree (and notes what occludes it there)
-               launch_light_cache(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, c->light_cache);
-               launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, true, true, &c->light_cache);
-            } else
-               launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, true);
+            launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, true);
             end_timed(c, sh_stream);
          }
          if (side_used) HIP_TRY(c, hipEventRecord(s.ev_shadowed, s.side));
@@ -1976,7 +1902,6 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->camera_tree_rays = ds.cam_tree_rays;
    out->camera_grid_tris_tested = ds.cam_tris_tested;
    out->sun_covered_rays = ds.sun_covered_rays;
-   out->light_cache_hits = ds.light_cache_hits;
    if (c->sun_valid) out->sun_grid_bytes = c->d_sun_cells.n * sizeof(uint32_t) + c->d_sun_entries.n * sizeof(SunGridEntry) + c->d_sun_recs.n * sizeof(float4) + c->d_sun_coarse.n * sizeof(float);
    if (c->cam_valid && c->cam_this_frame) out->camera_grid_bytes = c->d_cam_cells.n * sizeof(uint32_t) + c->d_cam_entries.n * sizeof(SunGridEntry);
    return UH_OK;
@@ -1997,7 +1922,7 @@ int uh_reset_stats(uh_ctx* c) {
    return UH_OK;
 }
 
-// The options (25): DESIGN.md section 7 has the table with defaults and what was measured. Variants that two rounds of measurements
+// The options (24): DESIGN.md section 7 has the table with defaults and what was measured. Variants that two rounds of measurements
 // left behind (batch traversal kernels, wave-per-tile primary rays, sub-frame interleave, the fused coarse-cover look-up, spatial
 // splits, insertion-based tree optimisation, the host-thread grid build) were removed in round 5 together with their options.
 int uh_set_option(uh_ctx* c, const char* name, int value) {
@@ -2047,8 +1972,8 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->sun_limits.max_entries = ((uint64_t)value << 20) / sizeof(SunGridEntry);
       c->sun_attempted = false;
    } else if (n == "sun_grid_force") {
-      // 1: the grid is never refused for what it would be worth (entries per occupied cell beyond 12, more than a fifth of the scene's surface
-      // handed to the tree): tests and studies of scenes the defaults would refuse; 0: the defaults
+      // 1: the grid is never refused for what it would be worth (more than 12 entries per occupied cell, more than a fifth of the scene's
+      // surface handed to the tree): tests and studies of scenes the defaults would refuse; 0: the defaults
       const SunGridLimits defaults;
       c->sun_limits.max_mean_list = value ? 1e30 : defaults.max_mean_list;
       c->sun_limits.max_fallback_area = value ? 2.0 : defaults.max_fallback_area;
@@ -2091,12 +2016,6 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       c->iso_reference = value != 0;
    else if (n == "furnace")
       c->furnace = value != 0;  // applies to the frames enqueued from now on
-   else if (n == "light_cache") {
-      // 1 (default): a light shadow ray first asks the packet that last occluded a ray of its neighbourhood towards its light (device_types.h
-      // LightCacheDev); 0: every light ray walks the tree. Same images and ray counts. Takes effect with the next uh_build_acceleration.
-      c->light_cache_enabled = value != 0;
-      c->built = false;
-   }
    // ---- how the frames are scheduled
    else if (n == "overlap")
       c->overlap_miss = c->overlap_shadow = value != 0;  // k_shade_miss and the shadow traversals on the slot's side stream

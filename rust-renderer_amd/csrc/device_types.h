@@ -15,14 +15,13 @@ namespace uh {
 constexpr uint32_t kMaxBounces = 64;
 // per bounce: RAY (paths whose ray the bounce traces; the shading kernels tell hits from misses by the hit
 // record, so no hit / miss queues exist) and LIGHT (scattered paths that carry a light sample)
-constexpr uint32_t kQueueKinds = 6;
+constexpr uint32_t kQueueKinds = 5;
 // Q_SUN_TREE: sun rays the grid kernel hands to the tree walk (border cells, long lists). Q_MISS: the paths of a bounce whose ray
 // left the scene - k_shade_hit meets them while it classifies the bounce's RAY queue and hands their ids to k_shade_miss
 // Q_CAM_TREE (bounce 0 only): primary rays the camera grid hands to the tree walk (pixels with long lists); shares queue 3 with
 // Q_SUN_TREE, which the same bounce's sun rays fill only after the shading kernel
-// Q_LIGHT_TREE: light shadow rays the occluder cache (LightCacheDev below) could not answer - k_trace_shadow walks the tree for them
-enum { Q_RAY = 0, Q_LIGHT = 1, Q_SUN_TREE = 2, Q_MISS = 3, Q_CAM_TREE = 4, Q_LIGHT_TREE = 5 };
-constexpr uint32_t kLaunchSlots = kMaxBounces * 5 + 8;  // per bounce: closest, sun (grid), sun leftovers (tree), light (occluder cache), light (tree); bounce 0: + camera grid, its leftovers
+enum { Q_RAY = 0, Q_LIGHT = 1, Q_SUN_TREE = 2, Q_MISS = 3, Q_CAM_TREE = 4 };
+constexpr uint32_t kLaunchSlots = kMaxBounces * 4 + 8;  // per bounce: closest, sun (grid), sun leftovers (tree), light; bounce 0: + camera grid, its leftovers
 
 // Queues are sharded: path p lives in shard shard_of_run(p / 64) for its whole life, every queue
 // has one segment (capacity PathState::shard_cap) and one counter per shard, and the blocks of a
@@ -63,7 +62,6 @@ struct DeviceStats {
    unsigned long long cam_tree_rays;  // primary rays k_trace_camera_grid handed to the tree walk
    unsigned long long cam_tris_tested;  // triangle packets k_trace_camera_grid tested (count_visits)
    unsigned long long sun_covered_rays; // sun rays k_trace_sun_grid answered from the cell's cover depth alone (count_visits)
-   unsigned long long light_cache_hits; // light shadow rays the occluder cache answered (they never walk the tree)
 };
 
 // per-mesh shading record (80 B): inverse instance rotation/scale + the material fields the
@@ -160,9 +158,8 @@ struct PathState {
    float4* radf;     // by path id: a finished path's radiance.rgb | its raygen rngState (the frame's next sample starts from it, rgen:28-31)
    float4* pixcol;   // by path id: sum over the frame's samples
    // 0,1 = ray ping-pong: path ids; 2 = light, 3 = sun rays for the tree walk: positions in the NEXT bounce's ray queue; 4 = misses:
-   // (position in the CURRENT one, id) pairs; 5 = light rays for the tree walk (what the occluder cache did not answer): positions in
-   // the NEXT bounce's ray queue; each kShards * shard_cap entries
-   uint32_t* queue[6];
+   // (position in the CURRENT one, id) pairs; each kShards * shard_cap entries
+   uint32_t* queue[5];
    uint32_t shard_cap;  // entries per shard segment = pixels a shard can own (multiple of 64)
 };
 __host__ __device__ inline float4* rec_quad(const PathRecs& rec, uint32_t pos, int quad) { return rec.base + rec.plane * (size_t)quad + pos; }
@@ -181,31 +178,6 @@ struct Images {
    UhReservoir* reservoirs[3];          // initial, temporal, spatial (the buffer this frame's spatial pass writes / the path tracer reads)
    const UhReservoir* prev_spatial;     // last frame's spatial_reuse_reservoirs, read by the temporal pass (renderers/mod.rs:294)
 };
-
-// The light shadow rays' occluder cache (reference.rgen:106-124: one visibility query per scattered path towards its sampled light; in
-// config 2 a third of the frame, 56 % of them occluded). "Occluded" is a boolean - SOME packet accepts the ray in (tmin, min(tmax,
-// distance to the light)] - so a packet that occluded an earlier ray from the same neighbourhood towards the same light is worth asking
-// first: if it accepts this ray too (the very tri_compute<ANY> of the tree walk), the verdict is in and no tree is walked; if not, the
-// ray walks the tree as ever, and whatever occludes it there replaces the entry. One entry per (light, cell of a coarse grid over the
-// scene's box): the packet index of the last occluder found, kEmptyRef before the first. The cache can only ever shorten a walk whose
-// verdict it has verified, so images and ray counts cannot change; entries are written without synchronisation (any packet index is
-// a valid question to ask).
-struct LightCacheDev {
-   uint32_t* entries;        // num_lights * nx * ny * nz packet indices
-   float lo[3], inv_cell[3]; // cell of a point p: floor((p - lo) * inv_cell), clamped
-   uint32_t nx, ny, nz, num_lights;
-};
-__host__ __device__ inline uint32_t light_cache_slot(const LightCacheDev& lc, uint32_t light, float x, float y, float z) {
-   float fx = (x - lc.lo[0]) * lc.inv_cell[0], fy = (y - lc.lo[1]) * lc.inv_cell[1], fz = (z - lc.lo[2]) * lc.inv_cell[2];
-   fx = !(fx >= 0.0f) ? 0.0f : fx;
-   fy = !(fy >= 0.0f) ? 0.0f : fy;
-   fz = !(fz >= 0.0f) ? 0.0f : fz;
-   uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy, iz = (uint32_t)fz;
-   ix = ix < lc.nx ? ix : lc.nx - 1;
-   iy = iy < lc.ny ? iy : lc.ny - 1;
-   iz = iz < lc.nz ? iz : lc.nz - 1;
-   return ((light * lc.nz + iz) * lc.ny + iy) * lc.nx + ix;
-}
 
 // Rows of the frame a reservoir-pass launch covers: the whole frame on one GPU; on a rank of an N-rank job (DESIGN.md
 // section 5, "band partition") the rank's band of rows plus what its spatial pass gathers from - at most two row intervals
@@ -238,12 +210,8 @@ void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, C
 void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
 // the paths still alive after the last bounce hand their radiance to the per-id array k_finish_sample reads
 void launch_flush_survivors(const LaunchCfg&, const FrameParams&, const PathState&, Control*);
-// leftovers: the rays come from the queue an earlier kernel listed them in (sun: what the grid handed over, Q_SUN_TREE; light: what the occluder
-// cache did not answer, Q_LIGHT_TREE) and are counted already; cache (light rays only): occluders found are noted there
 void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
-                         uint32_t cursor_slot, bool light, bool leftovers = false, const LightCacheDev* cache = nullptr);
-// the light shadow rays of a bounce against the occluder cache; what it does not answer goes to Q_LIGHT_TREE
-void launch_light_cache(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce, uint32_t cursor_slot, const LightCacheDev&);
+                         uint32_t cursor_slot, bool light, bool sun_leftovers = false);
 // sun shadow rays through the per-direction grid (sun_grid.h) instead of the tree
 void launch_trace_sun_grid(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
                            uint32_t cursor_slot, const SunGridDev&);

@@ -534,7 +534,6 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
       pop = true;
       if (tri_compute<ANY>(ta, tb, tc, packet, t.o, t.d, t.tmin, t.tlimit, t.best) && ANY) {
          occluded = true;
-         t.best.idx = packet;  // the occluder (k_trace_shadow notes it in the light rays' occluder cache)
          t.cur = kEmptyRef;
          pop = false;
       }
@@ -652,120 +651,10 @@ __device__ __forceinline__ ShadowRay make_shadow_ray(const SceneDev& sc, const F
    return s;
 }
 
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop the compiler cannot leave rolled (arrays indexed by its
-// counter stay in registers whatever the body holds)
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-   if constexpr (I < N) {
-      f(std::integral_constant<int, I>{});
-      static_for<N, I + 1>(f);
-   }
-}
-
-// the light a path's light ray goes to (rad.w carries the index; rgen:113's out-of-range / empty-reservoir case reads light 0's slot of the cache:
-// make_shadow_ray sends such a ray towards the origin, and whatever occludes THAT ray is a valid entry to ask for the next one like it)
-__device__ __forceinline__ uint32_t light_cache_index(const SceneDev& sc, float4 rad) {
-   const int light_index = (int)__float_as_uint(rad.w);
-   return (light_index >= 0 && (uint32_t)light_index < sc.num_lights) ? (uint32_t)light_index : 0u;
-}
-
-// The light shadow rays of a bounce against the occluder cache (LightCacheDev, device_types.h): a dense pass over the LIGHT queue, two
-// rays per lane with every step of the chain (queue entry -> origin / light -> cache entry -> packet) requested for both before the
-// first is used (the sun-grid kernel's form). A ray the cached packet occludes is done - nothing to write: an occluded light adds
-// nothing (rgen:118-122); the others are listed in Q_LIGHT_TREE for k_trace_shadow.
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_light_cache(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot,
-                                                         LightCacheDev lc) {
-   const uint32_t lane = lane_id();
-   const ShardCtx sx = shard_ctx();
-   const uint32_t seg = sx.shard * ps.shard_cap;
-   const PathRecs rec = ps.set[(bounce + 1) & 1];
-   const uint32_t count = ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)];
-   const uint32_t* __restrict__ queue = ps.queue[2] + seg;
-   uint32_t* q_tree = ps.queue[5] + seg;
-   uint32_t* n_tree = &ctl->q_count[qc_index(bounce, Q_LIGHT_TREE, sx.shard)];
-   uint32_t* cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
-   constexpr int K = 2;
-   typedef float f4_t __attribute__((ext_vector_type(4)));
-   const f4_t* __restrict__ tris = reinterpret_cast<const f4_t*>(sc.tris);
-   uint32_t n_hits = 0;
-   for (;;) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(cursor, 64u * K);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (base >= count) break;
-      uint32_t id[K];
-      bool valid[K];
-      static_for<K>([&](auto kc) {
-         constexpr int k = decltype(kc)::value;
-         const uint32_t i = base + 64u * k + lane;
-         valid[k] = i < count;
-         id[k] = valid[k] ? ld_stream(queue + i) : 0u;
-      });
-      float4 ro[K], rad[K];
-      static_for<K>([&](auto kc) {
-         constexpr int k = decltype(kc)::value;
-         ro[k] = rad[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-         if (valid[k]) {
-            ro[k] = ld_rec(rec_quad(rec, seg + id[k], REC_ORIGIN));
-            rad[k] = ld_rec(rec_quad(rec, seg + id[k], REC_RAD));
-         }
-      });
-      uint32_t at[K], pk[K];
-      static_for<K>([&](auto kc) {
-         constexpr int k = decltype(kc)::value;
-         at[k] = light_cache_slot(lc, light_cache_index(sc, rad[k]), ro[k].x, ro[k].y, ro[k].z);
-         pk[k] = valid[k] ? lc.entries[at[k]] : kEmptyRef;
-      });
-      f4_t ra[K], rb[K], rc[K];
-      bool ask[K];
-      static_for<K>([&](auto kc) {
-         constexpr int k = decltype(kc)::value;
-         ask[k] = valid[k] && pk[k] < sc.num_tris;
-         if (ask[k]) {
-            const f4_t* r = tris + kTriStride16 * (size_t)pk[k];
-            ra[k] = r[0];
-            rb[k] = r[1];
-            rc[k] = r[2];
-         }
-      });
-      bool walk[K];
-      static_for<K>([&](auto kc) {
-         constexpr int k = decltype(kc)::value;
-         bool occluded = false;
-         if (ask[k]) {
-            const ShadowRay s = make_shadow_ray<true>(sc, fp, ro[k], make_float4(0.0f, 0.0f, 0.0f, 0.0f), rad[k]);
-            Hit best;
-            best.t = s.rd.w;  // tmax (rgen:114-116)
-            best.u = best.v = 0.0f;
-            best.idx = kEmptyRef;
-            best.key = 0xffffffffu;
-            occluded = tri_compute<true>(make_float4(ra[k].x, ra[k].y, ra[k].z, ra[k].w), make_float4(rb[k].x, rb[k].y, rb[k].z, rb[k].w), make_float4(rc[k].x, rc[k].y, rc[k].z, rc[k].w), pk[k],
-                                         xyz(s.ro), xyz(s.rd), s.ro.w, s.tlimit, best);
-         }
-         walk[k] = valid[k] && !occluded;
-         n_hits += occluded ? 1u : 0u;
-      });
-      static_for<K>([&](auto kc) {
-         constexpr int k = decltype(kc)::value;
-         if (__ballot(walk[k]) != 0ull) {  // wave-uniform: every lane of the wave takes part in the append
-            const uint32_t slot = wave_append(n_tree, walk[k]);
-            if (walk[k]) st_stream(q_tree + slot, id[k]);
-         }
-      });
-   }
-   if (sx.lb == 0 && threadIdx.x == 0) atomicAdd(&stats->rays[UH_RAY_LIGHT_SHADOW], (unsigned long long)count);
-   // (one atomic per wave: the hits are what the bench line reports as answered by the cache)
-   for (int off = 32; off > 0; off >>= 1) n_hits += __shfl_xor(n_hits, off);
-   if (lane == 0 && n_hits) atomicAdd(&stats->light_cache_hits, (unsigned long long)n_hits);
-}
-
-// leftovers: the rays an earlier kernel could not answer and listed - sun rays k_trace_sun_grid could not serve from its grid (queue 3),
-// light rays k_light_cache's cached occluders did not occlude (queue 5); they are already counted.
-// lc.entries != null (light rays): the packet that occludes a ray is noted in the occluder cache at the ray's (light, cell)
+// leftovers (sun rays only): the rays k_trace_sun_grid could not serve from its grid (queue 3); they are already counted
 template <bool COUNT, bool LIGHT>
 __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce,
-                                                              uint32_t cursor_slot, bool leftovers, LightCacheDev lc) {
+                                                              uint32_t cursor_slot, bool leftovers) {
    __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
    __shared__ RayPool<3> s_pool[kWavesPerBlock];
    const uint32_t lane = lane_id();
@@ -777,14 +666,13 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    RaySource src;
    // sun rays leave from every scattered path = every position of the next bounce's ray queue (identity); light rays and the sun
    // rays the grid handed over from the positions listed in their queues
-   src.queue = LIGHT ? ps.queue[leftovers ? 5 : 2] + seg : leftovers ? ps.queue[3] + seg : nullptr;
-   src.count = LIGHT ? ctl->q_count[qc_index(bounce, leftovers ? Q_LIGHT_TREE : Q_LIGHT, sx.shard)]
-                     : leftovers ? ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
+   src.queue = LIGHT ? ps.queue[2] + seg : leftovers ? ps.queue[3] + seg : nullptr;
+   src.count = LIGHT ? ctl->q_count[qc_index(bounce, Q_LIGHT, sx.shard)] : leftovers ? ctl->q_count[qc_index(bounce, Q_SUN_TREE, sx.shard)] : ctl->q_count[qc_index(bounce + 1, Q_RAY, sx.shard)];
    src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
    src.wave_index = src.num_waves = 0;
    if (sx.lb == 0 && threadIdx.x == 0) {
       if (!leftovers) atomicAdd(&stats->rays[LIGHT ? UH_RAY_LIGHT_SHADOW : UH_RAY_SUN_SHADOW], (unsigned long long)src.count);
-      else if (src.count && !LIGHT) atomicAdd(&stats->sun_tree_rays, (unsigned long long)src.count);  // counted as sun rays by the grid kernel already
+      else if (src.count) atomicAdd(&stats->sun_tree_rays, (unsigned long long)src.count);  // counted as sun rays by the grid kernel already
    }
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
@@ -796,24 +684,18 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
    t.cur = kEmptyRef;
    t.sp = 0;
    uint32_t id = 0, n_nodes = 0, n_tris = 0;  // id: the path's position in the next bounce's queue
-   uint32_t cache_at = 0;                     // light rays: the ray's entry of the occluder cache
    float4 lit = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
    uint32_t spill[kSpillStack];
    auto take = [&](uint32_t slot) {
       id = pool.id[slot];
-      const float4 ro = pool.v[0][slot], rd4 = pool.v[2][slot];
-      const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, ro, pool.v[1][slot], rd4);
+      const ShadowRay s = make_shadow_ray<LIGHT>(sc, fp, pool.v[0][slot], pool.v[1][slot], pool.v[2][slot]);
       lit = s.lit;
-      if (LIGHT && lc.entries) cache_at = light_cache_slot(lc, light_cache_index(sc, rd4), ro.x, ro.y, ro.z);
       trav_init(t, s.ro, s.rd, s.ro.w, s.rd.w, s.tlimit);
    };
    while (refill_lanes<3>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
       if (t.cur != kEmptyRef) {
          bool occluded = false;
-         if (trav_step<true, COUNT>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris)) {
-            if (!occluded) st_stream(rad + id, lit);
-            else if (LIGHT && lc.entries) lc.entries[cache_at] = t.best.idx;  // the next ray of this neighbourhood towards this light asks it first
-         }
+         if (trav_step<true, COUNT>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris) && !occluded) st_stream(rad + id, lit);
       }
    }
    if (COUNT) {
@@ -833,6 +715,16 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
 // reads per test. INLINE: 64-byte records that CARRY their packet (v0 e1 e2 key | this entry's far depth | the next entry's) - one
 // sector and one round trip per test; sixty-four bytes per entry where the plain list has eight, so by default only while the records
 // stay within four times the packet array (context.hip attach_sun_inline_records, option "sun_grid_inline_max_mb").
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop the compiler cannot leave rolled (arrays indexed by its
+// counter stay in registers whatever the body holds)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+   if constexpr (I < N) {
+      f(std::integral_constant<int, I>{});
+      static_for<N, I + 1>(f);
+   }
+}
+
 // The ray's cell: (pu, pv) = its origin in the grid's frame; outside the grid (or NaN) it is a border cell.
 __device__ __forceinline__ void sun_cell_of(const SunGridDev& g, float pu, float pv, uint32_t& cx, uint32_t& cy) {
    float fx = (pu - g.u0) * g.inv_cell, fy = (pv - g.v0) * g.inv_cell;
@@ -1931,9 +1823,9 @@ void launch_flush_survivors(const LaunchCfg& c, const FrameParams& fp, const Pat
 }
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
-                         uint32_t bounce, uint32_t cursor_slot, bool light, bool leftovers, const LightCacheDev* cache) {
-   const LightCacheDev lc = cache ? *cache : LightCacheDev{};
-#define UH_SHADOW(COUNT, LIGHT) k_trace_shadow<COUNT, LIGHT><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, leftovers, lc)
+                         uint32_t bounce, uint32_t cursor_slot, bool light, bool sun_leftovers) {
+   // sun_leftovers: what the sun grid handed to the tree (queue 3)
+#define UH_SHADOW(COUNT, LIGHT) k_trace_shadow<COUNT, LIGHT><<<shadow_grid(c), kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, sun_leftovers)
    if (light) {
       if (c.count_visits) UH_SHADOW(true, true);
       else UH_SHADOW(false, true);
@@ -1942,15 +1834,6 @@ void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneD
       else UH_SHADOW(false, false);
    }
 #undef UH_SHADOW
-}
-
-void launch_light_cache(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce, uint32_t cursor_slot,
-                        const LightCacheDev& lc) {
-   const dim3 grid = sharded_grid(c.num_cus * 8);
-   if (c.count_visits)
-      k_light_cache<true><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, lc);
-   else
-      k_light_cache<false><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, bounce, cursor_slot, lc);
 }
 
 void launch_trace_sun_grid(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t bounce,

@@ -389,7 +389,6 @@ int uh_mgpu_get_stats(uh_mgpu* m, UhStats* out) {
       out->camera_tree_rays += s.camera_tree_rays;
       out->camera_grid_tris_tested += s.camera_grid_tris_tested;
       out->sun_covered_rays += s.sun_covered_rays;
-      out->light_cache_hits += s.light_cache_hits;
       out->frames = s.frames;
       out->bvh_nodes = s.bvh_nodes;
       out->bvh_triangles = s.bvh_triangles;

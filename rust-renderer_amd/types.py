@@ -139,7 +139,6 @@ class Stats(C.Structure):
         ("sun_covered_rays", C.c_uint64),
         ("sun_grid_bytes", C.c_uint64),
         ("camera_grid_bytes", C.c_uint64),
-        ("light_cache_hits", C.c_uint64),
     ]
 
     @property

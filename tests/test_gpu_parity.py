@@ -134,56 +134,6 @@ def test_full_frame_with_restir(atrium):
     assert list(gpu.get_stats().rays) == list(cpu.get_stats().rays)
 
 
-def test_light_occluder_cache_changes_nothing(atrium):
-    """option light_cache (default 1): a light shadow ray first asks the packet that last occluded a ray from its cell of a coarse world
-    grid towards its light (device_types.h LightCacheDev) and walks the tree only when that packet does not occlude it - a verdict the
-    cache gives is one it has verified with the tree walk's own triangle test, so images, reservoirs and ray counts equal the run with
-    the cache off (and the oracle's), while a good share of the light rays never see the tree. Batched and frame by frame, uniform and
-    reservoir light sampling (the split screen), after a refit and under the device builder."""
-    W, H = 160, 90
-    out = {}
-    for cache in (1, 0):
-        r = rr.Renderer(W, H)
-        r.set_option("light_cache", cache)
-        atrium.upload(r)
-        loop = rr.FrameLoop(r, atrium.make_view(W, H))
-        loop.frame(rr.PASS_ALL)
-        loop.frames(7, rr.PASS_ALL)
-        s = r.get_stats()
-        out[cache] = (r.read_accumulation().view(np.uint32), [r.read_reservoirs(k).tobytes() for k in range(3)], list(s.rays), int(s.light_cache_hits))
-        if cache:
-            moved = rr.transform3x4((1, 1, 1), (0.4, 0.0, -0.3))
-            r.set_instance_transform(0, moved)
-            r.rebuild_tlas()  # a refit keeps the entries (indices are the tree's): they are only ever asked, never trusted
-            loop.frames(3, rr.PASS_ALL)
-            ref = atrium.upload(rr.Renderer(W, H))
-            ref.set_option("light_cache", 0)
-            ref.build_acceleration()
-            lr = rr.FrameLoop(ref, atrium.make_view(W, H))
-            lr.frame(rr.PASS_ALL)
-            lr.frames(7, rr.PASS_ALL)
-            ref.set_instance_transform(0, moved)
-            ref.rebuild_tlas()
-            lr.frames(3, rr.PASS_ALL)
-            assert np.array_equal(r.read_accumulation().view(np.uint32), ref.read_accumulation().view(np.uint32))
-            assert list(r.get_stats().rays) == list(ref.get_stats().rays)
-    assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1] and out[1][2] == out[0][2]
-    light_rays = out[1][2][rr.RAY_LIGHT_SHADOW]
-    assert out[0][3] == 0 and out[1][3] > 0.1 * light_rays, (out[1][3], light_rays)
-    cpu = atrium.upload(oa.OracleRenderer(W, H))
-    lc = rr.FrameLoop(cpu, atrium.make_view(W, H))
-    for _ in range(8):
-        lc.frame(rr.PASS_ALL)
-    assert list(cpu.get_stats().rays) == out[1][2]
-    dev = rr.Renderer(W, H)
-    dev.set_option("device_build", 1)
-    atrium.upload(dev)
-    ld = rr.FrameLoop(dev, atrium.make_view(W, H))
-    ld.frame(rr.PASS_ALL)
-    ld.frames(7, rr.PASS_ALL)
-    assert np.array_equal(dev.read_accumulation().view(np.uint32), out[0][0]) and dev.get_stats().light_cache_hits > 0
-
-
 def test_restir_flags_off_copy_through(atrium):
     W, H = 64, 36
     gpu, cpu = make_pair(atrium, W, H)

@@ -1,13 +1,23 @@
 #!/bin/bash
-# same-box A/B of one library option: tools/ab_opt.sh name=a name=b [bench args...]
+# Same-box A/B of library options: tools/ab_opt.sh "<bench args>" "name=a [name2=b ...]" "name=c" ...  ("-" = defaults), two rounds interleaved.
+# Per run: the timed rate, ms per frame, the serialised per-kernel times of the bench's calibration frames, and the light cache's share.
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
-A=$1; B=$2; shift 2
-run() { opt=$1; shift; printf "%-28s %-40s" "$opt" "$*"; timeout -k 10 200 python bench.py --warmup 8 --no-cpu-baseline --no-tree-walk --opt $opt "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%.1f Mrays/s %.3f ms | pipelined %.3f interactive %.3f' % (d['value'], d['ms_per_step'], d['config'].get('pipelined_frame_ms') or 0, d['config'].get('interactive_frame_ms') or 0))"; }
-for rep in 1 2; do
-for o in $A $B; do
-  run $o --steps 64 "$@"
-  run $o --steps 20 "$@"
-done
-done
-for o in $A $B; do run $o --config 2 --steps 32 "$@"; done
+args=$1; shift
+run() {
+   set="$1"; opts=""
+   if [ "$set" != "-" ]; then for kv in $set; do opts="$opts --opt $kv"; done; fi
+   printf "%-34s " "$set"
+   timeout -k 10 300 python bench.py --warmup 8 --no-cpu-baseline --no-tree-walk $args $opts 2>gpurun_out/ab_opt_last.err | tail -1 | python -c "
+import sys, json
+try:
+   d = json.loads(sys.stdin.read())
+except Exception:
+   print('FAILED (gpurun_out/ab_opt_last.err)'); sys.exit(0)
+s = d['config'].get('serial_kernel_ms_per_frame') or {}
+lc = d.get('light_cache') or {}
+print('%8.1f Mrays/s %.4f ms | serial closest %.4f camera %.4f shadow %.4f shade %.4f | light cache answered %.3f | interactive %.3f pipelined %.3f' % (
+   d['value'], d['ms_per_step'], s.get('trace_closest', 0), s.get('camera_grid', 0), s.get('trace_shadow', 0), s.get('shade_hit_and_miss', 0), lc.get('share_of_light_rays', 0),
+   d['config'].get('interactive_frame_ms') or 0, d['config'].get('pipelined_frame_ms') or 0))"
+}
+for rep in 1 2; do for set in "$@"; do run "$set"; done; done
