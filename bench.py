@@ -141,6 +141,8 @@ def main():
     closest_rays = cs.rays[rr.RAY_BOUNCE] + (cs.camera_tree_rays if cs.camera_grid_cells else cs.rays[rr.RAY_PRIMARY])
     nodes_per_ray = cs.nodes_visited / max(closest_rays, 1)
     tris_per_ray = cs.tris_tested / max(closest_rays, 1)
+    light_nodes_per_ray = cs.light_nodes_visited / max(cs.rays[rr.RAY_LIGHT_SHADOW], 1)
+    light_tris_per_ray = cs.light_tris_tested / max(cs.rays[rr.RAY_LIGHT_SHADOW], 1)
     camera_tests_per_ray = cs.camera_grid_tris_tested / max(cs.rays[rr.RAY_PRIMARY] - cs.camera_tree_rays, 1) if cs.camera_grid_cells else None
     sun_rays_counted = max(cs.rays[rr.RAY_SUN_SHADOW], 1)
     sun_grid = {
@@ -165,7 +167,7 @@ def main():
     serial = (("frames_in_flight", 1), ("overlap", 0))
     for k, v in serial:
         renderer.set_option(k, v)
-    alone_ms = alone_rays = 0.0
+    alone_ms = alone_rays = alone_light_ms = alone_light_rays = 0.0
     frame_by_frame_ms = serial_ms_per_frame = None
     if not args.no_alone:
         loop.frames(16, pass_mask)  # creates the slot; the same wavefront size as below
@@ -174,8 +176,10 @@ def main():
         alone = renderer.get_stats()
         alone_ms = alone.trace_closest_ms / max(alone.trace_closest_launches, 1)
         alone_rays = float(alone.rays[rr.RAY_BOUNCE] + (alone.camera_tree_rays if alone.camera_grid_cells else alone.rays[rr.RAY_PRIMARY])) / max(alone.trace_closest_launches, 1)
+        alone_light_ms = alone.trace_light_ms / max(alone.trace_light_launches, 1)
+        alone_light_rays = float(alone.rays[rr.RAY_LIGHT_SHADOW]) / max(alone.trace_light_launches, 1)
         serial_ms_per_frame = {"trace_closest": alone.trace_closest_ms / 16, "camera_grid": alone.camera_grid_ms / 16, "trace_shadow": alone.trace_shadow_ms / 16,
-                               "shade_hit_and_miss": alone.shade_ms / 16}
+                               "trace_light": alone.trace_light_ms / 16, "shade_hit_and_miss": alone.shade_ms / 16}
         # what a caller of uh_render_frame sees with nothing overlapped: one frame per call, one stream, no batching
         # (per-kernel event timing is on in these frames: a few percent of launch overhead included)
         renderer.set_option("batch_frames", 1)
@@ -277,6 +281,24 @@ def main():
         renderer.set_option("sun_grid", 1)
         renderer.set_option("camera_grid", 1)
         frames_rendered += 16 + args.steps
+    # ---- and once more with the sun grid's lists kept a second time as 64-byte records that carry their packet (option sun_grid_inline_max_mb
+    # raised: round 4's default - 1.4 GB for this scene; since round 5 the default keeps those records within four times the packet array)
+    inline_records = None
+    if not args.no_tree_walk and sun_grid["in_use"] and not use_dist:
+        renderer.set_option("sun_grid_inline_max_mb", 16384)
+        loop.frames(16, pass_mask)
+        loop.reset()
+        renderer.reset_stats()
+        sync_all()
+        t2 = time.perf_counter()
+        loop.frames(args.steps, pass_mask)
+        sync_all()
+        e2 = time.perf_counter() - t2
+        s2 = renderer.get_stats()
+        inline_records = {"value": float(s2.path_rays) / e2 / 1e6, "ms_per_step": e2 / args.steps * 1e3, "sun_grid_bytes": int(s2.sun_grid_bytes),
+                          "sun_grid_bytes_over_packet_array": s2.sun_grid_bytes / max(64.0 * scene.num_triangles, 1.0)}
+        renderer.set_option("sun_grid_inline_max_mb", -1)
+        frames_rendered += 16 + args.steps
     if use_dist:
         t = [elapsed, my_rays, my_closest, st.trace_closest_ms, elapsed_tree or 0.0, tree_rays]
         tmax, tsum = rdzv.allreduce(t, "max"), rdzv.allreduce(t, "sum")
@@ -308,6 +330,7 @@ def main():
             "value_tree_walk": tree_rays / elapsed_tree / 1e6 if elapsed_tree else None,
             "ms_per_step_tree_walk": elapsed_tree / args.steps * 1e3 if elapsed_tree else None,
             "value_with_grid_builds": total_rays / (elapsed + ((sun_grid["build_ms"] if sun_grid["in_use"] else 0.0) + (camera_grid["build_ms"] if camera_grid["in_use"] else 0.0)) * 1e-3) / 1e6,
+            "value_sun_inline_records": inline_records,  # the same steps with the sun grid's 64-byte records beyond the default memory budget
             "sun_grid": sun_grid,
             "camera_grid": camera_grid,
             "dtype": "f32",
@@ -323,7 +346,12 @@ def main():
                 "pipelined_frame_ms": pipelined_frame_ms,      # one uh_render_frame per frame, four frames in flight, no batching: a moving camera
                 "serial_kernel_ms_per_frame": serial_ms_per_frame,  # HIP-event time by kernel kind, one 16-frame wavefront alone on the GPU, nothing overlapped
             },
-            "roofline": roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, signature(args, scene, W, H), rays_per_frame=total_rays / args.steps),
+            # the kernel the serialised wavefront spends most of its traversal time in: the closest-hit walk of the bounce rays - or, with
+            # many lights (config 2), the light shadow rays' walk
+            "roofline": (roofline(args, st, alone_light_ms, alone_light_rays, float(st.rays[rr.RAY_LIGHT_SHADOW]), light_nodes_per_ray, light_tris_per_ray, elapsed, signature(args, scene, W, H),
+                                  rays_per_frame=total_rays / args.steps, kernel="k_trace_shadow_light", launches=st.trace_light_launches, kernel_ms=st.trace_light_ms)
+                         if alone_light_ms * max(st.trace_light_launches, 0) > alone_ms * max(st.trace_closest_launches, 1) else
+                         roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, signature(args, scene, W, H), rays_per_frame=total_rays / args.steps)),
         }
         if os.environ.get("UH_BENCH_SIGNATURE"):  # tools/pmc_summary.py stamps counter profiles with it
             json.dump(dict(signature(args, scene, W, H), frames_total=frames_rendered), open(os.environ["UH_BENCH_SIGNATURE"], "w"))
@@ -352,14 +380,17 @@ def signature(args, scene, W, H):
 
 
 def load_profile(sig):
-    """profiles/bench_counters.json (tools/pmc_summary.py over the rocprofv3 --pmc passes of this very command line):
-    per-launch counter figures of the dominant kernel, used only when its signature equals this run's"""
+    """profiles/bench_counters.json (tools/pmc_summary.py over the rocprofv3 --pmc passes of bench command lines): one profile per
+    command line, keyed by its signature; per-launch counter figures of the kernels, used only by the run whose signature equals the profile's"""
     path = os.path.join(ROOT, "profiles", "bench_counters.json")
     try:
         prof = json.load(open(path))
     except Exception:
         return None
-    return prof if prof.get("signature") == sig else None
+    for p in prof.get("profiles", [prof]):
+        if p.get("signature") == sig:
+            return p
+    return None
 
 
 def classify_bound(k, hbm_frac, hbm_frac_raw):
@@ -388,8 +419,10 @@ def classify_bound(k, hbm_frac, hbm_frac_raw):
     return bound, note
 
 
-def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, sig, rays_per_frame=None, prof=False):
-    """Roofline block of the dominant kernel, k_trace_closest - every figure physical and <= 1 by construction.
+def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per_ray, elapsed, sig, rays_per_frame=None, prof=False, kernel="k_trace_closest", launches=None, kernel_ms=None):
+    """Roofline block of the dominant kernel (`kernel`: k_trace_closest, or k_trace_shadow_light - the light shadow rays' walk - with its
+    launch count and summed HIP-event time in `launches` / `kernel_ms`; my_closest / alone_rays are then that kernel's rays) - every figure
+    physical and <= 1 by construction.
     traffic   HBM-side bytes per launch from the rocprofv3 counter passes of this command line (profiles/bench_counters.json:
               2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; an upper bound for 48-byte gathers),
               scaled by rays per launch - quoted only when the profile's signature equals this run's
@@ -403,18 +436,20 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
               caches serve, not a roofline fraction
     bound     the busiest resource in the counter profile (classify_bound), not a literal
     prof      the counter profile (tests hand one in); False = profiles/bench_counters.json when its signature matches"""
-    launches = max(st.trace_closest_launches, 1)
-    avg_ms = st.trace_closest_ms / launches
+    n_launches = st.trace_closest_launches if launches is None else launches
+    launches = max(n_launches, 1)
+    avg_ms = (st.trace_closest_ms if kernel_ms is None else kernel_ms) / launches
     rays_per_launch = my_closest / launches
     per_ray_128 = 48.0 + nodes_per_ray * 128.0 + tris_per_ray * 48.0  # SURVEY.md 8d
     per_ray_48 = 48.0 + nodes_per_ray * 48.0 + tris_per_ray * 48.0    # nodes are 48-byte records (csrc/bvh.h)
     if prof is False:
         prof = load_profile(sig)
-    k = (prof or {}).get("kernels", {}).get("k_trace_closest", {})
+    k = (prof or {}).get("kernels", {}).get(kernel, {})
     traffic = k.get("hbm_bytes_per_launch")
-    if traffic and k.get("closest_rays_per_launch"):
+    prof_rays = k.get("rays_per_launch") or k.get("closest_rays_per_launch")
+    if traffic and prof_rays:
         # the profiled run's launches may carry another number of frames than this run's: a LAUNCH's traffic goes with its rays
-        traffic *= rays_per_launch / k["closest_rays_per_launch"]
+        traffic *= rays_per_launch / prof_rays
     # serialised duration of a launch of the timed size: the calibration launches are the same wavefronts, alone
     serial_ms = alone_ms * (rays_per_launch / alone_rays) if (alone_ms > 0 and alone_rays > 0) else None
     achieved = traffic / (serial_ms * 1e-3) / 1e9 if (traffic and serial_ms) else None
@@ -441,7 +476,7 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     prof_frac_raw = (k["hbm_bytes_per_launch_uncorrected"] / (k["launch_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9)) if (k.get("hbm_bytes_per_launch_uncorrected") and k.get("launch_ns")) else None
     bound, bound_note = classify_bound(k, prof_frac, prof_frac_raw)
     r = {
-        "kernel": "k_trace_closest",
+        "kernel": kernel,
         "bound": bound,
         "bound_note": bound_note,
         "achieved": achieved,
@@ -460,7 +495,7 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
         # records, for which it may overstate by up to 2x. The same fractions from the counters AS REPORTED are the lower bounds.
         "uncorrected": {"frac": (achieved / HBM_PEAK_GBS * uncorrected) if (achieved is not None and uncorrected) else None,
                         "frame_hbm_frac": (frame_bytes_lo / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)) if frame_bytes_lo else None},
-        "launches": st.trace_closest_launches,
+        "launches": n_launches,
         "rays_per_launch": rays_per_launch,
         "nodes_per_ray": nodes_per_ray,
         "tris_per_ray": tris_per_ray,
@@ -488,6 +523,7 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
                                if prof else None),
         "trace_closest_ms": st.trace_closest_ms,
         "trace_shadow_ms": st.trace_shadow_ms,
+        "trace_light_ms": getattr(st, "trace_light_ms", None),
         "shade_ms": st.shade_ms,
     }
     return r

@@ -205,7 +205,7 @@ typedef struct UhStats {
    float build_ms;              /* last uh_build_acceleration / uh_refit_acceleration, host wall time */
    float last_frame_ms;         /* hipEvent time of the last uh_render_frame (all passes) */
    float trace_closest_ms;      /* summed hipEvent time of closest-hit traversal launches since reset (option "time_kernels") */
-   float trace_shadow_ms;
+   float trace_shadow_ms;       /* the sun shadow rays: grid kernel + the tree walk of what it hands over */
    float shade_ms;
    uint32_t trace_closest_launches;
    uint32_t sun_grid_cells;     /* the sun-direction visibility grid in use (0 = none: the sun shadow rays walk the tree) */
@@ -220,10 +220,14 @@ typedef struct UhStats {
    uint64_t camera_tree_rays;   /* primary rays the grid handed to the tree walk (pixels with long lists); part of rays[UH_RAY_PRIMARY] */
    uint64_t camera_grid_tris_tested; /* triangle packets tested by the grid walk of the primary rays (option "count_visits") */
    float camera_grid_ms;        /* summed hipEvent time of the primary rays' launches when they go through the grid (option "time_kernels") */
-   uint32_t reserved0;
+   float trace_light_ms;        /* summed hipEvent time of the light shadow rays' traversal launches (reference.rgen:106-124; option "time_kernels"); not part of trace_shadow_ms */
    uint64_t sun_covered_rays;   /* sun shadow rays answered by their cell's cover depth alone (option "count_visits") */
    uint64_t sun_grid_bytes;     /* device memory of the sun grid in use: cell records + entry lists + coarse cover + the lists as 64-byte records (when within "sun_grid_inline_max_mb") */
    uint64_t camera_grid_bytes;  /* device memory of the camera grid in use: cell offsets + entry lists */
+   uint64_t light_nodes_visited; /* BVH4 nodes fetched / triangle packets tested by the light shadow rays' walks (option "count_visits"); */
+   uint64_t light_tris_tested;   /* not part of shadow_nodes_visited / shadow_tris_tested, which count the sun rays */
+   uint32_t trace_light_launches;
+   uint32_t reserved1;
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;

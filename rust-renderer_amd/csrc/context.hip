@@ -245,8 +245,8 @@ struct uh_ctx {
    bool furnace = false;  // option "furnace": reference.rmiss compiled with FURNACE_TEST (a miss returns white whatever view.sky_enabled says)
    uint64_t frames = 0;
    float build_ms = 0.0f, last_frame_ms = 0.0f;
-   float ms_by_kind[4] = {0, 0, 0, 0};  // trace_closest, trace_shadow, shade, camera grid (bounce 0 through the grid + its leftovers)
-   uint32_t trace_closest_launches = 0;
+   float ms_by_kind[5] = {0, 0, 0, 0, 0};  // trace_closest, sun shadow rays (grid + tree), shade, camera grid (bounce 0 through the grid + its leftovers), light shadow rays
+   uint32_t trace_closest_launches = 0, trace_light_launches = 0;
    bool frame_timed = false;
    std::vector<EventPair> pending, free_events;
    uint32_t bvh_nodes = 0, bvh_tris = 0;
@@ -386,6 +386,7 @@ void drain_timed(uh_ctx* c) {
       if (hipEventSynchronize(ep.stop) == hipSuccess && hipEventElapsedTime(&ms, ep.start, ep.stop) == hipSuccess) {
          c->ms_by_kind[ep.kind] += ms;
          if (ep.kind == 0) c->trace_closest_launches++;
+         if (ep.kind == 4) c->trace_light_launches++;
       }
       c->free_events.push_back(ep);
    }
@@ -1387,7 +1388,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
             end_timed(c, sh_stream);
          }
          if (fp.lights_enabled == 1) {
-            begin_timed(c, 1, sh_stream);
+            begin_timed(c, 4, sh_stream);
             launch_trace_shadow(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, true);
             end_timed(c, sh_stream);
          }
@@ -1889,6 +1890,10 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->trace_shadow_ms = c->ms_by_kind[1];
    out->shade_ms = c->ms_by_kind[2];
    out->camera_grid_ms = c->ms_by_kind[3];
+   out->trace_light_ms = c->ms_by_kind[4];
+   out->trace_light_launches = c->trace_light_launches;
+   out->light_nodes_visited = ds.light_nodes_visited;
+   out->light_tris_tested = ds.light_tris_tested;
    out->trace_closest_launches = c->trace_closest_launches;
    out->sun_grid_cells = c->sun_valid ? c->sun_cells : 0;
    out->sun_grid_entries = c->sun_valid ? c->sun_entries : 0;
@@ -1917,8 +1922,8 @@ int uh_reset_stats(uh_ctx* c) {
    HIP_TRY(c, hipMemsetAsync(c->dstats.p, 0, sizeof(DeviceStats), c->stream));
    HIP_TRY(c, hipStreamSynchronize(c->stream));
    c->frames = 0;
-   c->ms_by_kind[0] = c->ms_by_kind[1] = c->ms_by_kind[2] = c->ms_by_kind[3] = 0.0f;
-   c->trace_closest_launches = 0;
+   for (float& ms : c->ms_by_kind) ms = 0.0f;
+   c->trace_closest_launches = c->trace_light_launches = 0;
    return UH_OK;
 }
 

@@ -62,6 +62,7 @@ struct DeviceStats {
    unsigned long long cam_tree_rays;  // primary rays k_trace_camera_grid handed to the tree walk
    unsigned long long cam_tris_tested;  // triangle packets k_trace_camera_grid tested (count_visits)
    unsigned long long sun_covered_rays; // sun rays k_trace_sun_grid answered from the cell's cover depth alone (count_visits)
+   unsigned long long light_nodes_visited, light_tris_tested;  // the light shadow rays' walks (count_visits)
 };
 
 // per-mesh shading record (80 B): inverse instance rotation/scale + the material fields the

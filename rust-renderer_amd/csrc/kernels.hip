@@ -699,8 +699,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_trace_shadow(SceneDev sc, FramePa
       }
    }
    if (COUNT) {
-      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_nodes);
-      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_tris);
+      atomicAdd(LIGHT ? &stats->light_nodes_visited : &stats->shadow_nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(LIGHT ? &stats->light_tris_tested : &stats->shadow_tris_tested, (unsigned long long)n_tris);
    }
 }
 

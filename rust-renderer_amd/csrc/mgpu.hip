@@ -397,6 +397,10 @@ int uh_mgpu_get_stats(uh_mgpu* m, UhStats* out) {
       if (s.trace_closest_ms > out->trace_closest_ms) out->trace_closest_ms = s.trace_closest_ms;
       if (s.trace_shadow_ms > out->trace_shadow_ms) out->trace_shadow_ms = s.trace_shadow_ms;
       if (s.shade_ms > out->shade_ms) out->shade_ms = s.shade_ms;
+      if (s.trace_light_ms > out->trace_light_ms) out->trace_light_ms = s.trace_light_ms;
+      out->trace_light_launches += s.trace_light_launches;
+      out->light_nodes_visited += s.light_nodes_visited;
+      out->light_tris_tested += s.light_tris_tested;
       out->trace_closest_launches += s.trace_closest_launches;
       if (i == 0) {  // every GPU builds the same grid
          out->sun_grid_cells = s.sun_grid_cells;

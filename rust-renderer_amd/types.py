@@ -135,10 +135,14 @@ class Stats(C.Structure):
         ("camera_tree_rays", C.c_uint64),
         ("camera_grid_tris_tested", C.c_uint64),
         ("camera_grid_ms", C.c_float),
-        ("reserved0", C.c_uint32),
+        ("trace_light_ms", C.c_float),
         ("sun_covered_rays", C.c_uint64),
         ("sun_grid_bytes", C.c_uint64),
         ("camera_grid_bytes", C.c_uint64),
+        ("light_nodes_visited", C.c_uint64),
+        ("light_tris_tested", C.c_uint64),
+        ("trace_light_launches", C.c_uint32),
+        ("reserved1", C.c_uint32),
     ]
 
     @property

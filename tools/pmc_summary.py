@@ -17,8 +17,12 @@ def short(name):
 
 
 def base_name(k):
-    """kernel name without its template arguments: the variants of one kernel share a profile entry"""
-    return k.split("<")[0].strip()
+    """kernel name without its template arguments: the variants of one kernel share a profile entry - except the shadow walk of the LIGHT rays
+    (k_trace_shadow<COUNT, true>), which is a kernel of its own weight in config 2 (bench.py's roofline names it k_trace_shadow_light)"""
+    b = k.split("<")[0].strip()
+    if b == "k_trace_shadow" and "<" in k and k.split("<")[1].split(">")[0].split(",")[-1].strip() in ("true", "1"):
+        return "k_trace_shadow_light"
+    return b
 
 
 def main():
@@ -85,11 +89,13 @@ def main():
         # rays per k_trace_closest launch of the profiled run (the bench line its first pass printed): bench.py scales the
         # per-launch traffic by its own rays per launch
         profiled_rays = profiled_rays_per_frame = None
+        profiled_kernel = "k_trace_closest"
         try:
             for line in open(os.path.join(src, "pass1.log")):
                 if line.startswith("{") and '"roofline"' in line:
                     bl = json.loads(line)
                     profiled_rays = bl["roofline"]["rays_per_launch"]
+                    profiled_kernel = bl["roofline"].get("kernel", "k_trace_closest")
                     profiled_rays_per_frame = bl.get("config", {}).get("rays_per_frame")
         except OSError:
             pass
@@ -131,9 +137,17 @@ def main():
                 e["td_busy_frac"] = m.get("TD_TD_BUSY_sum", 0.0) / 256.0 / clk if m.get("TD_TD_BUSY_sum") else None
                 e["launch_clk"] = clk
             e["variant"] = k
-            if base_name(k) == "k_trace_closest" and profiled_rays:
-                e["closest_rays_per_launch"] = profiled_rays
-        json.dump(bench, open(os.path.join(ROOT, "profiles", "bench_counters.json"), "w"), indent=1)
+            if base_name(k) == profiled_kernel and profiled_rays:
+                e["rays_per_launch"] = profiled_rays  # of the kernel the profiled run's roofline names
+        # one file, one profile per command line (signature): this one replaces its predecessor of the same signature
+        path = os.path.join(ROOT, "profiles", "bench_counters.json")
+        try:
+            old = json.load(open(path))
+            profiles = old.get("profiles", [old] if old.get("signature") else [])
+        except Exception:
+            profiles = []
+        profiles = [p for p in profiles if p.get("signature") != bench["signature"]] + [bench]
+        json.dump({"note": "counter profiles of bench.py command lines, keyed by signature (bench.py load_profile)", "profiles": profiles}, open(path, "w"), indent=1)
     for k, v in out["kernels"].items():
         print(k, json.dumps({a: round(b, 4) for a, b in v["derived"].items()}))
         print("   ", {c: round(x["median"]) for c, x in v["counters"].items()})
