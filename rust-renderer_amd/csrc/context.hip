@@ -1104,12 +1104,16 @@ static int adopt_sun_grid(uh_ctx* c, const SunGridHost& g, bool ok, const float 
    c->sun_fallback_area = (float)g.fallback_area;
    c->sun_cells = c->sun_entries = 0;
    if (ok) {
-      // per cell two words: offset into the entries | cover depth (sun_grid.h)
-      std::vector<uint32_t> cells(2 * g.cell_start.size());
+      // per cell four words: offset into the entries | cover depth | the first entry (packet, far depth) (sun_grid.h kSunCellWords)
+      std::vector<uint32_t> cells(kSunCellWords * g.cell_start.size());
       for (size_t k = 0; k < g.cell_start.size(); k++) {
          const float cover = k < g.cell_cover.size() ? g.cell_cover[k] : -INFINITY;
-         cells[2 * k] = g.cell_start[k];
-         std::memcpy(&cells[2 * k + 1], &cover, 4);
+         cells[kSunCellWords * k] = g.cell_start[k];
+         std::memcpy(&cells[kSunCellWords * k + 1], &cover, 4);
+         SunGridEntry first{kEmptyRef, 0.0f};
+         if (k + 1 < g.cell_start.size() && g.cell_start[k + 1] > g.cell_start[k]) first = g.entries[g.cell_start[k]];
+         cells[kSunCellWords * k + 2] = first.packet;
+         std::memcpy(&cells[kSunCellWords * k + 3], &first.wmax, 4);
       }
       HIP_TRY(c, c->d_sun_cells.alloc(cells.size()));
       HIP_TRY(c, c->d_sun_entries.alloc(g.entries.size() ? g.entries.size() : 1));
@@ -1156,7 +1160,7 @@ static int adopt_sun_grid_device(uh_ctx* c, SunGridDevice& g, bool ok, const flo
       const size_t ncell = (size_t)g.params.nx * g.params.ny;
       c->d_sun_cells.p = g.cells;
       c->d_sun_cells.base = g.cells;
-      c->d_sun_cells.n = 2 * (ncell + 1);
+      c->d_sun_cells.n = kSunCellWords * (ncell + 1);
       c->d_sun_entries.p = g.entries;
       c->d_sun_entries.base = g.entries;
       c->d_sun_entries.n = (size_t)g.num_entries;
@@ -2324,7 +2328,7 @@ int uh_sun_grid_compare_builders(uh_ctx* c, uint64_t out[8]) {
    const size_t ncell = (size_t)c->sun_dev.nx * c->sun_dev.ny;
    std::vector<float> packets(12 * (size_t)n);
    HIP_TRY(c, hipMemcpy2D(packets.data(), sizeof(TriPacket), c->d_tris.p, 16 * kTriStride16, sizeof(TriPacket), n, hipMemcpyDeviceToHost));
-   std::vector<uint32_t> cells(2 * (ncell + 1));
+   std::vector<uint32_t> cells(kSunCellWords * (ncell + 1));
    std::vector<SunGridEntry> entries(c->sun_entries);
    HIP_TRY(c, hipMemcpy(cells.data(), c->d_sun_cells.p, cells.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
    if (!entries.empty()) HIP_TRY(c, hipMemcpy(entries.data(), c->d_sun_entries.p, entries.size() * sizeof(SunGridEntry), hipMemcpyDeviceToHost));
@@ -2350,10 +2354,10 @@ int uh_sun_grid_compare_builders(uh_ctx* c, uint64_t out[8]) {
    if (h.cell_start.size() != ncell + 1) return fail(c, UH_ERR_INVALID_ARGUMENT, "host grid has another raster");
    std::vector<uint32_t> a, b;
    for (size_t k = 0; k < ncell; k++) {
-      const uint32_t d0 = cells[2 * k], d1 = cells[2 * (k + 1)], h0 = h.cell_start[k], h1 = h.cell_start[k + 1];
+      const uint32_t d0 = cells[kSunCellWords * k], d1 = cells[kSunCellWords * (k + 1)], h0 = h.cell_start[k], h1 = h.cell_start[k + 1];
       uint32_t hc;
       std::memcpy(&hc, &h.cell_cover[k], 4);
-      if (cells[2 * k + 1] != hc) out[5]++;  // cover depth: bit for bit
+      if (cells[kSunCellWords * k + 1] != hc) out[5]++;  // cover depth: bit for bit
       if (d1 - d0 != h1 - h0 || d0 != h0) {
          out[3]++;  // another list length (or offset)
          continue;

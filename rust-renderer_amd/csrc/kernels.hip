@@ -765,7 +765,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
    const f4_t* __restrict__ recs = reinterpret_cast<const f4_t*>(g.recs);       // INLINE
    const f4_t* __restrict__ tris = reinterpret_cast<const f4_t*>(sc.tris);      // plain lists: the packets
    const uint2* __restrict__ entries = reinterpret_cast<const uint2*>(g.entries);
-   const uint2* __restrict__ cells = reinterpret_cast<const uint2*>(g.cell_start);
+   const uint4* __restrict__ cells = reinterpret_cast<const uint4*>(g.cell_start);  // offset | cover depth | the first entry: packet, far depth
    for (;;) {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(cursor, 64u * K);
@@ -805,12 +805,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
             covered[k] = valid[k] && sun_coarse_covered(cw[k], pw[k]);
          });
       }
-      uint2 cs[K];  // offset into the entries | cover depth
+      uint4 cs[K];  // offset into the entries | cover depth | first entry: packet | far depth
       uint32_t end[K];
       static_for<K>([&](auto kc) {
          constexpr int k = decltype(kc)::value;
          ask[k] = valid[k] && !covered[k];
-         cs[k] = make_uint2(0u, 0u);
+         cs[k] = make_uint4(0u, 0u, 0u, 0u);
          end[k] = 0u;
          if (ask[k]) {
             const uint32_t cell = cy[k] * g.nx + cx[k];
@@ -840,28 +840,23 @@ __global__ __launch_bounds__(kBlock) void k_trace_sun_grid(SceneDev sc, FramePar
                rb[k] = r[1];
                rc[k] = r[2];
             } else {
-               en[k] = entries[cs[k].x];
-               nxt[k] = cs[k].x + 1 < end[k] ? entries[cs[k].x + 1] : make_uint2(0u, 0u);  // adjacent: the same sector most of the time
+               // the list's first entry came with the cell record: its packet is asked for at once, the second entry beside it
+               en[k] = make_uint2(cs[k].z, cs[k].w);
+               // sorted by far depth, descending: a list whose first entry ends behind the origin has nothing in front of the ray
+               if (__uint_as_float(en[k].y) < pw[k]) {
+                  walk[k] = false;
+                  lit[k] = true;
+               } else {
+                  const f4_t* r = tris + kTriStride16 * (size_t)en[k].x;
+                  ra[k] = r[0];
+                  rb[k] = r[1];
+                  rc[k] = r[2];
+                  nxt[k] = cs[k].x + 1 < end[k] ? entries[cs[k].x + 1] : make_uint2(0u, 0u);
+               }
             }
          }
          if (COUNT) n_covered += covered[k] ? 1u : 0u;
       });
-      if constexpr (!INLINE) {
-         static_for<K>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            // sorted by far depth, descending: a list whose first entry ends behind the origin has nothing in front of the ray
-            if (walk[k] && __uint_as_float(en[k].y) < pw[k]) {
-               walk[k] = false;
-               lit[k] = true;
-            }
-            if (walk[k]) {
-               const f4_t* r = tris + kTriStride16 * (size_t)en[k].x;
-               ra[k] = r[0];
-               rb[k] = r[1];
-               rc[k] = r[2];
-            }
-         });
-      }
       static_for<K>([&](auto kc) {
          constexpr int k = decltype(kc)::value;
          if (walk[k]) {

@@ -34,6 +34,8 @@ constexpr double kSunCoverSlack = 900.0;
 constexpr float kSunCoarseSpread = 100.0f;
 constexpr float kSunCoarseReach = kSunCoverReach - kSunCoarseSpread;
 
+constexpr uint32_t kSunCellWords = 4;  // words per cell record of the sun grid (device side)
+
 struct SunGridEntry {
    uint32_t packet;  // triangle packet index (TriPacket array, leaf order)
    float wmax;       // far end of the packet's depth range along the sun direction, padded
@@ -49,7 +51,7 @@ struct SunGridDev {
    // exit - the same hit, a few more tests - and only longer ones go to the tree; when the grid's longest list fits (the usual
    // case: a few dozen pixels see more than max_walk packets) the tree-walk launch behind the grid kernel is not made at all
    uint32_t walk_whole;
-   const uint32_t* cell_start;   // nx * ny + 1 records of two words: offset into entries | cover depth (float bits): a ray of the
+   const uint32_t* cell_start;   // sun grid: nx * ny + 1 records of kSunCellWords words: offset into entries | cover depth (float bits) | the first entry's packet | its far depth; camera grid: plain offsets
                                  // cell that starts below the cover depth is occluded - some packet spans the whole cell in front of it
    const SunGridEntry* entries;
    // the lists once more, as 64-byte records that carry their packet (null: not built): sixteen floats per entry, in the entries'

@@ -81,10 +81,16 @@ def test_bound_is_read_from_the_counters(bench):
 
 
 def test_committed_profile_reads_the_same_fraction_at_20_and_64_steps(bench):
-    prof = json.load(open(os.path.join(ROOT, "profiles", "bench_counters.json")))
+    doc = json.load(open(os.path.join(ROOT, "profiles", "bench_counters.json")))
+    profiles = doc.get("profiles", [doc])
+    sigs = [json.dumps(p["signature"], sort_keys=True) for p in profiles]
+    assert len(set(sigs)) == len(sigs), "one profile per bench command line"
+    prof = next(p for p in profiles if p["signature"]["config"] == 1 and not p["signature"]["opts"])  # the bench line's own
     a, b = fake_run(bench, 20, prof), fake_run(bench, 64, prof)
     assert a["frame_hbm_frac"] == pytest.approx(b["frame_hbm_frac"], rel=1e-9)
     assert a["frame_hbm_frac"] == pytest.approx(prof["frame_hbm_bytes"] * (17.79e6 / prof["rays_per_frame"] if prof.get("rays_per_frame") else 1.0) / 2.15e-3 / 8e12, rel=1e-9)
+    for p in profiles:  # every profile names the kernels the roofline block may pick
+        assert "k_trace_closest" in p["kernels"], p["signature"]
 
 
 def test_metric_names_the_real_step_count():
