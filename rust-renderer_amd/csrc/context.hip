@@ -192,6 +192,9 @@ struct uh_ctx {
    // one frame per call with a wait after it 2.95 / 2.88 / 2.88 / 2.84 / 2.85 / 2.89 ms: fewer waves finish a small launch's tail sooner
    uint32_t closest_blocks_per_cu = 5, shadow_blocks_per_cu = 5;  // (config 2, whose light shadow rays are a third of the frame: 6/5, 5/5, 5/4, 6/4 = 8,230 / 8,266 / 7,997 / 7,950 Mrays/s)
    uint32_t cam_walk_whole = 512;     // option "camera_grid_walk_whole" (sun_grid.h SunGridDev::walk_whole)
+   // one frame per call: bounces 1 .. of a lone frame inside one persistent kernel (k_path_fused) instead of four launches per bounce
+   bool fused_bounces = false;  // option "fused_bounces"
+   uint32_t fused_blocks_per_cu = 3;
    static constexpr uint32_t kSingleFrameBlocksPerCu = 4;  // the cap on both for a wavefront of one frame (fewer persistent waves reach the end of a small launch's tail sooner: round 4's sweep)
    std::string err;
 
@@ -358,7 +361,7 @@ void set_transform(HostMesh& m, const float* w) {
 }
 
 LaunchCfg cfg(uh_ctx* c) {
-   return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits};
+   return LaunchCfg{c->stream, c->num_cus, c->closest_blocks_per_cu, c->shadow_blocks_per_cu, c->count_visits, c->fused_blocks_per_cu};
 }
 
 void begin_timed(uh_ctx* c, int kind, hipStream_t stream = nullptr) {
@@ -1345,7 +1348,9 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(Control), s.stream));
       uint32_t slot = 0;
       launch_generate(lc, fp, s.ps, ctl, smp);
-      for (uint32_t b = 0; b < fp.num_bounces; b++) {
+      // a lone frame: bounce 0 as a wavefront (its rays are coherent, the camera grid serves them), the others inside k_path_fused
+      const bool fused = c->fused_bounces && fp.batch_frames == 1 && fp.num_bounces >= 2;
+      for (uint32_t b = 0; b < (fused ? 1u : fp.num_bounces); b++) {
          begin_timed(c, (b == 0 && c->cam_this_frame) ? 3 : 0, s.stream);
          if (b == 0 && c->cam_this_frame) {
             // no tree walk for the primary rays of a camera at rest (and no launch for one when no pixel's list is too long for the grid kernel)
@@ -1402,9 +1407,19 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          HIP_TRY(c, hipEventRecord(s.ev_side_done, s.side));
          HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_side_done, 0));
       }
+      if (fused) {
+         // (the side stream's work of bounce 0 - sky, sun and light rays - has been waited for above: the shadow rays' results are in
+         // the records the kernel starts from, and the miss queue is free for the kernel's own entries)
+         begin_timed(c, 0, s.stream);
+         launch_path_fused(lc, fp, c->scene, s.ps, ctl, st, slot++, c->sun_dev, c->sun_this_frame);
+         end_timed(c, s.stream);
+         begin_timed(c, 2, s.stream);
+         launch_shade_miss(lc, fp, s.ps, ctl, st, 1);  // every path whose ray left the scene in bounces 1 .., listed under bounce 1
+         end_timed(c, s.stream);
+      }
       // the paths still alive after the last bounce: their radiance (with what the last bounce's shadow rays added) goes to the
       // per-id array the tail reads
-      if (fp.num_bounces > 0) launch_flush_survivors(lc, fp, s.ps, ctl);
+      if (fp.num_bounces > 0 && !fused) launch_flush_survivors(lc, fp, s.ps, ctl);
       const bool last = smp + 1 == fp.samples_per_frame;
       // the accumulate / store tail (rgen:130-144) is a read-modify-write on the accumulation image:
       // frames must apply it in order, everything before it may overlap with other frames in flight
@@ -2036,6 +2051,12 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
       (void)sync_all(c);
       c->frames_in_flight = (uint32_t)value;
       c->next_slot = 0;
+   } else if (n == "fused_bounces") {
+      // 0: a lone frame runs the wavefront of a batch (four launches per bounce); 1: its bounces 1 .. in one persistent kernel; 2..8: that
+      // kernel's blocks per CU
+      if (!range(0, 8)) return bad("must be 0 (off), 1 (on) or 2..8 (on, blocks per CU of its grid)");
+      c->fused_bounces = value != 0;
+      if (value >= 2) c->fused_blocks_per_cu = (uint32_t)value;
    } else if (n == "trace_blocks_per_cu") {
       if (!range(1, 8)) return bad("must be 1..8");
       c->closest_blocks_per_cu = c->shadow_blocks_per_cu = (uint32_t)value;  // persistent grids of the traversal kernels

@@ -191,7 +191,9 @@ __device__ __forceinline__ void inherit_frame(const uint4 w0, const uint4 w1, co
 #endif
 }
 
-template <bool ANY>
+// CAP (closest-hit order, k_path_fused): children beyond t.tlimit are culled as in a visibility walk - the kernel's shadow rays go
+// through the closest-hit walk (occluded <=> the closest hit lies within the limit) beside the other lanes' bounce rays
+template <bool ANY, bool CAP = false>
 __device__ __forceinline__ bool node_compute(const uint4 w0, const uint4 w1, const uint4 w2, Trav& t, uint32_t* lds_col, uint32_t* spill) {
    const uint32_t meta = w0.w;
    // a power-of-two step is its biased exponent moved to bits 23..30
@@ -203,7 +205,7 @@ __device__ __forceinline__ bool node_compute(const uint4 w0, const uint4 w1, con
    const uint32_t qnx = nx ? w1.w : w1.x, qfx = nx ? w1.x : w1.w;
    const uint32_t qny = ny ? w2.x : w1.y, qfy = ny ? w1.y : w2.x;
    const uint32_t qnz = nz ? w2.y : w1.z, qfz = nz ? w1.z : w2.y;
-   const float tcap = ANY ? fminf(t.best.t, t.tlimit) : t.best.t;  // closest: tlimit is +inf
+   const float tcap = (ANY || CAP) ? fminf(t.best.t, t.tlimit) : t.best.t;  // closest: tlimit is +inf
    float tn[4];
    const uint32_t n_tri = w2.z >> kChildBaseBits;
    const uint32_t tri0 = kLeafBit | w2.w, node0 = (w2.z & kChildBaseMask) - n_tri;
@@ -490,7 +492,7 @@ __device__ __forceinline__ bool refill_lanes(Feeder<NA>& f, const RaySource& src
 // its node, a lane at a leaf its triangle, then both groups compute. A lane that reaches a leaf tests it an iteration later,
 // but the wave waits for memory once per iteration (a chained node -> triangle step, two dependent round trips per
 // iteration, measured 3.21 against 3.10 ms per frame: profiles/README.md).
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool CAP = false>
 __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const float4* __restrict__ tris, Trav& t, uint32_t* lds_col, uint32_t* spill, bool& occluded,
                                           uint32_t& n_nodes, uint32_t& n_tris) {
    const bool at_node = !(t.cur & kLeafBit);
@@ -525,7 +527,7 @@ __device__ __forceinline__ bool trav_step(const uint4* __restrict__ nodes, const
    bool pop;  // one pop for both groups: an LDS read and its wait once per iteration, not once per branch
    if (at_node) {
       if (COUNT) n_nodes++;
-      pop = !node_compute<ANY>(w0, w1, w2, t, lds_col, spill);
+      pop = !node_compute<ANY, CAP>(w0, w1, w2, t, lds_col, spill);
    } else {
       if (COUNT) n_tris++;
       const float4 ta = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
@@ -1215,6 +1217,90 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
    return I * eta - N * (eta * dn + sqrtf(k));
 }
 
+// ---- the closest-hit shader's arithmetic, shared by k_shade_hit (one bounce of a wavefront) and k_path_fused (a lone frame's later
+// bounces inside one persistent kernel): the same expressions in the same order, so both give the path the same words
+struct SurfaceHit {
+   V3 world_normal, origin;  // rchit:32-37; where the path goes on from (and its shadow rays start): rgen:59-60
+   float uu, vv;             // rchit:39
+   uint32_t mesh_index;
+};
+// s0..s3: the hit's shading packet (SceneDev::shade); the mesh record comes second because its index is in the packet
+__device__ __forceinline__ void surface_normal_uv(const float4 s0, const float4 s1, const float4 s2, const float4 s3, float bu, float bv, V3& normal, float& uu, float& vv) {
+   const V3 n0 = v3(s0.x, s0.y, s0.z), n1 = v3(s0.w, s1.x, s1.y), n2 = v3(s1.z, s1.w, s2.x);
+   const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
+   const float bx = 1.0f - bu - bv, by = bu, bz = bv;                            // rchit:30
+   normal = (n0 * bx + n1 * by) + n2 * bz;                                       // rchit:31
+   uu = (uv0x * bx + uv1x * by) + uv2x * bz;                                     // rchit:39
+   vv = (uv0y * bx + uv1y * by) + uv2y * bz;
+}
+__device__ __forceinline__ V3 world_normal_of(const MeshShade& ms, V3 normal, V3 ray_dir) {
+   V3 wn = v3((normal.x * ms.w2o[0] + normal.y * ms.w2o[3]) + normal.z * ms.w2o[6],
+              (normal.x * ms.w2o[1] + normal.y * ms.w2o[4]) + normal.z * ms.w2o[7],
+              (normal.x * ms.w2o[2] + normal.y * ms.w2o[5]) + normal.z * ms.w2o[8]);  // rchit:32
+   V3 world_normal = normalize3(wn);
+   if (dot3(world_normal, ray_dir) > 0.0f) world_normal = vneg(world_normal);   // rchit:35-37
+   return world_normal;
+}
+// Does the path go on? Decided by the material type and the side the ray came from (rchit:47-89) - nothing the texels bring
+__device__ __forceinline__ bool path_scatters(const MeshShade& ms, V3 ray_dir, V3 world_normal) {
+   return (ms.type == 0.0f || ms.type == 4.0f) ? dot3(ray_dir, world_normal) < 0.0f : (ms.type == 1.0f || ms.type == 2.0f);
+}
+// rchit:47-89: the scatter direction; `color` in: texel x base colour (rchit:40-41), out: what the throughput is multiplied by
+__device__ __forceinline__ V3 material_scatter(const MeshShade& ms, V3 ray_dir, V3 world_normal, V3& color, uint32_t& seed) {
+   V3 scatter = v3(0, 0, 0);
+   if (ms.type == 0.0f) {                                                        // rchit:47-50
+      scatter = world_normal + random_point_in_unit_sphere(seed);            // scattered = dot(ray, normal) < 0: path_scatters
+   } else if (ms.type == 1.0f) {                                                 // rchit:52-59
+      scatter = reflect3(normalize3(ray_dir), world_normal);
+      scatter = scatter + ms.property * random_point_in_unit_sphere(seed);
+      color = v3(1, 1, 1);
+   } else if (ms.type == 2.0f) {                                                 // rchit:61-83
+      V3 nd = normalize3(ray_dir);
+      float dnd = dot3(nd, world_normal);
+      V3 outward = dnd > 0 ? vneg(world_normal) : world_normal;
+      float ratio = ms.property;
+      ratio = dnd > 0 ? ratio : 1.0f / ratio;
+      float cos_theta = fminf(dot3(-1.0f * nd, outward), 1.0f);
+      float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+      bool cannot_refract = ratio * sin_theta > 1.0f;
+      float reflectance = schlick_reflectance(cos_theta, ratio);
+      if (cannot_refract || reflectance > random_float(seed))
+         scatter = reflect3(nd, outward);
+      else
+         scatter = refract3(nd, outward, ratio);
+      color = v3(1, 1, 1);
+   } else if (ms.type == 4.0f) {
+      // EXTENSION (never produced by the reference's scenes): Cook-Torrance, see pbr_weight()
+      scatter = world_normal + random_point_in_unit_sphere(seed);
+      color = pbr_weight(world_normal, -1.0f * normalize3(ray_dir), normalize3(scatter), color, ms.metallic, ms.roughness);
+   } else {                                                                      // rchit:85-89: the path ends
+      color = v3(1, 1, 1);
+   }
+   return scatter;
+}
+// rgen:81-121: which light the scattered path asks, and the weight f its throughput gets if the light is visible from `origin`
+__device__ __forceinline__ bool select_light(const FrameParams& fp, const SceneDev& sc, uint32_t id, uint32_t& rng_x, V3 origin, float& f, int& light_index) {
+   float light_sample_weight = 0.0f, total_weights = 1.0f;
+   const uint32_t k = id % fp.n_owned;
+   const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
+   uint32_t px = pix % fp.W;
+   bool use_reservoir = (px > fp.W / 2 || fp.full_frame_restir) && fp.use_ris == 1;  // rgen:87
+   if (use_reservoir) {
+      UhReservoir rs = fp.spatial_of[id / fp.n_owned][pix];                // rgen:98 (the path's own frame of the batch)
+      light_sample_weight = rs.W_X;
+      total_weights = rs.W_sum;
+      light_index = rs.Y;
+   } else {
+      sample_light_uniform(fp.num_lights_used, rng_x, light_index, light_sample_weight);  // rgen:107
+      light_sample_weight = 1.0f / light_sample_weight;                    // rgen:108
+   }
+   if (total_weights != 0.0f) {                                            // rgen:112
+      f = target_function(sc.lights, sc.num_lights, light_index, origin) * light_sample_weight;  // rgen:121
+      return true;
+   }
+   return false;
+}
+
 __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(FrameParams fp, SceneDev sc, PathState ps, Control* ctl, DeviceStats* stats, uint32_t bounce) {
    // c / 255.0f table in LDS: the 12 per-fetch table gathers were texture-addresser traffic (the
    // kernel ran 86 % TA-busy at 2 % VALU, profiles/r01c_*); LDS serves them at no TA cost
@@ -1277,22 +1363,17 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          const float t = hr.x, bu = hr.y, bv = hr.z;
          const float4* sp = sc.shade + 4 * (size_t)pk;  // pk = hr.w, known since the classification: no wait for hr before these
          float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-         const V3 n0 = v3(s0.x, s0.y, s0.z), n1 = v3(s0.w, s1.x, s1.y), n2 = v3(s1.z, s1.w, s2.x);
-         const float uv0x = s2.y, uv0y = s2.z, uv1x = s2.w, uv1y = s3.x, uv2x = s3.y, uv2y = s3.z;
          const uint32_t mesh_index = __float_as_uint(s3.w);
          // rchit:22-23. The LDS copy is read unconditionally (clamped index, explicit ds_read: device_math.h lds_fetch)
          // and replaced from global memory for the meshes beyond the LDS table
          MeshShade ms = lds_fetch(s_mesh + (mesh_index < kLdsMeshes ? mesh_index : kLdsMeshes - 1));
          if (mesh_index >= n_lds_mesh) ms = sc.meshes[mesh_index];
-         const float bx = 1.0f - bu - bv, by = bu, bz = bv;                            // rchit:30
-         V3 normal = (n0 * bx + n1 * by) + n2 * bz;                                    // rchit:31
+         V3 normal;
+         float uu, vv;
+         surface_normal_uv(s0, s1, s2, s3, bu, bv, normal, uu, vv);                    // rchit:30-31, :39
          // keeps the compiler from sinking the early loads to their first use
          asm volatile("" : "+v"(rng.x), "+v"(rng.y), "+v"(thr4.x), "+v"(thr4.y), "+v"(thr4.z), "+v"(rad4.x), "+v"(rad4.y), "+v"(rad4.z));
-         V3 wn = v3((normal.x * ms.w2o[0] + normal.y * ms.w2o[3]) + normal.z * ms.w2o[6],
-                    (normal.x * ms.w2o[1] + normal.y * ms.w2o[4]) + normal.z * ms.w2o[7],
-                    (normal.x * ms.w2o[2] + normal.y * ms.w2o[5]) + normal.z * ms.w2o[8]);  // rchit:32
-         V3 world_normal = normalize3(wn);
-         if (dot3(world_normal, ray_dir) > 0.0f) world_normal = vneg(world_normal);   // rchit:35-37
+         const V3 world_normal = world_normal_of(ms, normal, ray_dir);                 // rchit:32-37
          // where the path goes on from (and its sun ray starts): needs nothing the texels bring
          V3 origin = v3(ro.x, ro.y, ro.z) + t * ray_dir;                               // rgen:59
          origin = offset_ray(origin, world_normal);                                    // rgen:60
@@ -1300,12 +1381,10 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          // bring -, so the scattered paths' places in the next bounce's queue are asked for together with the texels: the returning
          // atomic is in flight with them instead of a round trip of its own after the material evaluation. (Inside the divergent
          // block: the ballot sees the valid lanes, which are the only ones that can scatter.)
-         scattered = (ms.type == 0.0f || ms.type == 4.0f) ? dot3(ray_dir, world_normal) < 0.0f : (ms.type == 1.0f || ms.type == 2.0f);
+         scattered = path_scatters(ms, ray_dir, world_normal);
          const unsigned long long scat_mask = __ballot(scattered);
          const int scat_leader = __ffsll((long long)scat_mask) - 1;
          uint32_t scat_base = 0;
-         float uu = (uv0x * bx + uv1x * by) + uv2x * bz;                               // rchit:39
-         float vv = (uv0y * bx + uv1y * by) + uv2y * bz;
          V3 color = sample_texture_pre(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex, [&] {  // rchit:40
             // (the counter's address goes through a register the compiler cannot see into: for a wave-uniform address its atomic
             // optimiser rewrites the add as a wave reduction with a readfirstlane of the result - and a wait for it - on the spot)
@@ -1317,35 +1396,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
 
          uint32_t seed = rng.y;
-         V3 scatter = v3(0, 0, 0);
-         if (ms.type == 0.0f) {                                                        // rchit:47-50
-            scatter = world_normal + random_point_in_unit_sphere(seed);            // scattered = dot(ray, normal) < 0: above
-         } else if (ms.type == 1.0f) {                                                 // rchit:52-59
-            scatter = reflect3(normalize3(ray_dir), world_normal);
-            scatter = scatter + ms.property * random_point_in_unit_sphere(seed);
-            color = v3(1, 1, 1);
-         } else if (ms.type == 2.0f) {                                                 // rchit:61-83
-            V3 nd = normalize3(ray_dir);
-            float dnd = dot3(nd, world_normal);
-            V3 outward = dnd > 0 ? vneg(world_normal) : world_normal;
-            float ratio = ms.property;
-            ratio = dnd > 0 ? ratio : 1.0f / ratio;
-            float cos_theta = fminf(dot3(-1.0f * nd, outward), 1.0f);
-            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-            bool cannot_refract = ratio * sin_theta > 1.0f;
-            float reflectance = schlick_reflectance(cos_theta, ratio);
-            if (cannot_refract || reflectance > random_float(seed))
-               scatter = reflect3(nd, outward);
-            else
-               scatter = refract3(nd, outward, ratio);
-            color = v3(1, 1, 1);
-         } else if (ms.type == 4.0f) {
-            // EXTENSION (never produced by the reference's scenes): Cook-Torrance, see pbr_weight()
-            scatter = world_normal + random_point_in_unit_sphere(seed);
-            color = pbr_weight(world_normal, -1.0f * normalize3(ray_dir), normalize3(scatter), color, ms.metallic, ms.roughness);
-         } else {                                                                      // rchit:85-89: the path ends
-            color = v3(1, 1, 1);
-         }
+         const V3 scatter = material_scatter(ms, ray_dir, world_normal, color, seed);  // rchit:47-89
          rng.y = seed;                                                                 // rchit:91
          if (scat_leader >= 0) slot = (uint32_t)__builtin_amdgcn_readlane((int)scat_base, scat_leader) + __builtin_amdgcn_mbcnt_hi((uint32_t)(scat_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)scat_mask, 0u));
 
@@ -1357,26 +1408,7 @@ __global__ __launch_bounds__(kBlock, UH_SHADE_HIT_BLOCKS) void k_shade_hit(Frame
          } else {
             float f = 0.0f;
             int light_index = 0;
-            if (fp.lights_enabled == 1) {                                              // rgen:81-110
-               float light_sample_weight = 0.0f, total_weights = 1.0f;
-               const uint32_t k = id % fp.n_owned;
-               const uint32_t pix = fp.owned_pixels ? fp.owned_pixels[k] : k;
-               uint32_t px = pix % fp.W;
-               bool use_reservoir = (px > fp.W / 2 || fp.full_frame_restir) && fp.use_ris == 1;  // rgen:87
-               if (use_reservoir) {
-                  UhReservoir rs = fp.spatial_of[id / fp.n_owned][pix];                // rgen:98 (the path's own frame of the batch)
-                  light_sample_weight = rs.W_X;
-                  total_weights = rs.W_sum;
-                  light_index = rs.Y;
-               } else {
-                  sample_light_uniform(fp.num_lights_used, rng.x, light_index, light_sample_weight);  // rgen:107
-                  light_sample_weight = 1.0f / light_sample_weight;                    // rgen:108
-               }
-               if (total_weights != 0.0f) {                                            // rgen:112
-                  want_light = true;
-                  f = target_function(sc.lights, sc.num_lights, light_index, origin) * light_sample_weight;  // rgen:121
-               }
-            }
+            if (fp.lights_enabled == 1) want_light = select_light(fp, sc, id, rng.x, origin, f, light_index);  // rgen:81-121
             // the path's state for the next bounce; written below at the position the path gets in the next bounce's queue
             n_o = make_float4(origin.x, origin.y, origin.z, __uint_as_float(rng.x));
             n_d = make_float4(scatter.x, scatter.y, scatter.z, __uint_as_float(rng.y));  // rgen:61
@@ -1500,6 +1532,349 @@ __global__ __launch_bounds__(kBlock) void k_flush_survivors(FrameParams fp, Path
       const uint32_t id = ld_stream(queue + i);
       const float4 rad = ld_rec(rec_quad(rec, seg + i, REC_RAD)), ro = ld_rec(rec_quad(rec, seg + i, REC_ORIGIN));
       st_stream(ps.radf + id, make_float4(rad.x, rad.y, rad.z, ro.w));
+   }
+}
+
+// ------------------------------------------------------------------------------------------
+// path_fused - ONE FRAME PER CALL (a moving camera, renderers/mod.rs:357, main.rs:460-471): bounces 1 .. num_bounces - 1 of a lone
+// frame inside one persistent kernel. A lone frame's wavefront is some 28 launches of which every traversal launch ends in the tail of
+// its longest ray (about 60 dependent steps: 0.30-0.38 ms per bounce for 1.5 M rays against 0.19 ms at the batched rate, DESIGN.md
+// section 4) - nothing of the same frame can fill those tails across a launch boundary. Here a PATH STAYS IN ITS LANE: the lane walks
+// the tree for the path's ray (the same trav_step as k_trace_closest), waits at the hit until enough lanes of its wave stand at one,
+// then the wave shades them together (the same functions as k_shade_hit), asks the sun grid / walks the tree for the shadow rays on the
+// spot (their results are added to the path's radiance in the reference's order: sun, then light, rgen:63-122), and the lane goes on
+// with the scattered ray - bounce b + 1 starts while other lanes are still in bounce b. A lane whose path has ended takes the next
+// path of bounce 1's queue out of the wave's LDS pool (the Feeder of the traversal kernels). No wave waits for another: the kernel
+// ends when the queue is drained and every lane's path has ended.
+// What leaves the kernel: ended paths' radiance in the per-id array (as k_shade_hit / k_flush_survivors write it); the paths whose ray
+// left the scene write their state back to their record (set 1, their position in bounce 1's queue) and list themselves in the miss
+// queue under bounce 1 - one k_shade_miss launch behind this kernel integrates the sky for all of them.
+// Same words per path as the wavefront: the per-path arithmetic is shared (surface_normal_uv .. select_light, make_shadow_ray,
+// tri_compute), a path's random numbers depend on nothing but the path, and shadow rays are predicates.
+// ------------------------------------------------------------------------------------------
+// one sun ray through the grid (k_trace_sun_grid's walk for one ray): 0 = lit, 1 = occluded, 2 = the grid does not answer (border cell,
+// long list): the tree's
+template <bool COUNT, bool INLINE>
+__device__ __forceinline__ int sun_grid_query(const SunGridDev& g, const float4* __restrict__ packets, V3 o, V3 d, uint32_t& n_tris, uint32_t& n_covered) {
+   typedef float f4_t __attribute__((ext_vector_type(4)));
+   const f4_t* __restrict__ recs = reinterpret_cast<const f4_t*>(g.recs);
+   const f4_t* __restrict__ tris = reinterpret_cast<const f4_t*>(packets);
+   const uint2* __restrict__ entries = reinterpret_cast<const uint2*>(g.entries);
+   const uint4* __restrict__ cells = reinterpret_cast<const uint4*>(g.cell_start);
+   const float pu = dot_fma(v3(g.U[0], g.U[1], g.U[2]), o), pv = dot_fma(v3(g.V[0], g.V[1], g.V[2]), o), pw = dot_fma(v3(g.W[0], g.W[1], g.W[2]), o);
+   uint32_t cx, cy;
+   sun_cell_of(g, pu, pv, cx, cy);
+   if (g.coarse) {
+      const float cw = g.coarse[(cy >> g.coarse_shift) * g.coarse_nx + (cx >> g.coarse_shift)];
+      if (sun_coarse_covered(cw, pw)) {
+         if (COUNT) n_covered++;
+         return 1;
+      }
+   }
+   const uint32_t cell = cy * g.nx + cx;
+   const uint4 cs = cells[cell];
+   const uint32_t end = cells[cell + 1].x;
+   const float cover = __uint_as_float(cs.y);
+   if (pw < cover && cover - pw < kSunCoverReach) {
+      if (COUNT) n_covered++;
+      return 1;
+   }
+   if (cx == 0 || cy == 0 || cx + 1 == g.nx || cy + 1 == g.ny || end - cs.x > g.max_walk) return 2;
+   if (cs.x >= end) return 0;
+   Hit best;
+   best.t = 10000.0f;  // tmax (rgen:66)
+   best.u = best.v = 0.0f;
+   best.idx = kEmptyRef;
+   best.key = 0xffffffffu;
+   uint32_t e = cs.x;
+   if constexpr (INLINE) {
+      const f4_t* r = recs + 4 * (size_t)e;
+      for (;;) {
+         const f4_t na = r[0], nb = r[1], nc = r[2];
+         if (nc.z < pw) return 0;  // from here on every packet ends behind the origin
+         if (COUNT) n_tris++;
+         if (tri_compute<true>(make_float4(na.x, na.y, na.z, na.w), make_float4(nb.x, nb.y, nb.z, nb.w), make_float4(nc.x, nc.y, nc.z, nc.w), 0u, o, d, 0.001f, INFINITY, best)) return 1;
+         e++;
+         if (e >= end || nc.w < pw) return 0;
+         r += 4;
+      }
+   } else {
+      uint2 cur = make_uint2(cs.z, cs.w);  // the list's first entry came with the cell record
+      for (;;) {
+         if (__uint_as_float(cur.y) < pw) return 0;  // sorted by far depth, descending
+         const f4_t* r = tris + kTriStride16 * (size_t)cur.x;
+         const f4_t na = r[0], nb = r[1], nc = r[2];
+         e++;
+         const uint2 nx = e < end ? entries[e] : make_uint2(0u, 0u);  // in flight with the packet
+         if (COUNT) n_tris++;
+         if (tri_compute<true>(make_float4(na.x, na.y, na.z, na.w), make_float4(nb.x, nb.y, nb.z, nb.w), make_float4(nc.x, nc.y, nc.z, nc.w), cur.x, o, d, 0.001f, INFINITY, best)) return 1;
+         if (e >= end) return 0;
+         cur = nx;
+      }
+   }
+}
+
+#ifndef UH_FUSED_SHADE_AT
+#define UH_FUSED_SHADE_AT 32   // lanes of a wave standing at a hit that make a shading phase worth interrupting the others' walk
+#endif
+#ifndef UH_FUSED_SHADE_LATE
+#define UH_FUSED_SHADE_LATE 8  // ... once the queue is drained (the wave's remaining paths are its tail)
+#endif
+#ifndef UH_FUSED_BLOCKS
+#define UH_FUSED_BLOCKS 3      // blocks per CU the kernel's registers are sized for (measured: 3 ahead of 4)
+#endif
+template <bool COUNT, bool INLINE>
+__global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, uint32_t cursor_slot, SunGridDev g,
+                                                                         bool use_grid) {
+   constexpr uint32_t kFirst = 1;  // the paths are those of bounce 1's ray queue, their state lies in set 1 at their positions there
+   __shared__ float s_lut[256];
+   constexpr uint32_t kLdsMeshes = 128, kLdsTextures = 64;
+   __shared__ MeshShade s_mesh[kLdsMeshes];
+   __shared__ TexInfo s_tex[kLdsTextures];
+   __shared__ uint32_t s_stack[kWavesPerBlock][kLdsStack][64];
+   __shared__ RayPool<2> s_pool[kWavesPerBlock];
+   __shared__ uint32_t s_miss[kWavesPerBlock][2][128];  // per wave: (position, id) of the paths whose ray left the scene, handed to k_shade_miss 64 at a time
+   const uint32_t n_lds_mesh = sc.num_meshes < kLdsMeshes ? sc.num_meshes : kLdsMeshes;
+   const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
+   s_lut[threadIdx.x] = sc.unorm_lut[threadIdx.x];
+   if (threadIdx.x < n_lds_mesh) s_mesh[threadIdx.x] = sc.meshes[threadIdx.x];
+   if (threadIdx.x < n_lds_tex) s_tex[threadIdx.x] = sc.textures[threadIdx.x];
+   __syncthreads();
+   const uint32_t lane = lane_id();
+   const uint32_t wave = threadIdx.x >> 6;
+   uint32_t* lds_col = &s_stack[wave][0][lane];
+   RayPool<2>& pool = s_pool[wave];
+   uint32_t(*missed_list)[128] = s_miss[wave];
+   const ShardCtx sx = shard_ctx();
+   const uint32_t seg = sx.shard * ps.shard_cap;
+   const PathRecs rec = ps.set[kFirst & 1];
+   const uint32_t* __restrict__ queue = ps.queue[kFirst & 1] + seg;
+   RaySource src;
+   src.queue = nullptr;  // every position of the queue is a path: chunk k of the shard = positions 64 k ..
+   src.count = ctl->q_count[qc_index(kFirst, Q_RAY, sx.shard)];
+   src.cursor = &ctl->cursor[cursor_index(cursor_slot, sx.shard)];
+   src.wave_index = src.num_waves = 0;
+   uint2* q_miss = reinterpret_cast<uint2*>(ps.queue[4]) + seg;
+   uint32_t* n_miss = &ctl->q_count[qc_index(kFirst, Q_MISS, sx.shard)];
+   const uint4* __restrict__ nodes = sc.nodes;
+   const float4* __restrict__ tris = sc.tris;
+   auto source_of = [&](int a, uint32_t pos) { return (const float4*)rec_quad(rec, seg + pos, a == 0 ? REC_ORIGIN : REC_DIR); };
+   Feeder<2> f;
+   Trav t;
+   t.cur = kEmptyRef;
+   t.sp = 0;
+   // A lane is idle, walks the tree for a ray of its path (WALK: the bounce ray, or a shadow ray - a sun ray the grid did not answer,
+   // a light ray), or stands at the end of its bounce ray and waits for the wave's next shading phase (HIT)
+   enum : uint32_t { IDLE = 0, WALK = 1, HIT = 2 };
+   enum : uint32_t { BOUNCE_RAY = 0, SUN_RAY = 1, LIGHT_RAY = 2 };
+   uint32_t state = IDLE, kind = BOUNCE_RAY;
+   // the lane's path: id, position in bounce 1's queue, the bounce its ray belongs to, the two RNG words (raygen's, payload's),
+   // throughput and radiance - what the wavefront keeps in the path's record -, and while its shadow rays are out: the scattered ray
+   // it goes on with (it leaves from the shadow rays' origin, t.o), the light it asks and the weight f of rgen:121
+   uint32_t id = 0, pos = 0, bounce = 0;
+   uint2 rng = make_uint2(0u, 0u);
+   V3 thr = v3(0, 0, 0), rad = v3(0, 0, 0), scatter = v3(0, 0, 0);
+   float lf = 0.0f;
+   int light_index = 0;
+   bool sun_pending = false, light_pending = false;
+   uint32_t n_nodes = 0, n_tris = 0, n_snodes = 0, n_stris = 0, n_lnodes = 0, n_ltris = 0, n_covered = 0, mark_nodes = 0, mark_tris = 0;  // per lane (COUNT only)
+   uint32_t w_rays = 0, w_hits = 0, w_sun = 0, w_sun_tree = 0, w_light = 0, n_missed = 0;                                                 // per wave
+   uint32_t spill[kSpillStack];
+   auto take = [&](uint32_t slot) {
+      pos = f.pool_base + slot;
+      const float4 ro = pool.v[0][slot], rd = pool.v[1][slot];
+      trav_init(t, ro, rd, 0.001f, 10000.0f, INFINITY);  // rgen:45-47
+      rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
+      id = ld_stream(queue + pos);
+      const float4 t4 = ld_rec(rec_quad(rec, seg + pos, REC_THR)), r4 = ld_rec(rec_quad(rec, seg + pos, REC_RAD));
+      thr = v3(t4.x, t4.y, t4.z);
+      rad = v3(r4.x, r4.y, r4.z);
+      bounce = kFirst;
+      kind = BOUNCE_RAY;
+      state = WALK;
+   };
+   // `n` entries from the front of the wave's miss list go to the miss queue (one atomic per call)
+   auto flush_misses = [&](uint32_t n) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(n_miss, n);
+      base = __shfl(base, 0);
+      if (lane < n) st_stream(q_miss + base + lane, make_uint2(missed_list[0][lane], missed_list[1][lane]));
+   };
+   // The path's next ray from the hit it was shaded at (origin = t.o): the sun ray if the grid left it to the tree, the light ray, then
+   // the scattered ray of the next bounce - or, after the last bounce, the path's radiance to the per-id array (what
+   // k_flush_survivors writes)
+   auto next_ray = [&]() {
+      const float4 o4 = make_float4(t.o.x, t.o.y, t.o.z, 0.0f);
+      if (sun_pending) {
+         sun_pending = false;
+         const ShadowRay s = make_shadow_ray<false>(sc, fp, o4, make_float4(thr.x, thr.y, thr.z, lf), make_float4(rad.x, rad.y, rad.z, 0.0f));
+         trav_init(t, s.ro, s.rd, s.ro.w, s.rd.w, s.tlimit);
+         kind = SUN_RAY;
+         state = WALK;
+      } else if (light_pending) {
+         light_pending = false;
+         const ShadowRay s = make_shadow_ray<true>(sc, fp, o4, make_float4(thr.x, thr.y, thr.z, lf), make_float4(rad.x, rad.y, rad.z, __uint_as_float((uint32_t)light_index)));
+         trav_init(t, s.ro, s.rd, s.ro.w, s.rd.w, s.tlimit);
+         kind = LIGHT_RAY;
+         state = WALK;
+      } else {
+         bounce++;
+         if (bounce >= fp.num_bounces) {  // rgen:127 after the last bounce
+            st_stream(ps.radf + id, make_float4(rad.x, rad.y, rad.z, __uint_as_float(rng.x)));
+            state = IDLE;
+         } else {
+            trav_init(t, o4, make_float4(scatter.x, scatter.y, scatter.z, 0.0f), 0.001f, 10000.0f, INFINITY);  // rgen:61, :45-47
+            kind = BOUNCE_RAY;
+            state = WALK;
+         }
+      }
+      if (COUNT) {
+         mark_nodes = n_nodes;
+         mark_tris = n_tris;
+      }
+   };
+   const V3 sun_d = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);
+   while (refill_lanes<2>(f, src, pool, state == IDLE, source_of, take)) {
+      if (state == WALK) {
+         bool occluded = false;
+         bool ended = trav_step<false, COUNT, true>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris);
+         // a shadow ray is a predicate: occluded <=> some triangle accepts it within (tmin, tmax) and the light's distance <=> the closest
+         // such hit lies within it - the walk can stop at the first hit it finds there (rgen:69, :118-119 read nothing else)
+         const bool blocked = t.best.idx != kEmptyRef && t.best.t <= t.tlimit;
+         if (kind != BOUNCE_RAY && blocked) ended = true;
+         if (ended) {
+            if (kind == BOUNCE_RAY) {
+               state = HIT;
+            } else {
+               // rgen:69-78 / :118-122: an unoccluded ray adds the path's throughput (x the light's weight) to its radiance
+               if (!blocked) {
+                  const float w = kind == SUN_RAY ? 1.0f : lf;
+                  rad = kind == SUN_RAY ? v3(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z) : v3(rad.x + thr.x * w, rad.y + thr.y * w, rad.z + thr.z * w);
+               }
+               if (COUNT) {  // the walk's visits belong to the shadow counters
+                  const uint32_t dn = n_nodes - mark_nodes, dt = n_tris - mark_tris;
+                  n_nodes = mark_nodes;
+                  n_tris = mark_tris;
+                  if (kind == SUN_RAY) {
+                     n_snodes += dn;
+                     n_stris += dt;
+                  } else {
+                     n_lnodes += dn;
+                     n_ltris += dt;
+                  }
+               }
+               next_ray();  // (t.o is still the point the path's rays leave from)
+            }
+         }
+      }
+      const unsigned long long at_hit = __ballot(state == HIT);
+      if (at_hit == 0ull) continue;
+      const uint32_t n_at_hit = (uint32_t)__popcll(at_hit);
+      if (n_at_hit < (f.drained ? (uint32_t)UH_FUSED_SHADE_LATE : (uint32_t)UH_FUSED_SHADE_AT) && __ballot(state == WALK) != 0ull) continue;
+      // ---- shading phase: the lanes standing at the end of their bounce ray
+      w_rays += n_at_hit;
+      const bool missed = state == HIT && t.best.idx == kEmptyRef;
+      const unsigned long long mmask = __ballot(missed);
+      if (mmask != 0ull) {
+         // reference.rmiss: the sky integral is some thousand instructions - not here. The path's state goes back to its record and
+         // the path into the miss queue (through a per-wave list, 64 at a time); k_shade_miss(bounce 1) runs behind this kernel
+         const uint32_t mp = __builtin_amdgcn_mbcnt_hi((uint32_t)(mmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mmask, 0u));
+         if (missed) {
+            st_rec(rec_quad(rec, seg + pos, REC_ORIGIN), make_float4(t.o.x, t.o.y, t.o.z, __uint_as_float(rng.x)));
+            st_rec(rec_quad(rec, seg + pos, REC_DIR), make_float4(t.d.x, t.d.y, t.d.z, __uint_as_float(rng.y)));
+            st_rec(rec_quad(rec, seg + pos, REC_THR), make_float4(thr.x, thr.y, thr.z, 0.0f));
+            st_rec(rec_quad(rec, seg + pos, REC_RAD), make_float4(rad.x, rad.y, rad.z, 0.0f));
+            missed_list[0][n_missed + mp] = pos;
+            missed_list[1][n_missed + mp] = id;
+            state = IDLE;
+         }
+         n_missed += (uint32_t)__popcll(mmask);
+         __builtin_amdgcn_wave_barrier();
+         if (n_missed >= 64u) {
+            flush_misses(64u);
+            const uint32_t rest = n_missed - 64u;  // at most 63: to the front (one wave, LDS operations execute in order)
+            uint32_t tmp0 = 0, tmp1 = 0;
+            if (lane < rest) {
+               tmp0 = missed_list[0][64u + lane];
+               tmp1 = missed_list[1][64u + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) {
+               missed_list[0][lane] = tmp0;
+               missed_list[1][lane] = tmp1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_missed = rest;
+         }
+      }
+      const bool hit = state == HIT;
+      bool scattered = false, to_tree = false, want_light = false;
+      if (hit) {
+         const uint32_t pk = t.best.idx;
+         const float4* sp = sc.shade + 4 * (size_t)pk;
+         const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+         const uint32_t mesh_index = __float_as_uint(s3.w);
+         MeshShade ms = lds_fetch(s_mesh + (mesh_index < kLdsMeshes ? mesh_index : kLdsMeshes - 1));  // rchit:22-23
+         if (mesh_index >= n_lds_mesh) ms = sc.meshes[mesh_index];
+         V3 normal;
+         float uu, vv;
+         surface_normal_uv(s0, s1, s2, s3, t.best.u, t.best.v, normal, uu, vv);       // rchit:30-31, :39
+         const V3 ray_dir = t.d;
+         const V3 world_normal = world_normal_of(ms, normal, ray_dir);                 // rchit:32-37
+         V3 origin = t.o + t.best.t * ray_dir;                                         // rgen:59
+         origin = offset_ray(origin, world_normal);                                    // rgen:60
+         scattered = path_scatters(ms, ray_dir, world_normal);
+         V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);  // rchit:40
+         color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
+         uint32_t seed = rng.y;
+         scatter = material_scatter(ms, ray_dir, world_normal, color, seed);           // rchit:47-89
+         rng.y = seed;                                                                 // rchit:91
+         thr = thr * color;                                                            // rgen:48
+         if (!scattered) {                                                             // rgen:53-57: the path ends here
+            st_stream(ps.radf + id, make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, __uint_as_float(rng.x)));
+            state = IDLE;
+         } else {
+            lf = 0.0f;
+            light_index = 0;
+            light_pending = false;
+            if (fp.lights_enabled == 1) light_pending = select_light(fp, sc, id, rng.x, origin, lf, light_index);  // rgen:81-121
+            sun_pending = false;
+            if (fp.sun_shadow_enabled == 1) {                                          // rgen:63-79
+               int r = use_grid ? sun_grid_query<COUNT, INLINE>(g, tris, origin, sun_d, n_stris, n_covered) : 2;
+               if (COUNT && use_grid) n_snodes++;  // every sun ray looked one cell up
+#ifdef UH_FUSED_X_DEFER_LIT  // (measurement only: what the deferred sun rays cost - wrong image)
+               if (r == 2) r = 0;
+#endif
+               if (r == 0) rad = v3(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z);       // rgen:69-78
+               sun_pending = r == 2;
+               to_tree = sun_pending && use_grid;
+            }
+            want_light = light_pending;
+            t.o = origin;  // every ray the path sends from here leaves from this point
+            next_ray();
+         }
+      }
+      w_hits += (uint32_t)__popcll(__ballot(hit));
+      if (fp.sun_shadow_enabled == 1) w_sun += (uint32_t)__popcll(__ballot(scattered));
+      w_sun_tree += (uint32_t)__popcll(__ballot(to_tree));
+      w_light += (uint32_t)__popcll(__ballot(want_light));
+   }
+   if (n_missed) flush_misses(n_missed);
+   if (lane == 0) {
+      if (w_rays) atomicAdd(&stats->rays[UH_RAY_BOUNCE], (unsigned long long)w_rays);
+      if (w_hits) atomicAdd(&stats->closest_hits, (unsigned long long)w_hits);
+      if (w_sun) atomicAdd(&stats->rays[UH_RAY_SUN_SHADOW], (unsigned long long)w_sun);
+      if (w_sun_tree) atomicAdd(&stats->sun_tree_rays, (unsigned long long)w_sun_tree);
+      if (w_light) atomicAdd(&stats->rays[UH_RAY_LIGHT_SHADOW], (unsigned long long)w_light);
+   }
+   if (COUNT) {
+      atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
+      atomicAdd(&stats->tris_tested, (unsigned long long)n_tris);
+      atomicAdd(&stats->shadow_nodes_visited, (unsigned long long)n_snodes);
+      atomicAdd(&stats->shadow_tris_tested, (unsigned long long)n_stris);
+      atomicAdd(&stats->light_nodes_visited, (unsigned long long)n_lnodes);
+      atomicAdd(&stats->light_tris_tested, (unsigned long long)n_ltris);
+      atomicAdd(&stats->sun_covered_rays, (unsigned long long)n_covered);
    }
 }
 
@@ -1815,6 +2190,21 @@ void launch_shade_hit(const LaunchCfg& c, const FrameParams& fp, const SceneDev&
 }
 void launch_flush_survivors(const LaunchCfg& c, const FrameParams& fp, const PathState& ps, Control* ctl) {
    k_flush_survivors<<<shade_grid(c, fp.n_owned * fp.batch_frames), kBlock, 0, c.stream>>>(fp, ps, ctl);
+}
+
+// bounces 1 .. of a lone frame in one persistent kernel (k_path_fused); g: the sun grid when use_grid
+void launch_path_fused(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, uint32_t cursor_slot,
+                       const SunGridDev& g, bool use_grid) {
+   const dim3 grid = sharded_grid(c.num_cus * c.fused_blocks_per_cu);
+#define UH_FUSED(COUNT, INLINE) k_path_fused<COUNT, INLINE><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, cursor_slot, g, use_grid)
+   if (use_grid && g.recs) {
+      if (c.count_visits) UH_FUSED(true, true);
+      else UH_FUSED(false, true);
+   } else {
+      if (c.count_visits) UH_FUSED(true, false);
+      else UH_FUSED(false, false);
+   }
+#undef UH_FUSED
 }
 
 void launch_trace_shadow(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats,
