@@ -193,8 +193,8 @@ struct uh_ctx {
    uint32_t closest_blocks_per_cu = 5, shadow_blocks_per_cu = 5;  // (config 2, whose light shadow rays are a third of the frame: 6/5, 5/5, 5/4, 6/4 = 8,230 / 8,266 / 7,997 / 7,950 Mrays/s)
    uint32_t cam_walk_whole = 512;     // option "camera_grid_walk_whole" (sun_grid.h SunGridDev::walk_whole)
    // one frame per call: bounces 1 .. of a lone frame inside one persistent kernel (k_path_fused) instead of four launches per bounce
-   bool fused_bounces = false;  // option "fused_bounces"
-   uint32_t fused_blocks_per_cu = 3;
+   bool fused_bounces = true;  // option "fused_bounces"
+   uint32_t fused_blocks_per_cu = 4;
    static constexpr uint32_t kSingleFrameBlocksPerCu = 4;  // the cap on both for a wavefront of one frame (fewer persistent waves reach the end of a small launch's tail sooner: round 4's sweep)
    std::string err;
 
@@ -1350,6 +1350,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       launch_generate(lc, fp, s.ps, ctl, smp);
       // a lone frame: bounce 0 as a wavefront (its rays are coherent, the camera grid serves them), the others inside k_path_fused
       const bool fused = c->fused_bounces && fp.batch_frames == 1 && fp.num_bounces >= 2;
+      const bool fused_sun0 = fused && fp.sun_shadow_enabled == 1 && fp.lights_enabled != 1;  // bounce 0's sun rays inside the fused kernel too
       for (uint32_t b = 0; b < (fused ? 1u : fp.num_bounces); b++) {
          begin_timed(c, (b == 0 && c->cam_this_frame) ? 3 : 0, s.stream);
          if (b == 0 && c->cam_this_frame) {
@@ -1387,7 +1388,7 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
             lsh.stream = s.side;
             sh_stream = s.side;
          }
-         if (fp.sun_shadow_enabled == 1) {
+         if (fp.sun_shadow_enabled == 1 && !fused_sun0) {
             begin_timed(c, 1, sh_stream);
             if (c->sun_this_frame) {
                launch_trace_sun_grid(lsh, fp, c->scene, s.ps, ctl, st, b, slot++, c->sun_dev);
@@ -1403,19 +1404,21 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
          }
          if (side_used) HIP_TRY(c, hipEventRecord(s.ev_shadowed, s.side));
       }
-      if ((c->overlap_miss || c->overlap_shadow) && fp.num_bounces > 0) {
+      const bool join_side = (c->overlap_miss || c->overlap_shadow) && fp.num_bounces > 0;
+      // the side stream's work: the sky integrals, and - unless the fused kernel asks them itself - bounce 0's sun and light rays, whose
+      // results the fused kernel starts from
+      if (join_side && !fused_sun0) {
          HIP_TRY(c, hipEventRecord(s.ev_side_done, s.side));
          HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_side_done, 0));
       }
       if (fused) {
-         // (the side stream's work of bounce 0 - sky, sun and light rays - has been waited for above: the shadow rays' results are in
-         // the records the kernel starts from, and the miss queue is free for the kernel's own entries)
          begin_timed(c, 0, s.stream);
-         launch_path_fused(lc, fp, c->scene, s.ps, ctl, st, slot++, c->sun_dev, c->sun_this_frame);
+         launch_path_fused(lc, fp, c->scene, s.ps, ctl, st, c->sun_dev, c->sun_this_frame, fused_sun0);
          end_timed(c, s.stream);
-         begin_timed(c, 2, s.stream);
-         launch_shade_miss(lc, fp, s.ps, ctl, st, 1);  // every path whose ray left the scene in bounces 1 .., listed under bounce 1
-         end_timed(c, s.stream);
+      }
+      if (join_side && fused_sun0) {  // (bounce 0's sky integrals ran beside the fused kernel)
+         HIP_TRY(c, hipEventRecord(s.ev_side_done, s.side));
+         HIP_TRY(c, hipStreamWaitEvent(s.stream, s.ev_side_done, 0));
       }
       // the paths still alive after the last bounce: their radiance (with what the last bounce's shadow rays added) goes to the
       // per-id array the tail reads

@@ -200,7 +200,7 @@ struct LaunchCfg {
    uint32_t num_cus;
    uint32_t closest_blocks_per_cu, shadow_blocks_per_cu;
    bool count_visits;
-   uint32_t fused_blocks_per_cu = 3;  // k_path_fused (kernels.hip UH_FUSED_BLOCKS)
+   uint32_t fused_blocks_per_cu = 4;  // k_path_fused (kernels.hip UH_FUSED_BLOCKS)
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);
@@ -212,7 +212,7 @@ void launch_shade_miss(const LaunchCfg&, const FrameParams&, const PathState&, C
 void launch_shade_hit(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, const Images&, Control*, DeviceStats*, uint32_t bounce);
 // the paths still alive after the last bounce hand their radiance to the per-id array k_finish_sample reads
 void launch_flush_survivors(const LaunchCfg&, const FrameParams&, const PathState&, Control*);
-void launch_path_fused(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t cursor_slot, const SunGridDev& g, bool use_grid);
+void launch_path_fused(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, const SunGridDev& g, bool use_grid, bool sun_of_bounce0);
 void launch_trace_shadow(const LaunchCfg&, const FrameParams&, const SceneDev&, const PathState&, Control*, DeviceStats*, uint32_t bounce,
                          uint32_t cursor_slot, bool light, bool sun_leftovers = false);
 // sun shadow rays through the per-direction grid (sun_grid.h) instead of the tree
