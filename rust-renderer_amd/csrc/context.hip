@@ -194,7 +194,8 @@ struct uh_ctx {
    uint32_t cam_walk_whole = 512;     // option "camera_grid_walk_whole" (sun_grid.h SunGridDev::walk_whole)
    // one frame per call: bounces 1 .. of a lone frame inside one persistent kernel (k_path_fused) instead of four launches per bounce
    bool fused_bounces = true;  // option "fused_bounces"
-   uint32_t fused_blocks_per_cu = 4;
+   bool fused_always = false;  // fused_bounces = -1: also with frames in flight (tests)
+   uint32_t fused_blocks_per_cu = 3;
    static constexpr uint32_t kSingleFrameBlocksPerCu = 4;  // the cap on both for a wavefront of one frame (fewer persistent waves reach the end of a small launch's tail sooner: round 4's sweep)
    std::string err;
 
@@ -1349,7 +1350,11 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       uint32_t slot = 0;
       launch_generate(lc, fp, s.ps, ctl, smp);
       // a lone frame: bounce 0 as a wavefront (its rays are coherent, the camera grid serves them), the others inside k_path_fused
-      const bool fused = c->fused_bounces && fp.batch_frames == 1 && fp.num_bounces >= 2;
+      // ... when the caller waits for its frames (the frame before this one has left the GPU): the fused kernel fills the chip by
+      // itself, so with frames in flight - a caller that does not wait - the wavefront's small launches interleave better (2.2 against
+      // 2.5 ms per frame). Both give the same image.
+      const bool gpu_idle = !c->last_acc || hipEventQuery(c->last_acc) == hipSuccess;
+      const bool fused = c->fused_bounces && fp.batch_frames == 1 && fp.num_bounces >= 2 && fp.num_bounces <= 64 && s.ps.shard_cap < (1u << 23) && (gpu_idle || c->fused_always);
       const bool fused_sun0 = fused && fp.sun_shadow_enabled == 1 && fp.lights_enabled != 1;  // bounce 0's sun rays inside the fused kernel too
       for (uint32_t b = 0; b < (fused ? 1u : fp.num_bounces); b++) {
          begin_timed(c, (b == 0 && c->cam_this_frame) ? 3 : 0, s.stream);
@@ -2057,8 +2062,9 @@ int uh_set_option(uh_ctx* c, const char* name, int value) {
    } else if (n == "fused_bounces") {
       // 0: a lone frame runs the wavefront of a batch (four launches per bounce); 1: its bounces 1 .. in one persistent kernel; 2..8: that
       // kernel's blocks per CU
-      if (!range(0, 8)) return bad("must be 0 (off), 1 (on) or 2..8 (on, blocks per CU of its grid)");
+      if (!range(-1, 8)) return bad("must be 0 (off), 1 (on when no frame is in flight), -1 (always on) or 2..8 (as 1, and blocks per CU of its grid)");
       c->fused_bounces = value != 0;
+      c->fused_always = value == -1;
       if (value >= 2) c->fused_blocks_per_cu = (uint32_t)value;
    } else if (n == "trace_blocks_per_cu") {
       if (!range(1, 8)) return bad("must be 1..8");

@@ -200,7 +200,7 @@ struct LaunchCfg {
    uint32_t num_cus;
    uint32_t closest_blocks_per_cu, shadow_blocks_per_cu;
    bool count_visits;
-   uint32_t fused_blocks_per_cu = 4;  // k_path_fused (kernels.hip UH_FUSED_BLOCKS)
+   uint32_t fused_blocks_per_cu = 3;  // k_path_fused (kernels.hip UH_FUSED_BLOCKS)
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);
