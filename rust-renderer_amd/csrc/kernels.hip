@@ -1539,27 +1539,33 @@ __global__ __launch_bounds__(kBlock) void k_flush_survivors(FrameParams fp, Path
 // path_fused - ONE FRAME PER CALL (a moving camera, renderers/mod.rs:357, main.rs:460-471): bounces 1 .. num_bounces - 1 of a lone
 // frame inside one persistent kernel. A lone frame's wavefront is some 28 launches of which every traversal launch ends in the tail of
 // its longest ray (about 60 dependent steps: 0.30-0.38 ms per bounce for 1.5 M rays against 0.19 ms at the batched rate, DESIGN.md
-// section 4) - nothing of the same frame can fill those tails across a launch boundary. Here EVERY WAVE RUNS ITS OWN PIPELINE over a
-// contiguous range of the positions of bounce 1's ray queue (its shard's count / waves of the shard), with no word to any other wave:
-//   * the wave walks the tree for 64 rays at a time, lanes refilled from its LDS pool as in k_trace_closest; a lane whose bounce ray
-//     has ended leaves the hit in the wave's hit list (LDS) - or its path in the miss list - and takes the next ray at once;
-//   * whenever 64 hits have gathered the wave shades them (k_shade_hit's arithmetic; the rays still in flight wait in their lanes'
-//     registers), asks the sun grid on the spot, rewrites the paths' state IN PLACE (a path's record stays at its position of
-//     bounce 1's queue for the whole kernel) and appends an entry p | flags per scattered path to its WORK RING (its range of a queue
-//     array: a path has at most one entry alive, so the range's size is the ring's capacity) - from where the pool's feeder takes
-//     them: the next bounce's rays are walked beside the stragglers of this one, and the wave runs dry only once, at the very end;
-//   * whenever 64 misses have gathered it integrates the sky for them (reference.rmiss).
+// section 4) - nothing of the same frame can fill those tails across a launch boundary. Here EVERY BLOCK IS A PIPELINE of its own over
+// a contiguous range of the positions of bounce 1's ray queue (its shard's count / blocks of the shard), with no word to any other block:
+//   * THREE WALKING WAVES: persistent over the block's WORK RING (entries p | flags in the block's range of a queue array; chunks of
+//     64 claimed from a head counter in LDS), lanes refilled from an LDS pool as in k_trace_closest. A lane whose bounce ray has ended
+//     leaves the hit in its wave's hit ring (LDS) - or its path in the miss ring - and takes the next ray at once: a walking wave holds
+//     nothing but rays, and runs dry only once, when the block's paths have all ended.
+//   * ONE SHADING WAVE: takes 64 hits at a time from the three hit rings, shades them (k_shade_hit's arithmetic), asks the sun grid on
+//     the spot, rewrites the paths' state IN PLACE (a path's record stays at its position of bounce 1's queue for the whole kernel) and
+//     appends an entry per scattered path to the work ring - the next bounce's rays are walked beside the stragglers of this one;
+//     and it integrates the sky (reference.rmiss) for 64 missed paths at a time. It holds no ray, so the kernel's registers are
+//     the larger of the two roles', not their sum (a wave that did both kept a walk's state live through the shading: 168 registers,
+//     three waves per SIMD - round 5's third form).
 // An entry's flags: kHasRay - the path has a ray of the next bounce (its record's origin / direction); kSun - its sun ray was not
 // answered by the grid (border cell, long list - or no grid): the tree's; kLight - it asks a light (record: f in throughput.w, light
 // index in radiance.w); bits 23..28 - how many bounces follow the entry's ray. The lane that takes an entry walks the shadow rays first
 // - sun, then light: their results are added to the path's radiance in the reference's order (rgen:63-122) -, then the bounce ray.
 // Shadow rays go through the closest-hit walk beside the other lanes' bounce rays (occluded <=> the closest hit lies within the limit;
 // the walk stops at the first hit inside).
+// The block ends when its count of live paths reaches zero. Every wait (a walking wave for work or for room in its ring, the shading
+// wave for hits) sleeps and is bounded: a wave that waits too long raises the block's abort word, every wave leaves, and the frame is
+// reported as failed (DeviceStats::fused_aborts) - never a hang.
 // Same words per path as the wavefront: the per-path arithmetic is shared (surface_normal_uv .. select_light, make_shadow_ray,
 // tri_compute), a path's random numbers depend on nothing but the path, and shadow rays are predicates.
 // (Round 5's earlier forms, profiles/README.md: a path per LANE, parked at its hit until 32 lanes of the wave stood at one - lane
 // utilisation 0.40, 2.6 ms for the four bounces against the wavefront's 2.4; a wavefront per BLOCK, trace and shading phases between
-// block barriers - 2.29 ms: every phase ends in the drain of its last rays, as the wavefront's launches do.)
+// block barriers - 2.29 ms: every phase ends in the drain of its last rays, as the wavefront's launches do; a pipeline per WAVE - no
+// drains, 2.65 ms at three waves per SIMD.)
 // ------------------------------------------------------------------------------------------
 // one sun ray through the grid (k_trace_sun_grid's walk for one ray): 0 = lit, 1 = occluded, 2 = the grid does not answer (border cell,
 // long list): the tree's
@@ -1624,14 +1630,27 @@ __device__ __forceinline__ int sun_grid_query(const SunGridDev& g, const float4*
 }
 
 #ifndef UH_FUSED_BLOCKS
-#define UH_FUSED_BLOCKS 3      // blocks per CU the kernel's registers (a walk's state stays live through a shading phase) and LDS are sized for
+#define UH_FUSED_BLOCKS 5      // blocks per CU the kernel's registers and LDS are sized for
 #endif
-struct FusedWaveLds {
+constexpr uint32_t kFusedWalkers = kWavesPerBlock - 1;  // the block's last wave shades
+constexpr uint32_t kFusedHitRing = 96, kFusedMissRing = 96;  // entries per walking wave (a push is at most 64)
+constexpr uint32_t kFusedPatience = 6;        // sleeps without a full batch before the shading wave takes a partial one
+constexpr uint32_t kFusedSpinLimit = 1u << 22;  // sleeps before a waiting wave gives the block up (seconds)
+struct FusedWalkerLds {
    uint32_t stack[kLdsStack][64];
    RayPool<2> pool;
-   uint32_t hits[5][128];  // entry (position | bounces left), t, u, v, packet
-   uint32_t miss[128];     // positions of the paths whose ray left the scene
+   uint32_t hits[5][kFusedHitRing];  // entry (position | bounces left), t, u, v, packet
+   uint32_t miss[kFusedMissRing];    // positions of the paths whose ray left the scene
 };
+struct FusedCtl {
+   uint32_t work_head, work_tail;  // the work ring's counters (they only grow; index = counter mod the ring's capacity)
+   uint32_t live;                  // paths of the block that have not ended
+   uint32_t abort;
+   uint32_t hit_head[kFusedWalkers], hit_tail[kFusedWalkers], miss_head[kFusedWalkers], miss_tail[kFusedWalkers];
+};
+__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 template <bool COUNT, bool INLINE>
 __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, SunGridDev g, bool use_grid,
                                                                          bool sun_of_bounce0) {
@@ -1639,31 +1658,27 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
    // (positions fit 23 bits: the host fuses only when shard_cap < 2^23; bits 23..28: how many bounces follow the entry's ray)
    constexpr uint32_t kHasRay = 1u << 31, kSun = 1u << 30, kLight = 1u << 29, kLeftShift = 23, kLeftMask = 63u << kLeftShift, kPosMask = (1u << kLeftShift) - 1u;
    __shared__ float s_lut[256];
-   constexpr uint32_t kLdsMeshes = 128, kLdsTextures = 64;
+   constexpr uint32_t kLdsMeshes = 32, kLdsTextures = 16;  // (the shading wave's tables: what is beyond them comes from global memory)
    __shared__ MeshShade s_mesh[kLdsMeshes];
    __shared__ TexInfo s_tex[kLdsTextures];
-   __shared__ FusedWaveLds s_wave[kWavesPerBlock];
+   __shared__ FusedWalkerLds s_walk[kFusedWalkers];
+   __shared__ FusedCtl s_ctl;
    const uint32_t n_lds_mesh = sc.num_meshes < kLdsMeshes ? sc.num_meshes : kLdsMeshes;
    const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
    s_lut[threadIdx.x] = sc.unorm_lut[threadIdx.x];
    if (threadIdx.x < n_lds_mesh) s_mesh[threadIdx.x] = sc.meshes[threadIdx.x];
    if (threadIdx.x < n_lds_tex) s_tex[threadIdx.x] = sc.textures[threadIdx.x];
-   __syncthreads();  // the only one: from here on a wave is on its own
    const uint32_t lane = lane_id();
    const uint32_t wave = threadIdx.x >> 6;
-   FusedWaveLds& L = s_wave[wave];
-   uint32_t* lds_col = &L.stack[0][lane];
-   RayPool<2>& pool = L.pool;
    const ShardCtx sx = shard_ctx();
    const uint32_t seg = sx.shard * ps.shard_cap;
    const PathRecs rec = ps.set[kFirst & 1];
    const uint32_t* __restrict__ ids = ps.queue[kFirst & 1] + seg;  // path id by position
-   // the wave's range of positions [lo, lo + cap)
+   // the block's range of positions [lo, lo + cap)
    const uint32_t count1 = ctl->q_count[qc_index(kFirst, Q_RAY, sx.shard)];
-   const uint32_t waves = sx.nb * kWavesPerBlock, wi = sx.lb * kWavesPerBlock + wave;
-   const uint32_t per = (((count1 + waves - 1) / waves) + 63u) & ~63u;
-   const uint32_t lo = wi * per < count1 ? wi * per : count1, cap = (lo + per < count1 ? lo + per : count1) - lo;
-   uint32_t* ring = ps.queue[0] + seg + lo;  // the work ring: `cap` entries
+   const uint32_t per = (((count1 + sx.nb - 1) / sx.nb) + 63u) & ~63u;
+   const uint32_t lo = sx.lb * per < count1 ? sx.lb * per : count1, cap = (lo + per < count1 ? lo + per : count1) - lo;
+   uint32_t* ring = ps.queue[0] + seg + lo;  // the work ring: `cap` entries (a path has at most one entry alive)
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
    const V3 sun_d = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);
@@ -1674,8 +1689,8 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
    // on the spot, what it does not answer as the entry's sun ray. (Not when lights are on: bounce 0's light rays are the wavefront's,
    // and they come after the sun rays.)
    const uint32_t left1 = (fp.num_bounces - 2u) << kLeftShift;
-   for (uint32_t i0 = 0; i0 < cap; i0 += 64u) {
-      const uint32_t i = i0 + lane;
+   for (uint32_t i0 = 0; i0 < cap; i0 += kBlock) {
+      const uint32_t i = i0 + threadIdx.x;
       const bool valid = i < cap;
       uint32_t e = (lo + i) | kHasRay | left1;
       bool to_tree = false;
@@ -1699,269 +1714,224 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
          w_sun_tree += (uint32_t)__popcll(__ballot(to_tree));
       }
    }
-   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the wave reads back what it wrote: stores first)
-   // the ring (wave-uniform): entries [head, head + avail) modulo cap are waiting; the shading phase appends at tail
-   uint32_t head = 0, tail = 0, avail = cap;
-   // the pool's feeder, k_trace_closest's without the atomic: entries of the ring -> their ids' rays by LDS-DMA, one stage per refill event
-   uint32_t pool_pos = 0, pool_n = 0, load_n = 0, q_n = 0, q_e = 0;
-   bool loading = false;
-   auto source_of = [&](int a, uint32_t e) { return (const float4*)rec_quad(rec, seg + (e & kPosMask), a == 0 ? REC_ORIGIN : REC_DIR); };
-   auto advance = [&]() {
-      if (q_n) {  // the entries loaded one event ago: their rays into the pool
-         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pool's last entries have been read
-         if (lane < q_n) {
-            dma16(source_of(0, q_e), pool.v[0]);
-            dma16(source_of(1, q_e), pool.v[1]);
-            pool.id[lane] = q_e;
-         }
-         load_n = q_n;
-         loading = true;
-         q_n = 0;
-      }
-      if (avail) {  // the next chunk of the ring (not across its end)
-         uint32_t k = avail < kPool ? avail : kPool;
-         k = k < cap - head ? k : cap - head;
-         if (lane < k) q_e = ld_stream(ring + head + lane);
-         q_n = k;
-         head = head + k == cap ? 0u : head + k;
-         avail -= k;
-      }
-   };
-   Trav t;
-   t.cur = kEmptyRef;
-   t.sp = 0;
-   enum : uint32_t { BOUNCE_RAY = 0, SUN_RAY = 1, LIGHT_RAY = 2 };
-   uint32_t kind = BOUNCE_RAY, entry = 0, rng_x = 0, mark_nodes = 0, mark_tris = 0;
-   V3 thr = v3(0, 0, 0), rad = v3(0, 0, 0), scatter = v3(0, 0, 0);
-   float lf = 0.0f;
-   uint32_t light_bits = 0;
-   bool dirty = false;
-   uint32_t spill[kSpillStack];
-   uint32_t n_hits = 0, n_miss = 0;  // wave-uniform: entries of the hit / miss lists
-   // the entry's next ray (origin = t.o): sun, light, then the bounce ray - or, behind the last bounce, the path's radiance to the
-   // per-id array (what k_flush_survivors writes)
-   auto next_ray = [&]() {
-      const float4 o4 = make_float4(t.o.x, t.o.y, t.o.z, 0.0f);
-      if (entry & kSun) {
-         entry &= ~kSun;
-         const ShadowRay s = make_shadow_ray<false>(sc, fp, o4, make_float4(thr.x, thr.y, thr.z, lf), make_float4(rad.x, rad.y, rad.z, 0.0f));
-         trav_init(t, s.ro, s.rd, s.ro.w, s.rd.w, s.tlimit);
-         kind = SUN_RAY;
-      } else if (entry & kLight) {
-         entry &= ~kLight;
-         const ShadowRay s = make_shadow_ray<true>(sc, fp, o4, make_float4(thr.x, thr.y, thr.z, lf), make_float4(rad.x, rad.y, rad.z, __uint_as_float(light_bits)));
-         trav_init(t, s.ro, s.rd, s.ro.w, s.rd.w, s.tlimit);
-         kind = LIGHT_RAY;
-      } else {
-         const uint32_t p = entry & kPosMask;
-         if (entry & kHasRay) {
-            if (dirty) st_rec(rec_quad(rec, seg + p, REC_RAD), make_float4(rad.x, rad.y, rad.z, __uint_as_float(light_bits)));
-            trav_init(t, o4, make_float4(scatter.x, scatter.y, scatter.z, 0.0f), 0.001f, 10000.0f, INFINITY);  // rgen:61, :45-47
-            kind = BOUNCE_RAY;
-         } else {  // rgen:127 after the last bounce
-            st_stream(ps.radf + ld_stream(ids + p), make_float4(rad.x, rad.y, rad.z, __uint_as_float(rng_x)));
-            t.cur = kEmptyRef;
-         }
-      }
-      if (COUNT) {
-         mark_nodes = n_nodes;
-         mark_tris = n_tris;
-      }
-   };
-   auto take = [&](uint32_t slot) {
-      entry = pool.id[slot];
-      const float4 ro = pool.v[0][slot], rd = pool.v[1][slot];
-      if (entry & (kSun | kLight)) {
-         const uint32_t p = entry & kPosMask;
-         const float4 t4 = ld_rec(rec_quad(rec, seg + p, REC_THR)), r4 = ld_rec(rec_quad(rec, seg + p, REC_RAD));
-         thr = v3(t4.x, t4.y, t4.z);
-         lf = t4.w;
-         rad = v3(r4.x, r4.y, r4.z);
-         light_bits = __float_as_uint(r4.w);
-         scatter = v3(rd.x, rd.y, rd.z);
-         rng_x = __float_as_uint(ro.w);
-         dirty = false;
-         t.o = v3(ro.x, ro.y, ro.z);
-         next_ray();
-      } else {
-         trav_init(t, ro, rd, 0.001f, 10000.0f, INFINITY);  // rgen:45-47
-         kind = BOUNCE_RAY;
-      }
-   };
-   // ---- shading of the first `n` (<= 64) entries of the hit list; the scattered paths' entries go to the ring
-   auto shade = [&](uint32_t n) {
-      const bool valid = lane < n;
-      bool scattered = false, want_light = false, to_tree = false, keep = false;
-      uint32_t flags = 0, p = 0;
-      if (valid) {
-         const uint32_t pl = L.hits[0][lane];
-         const float hr_t = __uint_as_float(L.hits[1][lane]), hr_u = __uint_as_float(L.hits[2][lane]), hr_v = __uint_as_float(L.hits[3][lane]);
-         const uint32_t pk = L.hits[4][lane];
-         p = pl & kPosMask;
-         const uint32_t left = (pl & kLeftMask) >> kLeftShift;
-         const bool last = left == 0u;
-         const uint32_t id = ld_stream(ids + p);
-         const float4 ro = ld_rec(rec_quad(rec, seg + p, REC_ORIGIN)), rd = ld_rec(rec_quad(rec, seg + p, REC_DIR)), thr4 = ld_rec(rec_quad(rec, seg + p, REC_THR)),
-                      rad4 = ld_rec(rec_quad(rec, seg + p, REC_RAD));
-         uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
-         const V3 ray_dir = v3(rd.x, rd.y, rd.z);
-         const float4* sp = sc.shade + 4 * (size_t)pk;
-         const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-         const uint32_t mesh_index = __float_as_uint(s3.w);
-         MeshShade ms = lds_fetch(s_mesh + (mesh_index < kLdsMeshes ? mesh_index : kLdsMeshes - 1));  // rchit:22-23
-         if (mesh_index >= n_lds_mesh) ms = sc.meshes[mesh_index];
-         V3 normal;
-         float uu, vv;
-         surface_normal_uv(s0, s1, s2, s3, hr_u, hr_v, normal, uu, vv);                // rchit:30-31, :39
-         const V3 world_normal = world_normal_of(ms, normal, ray_dir);                 // rchit:32-37
-         V3 origin = v3(ro.x, ro.y, ro.z) + hr_t * ray_dir;                            // rgen:59
-         origin = offset_ray(origin, world_normal);                                    // rgen:60
-         scattered = path_scatters(ms, ray_dir, world_normal);
-         V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);  // rchit:40
-         color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
-         uint32_t seed = rng.y;
-         const V3 sc_dir = material_scatter(ms, ray_dir, world_normal, color, seed);   // rchit:47-89
-         rng.y = seed;                                                                 // rchit:91
-         const V3 th = v3(thr4.x, thr4.y, thr4.z) * color;                             // rgen:48
-         V3 ra = v3(rad4.x, rad4.y, rad4.z);
-         if (!scattered) {                                                             // rgen:53-57: the path ends here
-            st_stream(ps.radf + id, make_float4(ra.x + th.x, ra.y + th.y, ra.z + th.z, __uint_as_float(rng.x)));
-         } else {
-            float f = 0.0f;
-            int light_index = 0;
-            if (fp.lights_enabled == 1) want_light = select_light(fp, sc, id, rng.x, origin, f, light_index);  // rgen:81-121
-            if (fp.sun_shadow_enabled == 1) {                                          // rgen:63-79
-               int r = use_grid ? sun_grid_query<COUNT, INLINE>(g, tris, origin, sun_d, n_stris, n_covered) : 2;
-               if (COUNT && use_grid) n_snodes++;  // every sun ray looked one cell up
-               if (r == 0) ra = v3(ra.x + th.x, ra.y + th.y, ra.z + th.z);               // rgen:69-78
-               if (r == 2) flags |= kSun;
-               to_tree = r == 2 && use_grid;
-            }
-            if (want_light) flags |= kLight;
-            if (!last) flags |= kHasRay | ((left - 1u) << kLeftShift);
-            keep = (flags & (kHasRay | kSun | kLight)) != 0u;
-            if (!keep) {  // behind the last bounce with no shadow ray out: rgen:127 (what k_flush_survivors writes)
-               st_stream(ps.radf + id, make_float4(ra.x, ra.y, ra.z, __uint_as_float(rng.x)));
-            } else {  // the path's state, in place
-               st_rec(rec_quad(rec, seg + p, REC_ORIGIN), make_float4(origin.x, origin.y, origin.z, __uint_as_float(rng.x)));
-               st_rec(rec_quad(rec, seg + p, REC_DIR), make_float4(sc_dir.x, sc_dir.y, sc_dir.z, __uint_as_float(rng.y)));  // rgen:61
-               st_rec(rec_quad(rec, seg + p, REC_THR), make_float4(th.x, th.y, th.z, f));
-               st_rec(rec_quad(rec, seg + p, REC_RAD), make_float4(ra.x, ra.y, ra.z, __uint_as_float((uint32_t)light_index)));
-            }
-         }
-      }
-      // the kept paths' entries to the ring's tail
-      const unsigned long long km = __ballot(keep);
-      if (km) {
-         uint32_t at = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-         at = at >= cap ? at - cap : at;
-         if (keep) ring[at] = p | flags;
-         const uint32_t nk = (uint32_t)__popcll(km);
-         tail = tail + nk >= cap ? tail + nk - cap : tail + nk;
-         avail += nk;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (records and entries are read back by this wave: stores first)
-      w_hits += n;
-      if (fp.sun_shadow_enabled == 1) w_sun += (uint32_t)__popcll(__ballot(scattered));
-      w_sun_tree += (uint32_t)__popcll(__ballot(to_tree));
-      w_light += (uint32_t)__popcll(__ballot(want_light));
-      // the list's tail (at most 63 entries) to the front: one wave, LDS operations execute in order
-      const uint32_t rest = n_hits - n;
-      uint32_t tmp[5] = {0, 0, 0, 0, 0};
-      if (lane < rest)
-         for (int k = 0; k < 5; k++) tmp[k] = L.hits[k][n + lane];
-      __builtin_amdgcn_wave_barrier();
-      if (lane < rest)
-         for (int k = 0; k < 5; k++) L.hits[k][lane] = tmp[k];
-      __builtin_amdgcn_wave_barrier();
-      n_hits = rest;
-   };
-   // reference.rmiss for the first `n` (<= 64) paths of the miss list: their state is where shade_miss_path reads it (their records of
-   // set 1, untouched since their ray was made)
-   auto integrate_sky = [&](uint32_t n) {
-      if (lane < n) {
-         const uint32_t p = L.miss[lane];
-         shade_miss_path(fp, ps, seg + p, ld_stream(ids + p), kFirst);
-      }
-      w_miss += n;
-      const uint32_t rest = n_miss - n;
-      uint32_t tmp = 0;
-      if (lane < rest) tmp = L.miss[n + lane];
-      __builtin_amdgcn_wave_barrier();
-      if (lane < rest) L.miss[lane] = tmp;
-      __builtin_amdgcn_wave_barrier();
-      n_miss = rest;
-   };
+   if (threadIdx.x == 0) {
+      s_ctl.work_head = 0;
+      s_ctl.work_tail = cap;
+      s_ctl.live = cap;
+      s_ctl.abort = 0;
+      for (uint32_t w = 0; w < kFusedWalkers; w++) s_ctl.hit_head[w] = s_ctl.hit_tail[w] = s_ctl.miss_head[w] = s_ctl.miss_tail[w] = 0;
+   }
+   __syncthreads();  // the only one (workgroup-scope release / acquire: the entries and records above are visible to the block's waves)
 
-   for (uint32_t iterations = 0; iterations < (1u << 24); iterations++) {  // (an exit every wave reaches whatever the data)
-      const bool lane_idle = t.cur == kEmptyRef;
-      const unsigned long long idle = __ballot(lane_idle);
-      uint32_t shade_n = 0, sky_n = 0;  // (one call site each: the shading code is in the kernel once)
-      if (idle != 0ull) {
-         const uint32_t n_idle = (uint32_t)__popcll(idle);
-         if (loading) {  // the DMA issued one event ago has landed (its wait also covers every older load of the wave)
-            wait_vm0();
-            pool_pos = 0;
-            pool_n = load_n;
-            loading = false;
+   if (wave < kFusedWalkers) {
+      // ================= a walking wave
+      FusedWalkerLds& L = s_walk[wave];
+      uint32_t* lds_col = &L.stack[0][lane];
+      RayPool<2>& pool = L.pool;
+      uint32_t hit_tail = 0, miss_tail = 0;  // this wave's rings: it owns the tails
+      uint32_t pool_pos = 0, pool_n = 0, load_n = 0, q_n = 0, q_e = 0;
+      bool loading = false;
+      auto source_of = [&](int a, uint32_t e) { return (const float4*)rec_quad(rec, seg + (e & kPosMask), a == 0 ? REC_ORIGIN : REC_DIR); };
+      // the pool's feeder, k_trace_closest's: entries claimed from the ring -> their rays by LDS-DMA, one stage per refill event
+      auto advance = [&]() {
+         if (q_n) {  // the entries loaded one event ago: their rays into the pool
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pool's last entries have been read
+            if (lane < q_n) {
+               dma16(source_of(0, q_e), pool.v[0]);
+               dma16(source_of(1, q_e), pool.v[1]);
+               pool.id[lane] = q_e;
+            }
+            load_n = q_n;
+            loading = true;
+            q_n = 0;
          }
-         const uint32_t in_pool = pool_n - pool_pos;
-         if (in_pool != 0 && (n_idle >= (uint32_t)kRefill || n_idle == 64u)) {
-            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            if (lane_idle && prefix < in_pool) take(pool_pos + prefix);
-            pool_pos += n_idle < in_pool ? n_idle : in_pool;
-         }
-         if (pool_pos >= pool_n && !loading) {
-            if (q_n == 0 && avail == 0) {
-               if (n_idle == 64u && in_pool == 0) {  // nothing waiting, nothing in flight: what is left is in the lists
-                  if (n_hits) shade_n = n_hits < 64u ? n_hits : 64u;  // (may put new entries into the ring)
-                  else if (n_miss) sky_n = n_miss;                     // the last misses: on a partial wave, once
-                  else break;
+         // the next chunk of the ring (not across its end): a compare-and-swap on the head, the three walkers being its only takers
+         uint32_t k = 0, base = 0;
+         if (lane == 0) {
+            for (int tries = 0; tries < 8; tries++) {
+               const uint32_t h = lds_load(&s_ctl.work_head), a = lds_load(&s_ctl.work_tail) - h;
+               if (a == 0u) break;
+               const uint32_t at = h % cap;
+               uint32_t kk = a < kPool ? a : kPool;
+               kk = kk < cap - at ? kk : cap - at;
+               if (atomicCAS(&s_ctl.work_head, h, h + kk) == h) {
+                  k = kk;
+                  base = at;
+                  break;
                }
-            } else
-               advance();
-         }
-      }
-      bool push_hit = false, push_miss = false;
-      if (t.cur != kEmptyRef) {
-         bool occluded = false;
-         bool ended = trav_step<false, COUNT, true>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris);
-         // a shadow ray is a predicate: occluded <=> some triangle accepts it within (tmin, tmax) and the light's distance <=> the
-         // closest such hit lies within it - the walk can stop at the first hit it finds there (rgen:69, :118-119 read nothing else)
-         const bool blocked = t.best.idx != kEmptyRef && t.best.t <= t.tlimit;
-         if (kind != BOUNCE_RAY && blocked) ended = true;
-         if (ended) {
-            if (kind == BOUNCE_RAY) {
-               push_hit = t.best.idx != kEmptyRef;
-               push_miss = !push_hit;
-               t.cur = kEmptyRef;
-            } else {
-               // rgen:69-78 / :118-122: an unoccluded ray adds the path's throughput (x the light's weight) to its radiance
-               if (!blocked) {
-                  rad = kind == SUN_RAY ? v3(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z) : v3(rad.x + thr.x * lf, rad.y + thr.y * lf, rad.z + thr.z * lf);
-                  dirty = true;
-               }
-               if (COUNT) {  // the walk's visits belong to the shadow counters
-                  const uint32_t dn = n_nodes - mark_nodes, dt = n_tris - mark_tris;
-                  n_nodes = mark_nodes;
-                  n_tris = mark_tris;
-                  if (kind == SUN_RAY) {
-                     n_snodes += dn;
-                     n_stris += dt;
-                  } else {
-                     n_lnodes += dn;
-                     n_ltris += dt;
-                  }
-               }
-               next_ray();  // (t.o is still the point the path's rays leave from)
             }
          }
-      }
-      const unsigned long long hm = __ballot(push_hit), mm = __ballot(push_miss);
-      if ((hm | mm) != 0ull) {
+         k = __builtin_amdgcn_readfirstlane(k);
+         base = __builtin_amdgcn_readfirstlane(base);
+         if (k) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < k) q_e = ld_stream(ring + base + lane);
+            q_n = k;
+         }
+      };
+      Trav t;
+      t.cur = kEmptyRef;
+      t.sp = 0;
+      enum : uint32_t { BOUNCE_RAY = 0, SUN_RAY = 1, LIGHT_RAY = 2 };
+      uint32_t kind = BOUNCE_RAY, entry = 0, rng_x = 0, mark_nodes = 0, mark_tris = 0;
+      V3 thr = v3(0, 0, 0), rad = v3(0, 0, 0), scatter = v3(0, 0, 0);
+      float lf = 0.0f;
+      uint32_t light_bits = 0;
+      bool dirty = false, path_done = false;
+      uint32_t spill[kSpillStack];
+      // the entry's next ray (origin = t.o): sun, light, then the bounce ray - or, behind the last bounce, the path's radiance to the
+      // per-id array (what k_flush_survivors writes)
+      auto next_ray = [&]() {
+         const float4 o4 = make_float4(t.o.x, t.o.y, t.o.z, 0.0f);
+         if (entry & kSun) {
+            entry &= ~kSun;
+            const ShadowRay s = make_shadow_ray<false>(sc, fp, o4, make_float4(thr.x, thr.y, thr.z, lf), make_float4(rad.x, rad.y, rad.z, 0.0f));
+            trav_init(t, s.ro, s.rd, s.ro.w, s.rd.w, s.tlimit);
+            kind = SUN_RAY;
+         } else if (entry & kLight) {
+            entry &= ~kLight;
+            const ShadowRay s = make_shadow_ray<true>(sc, fp, o4, make_float4(thr.x, thr.y, thr.z, lf), make_float4(rad.x, rad.y, rad.z, __uint_as_float(light_bits)));
+            trav_init(t, s.ro, s.rd, s.ro.w, s.rd.w, s.tlimit);
+            kind = LIGHT_RAY;
+         } else {
+            const uint32_t p = entry & kPosMask;
+            if (entry & kHasRay) {
+               if (dirty) st_rec(rec_quad(rec, seg + p, REC_RAD), make_float4(rad.x, rad.y, rad.z, __uint_as_float(light_bits)));
+               trav_init(t, o4, make_float4(scatter.x, scatter.y, scatter.z, 0.0f), 0.001f, 10000.0f, INFINITY);  // rgen:61, :45-47
+               kind = BOUNCE_RAY;
+            } else {  // rgen:127 after the last bounce
+               st_stream(ps.radf + ld_stream(ids + p), make_float4(rad.x, rad.y, rad.z, __uint_as_float(rng_x)));
+               t.cur = kEmptyRef;
+               path_done = true;
+            }
+         }
+         if (COUNT) {
+            mark_nodes = n_nodes;
+            mark_tris = n_tris;
+         }
+      };
+      auto take = [&](uint32_t slot) {
+         entry = pool.id[slot];
+         const float4 ro = pool.v[0][slot], rd = pool.v[1][slot];
+         if (entry & (kSun | kLight)) {
+            const uint32_t p = entry & kPosMask;
+            const float4 t4 = ld_rec(rec_quad(rec, seg + p, REC_THR)), r4 = ld_rec(rec_quad(rec, seg + p, REC_RAD));
+            thr = v3(t4.x, t4.y, t4.z);
+            lf = t4.w;
+            rad = v3(r4.x, r4.y, r4.z);
+            light_bits = __float_as_uint(r4.w);
+            scatter = v3(rd.x, rd.y, rd.z);
+            rng_x = __float_as_uint(ro.w);
+            dirty = false;
+            t.o = v3(ro.x, ro.y, ro.z);
+            next_ray();
+         } else {
+            trav_init(t, ro, rd, 0.001f, 10000.0f, INFINITY);  // rgen:45-47
+            kind = BOUNCE_RAY;
+         }
+      };
+      uint32_t sleeps = 0;
+#ifdef UH_FUSED_PROFILE  // (measurement only, with count_visits: a walker's clock - all / waiting for work / waiting for room in its rings; the shading wave's - all / busy; in the light counters)
+      unsigned long long c_begin = wall_clock64(), c_work = 0, c_room = 0;
+#endif
+      for (uint32_t iterations = 0; iterations < (1u << 24); iterations++) {  // (an exit every wave reaches whatever the data)
+         const bool lane_idle = t.cur == kEmptyRef;
+         const unsigned long long idle = __ballot(lane_idle);
+         if (idle != 0ull) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (loading) {  // the DMA issued one event ago has landed (its wait also covers every older load of the wave)
+               wait_vm0();
+               pool_pos = 0;
+               pool_n = load_n;
+               loading = false;
+            }
+            const uint32_t in_pool = pool_n - pool_pos;
+            if (in_pool != 0 && (n_idle >= (uint32_t)kRefill || n_idle == 64u)) {
+               const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+               if (lane_idle && prefix < in_pool) take(pool_pos + prefix);
+               pool_pos += n_idle < in_pool ? n_idle : in_pool;
+            }
+            if (pool_pos >= pool_n && !loading) {
+               advance();
+               if (q_n == 0 && !loading && n_idle == 64u && in_pool == 0) {
+                  // nothing to walk and nothing claimed: the block's paths are with the shading wave, in another walker - or all ended
+                  if (lds_load(&s_ctl.live) == 0u || lds_load(&s_ctl.abort) != 0u) break;
+                  if (++sleeps > kFusedSpinLimit) {
+                     lds_store(&s_ctl.abort, 1u);
+                     break;
+                  }
+#ifdef UH_FUSED_PROFILE
+                  const unsigned long long c0 = wall_clock64();
+#endif
+                  __builtin_amdgcn_s_sleep(8);
+#ifdef UH_FUSED_PROFILE
+                  c_work += wall_clock64() - c0;
+#endif
+                  continue;
+               }
+            }
+         }
+         bool push_hit = false, push_miss = false;
+         path_done = false;
+         if (t.cur != kEmptyRef) {
+            bool occluded = false;
+            bool ended = trav_step<false, COUNT, true>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris);
+            // a shadow ray is a predicate: occluded <=> some triangle accepts it within (tmin, tmax) and the light's distance <=> the
+            // closest such hit lies within it - the walk can stop at the first hit it finds there (rgen:69, :118-119 read nothing else)
+            const bool blocked = t.best.idx != kEmptyRef && t.best.t <= t.tlimit;
+            if (kind != BOUNCE_RAY && blocked) ended = true;
+            if (ended) {
+               if (kind == BOUNCE_RAY) {
+                  push_hit = t.best.idx != kEmptyRef;
+                  push_miss = !push_hit;
+                  t.cur = kEmptyRef;
+               } else {
+                  // rgen:69-78 / :118-122: an unoccluded ray adds the path's throughput (x the light's weight) to its radiance
+                  if (!blocked) {
+                     rad = kind == SUN_RAY ? v3(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z) : v3(rad.x + thr.x * lf, rad.y + thr.y * lf, rad.z + thr.z * lf);
+                     dirty = true;
+                  }
+                  if (COUNT) {  // the walk's visits belong to the shadow counters
+                     const uint32_t dn = n_nodes - mark_nodes, dt = n_tris - mark_tris;
+                     n_nodes = mark_nodes;
+                     n_tris = mark_tris;
+                     if (kind == SUN_RAY) {
+                        n_snodes += dn;
+                        n_stris += dt;
+                     } else {
+                        n_lnodes += dn;
+                        n_ltris += dt;
+                     }
+                  }
+                  next_ray();  // (t.o is still the point the path's rays leave from)
+               }
+            }
+         }
+         const unsigned long long hm = __ballot(push_hit), mm = __ballot(push_miss), dm = __ballot(path_done);
+         if ((hm | mm | dm) == 0ull) continue;
          w_rays += (uint32_t)__popcll(hm) + (uint32_t)__popcll(mm);
+         if (dm) {  // paths that ended in this wave (their last shadow ray came back)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicSub(&s_ctl.live, (uint32_t)__popcll(dm));
+         }
          if (hm) {
-            const uint32_t at = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+            const uint32_t nh = (uint32_t)__popcll(hm);
+#ifdef UH_FUSED_PROFILE
+            const unsigned long long c0 = wall_clock64();
+#endif
+            // room in the ring: the shading wave moves the head
+            for (uint32_t spins = 0; hit_tail + nh - lds_load(&s_ctl.hit_head[wave]) > kFusedHitRing; spins++) {
+               if (lds_load(&s_ctl.abort) != 0u) break;
+               if (spins > kFusedSpinLimit) {
+                  lds_store(&s_ctl.abort, 1u);
+                  break;
+               }
+               __builtin_amdgcn_s_sleep(4);
+            }
+#ifdef UH_FUSED_PROFILE
+            c_room += wall_clock64() - c0;
+#endif
+            const uint32_t at = (hit_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u))) % kFusedHitRing;
             if (push_hit) {
                L.hits[0][at] = entry & (kPosMask | kLeftMask);
                L.hits[1][at] = __float_as_uint(t.best.t);
@@ -1969,19 +1939,199 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
                L.hits[3][at] = __float_as_uint(t.best.v);
                L.hits[4][at] = t.best.idx;
             }
-            n_hits += (uint32_t)__popcll(hm);
+            hit_tail += nh;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entries, then the tail
+            if (lane == 0) lds_store(&s_ctl.hit_tail[wave], hit_tail);
          }
          if (mm) {
-            const uint32_t at = n_miss + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            const uint32_t nm = (uint32_t)__popcll(mm);
+            for (uint32_t spins = 0; miss_tail + nm - lds_load(&s_ctl.miss_head[wave]) > kFusedMissRing; spins++) {
+               if (lds_load(&s_ctl.abort) != 0u) break;
+               if (spins > kFusedSpinLimit) {
+                  lds_store(&s_ctl.abort, 1u);
+                  break;
+               }
+               __builtin_amdgcn_s_sleep(4);
+            }
+            const uint32_t at = (miss_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))) % kFusedMissRing;
             if (push_miss) L.miss[at] = entry & kPosMask;
-            n_miss += (uint32_t)__popcll(mm);
+            miss_tail += nm;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) lds_store(&s_ctl.miss_tail[wave], miss_tail);
          }
-         __builtin_amdgcn_wave_barrier();
-         if (n_hits >= 64u) shade_n = 64u;
-         if (n_miss >= 64u) sky_n = 64u;
+         if (lds_load(&s_ctl.abort) != 0u) break;
       }
-      if (shade_n) shade(shade_n);
-      if (sky_n) integrate_sky(sky_n);
+#ifdef UH_FUSED_PROFILE
+      if (COUNT && lane == 0) {
+         atomicAdd(&stats->light_nodes_visited, wall_clock64() - c_begin);
+         atomicAdd(&stats->light_tris_tested, c_work);
+         atomicAdd(&stats->sun_covered_rays, c_room);
+      }
+#endif
+   } else {
+      // ================= the shading wave
+#ifdef UH_FUSED_PROFILE
+      unsigned long long c_begin = wall_clock64(), c_idle = 0;
+#endif
+      uint32_t hit_head[kFusedWalkers], miss_head[kFusedWalkers];  // it owns the rings' heads (wave-uniform)
+      for (uint32_t w = 0; w < kFusedWalkers; w++) hit_head[w] = miss_head[w] = 0;
+      uint32_t tail = cap;  // and the work ring's tail
+      uint32_t waited = 0, sleeps = 0;
+      for (;;) {
+         uint32_t hc[kFusedWalkers], mc[kFusedWalkers], h = 0, m = 0;
+         for (uint32_t w = 0; w < kFusedWalkers; w++) {
+            hc[w] = lds_load(&s_ctl.hit_tail[w]) - hit_head[w];
+            mc[w] = lds_load(&s_ctl.miss_tail[w]) - miss_head[w];
+            h += hc[w];
+            m += mc[w];
+         }
+         const bool take_hits = h >= 64u || (h != 0u && waited > kFusedPatience);
+         const bool take_miss = !take_hits && (m >= 64u || (m != 0u && waited > kFusedPatience));
+         if (!take_hits && !take_miss) {
+            if (lds_load(&s_ctl.live) == 0u || lds_load(&s_ctl.abort) != 0u) break;
+            if (++sleeps > kFusedSpinLimit) {
+               lds_store(&s_ctl.abort, 1u);
+               break;
+            }
+            waited++;
+#ifdef UH_FUSED_PROFILE
+            const unsigned long long c0 = wall_clock64();
+#endif
+            __builtin_amdgcn_s_sleep(16);
+#ifdef UH_FUSED_PROFILE
+            c_idle += wall_clock64() - c0;
+#endif
+            continue;
+         }
+         waited = 0;
+         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the tails, then the entries
+         // lane k takes the k-th waiting entry, the rings in order
+         uint32_t n = 0, from = 0, at = 0;
+         {
+            uint32_t k = lane;
+            bool found = false;
+            for (uint32_t w = 0; w < kFusedWalkers; w++) {
+               const uint32_t c = take_hits ? hc[w] : mc[w];
+               const uint32_t tk = c < 64u - n ? c : 64u - n;  // entries this batch takes from ring w
+               if (!found && k < tk) {
+                  from = w;
+                  at = ((take_hits ? hit_head[w] : miss_head[w]) + k) % (take_hits ? kFusedHitRing : kFusedMissRing);
+                  found = true;
+               }
+               if (!found) k -= tk;
+               n += tk;
+               if (take_hits) hit_head[w] += tk;
+               else miss_head[w] += tk;
+            }
+         }
+         const bool valid = lane < n;
+         uint32_t ended = 0;  // paths that end in this batch (wave-uniform)
+         if (take_miss) {
+            // reference.rmiss: the paths' state is where shade_miss_path reads it (their records of set 1, untouched since their ray was made)
+            uint32_t p = 0;
+            if (valid) p = s_walk[from].miss[at];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // read, then the heads
+            if (lane == 0)
+               for (uint32_t w = 0; w < kFusedWalkers; w++) lds_store(&s_ctl.miss_head[w], miss_head[w]);
+            if (valid) shade_miss_path(fp, ps, seg + p, ld_stream(ids + p), kFirst);
+            w_miss += n;
+            ended = n;
+         } else {
+            uint32_t pl = 0, pk = 0;
+            float hr_t = 0.0f, hr_u = 0.0f, hr_v = 0.0f;
+            if (valid) {
+               const FusedWalkerLds& R = s_walk[from];
+               pl = R.hits[0][at];
+               hr_t = __uint_as_float(R.hits[1][at]);
+               hr_u = __uint_as_float(R.hits[2][at]);
+               hr_v = __uint_as_float(R.hits[3][at]);
+               pk = R.hits[4][at];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // read, then the heads
+            if (lane == 0)
+               for (uint32_t w = 0; w < kFusedWalkers; w++) lds_store(&s_ctl.hit_head[w], hit_head[w]);
+            bool scattered = false, want_light = false, to_tree = false, keep = false;
+            uint32_t flags = 0;
+            const uint32_t p = pl & kPosMask;
+            if (valid) {
+               const uint32_t left = (pl & kLeftMask) >> kLeftShift;
+               const bool last = left == 0u;
+               const uint32_t id = ld_stream(ids + p);
+               const float4 ro = ld_rec(rec_quad(rec, seg + p, REC_ORIGIN)), rd = ld_rec(rec_quad(rec, seg + p, REC_DIR)), thr4 = ld_rec(rec_quad(rec, seg + p, REC_THR)),
+                            rad4 = ld_rec(rec_quad(rec, seg + p, REC_RAD));
+               uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
+               const V3 ray_dir = v3(rd.x, rd.y, rd.z);
+               const float4* sp = sc.shade + 4 * (size_t)pk;
+               const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+               const uint32_t mesh_index = __float_as_uint(s3.w);
+               MeshShade ms = lds_fetch(s_mesh + (mesh_index < kLdsMeshes ? mesh_index : kLdsMeshes - 1));  // rchit:22-23
+               if (mesh_index >= n_lds_mesh) ms = sc.meshes[mesh_index];
+               V3 normal;
+               float uu, vv;
+               surface_normal_uv(s0, s1, s2, s3, hr_u, hr_v, normal, uu, vv);                // rchit:30-31, :39
+               const V3 world_normal = world_normal_of(ms, normal, ray_dir);                 // rchit:32-37
+               V3 origin = v3(ro.x, ro.y, ro.z) + hr_t * ray_dir;                            // rgen:59
+               origin = offset_ray(origin, world_normal);                                    // rgen:60
+               scattered = path_scatters(ms, ray_dir, world_normal);
+               V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);  // rchit:40
+               color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
+               uint32_t seed = rng.y;
+               const V3 sc_dir = material_scatter(ms, ray_dir, world_normal, color, seed);   // rchit:47-89
+               rng.y = seed;                                                                 // rchit:91
+               const V3 th = v3(thr4.x, thr4.y, thr4.z) * color;                             // rgen:48
+               V3 ra = v3(rad4.x, rad4.y, rad4.z);
+               if (!scattered) {                                                             // rgen:53-57: the path ends here
+                  st_stream(ps.radf + id, make_float4(ra.x + th.x, ra.y + th.y, ra.z + th.z, __uint_as_float(rng.x)));
+               } else {
+                  float f = 0.0f;
+                  int light_index = 0;
+                  if (fp.lights_enabled == 1) want_light = select_light(fp, sc, id, rng.x, origin, f, light_index);  // rgen:81-121
+                  if (fp.sun_shadow_enabled == 1) {                                          // rgen:63-79
+                     int r = use_grid ? sun_grid_query<COUNT, INLINE>(g, tris, origin, sun_d, n_stris, n_covered) : 2;
+                     if (COUNT && use_grid) n_snodes++;  // every sun ray looked one cell up
+                     if (r == 0) ra = v3(ra.x + th.x, ra.y + th.y, ra.z + th.z);               // rgen:69-78
+                     if (r == 2) flags |= kSun;
+                     to_tree = r == 2 && use_grid;
+                  }
+                  if (want_light) flags |= kLight;
+                  if (!last) flags |= kHasRay | ((left - 1u) << kLeftShift);
+                  keep = (flags & (kHasRay | kSun | kLight)) != 0u;
+                  if (!keep) {  // behind the last bounce with no shadow ray out: rgen:127 (what k_flush_survivors writes)
+                     st_stream(ps.radf + id, make_float4(ra.x, ra.y, ra.z, __uint_as_float(rng.x)));
+                  } else {  // the path's state, in place
+                     st_rec(rec_quad(rec, seg + p, REC_ORIGIN), make_float4(origin.x, origin.y, origin.z, __uint_as_float(rng.x)));
+                     st_rec(rec_quad(rec, seg + p, REC_DIR), make_float4(sc_dir.x, sc_dir.y, sc_dir.z, __uint_as_float(rng.y)));  // rgen:61
+                     st_rec(rec_quad(rec, seg + p, REC_THR), make_float4(th.x, th.y, th.z, f));
+                     st_rec(rec_quad(rec, seg + p, REC_RAD), make_float4(ra.x, ra.y, ra.z, __uint_as_float((uint32_t)light_index)));
+                  }
+               }
+            }
+            // the kept paths' entries to the work ring's tail
+            const unsigned long long km = __ballot(keep);
+            if (km) {
+               const uint32_t idx = (tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))) % cap;
+               if (keep) ring[idx] = p | flags;
+               tail += (uint32_t)__popcll(km);
+               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // records and entries, then the tail
+               if (lane == 0) lds_store(&s_ctl.work_tail, tail);
+            }
+            w_hits += n;
+            if (fp.sun_shadow_enabled == 1) w_sun += (uint32_t)__popcll(__ballot(scattered));
+            w_sun_tree += (uint32_t)__popcll(__ballot(to_tree));
+            w_light += (uint32_t)__popcll(__ballot(want_light));
+            ended = n - (uint32_t)__popcll(km);
+         }
+         if (ended) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicSub(&s_ctl.live, ended);
+         }
+      }
+#ifdef UH_FUSED_PROFILE
+      if (COUNT && lane == 0) {
+         atomicAdd(&stats->cam_tris_tested, wall_clock64() - c_begin);
+         atomicAdd(&stats->cam_tree_rays, c_idle);
+      }
+#endif
    }
    if (lane == 0) {
       if (w_rays) atomicAdd(&stats->rays[UH_RAY_BOUNCE], (unsigned long long)w_rays);
@@ -1990,6 +2140,7 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
       if (w_sun_tree) atomicAdd(&stats->sun_tree_rays, (unsigned long long)w_sun_tree);
       if (w_light) atomicAdd(&stats->rays[UH_RAY_LIGHT_SHADOW], (unsigned long long)w_light);
       if (w_miss) atomicAdd(&stats->misses, (unsigned long long)w_miss);
+      if (wave == 0 && lds_load(&s_ctl.abort) != 0u) atomicAdd(&stats->fused_aborts, 1ull);
    }
    if (COUNT) {
       atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
