@@ -227,7 +227,7 @@ typedef struct UhStats {
    uint64_t light_nodes_visited; /* BVH4 nodes fetched / triangle packets tested by the light shadow rays' walks (option "count_visits"); */
    uint64_t light_tris_tested;   /* not part of shadow_nodes_visited / shadow_tris_tested, which count the sun rays */
    uint32_t trace_light_launches;
-   uint32_t fused_aborts;       /* blocks of the fused one-frame kernel that gave up a wait: a frame with one is wrong (never seen; tests assert 0) */
+   uint32_t reserved1;
 } UhStats;
 
 typedef struct uh_ctx uh_ctx;

@@ -195,7 +195,7 @@ struct uh_ctx {
    // one frame per call: bounces 1 .. of a lone frame inside one persistent kernel (k_path_fused) instead of four launches per bounce
    bool fused_bounces = true;  // option "fused_bounces"
    bool fused_always = false;  // fused_bounces = -1: also with frames in flight (tests)
-   uint32_t fused_blocks_per_cu = 5;
+   uint32_t fused_blocks_per_cu = 4;
    static constexpr uint32_t kSingleFrameBlocksPerCu = 4;  // the cap on both for a wavefront of one frame (fewer persistent waves reach the end of a small launch's tail sooner: round 4's sweep)
    std::string err;
 
@@ -1919,7 +1919,6 @@ int uh_get_stats(uh_ctx* c, UhStats* out) {
    out->camera_grid_ms = c->ms_by_kind[3];
    out->trace_light_ms = c->ms_by_kind[4];
    out->trace_light_launches = c->trace_light_launches;
-   out->fused_aborts = (uint32_t)std::min<unsigned long long>(ds.fused_aborts, 0xffffffffull);
    out->light_nodes_visited = ds.light_nodes_visited;
    out->light_tris_tested = ds.light_tris_tested;
    out->trace_closest_launches = c->trace_closest_launches;

@@ -63,7 +63,6 @@ struct DeviceStats {
    unsigned long long cam_tris_tested;  // triangle packets k_trace_camera_grid tested (count_visits)
    unsigned long long sun_covered_rays; // sun rays k_trace_sun_grid answered from the cell's cover depth alone (count_visits)
    unsigned long long light_nodes_visited, light_tris_tested;  // the light shadow rays' walks (count_visits)
-   unsigned long long fused_aborts;  // blocks of k_path_fused that gave up a wait (a frame with one is wrong; never seen)
 };
 
 // per-mesh shading record (80 B): inverse instance rotation/scale + the material fields the
@@ -201,7 +200,7 @@ struct LaunchCfg {
    uint32_t num_cus;
    uint32_t closest_blocks_per_cu, shadow_blocks_per_cu;
    bool count_visits;
-   uint32_t fused_blocks_per_cu = 5;  // k_path_fused (kernels.hip UH_FUSED_BLOCKS)
+   uint32_t fused_blocks_per_cu = 4;  // k_path_fused (kernels.hip UH_FUSED_BLOCKS)
 };
 
 void launch_generate(const LaunchCfg&, const FrameParams&, const PathState&, Control*, uint32_t sample);

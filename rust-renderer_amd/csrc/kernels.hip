@@ -1539,33 +1539,34 @@ __global__ __launch_bounds__(kBlock) void k_flush_survivors(FrameParams fp, Path
 // path_fused - ONE FRAME PER CALL (a moving camera, renderers/mod.rs:357, main.rs:460-471): bounces 1 .. num_bounces - 1 of a lone
 // frame inside one persistent kernel. A lone frame's wavefront is some 28 launches of which every traversal launch ends in the tail of
 // its longest ray (about 60 dependent steps: 0.30-0.38 ms per bounce for 1.5 M rays against 0.19 ms at the batched rate, DESIGN.md
-// section 4) - nothing of the same frame can fill those tails across a launch boundary. Here EVERY BLOCK IS A PIPELINE of its own over
-// a contiguous range of the positions of bounce 1's ray queue (its shard's count / blocks of the shard), with no word to any other block:
-//   * THREE WALKING WAVES: persistent over the block's WORK RING (entries p | flags in the block's range of a queue array; chunks of
-//     64 claimed from a head counter in LDS), lanes refilled from an LDS pool as in k_trace_closest. A lane whose bounce ray has ended
-//     leaves the hit in its wave's hit ring (LDS) - or its path in the miss ring - and takes the next ray at once: a walking wave holds
-//     nothing but rays, and runs dry only once, when the block's paths have all ended.
-//   * ONE SHADING WAVE: takes 64 hits at a time from the three hit rings, shades them (k_shade_hit's arithmetic), asks the sun grid on
-//     the spot, rewrites the paths' state IN PLACE (a path's record stays at its position of bounce 1's queue for the whole kernel) and
-//     appends an entry per scattered path to the work ring - the next bounce's rays are walked beside the stragglers of this one;
-//     and it integrates the sky (reference.rmiss) for 64 missed paths at a time. It holds no ray, so the kernel's registers are
-//     the larger of the two roles', not their sum (a wave that did both kept a walk's state live through the shading: 168 registers,
-//     three waves per SIMD - round 5's third form).
-// An entry's flags: kHasRay - the path has a ray of the next bounce (its record's origin / direction); kSun - its sun ray was not
-// answered by the grid (border cell, long list - or no grid): the tree's; kLight - it asks a light (record: f in throughput.w, light
-// index in radiance.w); bits 23..28 - how many bounces follow the entry's ray. The lane that takes an entry walks the shadow rays first
-// - sun, then light: their results are added to the path's radiance in the reference's order (rgen:63-122) -, then the bounce ray.
-// Shadow rays go through the closest-hit walk beside the other lanes' bounce rays (occluded <=> the closest hit lies within the limit;
-// the walk stops at the first hit inside).
-// The block ends when its count of live paths reaches zero. Every wait (a walking wave for work or for room in its ring, the shading
-// wave for hits) sleeps and is bounded: a wave that waits too long raises the block's abort word, every wave leaves, and the frame is
-// reported as failed (DeviceStats::fused_aborts) - never a hang.
+// section 4) - nothing of the same frame can fill those tails across a launch boundary. Here EVERY BLOCK RUNS ITS OWN WAVEFRONT: a
+// block owns a contiguous range of the positions of bounce 1's ray queue (its shard's count / blocks of the shard) and takes those paths
+// through all the remaining bounces by itself - trace phase, block barrier, shading phase, block barrier, ... - with no word to any
+// other block.
+// The paths never move: a path's state stays in its record of set 1 at its position p (shading rewrites it in place), its hit record
+// at hit[p]; what a phase hands to the next is a LIST of entries p | flags in the block's range of two of the queue arrays:
+//    kHasRay    the path has a ray of the next bounce to trace (its record's origin / direction)
+//    kSun       its sun ray was not answered by the grid (border cell, long list - or no grid): the tree's
+//    kLight     it asks a light (record: f in throughput.w, light index in radiance.w)
+// Trace phase: the block's waves are persistent over the list (the Feeder of the traversal kernels, chunks from a cursor in LDS); a
+// lane takes an entry, walks the path's shadow rays first - sun, then light: their results are added to the path's radiance in the
+// reference's order (rgen:63-122) -, then its bounce ray, and leaves the hit record. Shadow rays go through the closest-hit walk
+// beside the other lanes' bounce rays (occluded <=> the closest hit lies within the limit; the walk stops at the first hit inside).
+// Shading phase: k_shade_hit's, over the block's list - hits compacted per wave in LDS and shaded 64 at a time, the sun grid asked on
+// the spot; the paths whose ray left the scene gathered per wave too and the sky integrated for 64 of them at a time (reference.rmiss;
+// what is left of the list waits in two registers per lane for the next shading phase); ended paths' radiance to the per-id array.
+// Bounce 0's sun rays are asked here as well (sun_of_bounce0), so the frame is k_generate, the camera grid, k_shade_hit(0) and
+// k_shade_miss(0), this kernel, k_finish_sample.
 // Same words per path as the wavefront: the per-path arithmetic is shared (surface_normal_uv .. select_light, make_shadow_ray,
 // tri_compute), a path's random numbers depend on nothing but the path, and shadow rays are predicates.
-// (Round 5's earlier forms, profiles/README.md: a path per LANE, parked at its hit until 32 lanes of the wave stood at one - lane
-// utilisation 0.40, 2.6 ms for the four bounces against the wavefront's 2.4; a wavefront per BLOCK, trace and shading phases between
-// block barriers - 2.29 ms: every phase ends in the drain of its last rays, as the wavefront's launches do; a pipeline per WAVE - no
-// drains, 2.65 ms at three waves per SIMD.)
+// Round 5 built this kernel four ways, all bit-identical, measured on the same frames (profiles/README.md "One frame per call"): a
+// path per LANE (the lane parked at its hit until 32 lanes of the wave stood at one, then the wave shaded them: lane utilisation 0.40,
+// 2.6 ms for the four bounces); THIS one (2.29 ms; the wavefront's launches span 2.44); a pipeline per WAVE (hits gathered in LDS and
+// shaded 64 at a time between walking steps, the next bounce's rays walked beside this one's stragglers: no drains, lane utilisation
+// 0.54 - but a walk's state stays live through the shading: 168 registers, three waves per SIMD, 2.65 ms); a pipeline per BLOCK of
+// three walking waves and one shading wave with rings in LDS (101 registers; 2.45-2.54 ms: the shading wave is busy 0.97 of its
+// clock). What they show: the walk's rate follows the number of waves that walk - a kernel that also shades has 16, the wavefront's
+// traversal kernel 20 to 24 -, and a lone frame's work cannot be had at the batched rate in one kernel.
 // ------------------------------------------------------------------------------------------
 // one sun ray through the grid (k_trace_sun_grid's walk for one ray): 0 = lit, 1 = occluded, 2 = the grid does not answer (border cell,
 // long list): the tree's
@@ -1629,40 +1630,39 @@ __device__ __forceinline__ int sun_grid_query(const SunGridDev& g, const float4*
    }
 }
 
-#ifndef UH_FUSED_BLOCKS
-#define UH_FUSED_BLOCKS 5      // blocks per CU the kernel's registers and LDS are sized for
+#ifndef UH_FUSED_STAGGER
+#define UH_FUSED_STAGGER 0     // 1: the blocks of a CU offset against each other by quarters of a phase (k_path_fused STAGGER; measured 2.545 against 2.505 ms per frame: off)
 #endif
-constexpr uint32_t kFusedWalkers = kWavesPerBlock - 1;  // the block's last wave shades
-constexpr uint32_t kFusedHitRing = 96, kFusedMissRing = 96;  // entries per walking wave (a push is at most 64)
-constexpr uint32_t kFusedPatience = 6;        // sleeps without a full batch before the shading wave takes a partial one
-constexpr uint32_t kFusedSpinLimit = 1u << 22;  // sleeps before a waiting wave gives the block up (seconds)
-struct FusedWalkerLds {
-   uint32_t stack[kLdsStack][64];
-   RayPool<2> pool;
-   uint32_t hits[5][kFusedHitRing];  // entry (position | bounces left), t, u, v, packet
-   uint32_t miss[kFusedMissRing];    // positions of the paths whose ray left the scene
+#ifndef UH_FUSED_BLOCKS
+#define UH_FUSED_BLOCKS 4      // blocks per CU the kernel's registers and LDS are sized for
+#endif
+struct FusedTraceLds {
+   uint32_t stack[kWavesPerBlock][kLdsStack][64];
+   RayPool<2> pool[kWavesPerBlock];
 };
-struct FusedCtl {
-   uint32_t work_head, work_tail;  // the work ring's counters (they only grow; index = counter mod the ring's capacity)
-   uint32_t live;                  // paths of the block that have not ended
-   uint32_t abort;
-   uint32_t hit_head[kFusedWalkers], hit_tail[kFusedWalkers], miss_head[kFusedWalkers], miss_tail[kFusedWalkers];
+struct FusedShadeLds {
+   uint32_t list[kWavesPerBlock][6][128];  // per wave: path ids, positions, the hit record's four words
+   uint32_t miss[kWavesPerBlock][2][128];  // per wave: (position, id) of the paths that missed
 };
-__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
 template <bool COUNT, bool INLINE>
 __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev sc, FrameParams fp, PathState ps, Control* ctl, DeviceStats* stats, SunGridDev g, bool use_grid,
-                                                                         bool sun_of_bounce0) {
+                                                                         bool sun_of_bounce0, uint32_t stagger_unit) {
    constexpr uint32_t kFirst = 1;  // the paths are those of bounce 1's ray queue, their state lies in set 1 at their positions there
    // (positions fit 23 bits: the host fuses only when shard_cap < 2^23; bits 23..28: how many bounces follow the entry's ray)
    constexpr uint32_t kHasRay = 1u << 31, kSun = 1u << 30, kLight = 1u << 29, kLeftShift = 23, kLeftMask = 63u << kLeftShift, kPosMask = (1u << kLeftShift) - 1u;
    __shared__ float s_lut[256];
-   constexpr uint32_t kLdsMeshes = 32, kLdsTextures = 16;  // (the shading wave's tables: what is beyond them comes from global memory)
+#if UH_FUSED_BLOCKS >= 5
+   constexpr uint32_t kLdsMeshes = 48, kLdsTextures = 32;  // (32 KiB of LDS per block)
+#else
+   constexpr uint32_t kLdsMeshes = 128, kLdsTextures = 64;
+#endif
    __shared__ MeshShade s_mesh[kLdsMeshes];
    __shared__ TexInfo s_tex[kLdsTextures];
-   __shared__ FusedWalkerLds s_walk[kFusedWalkers];
-   __shared__ FusedCtl s_ctl;
+   __shared__ union {
+      FusedTraceLds t;
+      FusedShadeLds s;
+   } u;  // the phases alternate
+   __shared__ uint32_t s_cursor, s_count[2];
    const uint32_t n_lds_mesh = sc.num_meshes < kLdsMeshes ? sc.num_meshes : kLdsMeshes;
    const uint32_t n_lds_tex = sc.num_textures < kLdsTextures ? sc.num_textures : kLdsTextures;
    s_lut[threadIdx.x] = sc.unorm_lut[threadIdx.x];
@@ -1674,24 +1674,31 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
    const uint32_t seg = sx.shard * ps.shard_cap;
    const PathRecs rec = ps.set[kFirst & 1];
    const uint32_t* __restrict__ ids = ps.queue[kFirst & 1] + seg;  // path id by position
-   // the block's range of positions [lo, lo + cap)
+   // the block's range of positions [lo, hi)
    const uint32_t count1 = ctl->q_count[qc_index(kFirst, Q_RAY, sx.shard)];
    const uint32_t per = (((count1 + sx.nb - 1) / sx.nb) + 63u) & ~63u;
-   const uint32_t lo = sx.lb * per < count1 ? sx.lb * per : count1, cap = (lo + per < count1 ? lo + per : count1) - lo;
-   uint32_t* ring = ps.queue[0] + seg + lo;  // the work ring: `cap` entries (a path has at most one entry alive)
+   const uint32_t lo = sx.lb * per < count1 ? sx.lb * per : count1, hi = lo + per < count1 ? lo + per : count1;
+   uint32_t* lists[2] = {ps.queue[0] + seg + lo, ps.queue[3] + seg + lo};  // at most hi - lo entries each (one per path of the block)
    const uint4* __restrict__ nodes = sc.nodes;
    const float4* __restrict__ tris = sc.tris;
    const V3 sun_d = v3(fp.sun_dir[0], fp.sun_dir[1], fp.sun_dir[2]);
    uint32_t n_nodes = 0, n_tris = 0, n_snodes = 0, n_stris = 0, n_lnodes = 0, n_ltris = 0, n_covered = 0;  // per lane (COUNT only)
    uint32_t w_rays = 0, w_hits = 0, w_sun = 0, w_sun_tree = 0, w_light = 0, w_miss = 0;                      // per wave
-   // bounce 1's entries: every position of the range, a ray each. sun_of_bounce0: bounce 0's sun rays (rgen:63-79 for the paths
+   // bounce 1's list: every position of the range, a ray each. sun_of_bounce0: bounce 0's sun rays (rgen:63-79 for the paths
    // k_shade_hit(0) scattered) are asked here instead of by a k_trace_sun_grid / k_trace_shadow pair in front of this kernel - the grid
-   // on the spot, what it does not answer as the entry's sun ray. (Not when lights are on: bounce 0's light rays are the wavefront's,
-   // and they come after the sun rays.)
-   const uint32_t left1 = (fp.num_bounces - 2u) << kLeftShift;
-   for (uint32_t i0 = 0; i0 < cap; i0 += kBlock) {
+   // on the spot, what it does not answer as the entry's sun ray in the first trace phase. (Not when lights are on: bounce 0's light
+   // rays are the wavefront's, and they come after the sun rays.)
+   // STAGGER: the blocks of a CU would run their phases in step - all trace, all drain their last rays, all shade. The block of
+   // dispatch round r (blockIdx / stagger_unit: a CU's resident blocks come from different rounds) therefore puts only the first
+   // 1 - (r mod 4) / 4 of its range into the first list and the rest straight into the second: its phases are [part], [all], ..,
+   // [rest] - one more than the others', offset against theirs by a quarter, a half, three quarters of a phase - and one block's
+   // drain runs under the others' full lists
+   const uint32_t n_range = hi - lo, round = (blockIdx.x / (stagger_unit ? stagger_unit : 1u)) & 3u;
+   const uint32_t n_first = stagger_unit ? ((n_range * (4u - round) / 4u + 63u) & ~63u) < n_range ? ((n_range * (4u - round) / 4u + 63u) & ~63u) : n_range : n_range;
+   const uint32_t left1 = (fp.num_bounces - 2u) << kLeftShift;  // bounce 1's rays
+   for (uint32_t i0 = 0; i0 < n_range; i0 += kBlock) {
       const uint32_t i = i0 + threadIdx.x;
-      const bool valid = i < cap;
+      const bool valid = i < n_range;
       uint32_t e = (lo + i) | kHasRay | left1;
       bool to_tree = false;
       if (valid && sun_of_bounce0) {
@@ -1708,67 +1715,33 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
          if (r == 2) e |= kSun;
          to_tree = r == 2 && use_grid;
       }
-      if (valid) ring[i] = e;
+      if (valid) {
+         if (i < n_first) lists[0][i] = e;
+         else lists[1][i - n_first] = e;
+      }
       if (sun_of_bounce0) {
          w_sun += (uint32_t)__popcll(__ballot(valid));
          w_sun_tree += (uint32_t)__popcll(__ballot(to_tree));
       }
    }
    if (threadIdx.x == 0) {
-      s_ctl.work_head = 0;
-      s_ctl.work_tail = cap;
-      s_ctl.live = cap;
-      s_ctl.abort = 0;
-      for (uint32_t w = 0; w < kFusedWalkers; w++) s_ctl.hit_head[w] = s_ctl.hit_tail[w] = s_ctl.miss_head[w] = s_ctl.miss_tail[w] = 0;
+      s_count[0] = n_first;
+      s_count[1] = n_range - n_first;
+      s_cursor = 0;
    }
-   __syncthreads();  // the only one (workgroup-scope release / acquire: the entries and records above are visible to the block's waves)
+   __syncthreads();
 
-   if (wave < kFusedWalkers) {
-      // ================= a walking wave
-      FusedWalkerLds& L = s_walk[wave];
-      uint32_t* lds_col = &L.stack[0][lane];
-      RayPool<2>& pool = L.pool;
-      uint32_t hit_tail = 0, miss_tail = 0;  // this wave's rings: it owns the tails
-      uint32_t pool_pos = 0, pool_n = 0, load_n = 0, q_n = 0, q_e = 0;
-      bool loading = false;
+   // ---- trace phase over lists[which]
+   auto trace_phase = [&](uint32_t which) {
+      uint32_t* lds_col = &u.t.stack[wave][0][lane];
+      RayPool<2>& pool = u.t.pool[wave];
+      RaySource src;
+      src.queue = lists[which];
+      src.count = s_count[which];
+      src.cursor = &s_cursor;
+      src.wave_index = src.num_waves = 0;
       auto source_of = [&](int a, uint32_t e) { return (const float4*)rec_quad(rec, seg + (e & kPosMask), a == 0 ? REC_ORIGIN : REC_DIR); };
-      // the pool's feeder, k_trace_closest's: entries claimed from the ring -> their rays by LDS-DMA, one stage per refill event
-      auto advance = [&]() {
-         if (q_n) {  // the entries loaded one event ago: their rays into the pool
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pool's last entries have been read
-            if (lane < q_n) {
-               dma16(source_of(0, q_e), pool.v[0]);
-               dma16(source_of(1, q_e), pool.v[1]);
-               pool.id[lane] = q_e;
-            }
-            load_n = q_n;
-            loading = true;
-            q_n = 0;
-         }
-         // the next chunk of the ring (not across its end): a compare-and-swap on the head, the three walkers being its only takers
-         uint32_t k = 0, base = 0;
-         if (lane == 0) {
-            for (int tries = 0; tries < 8; tries++) {
-               const uint32_t h = lds_load(&s_ctl.work_head), a = lds_load(&s_ctl.work_tail) - h;
-               if (a == 0u) break;
-               const uint32_t at = h % cap;
-               uint32_t kk = a < kPool ? a : kPool;
-               kk = kk < cap - at ? kk : cap - at;
-               if (atomicCAS(&s_ctl.work_head, h, h + kk) == h) {
-                  k = kk;
-                  base = at;
-                  break;
-               }
-            }
-         }
-         k = __builtin_amdgcn_readfirstlane(k);
-         base = __builtin_amdgcn_readfirstlane(base);
-         if (k) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane < k) q_e = ld_stream(ring + base + lane);
-            q_n = k;
-         }
-      };
+      Feeder<2> f;
       Trav t;
       t.cur = kEmptyRef;
       t.sp = 0;
@@ -1777,7 +1750,7 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
       V3 thr = v3(0, 0, 0), rad = v3(0, 0, 0), scatter = v3(0, 0, 0);
       float lf = 0.0f;
       uint32_t light_bits = 0;
-      bool dirty = false, path_done = false;
+      bool dirty = false;
       uint32_t spill[kSpillStack];
       // the entry's next ray (origin = t.o): sun, light, then the bounce ray - or, behind the last bounce, the path's radiance to the
       // per-id array (what k_flush_survivors writes)
@@ -1802,7 +1775,6 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
             } else {  // rgen:127 after the last bounce
                st_stream(ps.radf + ld_stream(ids + p), make_float4(rad.x, rad.y, rad.z, __uint_as_float(rng_x)));
                t.cur = kEmptyRef;
-               path_done = true;
             }
          }
          if (COUNT) {
@@ -1830,49 +1802,7 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
             kind = BOUNCE_RAY;
          }
       };
-      uint32_t sleeps = 0;
-#ifdef UH_FUSED_PROFILE  // (measurement only, with count_visits: a walker's clock - all / waiting for work / waiting for room in its rings; the shading wave's - all / busy; in the light counters)
-      unsigned long long c_begin = wall_clock64(), c_work = 0, c_room = 0;
-#endif
-      for (uint32_t iterations = 0; iterations < (1u << 24); iterations++) {  // (an exit every wave reaches whatever the data)
-         const bool lane_idle = t.cur == kEmptyRef;
-         const unsigned long long idle = __ballot(lane_idle);
-         if (idle != 0ull) {
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (loading) {  // the DMA issued one event ago has landed (its wait also covers every older load of the wave)
-               wait_vm0();
-               pool_pos = 0;
-               pool_n = load_n;
-               loading = false;
-            }
-            const uint32_t in_pool = pool_n - pool_pos;
-            if (in_pool != 0 && (n_idle >= (uint32_t)kRefill || n_idle == 64u)) {
-               const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-               if (lane_idle && prefix < in_pool) take(pool_pos + prefix);
-               pool_pos += n_idle < in_pool ? n_idle : in_pool;
-            }
-            if (pool_pos >= pool_n && !loading) {
-               advance();
-               if (q_n == 0 && !loading && n_idle == 64u && in_pool == 0) {
-                  // nothing to walk and nothing claimed: the block's paths are with the shading wave, in another walker - or all ended
-                  if (lds_load(&s_ctl.live) == 0u || lds_load(&s_ctl.abort) != 0u) break;
-                  if (++sleeps > kFusedSpinLimit) {
-                     lds_store(&s_ctl.abort, 1u);
-                     break;
-                  }
-#ifdef UH_FUSED_PROFILE
-                  const unsigned long long c0 = wall_clock64();
-#endif
-                  __builtin_amdgcn_s_sleep(8);
-#ifdef UH_FUSED_PROFILE
-                  c_work += wall_clock64() - c0;
-#endif
-                  continue;
-               }
-            }
-         }
-         bool push_hit = false, push_miss = false;
-         path_done = false;
+      while (refill_lanes<2>(f, src, pool, t.cur == kEmptyRef, source_of, take)) {
          if (t.cur != kEmptyRef) {
             bool occluded = false;
             bool ended = trav_step<false, COUNT, true>(nodes, tris, t, lds_col, spill, occluded, n_nodes, n_tris);
@@ -1882,8 +1812,7 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
             if (kind != BOUNCE_RAY && blocked) ended = true;
             if (ended) {
                if (kind == BOUNCE_RAY) {
-                  push_hit = t.best.idx != kEmptyRef;
-                  push_miss = !push_hit;
+                  st_rec(ps.hit + seg + (entry & kPosMask), make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.idx)));
                   t.cur = kEmptyRef;
                } else {
                   // rgen:69-78 / :118-122: an unoccluded ray adds the path's throughput (x the light's weight) to its radiance
@@ -1907,231 +1836,212 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
                }
             }
          }
-         const unsigned long long hm = __ballot(push_hit), mm = __ballot(push_miss), dm = __ballot(path_done);
-         if ((hm | mm | dm) == 0ull) continue;
-         w_rays += (uint32_t)__popcll(hm) + (uint32_t)__popcll(mm);
-         if (dm) {  // paths that ended in this wave (their last shadow ray came back)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) atomicSub(&s_ctl.live, (uint32_t)__popcll(dm));
-         }
-         if (hm) {
-            const uint32_t nh = (uint32_t)__popcll(hm);
-#ifdef UH_FUSED_PROFILE
-            const unsigned long long c0 = wall_clock64();
-#endif
-            // room in the ring: the shading wave moves the head
-            for (uint32_t spins = 0; hit_tail + nh - lds_load(&s_ctl.hit_head[wave]) > kFusedHitRing; spins++) {
-               if (lds_load(&s_ctl.abort) != 0u) break;
-               if (spins > kFusedSpinLimit) {
-                  lds_store(&s_ctl.abort, 1u);
-                  break;
-               }
-               __builtin_amdgcn_s_sleep(4);
-            }
-#ifdef UH_FUSED_PROFILE
-            c_room += wall_clock64() - c0;
-#endif
-            const uint32_t at = (hit_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u))) % kFusedHitRing;
-            if (push_hit) {
-               L.hits[0][at] = entry & (kPosMask | kLeftMask);
-               L.hits[1][at] = __float_as_uint(t.best.t);
-               L.hits[2][at] = __float_as_uint(t.best.u);
-               L.hits[3][at] = __float_as_uint(t.best.v);
-               L.hits[4][at] = t.best.idx;
-            }
-            hit_tail += nh;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entries, then the tail
-            if (lane == 0) lds_store(&s_ctl.hit_tail[wave], hit_tail);
-         }
-         if (mm) {
-            const uint32_t nm = (uint32_t)__popcll(mm);
-            for (uint32_t spins = 0; miss_tail + nm - lds_load(&s_ctl.miss_head[wave]) > kFusedMissRing; spins++) {
-               if (lds_load(&s_ctl.abort) != 0u) break;
-               if (spins > kFusedSpinLimit) {
-                  lds_store(&s_ctl.abort, 1u);
-                  break;
-               }
-               __builtin_amdgcn_s_sleep(4);
-            }
-            const uint32_t at = (miss_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))) % kFusedMissRing;
-            if (push_miss) L.miss[at] = entry & kPosMask;
-            miss_tail += nm;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) lds_store(&s_ctl.miss_tail[wave], miss_tail);
-         }
-         if (lds_load(&s_ctl.abort) != 0u) break;
       }
-#ifdef UH_FUSED_PROFILE
-      if (COUNT && lane == 0) {
-         atomicAdd(&stats->light_nodes_visited, wall_clock64() - c_begin);
-         atomicAdd(&stats->light_tris_tested, c_work);
-         atomicAdd(&stats->sun_covered_rays, c_room);
+   };
+
+   uint32_t carry_n = 0, carry_pos = 0, carry_id = 0;
+   // ---- shading phase over lists[which] (the entries with a bounce ray: its hit record lies at hit[p]); the scattered paths' entries
+   // go to lists[which ^ 1]
+   auto shade_phase = [&](uint32_t which) {
+      const uint32_t count = s_count[which];
+      const uint32_t* __restrict__ cur_list = lists[which];
+      uint32_t* nxt_list = lists[which ^ 1];
+      uint32_t(*list)[128] = u.s.list[wave];
+      uint32_t(*missed)[128] = u.s.miss[wave];
+      uint32_t n_list = 0, n_missed = carry_n, n_rays = 0;  // wave-uniform
+      if (lane < carry_n) {  // the misses the last shading phase left (fewer than 64: the sky integral runs on full waves)
+         missed[0][lane] = carry_pos;
+         missed[1][lane] = carry_id;
       }
-#endif
-   } else {
-      // ================= the shading wave
-#ifdef UH_FUSED_PROFILE
-      unsigned long long c_begin = wall_clock64(), c_idle = 0;
-#endif
-      uint32_t hit_head[kFusedWalkers], miss_head[kFusedWalkers];  // it owns the rings' heads (wave-uniform)
-      for (uint32_t w = 0; w < kFusedWalkers; w++) hit_head[w] = miss_head[w] = 0;
-      uint32_t tail = cap;  // and the work ring's tail
-      uint32_t waited = 0, sleeps = 0;
-      for (;;) {
-         uint32_t hc[kFusedWalkers], mc[kFusedWalkers], h = 0, m = 0;
-         for (uint32_t w = 0; w < kFusedWalkers; w++) {
-            hc[w] = lds_load(&s_ctl.hit_tail[w]) - hit_head[w];
-            mc[w] = lds_load(&s_ctl.miss_tail[w]) - miss_head[w];
-            h += hc[w];
-            m += mc[w];
-         }
-         const bool take_hits = h >= 64u || (h != 0u && waited > kFusedPatience);
-         const bool take_miss = !take_hits && (m >= 64u || (m != 0u && waited > kFusedPatience));
-         if (!take_hits && !take_miss) {
-            if (lds_load(&s_ctl.live) == 0u || lds_load(&s_ctl.abort) != 0u) break;
-            if (++sleeps > kFusedSpinLimit) {
-               lds_store(&s_ctl.abort, 1u);
-               break;
-            }
-            waited++;
-#ifdef UH_FUSED_PROFILE
-            const unsigned long long c0 = wall_clock64();
-#endif
-            __builtin_amdgcn_s_sleep(16);
-#ifdef UH_FUSED_PROFILE
-            c_idle += wall_clock64() - c0;
-#endif
-            continue;
-         }
-         waited = 0;
-         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the tails, then the entries
-         // lane k takes the k-th waiting entry, the rings in order
-         uint32_t n = 0, from = 0, at = 0;
-         {
-            uint32_t k = lane;
-            bool found = false;
-            for (uint32_t w = 0; w < kFusedWalkers; w++) {
-               const uint32_t c = take_hits ? hc[w] : mc[w];
-               const uint32_t tk = c < 64u - n ? c : 64u - n;  // entries this batch takes from ring w
-               if (!found && k < tk) {
-                  from = w;
-                  at = ((take_hits ? hit_head[w] : miss_head[w]) + k) % (take_hits ? kFusedHitRing : kFusedMissRing);
-                  found = true;
+      __builtin_amdgcn_wave_barrier();
+      auto shade = [&](uint32_t id, uint32_t pl, float4 hr, bool valid) {  // pl: the path's position | the bounces left behind this ray
+         bool scattered = false, want_light = false, to_tree = false, keep = false;
+         uint32_t flags = 0;
+         const uint32_t p = pl & kPosMask;
+         if (valid) {
+            const uint32_t left = (pl & kLeftMask) >> kLeftShift;
+            const bool last = left == 0u;
+            const uint32_t pk = __float_as_uint(hr.w);
+            const float4 ro = ld_rec(rec_quad(rec, seg + p, REC_ORIGIN)), rd = ld_rec(rec_quad(rec, seg + p, REC_DIR)), thr4 = ld_rec(rec_quad(rec, seg + p, REC_THR)),
+                         rad4 = ld_rec(rec_quad(rec, seg + p, REC_RAD));
+            uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
+            const V3 ray_dir = v3(rd.x, rd.y, rd.z);
+            const float4* sp = sc.shade + 4 * (size_t)pk;
+            const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+            const uint32_t mesh_index = __float_as_uint(s3.w);
+            MeshShade ms = lds_fetch(s_mesh + (mesh_index < kLdsMeshes ? mesh_index : kLdsMeshes - 1));  // rchit:22-23
+            if (mesh_index >= n_lds_mesh) ms = sc.meshes[mesh_index];
+            V3 normal;
+            float uu, vv;
+            surface_normal_uv(s0, s1, s2, s3, hr.y, hr.z, normal, uu, vv);                // rchit:30-31, :39
+            const V3 world_normal = world_normal_of(ms, normal, ray_dir);                 // rchit:32-37
+            V3 origin = v3(ro.x, ro.y, ro.z) + hr.x * ray_dir;                            // rgen:59
+            origin = offset_ray(origin, world_normal);                                    // rgen:60
+            scattered = path_scatters(ms, ray_dir, world_normal);
+            V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);  // rchit:40
+            color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
+            uint32_t seed = rng.y;
+            const V3 scatter = material_scatter(ms, ray_dir, world_normal, color, seed);  // rchit:47-89
+            rng.y = seed;                                                                 // rchit:91
+            const V3 thr = v3(thr4.x, thr4.y, thr4.z) * color;                            // rgen:48
+            V3 rad = v3(rad4.x, rad4.y, rad4.z);
+            if (!scattered) {                                                             // rgen:53-57: the path ends here
+               st_stream(ps.radf + id, make_float4(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z, __uint_as_float(rng.x)));
+            } else {
+               float lf = 0.0f;
+               int light_index = 0;
+               if (fp.lights_enabled == 1) want_light = select_light(fp, sc, id, rng.x, origin, lf, light_index);  // rgen:81-121
+               if (fp.sun_shadow_enabled == 1) {                                          // rgen:63-79
+                  int r = use_grid ? sun_grid_query<COUNT, INLINE>(g, tris, origin, sun_d, n_stris, n_covered) : 2;
+                  if (COUNT && use_grid) n_snodes++;  // every sun ray looked one cell up
+                  if (r == 0) rad = v3(rad.x + thr.x, rad.y + thr.y, rad.z + thr.z);       // rgen:69-78
+                  if (r == 2) flags |= kSun;
+                  to_tree = r == 2 && use_grid;
                }
-               if (!found) k -= tk;
-               n += tk;
-               if (take_hits) hit_head[w] += tk;
-               else miss_head[w] += tk;
-            }
-         }
-         const bool valid = lane < n;
-         uint32_t ended = 0;  // paths that end in this batch (wave-uniform)
-         if (take_miss) {
-            // reference.rmiss: the paths' state is where shade_miss_path reads it (their records of set 1, untouched since their ray was made)
-            uint32_t p = 0;
-            if (valid) p = s_walk[from].miss[at];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // read, then the heads
-            if (lane == 0)
-               for (uint32_t w = 0; w < kFusedWalkers; w++) lds_store(&s_ctl.miss_head[w], miss_head[w]);
-            if (valid) shade_miss_path(fp, ps, seg + p, ld_stream(ids + p), kFirst);
-            w_miss += n;
-            ended = n;
-         } else {
-            uint32_t pl = 0, pk = 0;
-            float hr_t = 0.0f, hr_u = 0.0f, hr_v = 0.0f;
-            if (valid) {
-               const FusedWalkerLds& R = s_walk[from];
-               pl = R.hits[0][at];
-               hr_t = __uint_as_float(R.hits[1][at]);
-               hr_u = __uint_as_float(R.hits[2][at]);
-               hr_v = __uint_as_float(R.hits[3][at]);
-               pk = R.hits[4][at];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // read, then the heads
-            if (lane == 0)
-               for (uint32_t w = 0; w < kFusedWalkers; w++) lds_store(&s_ctl.hit_head[w], hit_head[w]);
-            bool scattered = false, want_light = false, to_tree = false, keep = false;
-            uint32_t flags = 0;
-            const uint32_t p = pl & kPosMask;
-            if (valid) {
-               const uint32_t left = (pl & kLeftMask) >> kLeftShift;
-               const bool last = left == 0u;
-               const uint32_t id = ld_stream(ids + p);
-               const float4 ro = ld_rec(rec_quad(rec, seg + p, REC_ORIGIN)), rd = ld_rec(rec_quad(rec, seg + p, REC_DIR)), thr4 = ld_rec(rec_quad(rec, seg + p, REC_THR)),
-                            rad4 = ld_rec(rec_quad(rec, seg + p, REC_RAD));
-               uint2 rng = make_uint2(__float_as_uint(ro.w), __float_as_uint(rd.w));
-               const V3 ray_dir = v3(rd.x, rd.y, rd.z);
-               const float4* sp = sc.shade + 4 * (size_t)pk;
-               const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-               const uint32_t mesh_index = __float_as_uint(s3.w);
-               MeshShade ms = lds_fetch(s_mesh + (mesh_index < kLdsMeshes ? mesh_index : kLdsMeshes - 1));  // rchit:22-23
-               if (mesh_index >= n_lds_mesh) ms = sc.meshes[mesh_index];
-               V3 normal;
-               float uu, vv;
-               surface_normal_uv(s0, s1, s2, s3, hr_u, hr_v, normal, uu, vv);                // rchit:30-31, :39
-               const V3 world_normal = world_normal_of(ms, normal, ray_dir);                 // rchit:32-37
-               V3 origin = v3(ro.x, ro.y, ro.z) + hr_t * ray_dir;                            // rgen:59
-               origin = offset_ray(origin, world_normal);                                    // rgen:60
-               scattered = path_scatters(ms, ray_dir, world_normal);
-               V3 color = sample_texture(sc, s_lut, ms.diffuse_map, uu, vv, s_tex, n_lds_tex);  // rchit:40
-               color = color * v3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);    // rchit:41
-               uint32_t seed = rng.y;
-               const V3 sc_dir = material_scatter(ms, ray_dir, world_normal, color, seed);   // rchit:47-89
-               rng.y = seed;                                                                 // rchit:91
-               const V3 th = v3(thr4.x, thr4.y, thr4.z) * color;                             // rgen:48
-               V3 ra = v3(rad4.x, rad4.y, rad4.z);
-               if (!scattered) {                                                             // rgen:53-57: the path ends here
-                  st_stream(ps.radf + id, make_float4(ra.x + th.x, ra.y + th.y, ra.z + th.z, __uint_as_float(rng.x)));
-               } else {
-                  float f = 0.0f;
-                  int light_index = 0;
-                  if (fp.lights_enabled == 1) want_light = select_light(fp, sc, id, rng.x, origin, f, light_index);  // rgen:81-121
-                  if (fp.sun_shadow_enabled == 1) {                                          // rgen:63-79
-                     int r = use_grid ? sun_grid_query<COUNT, INLINE>(g, tris, origin, sun_d, n_stris, n_covered) : 2;
-                     if (COUNT && use_grid) n_snodes++;  // every sun ray looked one cell up
-                     if (r == 0) ra = v3(ra.x + th.x, ra.y + th.y, ra.z + th.z);               // rgen:69-78
-                     if (r == 2) flags |= kSun;
-                     to_tree = r == 2 && use_grid;
-                  }
-                  if (want_light) flags |= kLight;
-                  if (!last) flags |= kHasRay | ((left - 1u) << kLeftShift);
-                  keep = (flags & (kHasRay | kSun | kLight)) != 0u;
-                  if (!keep) {  // behind the last bounce with no shadow ray out: rgen:127 (what k_flush_survivors writes)
-                     st_stream(ps.radf + id, make_float4(ra.x, ra.y, ra.z, __uint_as_float(rng.x)));
-                  } else {  // the path's state, in place
-                     st_rec(rec_quad(rec, seg + p, REC_ORIGIN), make_float4(origin.x, origin.y, origin.z, __uint_as_float(rng.x)));
-                     st_rec(rec_quad(rec, seg + p, REC_DIR), make_float4(sc_dir.x, sc_dir.y, sc_dir.z, __uint_as_float(rng.y)));  // rgen:61
-                     st_rec(rec_quad(rec, seg + p, REC_THR), make_float4(th.x, th.y, th.z, f));
-                     st_rec(rec_quad(rec, seg + p, REC_RAD), make_float4(ra.x, ra.y, ra.z, __uint_as_float((uint32_t)light_index)));
-                  }
+               if (want_light) flags |= kLight;
+               if (!last) flags |= kHasRay | ((left - 1u) << kLeftShift);
+               keep = (flags & (kHasRay | kSun | kLight)) != 0u;
+               if (!keep) {  // behind the last bounce with no shadow ray out: rgen:127 (what k_flush_survivors writes)
+                  st_stream(ps.radf + id, make_float4(rad.x, rad.y, rad.z, __uint_as_float(rng.x)));
+               } else {  // the path's state, in place
+                  st_rec(rec_quad(rec, seg + p, REC_ORIGIN), make_float4(origin.x, origin.y, origin.z, __uint_as_float(rng.x)));
+                  st_rec(rec_quad(rec, seg + p, REC_DIR), make_float4(scatter.x, scatter.y, scatter.z, __uint_as_float(rng.y)));  // rgen:61
+                  st_rec(rec_quad(rec, seg + p, REC_THR), make_float4(thr.x, thr.y, thr.z, lf));
+                  st_rec(rec_quad(rec, seg + p, REC_RAD), make_float4(rad.x, rad.y, rad.z, __uint_as_float((uint32_t)light_index)));
                }
             }
-            // the kept paths' entries to the work ring's tail
-            const unsigned long long km = __ballot(keep);
-            if (km) {
-               const uint32_t idx = (tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))) % cap;
-               if (keep) ring[idx] = p | flags;
-               tail += (uint32_t)__popcll(km);
-               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // records and entries, then the tail
-               if (lane == 0) lds_store(&s_ctl.work_tail, tail);
+         }
+         const uint32_t slot = wave_append(&s_count[which ^ 1], keep);
+         if (keep) nxt_list[slot] = p | flags;
+         if (fp.sun_shadow_enabled == 1) w_sun += (uint32_t)__popcll(__ballot(scattered));
+         w_sun_tree += (uint32_t)__popcll(__ballot(to_tree));
+         w_light += (uint32_t)__popcll(__ballot(want_light));
+      };
+      // reference.rmiss for `n` paths from the front of the wave's miss list: their state is where shade_miss_path reads it (their
+      // records of set 1, untouched since their ray was made)
+      auto flush_misses = [&](uint32_t n) {
+         if (lane < n) shade_miss_path(fp, ps, seg + missed[0][lane], missed[1][lane], kFirst);
+         w_miss += n;
+      };
+      auto entry_of = [&](uint32_t k) { return make_float4(__uint_as_float(list[2][k]), __uint_as_float(list[3][k]), __uint_as_float(list[4][k]), __uint_as_float(list[5][k])); };
+      const uint32_t rounds = (count + kBlock - 1) / kBlock;
+      for (uint32_t r = 0; r < rounds; r++) {
+         const uint32_t i = r * kBlock + threadIdx.x;
+         uint32_t id = 0, p = 0;
+         float4 hr = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmptyRef));
+         bool has_ray = false;
+         if (i < count) {
+            const uint32_t e = cur_list[i];
+            has_ray = (e & kHasRay) != 0u;  // (an entry without one was a shadow ray behind the last bounce: the trace phase finished it)
+            p = e & (kPosMask | kLeftMask);
+            if (has_ray) {
+               id = ld_stream(ids + (e & kPosMask));
+               hr = ld_rec(ps.hit + seg + (e & kPosMask));
             }
-            w_hits += n;
-            if (fp.sun_shadow_enabled == 1) w_sun += (uint32_t)__popcll(__ballot(scattered));
-            w_sun_tree += (uint32_t)__popcll(__ballot(to_tree));
-            w_light += (uint32_t)__popcll(__ballot(want_light));
-            ended = n - (uint32_t)__popcll(km);
          }
-         if (ended) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) atomicSub(&s_ctl.live, ended);
+         const bool is_hit = __float_as_uint(hr.w) != kEmptyRef;
+         const unsigned long long mask = __ballot(is_hit);
+         const unsigned long long mmask = __ballot(has_ray && !is_hit);
+         n_rays += (uint32_t)__popcll(__ballot(has_ray));
+         if (mmask) {
+            // reference.rmiss for the paths whose ray left the scene, 64 at a time
+            const uint32_t mp = __builtin_amdgcn_mbcnt_hi((uint32_t)(mmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mmask, 0u));
+            if (has_ray && !is_hit) {
+               missed[0][n_missed + mp] = p & kPosMask;
+               missed[1][n_missed + mp] = id;
+            }
+            n_missed += (uint32_t)__popcll(mmask);
+            __builtin_amdgcn_wave_barrier();
+            if (n_missed >= 64u) {
+               flush_misses(64u);
+               const uint32_t rest = n_missed - 64u;
+               uint32_t tmp0 = 0, tmp1 = 0;
+               if (lane < rest) {
+                  tmp0 = missed[0][64u + lane];
+                  tmp1 = missed[1][64u + lane];
+               }
+               __builtin_amdgcn_wave_barrier();
+               if (lane < rest) {
+                  missed[0][lane] = tmp0;
+                  missed[1][lane] = tmp1;
+               }
+               __builtin_amdgcn_wave_barrier();
+               n_missed = rest;
+            }
+         }
+         if (mask == 0ull) continue;
+         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+         if (is_hit) {
+            list[0][n_list + prefix] = id;
+            list[1][n_list + prefix] = p;
+            list[2][n_list + prefix] = __float_as_uint(hr.x);
+            list[3][n_list + prefix] = __float_as_uint(hr.y);
+            list[4][n_list + prefix] = __float_as_uint(hr.z);
+            list[5][n_list + prefix] = __float_as_uint(hr.w);
+         }
+         n_list += (uint32_t)__popcll(mask);
+         __builtin_amdgcn_wave_barrier();
+         if (n_list >= 64u) {
+            shade(list[0][lane], list[1][lane], entry_of(lane), true);
+            w_hits += 64u;
+            const uint32_t rest = n_list - 64u;
+            uint32_t tmp[6] = {0, 0, 0, 0, 0, 0};
+            if (lane < rest)
+               for (int k = 0; k < 6; k++) tmp[k] = list[k][64u + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest)
+               for (int k = 0; k < 6; k++) list[k][lane] = tmp[k];
+            __builtin_amdgcn_wave_barrier();
+            n_list = rest;
          }
       }
-#ifdef UH_FUSED_PROFILE
-      if (COUNT && lane == 0) {
-         atomicAdd(&stats->cam_tris_tested, wall_clock64() - c_begin);
-         atomicAdd(&stats->cam_tree_rays, c_idle);
+      if (n_list) {
+         shade(lane < n_list ? list[0][lane] : 0u, lane < n_list ? list[1][lane] : 0u, lane < n_list ? entry_of(lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f), lane < n_list);
+         w_hits += n_list;
       }
+      // the rest waits in registers for the next shading phase (the list's LDS is the trace phase's stacks)
+      carry_n = n_missed;
+      if (lane < n_missed) {
+         carry_pos = missed[0][lane];
+         carry_id = missed[1][lane];
+      }
+      w_rays += n_rays;
+   };
+
+   uint32_t which = 0;
+#ifdef UH_FUSED_PROFILE  // (measurement only, with count_visits: the waves' clock in the trace phases / at the barriers / in the shading phases, in the light counters)
+   unsigned long long c_trace = 0, c_wait = 0, c_shade = 0;
+#define UH_TICK(acc)                                  \
+   {                                                  \
+      const unsigned long long now = wall_clock64();  \
+      acc += now - c_last;                            \
+      c_last = now;                                   \
+   }
+   unsigned long long c_last = wall_clock64();
+#else
+#define UH_TICK(acc)
 #endif
+   // phases until a shading phase leaves no entry (every phase takes its entries one bounce on: at most num_bounces + 1 rounds)
+   for (uint32_t round_no = 0; round_no < kMaxBounces + 2u; round_no++) {
+      if (s_count[which] == 0u && s_count[which ^ 1] == 0u) break;  // (block-uniform: read behind a barrier)
+      trace_phase(which);
+      UH_TICK(c_trace)
+      __syncthreads();  // (workgroup-scope release / acquire: the hit records and radiance the block's waves wrote are visible to all of them)
+      UH_TICK(c_wait)
+      shade_phase(which);
+      UH_TICK(c_shade)
+      __syncthreads();
+      UH_TICK(c_wait)
+      if (threadIdx.x == 0) {
+         s_count[which] = 0;
+         s_cursor = 0;
+      }
+      which ^= 1;
+      __syncthreads();
+   }
+   if (carry_n) {  // the last misses: reference.rmiss on a partial wave, once
+      if (lane < carry_n) shade_miss_path(fp, ps, seg + carry_pos, carry_id, kFirst);
+      w_miss += carry_n;
    }
    if (lane == 0) {
       if (w_rays) atomicAdd(&stats->rays[UH_RAY_BOUNCE], (unsigned long long)w_rays);
@@ -2140,7 +2050,6 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
       if (w_sun_tree) atomicAdd(&stats->sun_tree_rays, (unsigned long long)w_sun_tree);
       if (w_light) atomicAdd(&stats->rays[UH_RAY_LIGHT_SHADOW], (unsigned long long)w_light);
       if (w_miss) atomicAdd(&stats->misses, (unsigned long long)w_miss);
-      if (wave == 0 && lds_load(&s_ctl.abort) != 0u) atomicAdd(&stats->fused_aborts, 1ull);
    }
    if (COUNT) {
       atomicAdd(&stats->nodes_visited, (unsigned long long)n_nodes);
@@ -2150,7 +2059,15 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
       atomicAdd(&stats->light_nodes_visited, (unsigned long long)n_lnodes);
       atomicAdd(&stats->light_tris_tested, (unsigned long long)n_ltris);
       atomicAdd(&stats->sun_covered_rays, (unsigned long long)n_covered);
+#ifdef UH_FUSED_PROFILE
+      if (lane == 0) {
+         atomicAdd(&stats->light_nodes_visited, c_trace);
+         atomicAdd(&stats->light_tris_tested, c_wait);
+         atomicAdd(&stats->sun_covered_rays, c_shade);
+      }
+#endif
    }
+#undef UH_TICK
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2471,7 +2388,7 @@ void launch_flush_survivors(const LaunchCfg& c, const FrameParams& fp, const Pat
 void launch_path_fused(const LaunchCfg& c, const FrameParams& fp, const SceneDev& sc, const PathState& ps, Control* ctl, DeviceStats* stats, const SunGridDev& g,
                        bool use_grid, bool sun_of_bounce0) {
    const dim3 grid = sharded_grid(c.num_cus * c.fused_blocks_per_cu);
-#define UH_FUSED(COUNT, INLINE) k_path_fused<COUNT, INLINE><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, g, use_grid, sun_of_bounce0)
+#define UH_FUSED(COUNT, INLINE) k_path_fused<COUNT, INLINE><<<grid, kBlock, 0, c.stream>>>(sc, fp, ps, ctl, stats, g, use_grid, sun_of_bounce0, UH_FUSED_STAGGER ? c.num_cus : 0u)
    if (use_grid && g.recs) {
       if (c.count_visits) UH_FUSED(true, true);
       else UH_FUSED(false, true);

@@ -142,7 +142,7 @@ class Stats(C.Structure):
         ("light_nodes_visited", C.c_uint64),
         ("light_tris_tested", C.c_uint64),
         ("trace_light_launches", C.c_uint32),
-        ("fused_aborts", C.c_uint32),
+        ("reserved1", C.c_uint32),
     ]
 
     @property
