@@ -320,7 +320,7 @@ int uh_trace_any(uh_ctx* ctx, const float* rays, uint32_t n, uint8_t* out_occlud
 /* ---- stats / options ------------------------------------------------------------------- */
 int uh_get_stats(uh_ctx* ctx, UhStats* out);
 int uh_reset_stats(uh_ctx* ctx);
-/* The 24 options (DESIGN.md section 7 has the defaults and what was measured); unknown names return UH_ERR_INVALID_ARGUMENT.
+/* The 25 options (DESIGN.md section 7 has the defaults and what was measured); unknown names return UH_ERR_INVALID_ARGUMENT.
  *  diagnostics   "count_visits" (0/1: UhStats' node / triangle / cover counters), "time_kernels" (0/1: hipEvent time per kernel kind)
  *  results       "full_frame_restir" (0/1; 1 = documented divergence: the reservoir for every pixel instead of the reference's
  *                x > W/2 split), "furnace" (0/1: the reference's FURNACE_TEST build of the miss shader, reference.rmiss:14-28 - a path
@@ -345,7 +345,12 @@ int uh_reset_stats(uh_ctx* ctx);
  *                the primary rays' state is not stored - the kernels of the first bounce compute it from the path id; same images)
  *  scheduling    "frames_in_flight" (1..8, default 4), "batch_frames" (0 = auto), "overlap" (0/1, default 1: the miss shader and the
  *                shadow traversals on a second stream beside the next bounce's traversal), "trace_blocks_per_cu" (1..8: persistent
- *                grid of the traversal kernels)
+ *                grid of the traversal kernels), "fused_bounces" (default 1: a frame that goes alone - uh_render_frame, or a call
+ *                of one frame - and finds the GPU idle, i.e. a caller that waits for its frames, runs its bounces 1 .. inside one
+ *                persistent kernel, a wavefront per block, instead of four launches per bounce: same images, 2.5 ms against 2.85
+ *                for a 1080p frame, 0.99 against 1.57 at 960 x 540; with frames in flight the launches interleave better and are
+ *                kept, and so they are for frames of more than 4 M paths, whose launches are large already. 0: never; -1: always;
+ *                2..8: as 1, and the kernel's blocks per CU)
  * Removed in round 5 with the measured-negative variants they selected: "closest_variant" / "shadow_variant" / "trace_variant" (batch
  * traversal kernels), "primary_tiles", "interleave", "sun_grid_fused", "sun_leftover_batch", "sun_grid_async", "sun_grid_inline",
  * "spatial_splits", "bvh_optimise", "raw_visit_counts", "ploc_radius", "overlap_miss" / "overlap_shadow" (now "overlap"),

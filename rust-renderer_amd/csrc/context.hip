@@ -194,7 +194,8 @@ struct uh_ctx {
    uint32_t cam_walk_whole = 512;     // option "camera_grid_walk_whole" (sun_grid.h SunGridDev::walk_whole)
    // one frame per call: bounces 1 .. of a lone frame inside one persistent kernel (k_path_fused) instead of four launches per bounce
    bool fused_bounces = true;  // option "fused_bounces"
-   bool fused_always = false;  // fused_bounces = -1: also with frames in flight (tests)
+   bool fused_always = false;  // fused_bounces = -1: also with frames in flight and for frames of any size (tests)
+   static constexpr uint32_t kFusedMaxPaths = 4u << 20;
    uint32_t fused_blocks_per_cu = 4;
    static constexpr uint32_t kSingleFrameBlocksPerCu = 4;  // the cap on both for a wavefront of one frame (fewer persistent waves reach the end of a small launch's tail sooner: round 4's sweep)
    std::string err;
@@ -1353,8 +1354,11 @@ static int enqueue_path_trace(uh_ctx* c, Slot& s, const FrameParams& fp) {
       // ... when the caller waits for its frames (the frame before this one has left the GPU): the fused kernel fills the chip by
       // itself, so with frames in flight - a caller that does not wait - the wavefront's small launches interleave better (2.2 against
       // 2.5 ms per frame). Both give the same image.
+      // ... and when the frame is not so large that its launches are wavefronts of a batch's size already (a 4K frame: 8.3 M paths -
+      // the fused kernel 2.5 % behind on config 1, 12 % on config 3; at 1080p 12 % ahead, at 960 x 540 37 %, profiles/README.md)
       const bool gpu_idle = !c->last_acc || hipEventQuery(c->last_acc) == hipSuccess;
-      const bool fused = c->fused_bounces && fp.batch_frames == 1 && fp.num_bounces >= 2 && fp.num_bounces <= 64 && s.ps.shard_cap < (1u << 23) && (gpu_idle || c->fused_always);
+      const bool fused = c->fused_bounces && fp.batch_frames == 1 && fp.num_bounces >= 2 && fp.num_bounces <= 64 && s.ps.shard_cap < (1u << 23) &&
+                         ((gpu_idle && fp.n_owned <= uh_ctx::kFusedMaxPaths) || c->fused_always);
       const bool fused_sun0 = fused && fp.sun_shadow_enabled == 1 && fp.lights_enabled != 1;  // bounce 0's sun rays inside the fused kernel too
       for (uint32_t b = 0; b < (fused ? 1u : fp.num_bounces); b++) {
          begin_timed(c, (b == 0 && c->cam_this_frame) ? 3 : 0, s.stream);

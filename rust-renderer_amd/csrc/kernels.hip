@@ -1651,7 +1651,9 @@ __global__ __launch_bounds__(kBlock, UH_FUSED_BLOCKS) void k_path_fused(SceneDev
    // (positions fit 23 bits: the host fuses only when shard_cap < 2^23; bits 23..28: how many bounces follow the entry's ray)
    constexpr uint32_t kHasRay = 1u << 31, kSun = 1u << 30, kLight = 1u << 29, kLeftShift = 23, kLeftMask = 63u << kLeftShift, kPosMask = (1u << kLeftShift) - 1u;
    __shared__ float s_lut[256];
-#if UH_FUSED_BLOCKS >= 5
+#if UH_FUSED_BLOCKS >= 6
+   constexpr uint32_t kLdsMeshes = 4, kLdsTextures = 2;    // (26.6 KiB of LDS per block: the mesh and texture records from global memory)
+#elif UH_FUSED_BLOCKS >= 5
    constexpr uint32_t kLdsMeshes = 48, kLdsTextures = 32;  // (32 KiB of LDS per block)
 #else
    constexpr uint32_t kLdsMeshes = 128, kLdsTextures = 64;

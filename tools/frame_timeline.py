@@ -35,13 +35,15 @@ def main():
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--report")
     a = ap.parse_args()
     if a.report:
         return report(a.report)
     import rust_renderer_amd as rr
-    W, H = 1920, 1080
+    W, H = a.width, a.height
     scene = rr.scenes.scene_for_config(a.config, tex_size=a.tex_size)
     r = rr.Renderer(W, H)
     for kv in a.opt:
@@ -49,7 +51,8 @@ def main():
         r.set_option(k, int(v))
     scene.upload(r)
     mask = rr.PASS_ALL if a.config == 2 else rr.PASS_REFERENCE_PT
-    loop = rr.FrameLoop(r, scene.make_view(W, H))
+    view_kw = {}  # (the scene's own view flags: scenes.scene_for_config)
+    loop = rr.FrameLoop(r, scene.make_view(W, H, **view_kw))
     for _ in range(4):
         loop.frame(mask)
         r.synchronize()
