@@ -1566,7 +1566,8 @@ __global__ __launch_bounds__(kBlock) void k_flush_survivors(FrameParams fp, Path
 // 0.54 - but a walk's state stays live through the shading: 168 registers, three waves per SIMD, 2.65 ms); a pipeline per BLOCK of
 // three walking waves and one shading wave with rings in LDS (101 registers; 2.45-2.54 ms: the shading wave is busy 0.97 of its
 // clock). What they show: the walk's rate follows the number of waves that walk - a kernel that also shades has 16, the wavefront's
-// traversal kernel 20 to 24 -, and a lone frame's work cannot be had at the batched rate in one kernel.
+// traversal kernel 20 to 24 -, and a lone frame's work cannot be had at the batched rate in one kernel. (Two rays per lane in the
+// trace phases, both records asked for before either is used: 40 % slower - the walk does not wait for latency.)
 // ------------------------------------------------------------------------------------------
 // one sun ray through the grid (k_trace_sun_grid's walk for one ray): 0 = lit, 1 = occluded, 2 = the grid does not answer (border cell,
 // long list): the tree's
