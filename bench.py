@@ -393,6 +393,12 @@ def load_profile(sig):
     return None
 
 
+# bytes a ray walk STREAMS per ray (wide coalesced reads, which gfx950's FETCH_SIZE reports at half): origin and direction quads through
+# the LDS pool's DMA; the light rays' walk three quads (origin, throughput, radiance) and its queue entry. Everything else it reads is
+# a scattered record read, which the counter reports exactly (tools/microbench/fetch_size.hip).
+STREAMED_READ_BYTES_PER_RAY = {"k_trace_closest": 32.0, "k_trace_shadow_light": 52.0}
+
+
 def classify_bound(k, hbm_frac, hbm_frac_raw):
     """What limits the dominant kernel, read from the counter profile (never a literal): the busiest of the resources the
     passes measured. `hbm` = HBM-side bytes / serialised launch time / 8 TB/s (corrected; raw in the note), `vmem-issue` = the
@@ -423,9 +429,14 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     """Roofline block of the dominant kernel (`kernel`: k_trace_closest, or k_trace_shadow_light - the light shadow rays' walk - with its
     launch count and summed HIP-event time in `launches` / `kernel_ms`; my_closest / alone_rays are then that kernel's rays) - every figure
     physical and <= 1 by construction.
-    traffic   HBM-side bytes per launch from the rocprofv3 counter passes of this command line (profiles/bench_counters.json:
-              2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; an upper bound for 48-byte gathers),
-              scaled by rays per launch - quoted only when the profile's signature equals this run's
+    traffic   HBM-side bytes per launch from the rocprofv3 counter passes of this command line (profiles/bench_counters.json),
+              scaled by rays per launch - quoted only when the profile's signature equals this run's. Correction as
+              MI355X_MICROARCH.md prescribes AND calibrates: gfx950's FETCH_SIZE reports half of a wide streaming read (16 B per
+              lane, coalesced) and - measured here on byte counts known by construction, tools/microbench/fetch_size.hip,
+              profiles/r05_fetch_size_calibration.txt - exactly the 64-byte lines of scattered record reads (64-, 48-, 16- and
+              4-byte gathers alike). A ray walk streams 32 (light rays: 52) bytes per ray and gathers everything else, so
+              traffic = FETCH_SIZE + WRITE_SIZE + half the streamed bytes. `all_reads_doubled` keeps round 2-4's figure
+              (2 x FETCH_SIZE + WRITE_SIZE: right for a kernel that only streams, an upper bound here), `uncorrected` the counters' own
     achieved  traffic / the kernel's SERIALISED launch duration, measured live with HIP events on the library's stream with
               the kernel alone on the GPU in launches of the timed size (frac = achieved / 8 TB/s)
     overlapped  the same bytes over the timed region's average launch duration, during which other frames' kernels share the chip
@@ -445,14 +456,19 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     if prof is False:
         prof = load_profile(sig)
     k = (prof or {}).get("kernels", {}).get(kernel, {})
-    traffic = k.get("hbm_bytes_per_launch")
+    traffic_x2 = k.get("hbm_bytes_per_launch")  # 2 x FETCH_SIZE + WRITE_SIZE
     prof_rays = k.get("rays_per_launch") or k.get("closest_rays_per_launch")
-    if traffic and prof_rays:
+    if traffic_x2 and prof_rays:
         # the profiled run's launches may carry another number of frames than this run's: a LAUNCH's traffic goes with its rays
-        traffic *= rays_per_launch / prof_rays
+        traffic_x2 *= rays_per_launch / prof_rays
+    # what the counters report (FETCH_SIZE + WRITE_SIZE) and the calibrated figure: only the streamed reads are reported at half
+    raw_share = (k.get("hbm_bytes_per_launch_uncorrected") or 0.0) / k["hbm_bytes_per_launch"] if traffic_x2 else None
+    streamed = STREAMED_READ_BYTES_PER_RAY.get(kernel, 0.0) * rays_per_launch
+    traffic = min(traffic_x2, traffic_x2 * raw_share + 0.5 * streamed) if (traffic_x2 and raw_share) else traffic_x2
     # serialised duration of a launch of the timed size: the calibration launches are the same wavefronts, alone
     serial_ms = alone_ms * (rays_per_launch / alone_rays) if (alone_ms > 0 and alone_rays > 0) else None
     achieved = traffic / (serial_ms * 1e-3) / 1e9 if (traffic and serial_ms) else None
+    achieved_x2 = traffic_x2 / (serial_ms * 1e-3) / 1e9 if (traffic_x2 and serial_ms) else None
     overlapped = traffic / (avg_ms * 1e-3) / 1e9 if (traffic and avg_ms > 0) else None
     frame_bytes = (prof or {}).get("frame_hbm_bytes")
     frame_bytes_lo = (prof or {}).get("frame_hbm_bytes_uncorrected")
@@ -462,7 +478,7 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
         frame_bytes *= rays_per_frame / prof_rpf
         frame_bytes_lo = frame_bytes_lo * rays_per_frame / prof_rpf if frame_bytes_lo else None
     ms_per_step = elapsed / args.steps * 1e3
-    uncorrected = (k.get("hbm_bytes_per_launch_uncorrected") or 0.0) / k["hbm_bytes_per_launch"] if traffic else None  # share of `traffic` the raw counters report
+    uncorrected = raw_share  # share of the doubled figure that the raw counters report
     # vector-memory issue: every per-lane load or store of <= 16 B takes one slot of the CU's texture addresser / data path, and
     # that path retires about one lane per clock (profiles/r02_microbench_rates.txt). Lane operations of one closest-hit ray: 3
     # per node visit (48-B node), 3 per triangle tested (48-B packet), 3 for the ray (2 LDS-DMA, by queue position) + hit.
@@ -472,8 +488,13 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
     ref = serial_ms or avg_ms
     frac = (achieved / HBM_PEAK_GBS) if achieved is not None else None
     # the bound is classified on the profile's own serialised launch (bytes and duration from the same counter pass)
-    prof_frac = (k["hbm_bytes_per_launch"] / (k["launch_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9)) if (k.get("hbm_bytes_per_launch") and k.get("launch_ns")) else frac
     prof_frac_raw = (k["hbm_bytes_per_launch_uncorrected"] / (k["launch_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9)) if (k.get("hbm_bytes_per_launch_uncorrected") and k.get("launch_ns")) else None
+    prof_frac = frac
+    if k.get("hbm_bytes_per_launch") and k.get("launch_ns"):
+        prof_bytes = k["hbm_bytes_per_launch"]
+        if k.get("hbm_bytes_per_launch_uncorrected") and prof_rays:
+            prof_bytes = min(prof_bytes, k["hbm_bytes_per_launch_uncorrected"] + 0.5 * STREAMED_READ_BYTES_PER_RAY.get(kernel, 0.0) * prof_rays)
+        prof_frac = prof_bytes / (k["launch_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9)
     bound, bound_note = classify_bound(k, prof_frac, prof_frac_raw)
     r = {
         "kernel": kernel,
@@ -493,8 +514,11 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
         "frame_hbm_bytes": frame_bytes,
         # the x2 FETCH_SIZE correction is calibrated for coalesced wide reads; these kernels gather 16-B lanes from 48/64-byte
         # records, for which it may overstate by up to 2x. The same fractions from the counters AS REPORTED are the lower bounds.
-        "uncorrected": {"frac": (achieved / HBM_PEAK_GBS * uncorrected) if (achieved is not None and uncorrected) else None,
+        "uncorrected": {"frac": (achieved_x2 / HBM_PEAK_GBS * uncorrected) if (achieved_x2 is not None and uncorrected) else None,
                         "frame_hbm_frac": (frame_bytes_lo / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)) if frame_bytes_lo else None},
+        # round 2-4's figure: every read doubled (right for a kernel that only streams; an upper bound for one that gathers records)
+        "all_reads_doubled": {"traffic": traffic_x2, "achieved": achieved_x2, "frac": (achieved_x2 / HBM_PEAK_GBS) if achieved_x2 is not None else None},
+        "streamed_read_bytes_per_launch": streamed,
         "launches": n_launches,
         "rays_per_launch": rays_per_launch,
         "nodes_per_ray": nodes_per_ray,
@@ -518,7 +542,10 @@ def roofline(args, st, alone_ms, alone_rays, my_closest, nodes_per_ray, tris_per
         "valu": {kk: k.get(kk) for kk in ("wave_instr_per_launch", "issue_frac", "lane_utilisation", "ta_busy_frac", "td_busy_frac")} if k else None,
         # every kernel against the HBM roofline, alone on the GPU (counter passes serialise the kernels): HBM-side bytes per
         # launch over the launch's duration from the counter CSV's own timestamps
-        "hbm_frac_by_kernel": ({name: round(v["hbm_bytes_per_launch"] / (v["launch_ns"] * 1e-9) / 8e12, 3)
+        # [every read doubled, as reported]: the first is right for the kernels that stream (k_generate, k_finish_sample, most of
+        # k_shade_hit's state), the second for those that gather records (the walks, the grids) - tools/microbench/fetch_size.hip
+        "hbm_frac_by_kernel": ({name: [round(v["hbm_bytes_per_launch"] / (v["launch_ns"] * 1e-9) / 8e12, 3),
+                                       round((v.get("hbm_bytes_per_launch_uncorrected") or 0.0) / (v["launch_ns"] * 1e-9) / 8e12, 3)]
                                 for name, v in prof["kernels"].items() if name.startswith("k_") and v.get("launch_ns") and v.get("hbm_bytes_per_launch")}
                                if prof else None),
         "trace_closest_ms": st.trace_closest_ms,

@@ -50,8 +50,13 @@ def test_frame_fraction_does_not_depend_on_the_step_count(bench):
     assert r64["frame_hbm_frac"] == pytest.approx(want, rel=1e-9)
     assert r20["uncorrected"]["frame_hbm_frac"] == pytest.approx(r64["uncorrected"]["frame_hbm_frac"], rel=1e-9)
     # a LAUNCH's traffic does go with the rays it carries: 20 steps = 2 wavefronts of 10 frames on average
-    assert r20["traffic"] == pytest.approx(14.09e9 * (10 / 16), rel=1e-9)
-    assert r64["traffic"] == pytest.approx(14.09e9, rel=1e-9)
+    assert r20["all_reads_doubled"]["traffic"] == pytest.approx(14.09e9 * (10 / 16), rel=1e-9)
+    assert r64["all_reads_doubled"]["traffic"] == pytest.approx(14.09e9, rel=1e-9)
+    # the calibrated figure: the counters as reported + half of what the walk streams (32 bytes per ray); scattered record reads are
+    # reported exactly (tools/microbench/fetch_size.hip)
+    assert r64["traffic"] == pytest.approx(7.51e9 + 0.5 * 32.0 * 29.45e6, rel=1e-9)
+    assert r20["traffic"] == pytest.approx((7.51e9 + 0.5 * 32.0 * 29.45e6) * (10 / 16), rel=1e-9)
+    assert r64["uncorrected"]["frac"] < r64["frac"] < r64["all_reads_doubled"]["frac"]
     # ... and the serialised fraction is the same for both (bytes and time scale together)
     assert r20["frac"] == pytest.approx(r64["frac"], rel=1e-9)
     assert 0.0 < r64["frac"] < 1.0
@@ -72,7 +77,7 @@ def test_bound_is_read_from_the_counters(bench):
     assert "0.92" in r["bound_note"] and "0.57" in r["bound_note"]
     prof = json.loads(json.dumps(PROFILE))
     k = prof["kernels"]["k_trace_closest"]
-    k["ta_busy_frac"], k["issue_frac"], k["hbm_bytes_per_launch"] = 0.3, 0.2, 24e9  # 24 GB in 3.667 ms = 0.82 of the peak
+    k["ta_busy_frac"], k["issue_frac"], k["hbm_bytes_per_launch"], k["hbm_bytes_per_launch_uncorrected"] = 0.3, 0.2, 47e9, 24e9  # 24.5 GB (calibrated) in 3.667 ms = 0.83 of the peak
     assert fake_run(bench, 64, prof)["bound"] == "hbm"
     k["issue_frac"] = 0.8
     assert fake_run(bench, 64, prof)["bound"] == "hbm/valu"
