@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: trace only one rank's tiles of an N-rank partition (what one rank sees at --gpus N)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="the rank --emulate-world stands in for")
     ap.add_argument("--force-dist", action="store_true", help="run the rendezvous + RCCL composition path even with one rank (rehearsal on a 1-GPU box)")
+    ap.add_argument("--rank-device", type=int, default=None, help="every rank on this device instead of its LOCAL_RANK's (rehearsal of N rank processes on a 1-GPU box: tests/test_gpu_rehearsal.py)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments), e.g. sun_grid=0")
     ap.add_argument("--full-frame-reservoir-passes", action="store_true", help="N > 1: every rank runs the G-buffer cast and the reservoir passes for the whole frame (rounds 1-2) instead of its band of rows + one all-gather per frame")
     ap.add_argument("--spp", type=int, default=1, help="samples_per_frame (reference default 1, UI maximum 10); SURVEY 8d also asks for 64 spp as 8 frames x 8")
@@ -101,7 +102,7 @@ def main():
     if args.cook_torrance and args.config in (1, 2, 3):
         kw["cook_torrance"] = True
     scene = rr.scenes.scene_for_config(args.config, **kw)
-    renderer = rr.Renderer(W, H, device=local_rank)
+    renderer = rr.Renderer(W, H, device=local_rank if args.rank_device is None else args.rank_device)
     for kv in args.opt:
         k, v = kv.split("=")
         renderer.set_option(k, int(v))
